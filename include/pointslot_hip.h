@@ -1,0 +1,117 @@
+/* pointslot_hip.h — C-ABI of libpointslot_hip.so: the MI355X (gfx950) implementation of the SLOT
+ * front-end / back-end hot path of pkzhou/PointSLOT.
+ *
+ * The reference has no FFI layer: callers use the C++ classes ORB_SLAM2::ORBextractor, ORBmatcher
+ * and Optimizer directly.  This header is the boundary a maintainer would
+ * bind from those classes (the shim classes are in pointslot_amd/host/, the recipe in
+ * INTEGRATION.md).  Every entry point cites the reference function it replaces.
+ *
+ * Conventions: plain C, POD structs, caller-owned buffers, no exceptions.  Every function returns
+ * PS_OK (0) or a negative ps_status.  Handles are not re-entrant (like an ORBextractor instance,
+ * which owns mvImagePyramid); distinct handles may be used from distinct threads concurrently.
+ * Pointers named d_* are device (HBM) pointers, everything else is host memory.
+ */
+#ifndef POINTSLOT_HIP_H
+#define POINTSLOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ps_status {
+  PS_OK = 0,
+  PS_ERR_INVALID = -1,   /* bad argument (null pointer, non-positive size, unsupported shape) */
+  PS_ERR_HIP = -2,       /* a HIP runtime call failed; ps_last_error() has the text          */
+  PS_ERR_CAPACITY = -3,  /* caller buffer or plan capacity too small                          */
+  PS_ERR_NO_DEVICE = -4  /* no gfx950 device visible                                          */
+} ps_status;
+
+/* Binary-compatible with cv::KeyPoint (OpenCV 3.x): pt.x, pt.y, size, angle, response, octave,
+ * class_id — 28 bytes.  Filled exactly as ORBextractor::operator() fills it
+ * (/root/reference/src/ORBextractor.cc:837-852,1095-1101). */
+typedef struct ps_keypoint {
+  float x, y;
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+  int32_t class_id;
+} ps_keypoint;
+
+const char* ps_last_error(void);
+int ps_device_count(int* count);
+const char* ps_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * ORB extractor — replaces ORB_SLAM2::ORBextractor (/root/reference/include/ORBextractor.h:51-85,
+ * src/ORBextractor.cc:410-470 ctor, :1043-1105 operator()).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ps_orb ps_orb;
+
+typedef struct ps_orb_config {
+  int32_t nfeatures;      /* ORBextractor.nFeatures   (yaml: 1000; BASELINE config 2: 2000) */
+  float scale_factor;     /* ORBextractor.scaleFactor (1.2)                                  */
+  int32_t nlevels;        /* ORBextractor.nLevels     (8; 1..8 supported)                    */
+  int32_t ini_th_fast;    /* ORBextractor.iniThFAST   (20)                                   */
+  int32_t min_th_fast;    /* ORBextractor.minThFAST   (5)                                    */
+  int32_t max_batch;      /* images processed per ps_orb_extract_batch_device call (>= 1)    */
+  int32_t device;         /* HIP device ordinal                                              */
+} ps_orb_config;
+
+int ps_orb_create(const ps_orb_config* cfg, ps_orb** out);
+void ps_orb_destroy(ps_orb* h);
+
+/* Getters of ORBextractor.h:61-83.  Each array has nlevels entries; any pointer may be NULL. */
+int ps_orb_get_tables(const ps_orb* h, float* scale_factors, float* inv_scale_factors,
+                      float* level_sigma2, float* inv_level_sigma2, int32_t* features_per_level);
+
+/* Level geometry for an image of w x h: level sizes (ORBextractor.cc:1111-1112).  The padded plane
+ * of a level is (w_l + 38) x (h_l + 38) (EDGE_THRESHOLD = 19 on every side, :1113). */
+int ps_orb_level_size(const ps_orb* h, int w, int hgt, int level, int32_t* w_l, int32_t* h_l);
+
+/* ORBextractor::operator()(image, mask (ignored), keypoints, descriptors) for ONE host image.
+ *   img/stride : CV_8UC1 image, `stride` bytes per row.  w <= 0 || hgt <= 0 || !img => *n = 0, PS_OK
+ *                (the reference returns silently on an empty image, ORBextractor.cc:1046-1047).
+ *   kps, desc  : caller buffers with room for `cap` keypoints / cap x 32 descriptor bytes.  The
+ *                extractor may return up to nfeatures + 3 * nlevels keypoints (the quadtree stops
+ *                at >= quota leaves per level, ORBextractor.cc:669-737).
+ *   pyramid_out: NULL, or nlevels pointers; plane l receives the padded level image, tightly packed
+ *                (w_l + 38) bytes per row — the contents of mvImagePyramid[l]'s parent buffer
+ *                (ORBextractor.cc:1113-1128) that Frame::ComputeStereoMatches reads. */
+int ps_orb_extract(ps_orb* h, const uint8_t* img, int w, int hgt, int stride, ps_keypoint* kps,
+                   uint8_t* desc, int cap, int* n, uint8_t* const* pyramid_out);
+
+/* Batched, device-resident form of the same call: `nimg` images of identical size already in HBM
+ * (image i at d_imgs + i * image_pitch, rows `stride` bytes apart).  Results stay in HBM inside the
+ * handle; the call is asynchronous on `stream` (a hipStream_t, NULL = the handle's own stream). */
+int ps_orb_extract_batch_device(ps_orb* h, const uint8_t* d_imgs, int nimg, int w, int hgt, int stride,
+                                size_t image_pitch, void* stream);
+/* Device views of the last batch: keypoints [nimg][kp_capacity], descriptors
+ * [nimg][kp_capacity][32], counts [nimg]. */
+int ps_orb_batch_device_outputs(const ps_orb* h, const ps_keypoint** d_kps, const uint8_t** d_desc,
+                                const int32_t** d_counts, int32_t* kp_capacity);
+/* Blocks until the batch is complete and copies image i's results to the host. */
+int ps_orb_batch_fetch(ps_orb* h, int image, ps_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* Waits for all work queued on the handle. */
+int ps_orb_sync(ps_orb* h);
+
+/* Test/diagnostic access to intermediates of the last call (blocking).  `what`:
+ *   0 padded plane (tight, (w_l+38) x (h_l+38) bytes)      1 blurred plane (tight, w_l x h_l)
+ *   2 FAST candidates in reference emission order, int32 triples (x, y, score) relative to
+ *     minBorder (ORBextractor.cc:822-824); returns the count in *n
+ *   3 selected keypoints of the level, int32 triples (x, y, score) in level coordinates, in
+ *     DistributeOctTree's output order; count in *n */
+int ps_orb_debug_read(ps_orb* h, int image, int level, int what, void* out, size_t out_bytes, int* n);
+
+/* Per-kernel timing of the last ps_orb_extract_batch_device call, measured with HIP events on the
+ * stream the kernels ran on.  names/ms arrays of length `cap`; *n receives the stage count. */
+int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n);
+int ps_orb_enable_stage_timing(ps_orb* h, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTSLOT_HIP_H */

@@ -1,0 +1,452 @@
+// Host side of the ORB extractor C-ABI (include/pointslot_hip.h): plan construction (level
+// geometry, FAST cell grid, resize coefficient tables, arena layout), stream orchestration and the
+// host<->device copies.  Replaces ORB_SLAM2::ORBextractor — /root/reference/src/ORBextractor.cc.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/pointslot_hip.h"
+#include "orb_plan.h"
+#include "ps_common.h"
+
+extern "C" {
+void psk_orb_launch_pyramid(const OrbPlan*, int, uint8_t*, const uint8_t*, int, size_t, const int4*, int, hipStream_t);
+void psk_orb_launch_fast(const OrbPlan*, uint8_t*, int, hipStream_t);
+void psk_orb_launch_quadtree(const OrbPlan*, uint8_t*, int, hipStream_t);
+void psk_orb_launch_blur(const OrbPlan*, uint8_t*, int, hipStream_t);
+void psk_orb_launch_describe(const OrbPlan*, uint8_t*, void*, uint8_t*, int32_t*, int, hipStream_t);
+}
+
+namespace {
+
+inline int cv_round(double v) { return (int)nearbyint(v); }   // cvRound: round half to even
+inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+enum { ST_PYRAMID = 0, ST_FAST, ST_QUADTREE, ST_BLUR, ST_DESCRIBE, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"orb_pyramid_level", "orb_fast_cells", "orb_quadtree", "orb_blur",
+                                     "orb_describe"};
+
+}  // namespace
+
+struct ps_orb {
+  ps_orb_config cfg;
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> quota;
+  OrbPlan plan;
+  bool planned = false;
+  std::vector<int4> tabs_host;
+  // device
+  uint8_t* d_arena = nullptr;
+  int4* d_tabs = nullptr;
+  ps_keypoint* d_kps = nullptr;
+  uint8_t* d_desc = nullptr;
+  int32_t* d_counts = nullptr;
+  uint8_t* d_img = nullptr;       // staging for ps_orb_extract (one host image)
+  size_t d_img_bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[ST_COUNT + 1] = {};
+  bool timing = false;
+  bool timed_valid = false;
+  int last_nimg = 0;
+};
+
+namespace {
+
+// ORBextractor ctor tables, /root/reference/src/ORBextractor.cc:415-446.  scaleFactor is stored in a
+// double member (include/ORBextractor.h:98), so the products below are double then narrowed.
+void build_tables(ps_orb* h) {
+  const int nl = h->cfg.nlevels;
+  const double sf = (double)h->cfg.scale_factor;
+  h->scale.assign(nl, 1.f);
+  h->sigma2.assign(nl, 1.f);
+  for (int i = 1; i < nl; i++) {
+    h->scale[i] = (float)(h->scale[i - 1] * sf);
+    h->sigma2[i] = h->scale[i] * h->scale[i];
+  }
+  h->inv_scale.resize(nl);
+  h->inv_sigma2.resize(nl);
+  for (int i = 0; i < nl; i++) {
+    h->inv_scale[i] = 1.0f / h->scale[i];
+    h->inv_sigma2[i] = 1.0f / h->sigma2[i];
+  }
+  h->quota.resize(nl);
+  const float factor = (float)(1.0f / sf);
+  float want = h->cfg.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int l = 0; l < nl - 1; l++) {
+    h->quota[l] = cv_round(want);
+    sum += h->quota[l];
+    want *= factor;
+  }
+  h->quota[nl - 1] = h->cfg.nfeatures - sum > 0 ? h->cfg.nfeatures - sum : 0;
+}
+
+void level_size(const ps_orb* h, int w, int hgt, int l, int* wl, int* hl) {
+  const float s = h->inv_scale[l];   // ORBextractor.cc:1111-1112
+  *wl = cv_round((float)w * s);
+  *hl = cv_round((float)hgt * s);
+}
+
+// OpenCV 3.4 resize(INTER_LINEAR) coefficient tables for src (sw x sh) -> dst (dw x dh), 8-bit:
+// fx = (float)((dx + 0.5) * scale - 0.5); sx = floor(fx); fx -= sx; clamp; alpha = sat<short>(c*2048)
+inline int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+void resize_tables(int sw, int sh, int dw, int dh, std::vector<int4>& out, uint32_t* xoff, uint32_t* yoff) {
+  const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+  *xoff = (uint32_t)out.size();
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    const float c0 = 1.f - fx, c1 = fx;
+    int4 e;
+    e.x = sx;
+    e.y = sx + 1 < sw ? sx + 1 : sx;
+    e.z = sat_short(cv_round(c0 * 2048.f));
+    e.w = sat_short(cv_round(c1 * 2048.f));
+    out.push_back(e);
+  }
+  *yoff = (uint32_t)out.size();
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor(fy);
+    fy -= sy;
+    const float c0 = 1.f - fy, c1 = fy;
+    auto clip = [&](int v) { return v >= 0 ? (v < sh ? v : sh - 1) : 0; };
+    int4 e;
+    e.x = clip(sy);
+    e.y = clip(sy + 1);
+    e.z = sat_short(cv_round(c0 * 2048.f));
+    e.w = sat_short(cv_round(c1 * 2048.f));
+    out.push_back(e);
+  }
+}
+
+int free_device(ps_orb* h) {
+  if (h->d_arena) hipFree(h->d_arena);
+  if (h->d_tabs) hipFree(h->d_tabs);
+  if (h->d_kps) hipFree(h->d_kps);
+  if (h->d_desc) hipFree(h->d_desc);
+  if (h->d_counts) hipFree(h->d_counts);
+  h->d_arena = nullptr; h->d_tabs = nullptr; h->d_kps = nullptr; h->d_desc = nullptr; h->d_counts = nullptr;
+  return 0;
+}
+
+int build_plan(ps_orb* h, int w, int hgt) {
+  OrbPlan& P = h->plan;
+  memset(&P, 0, sizeof(P));
+  const int nl = h->cfg.nlevels;
+  P.nlevels = nl;
+  P.img_w = w;
+  P.img_h = hgt;
+  P.ini_th = h->cfg.ini_th_fast;
+  P.min_th = h->cfg.min_th_fast;
+  h->tabs_host.clear();
+  size_t off = 0;
+  uint32_t cand_elems = 0, key_elems = 0;
+  int cells = 0, sel = 0;
+  for (int l = 0; l < nl; l++) {
+    OrbLevel& L = P.lv[l];
+    level_size(h, w, hgt, l, &L.w, &L.h);
+    if (L.w < 2 * PS_EDGE + 30 || L.h < 2 * PS_EDGE + 30 || L.w > 4000 || L.h > 4000)
+      return ps_set_error(PS_ERR_INVALID, "image %dx%d: level %d is %dx%d, outside the supported range", w, hgt, l, L.w, L.h);
+    L.stride = (int)align_up(L.w + 2 * PS_EDGE, 64);
+    L.bstride = (int)align_up(L.w, 64);
+    off = align_up(off, 256);
+    L.plane_off = (uint32_t)off;
+    off += (size_t)L.stride * (L.h + 2 * PS_EDGE);
+    // FAST cell grid: ORBextractor.cc:773-787
+    const int maxBX = L.w - PS_EDGE + 3, maxBY = L.h - PS_EDGE + 3;
+    const float width = (float)(maxBX - PS_MINB), height = (float)(maxBY - PS_MINB);
+    L.n_cols = (int)(width / 30.f);
+    L.n_rows = (int)(height / 30.f);
+    L.w_cell = (int)ceilf(width / L.n_cols);
+    L.h_cell = (int)ceilf(height / L.n_rows);
+    if (L.w_cell + 6 > PS_FAST_WIN || L.h_cell + 6 > PS_FAST_WIN)
+      return ps_set_error(PS_ERR_INVALID, "FAST cell %dx%d exceeds the kernel window", L.w_cell, L.h_cell);
+    L.cell_base = cells;
+    cells += L.n_cols * L.n_rows;
+    if (L.n_cols * L.n_rows > PS_QT_NCAP)
+      return ps_set_error(PS_ERR_INVALID, "level %d has %d cells (> %d)", l, L.n_cols * L.n_rows, PS_QT_NCAP);
+    L.cell_cap = ((L.w_cell + 1) / 2) * ((L.h_cell + 1) / 2);   // strict 3x3 maxima: <= 1 per 2x2 block
+    L.cand_off = cand_elems;
+    cand_elems += (uint32_t)(L.n_cols * L.n_rows * L.cell_cap);
+    L.key_cap = L.n_cols * L.n_rows * L.cell_cap;
+    if (L.key_cap >= (1 << 20)) return ps_set_error(PS_ERR_INVALID, "level %d key capacity too large", l);
+    L.key_off = key_elems;
+    key_elems += 2u * (uint32_t)L.key_cap;
+    L.quota = h->quota[l];
+    // DistributeOctTree init: ORBextractor.cc:543-545
+    L.n_ini = (int)roundf((float)(maxBX - PS_MINB) / (float)(maxBY - PS_MINB));
+    if (L.n_ini < 1) return ps_set_error(PS_ERR_INVALID, "level %d is taller than wide; unsupported", l);
+    L.h_x = (float)(maxBX - PS_MINB) / (float)L.n_ini;
+    if (L.quota + 4 > PS_QT_NCAP || 4 * L.n_ini > PS_QT_NCAP)
+      return ps_set_error(PS_ERR_INVALID, "feature quota %d exceeds the quadtree node capacity", L.quota);
+    L.sel_off = sel;
+    L.sel_cap = (L.quota + 3 > 4 * L.n_ini ? L.quota + 3 : 4 * L.n_ini) + 1;
+    sel += L.sel_cap;
+    L.scale = h->scale[l];
+    L.kp_size = (float)(int)(31 * h->scale[l]);   // ORBextractor.cc:839: const int scaledPatchSize
+    if (l > 0) resize_tables(P.lv[l - 1].w, P.lv[l - 1].h, L.w, L.h, h->tabs_host, &L.xtab_off, &L.ytab_off);
+  }
+  for (int l = 0; l < nl; l++) {
+    OrbLevel& L = P.lv[l];
+    off = align_up(off, 256);
+    L.blur_off = (uint32_t)off;
+    off += (size_t)L.bstride * L.h;
+  }
+  P.n_cells = cells;
+  P.sel_total = sel;
+  P.kp_cap = (int)align_up(sel, 64);
+  off = align_up(off, 256); P.cellcnt_off = off; off += (size_t)cells * 4;
+  off = align_up(off, 256); P.cand_base = off;   off += (size_t)cand_elems * 4;
+  off = align_up(off, 256); P.key_base = off;    off += (size_t)key_elems * 4;
+  off = align_up(off, 256); P.sel_base = off;    off += (size_t)sel * 4;
+  off = align_up(off, 256); P.selcnt_off = off;  off += PS_ORB_MAX_LEVELS * 4;
+  P.ncand_off = off; off += PS_ORB_MAX_LEVELS * 4;
+  P.arena_bytes = align_up(off, 4096);
+  if (P.arena_bytes >= (1ull << 32)) return ps_set_error(PS_ERR_INVALID, "arena too large");
+
+  free_device(h);
+  const int B = h->cfg.max_batch;
+  PS_HIP(hipMalloc(&h->d_arena, P.arena_bytes * B));
+  PS_HIP(hipMemsetAsync(h->d_arena, 0, P.arena_bytes * B, h->stream));
+  PS_HIP(hipMalloc(&h->d_tabs, (h->tabs_host.size() + 1) * sizeof(int4)));
+  if (!h->tabs_host.empty())
+    PS_HIP(hipMemcpyAsync(h->d_tabs, h->tabs_host.data(), h->tabs_host.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+  PS_HIP(hipMalloc(&h->d_kps, (size_t)B * P.kp_cap * sizeof(ps_keypoint)));
+  PS_HIP(hipMalloc(&h->d_desc, (size_t)B * P.kp_cap * 32));
+  PS_HIP(hipMalloc(&h->d_counts, (size_t)B * 4));
+  PS_HIP(hipMemsetAsync(h->d_counts, 0, (size_t)B * 4, h->stream));
+  PS_HIP(hipStreamSynchronize(h->stream));
+  h->planned = true;
+  return PS_OK;
+}
+
+int run_batch(ps_orb* h, const uint8_t* d_imgs, int nimg, int stride, size_t pitch, hipStream_t st) {
+  const OrbPlan* P = &h->plan;
+  const bool tm = h->timing;
+  if (tm) PS_HIP(hipEventRecord(h->ev[0], st));
+  for (int l = 0; l < P->nlevels; l++)
+    psk_orb_launch_pyramid(P, l, h->d_arena, d_imgs, stride, pitch, h->d_tabs, nimg, st);
+  if (tm) PS_HIP(hipEventRecord(h->ev[1], st));
+  psk_orb_launch_fast(P, h->d_arena, nimg, st);
+  if (tm) PS_HIP(hipEventRecord(h->ev[2], st));
+  psk_orb_launch_quadtree(P, h->d_arena, nimg, st);
+  if (tm) PS_HIP(hipEventRecord(h->ev[3], st));
+  psk_orb_launch_blur(P, h->d_arena, nimg, st);
+  if (tm) PS_HIP(hipEventRecord(h->ev[4], st));
+  psk_orb_launch_describe(P, h->d_arena, h->d_kps, h->d_desc, h->d_counts, nimg, st);
+  if (tm) PS_HIP(hipEventRecord(h->ev[5], st));
+  PS_HIP(hipGetLastError());
+  h->timed_valid = tm;
+  h->last_nimg = nimg;
+  return PS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ps_orb_create(const ps_orb_config* cfg, ps_orb** out) {
+  if (!cfg || !out) return ps_set_error(PS_ERR_INVALID, "ps_orb_create: null argument");
+  if (cfg->nlevels < 1 || cfg->nlevels > PS_ORB_MAX_LEVELS || cfg->nfeatures < 1 || cfg->scale_factor <= 1.f ||
+      cfg->max_batch < 1 || cfg->ini_th_fast < cfg->min_th_fast || cfg->min_th_fast < 1)
+    return ps_set_error(PS_ERR_INVALID, "ps_orb_create: unsupported configuration");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return ps_set_error(PS_ERR_NO_DEVICE, "no HIP device visible");
+  if (cfg->device < 0 || cfg->device >= ndev) return ps_set_error(PS_ERR_INVALID, "bad device ordinal");
+  PS_HIP(hipSetDevice(cfg->device));
+  ps_orb* h = new ps_orb();
+  h->cfg = *cfg;
+  build_tables(h);
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return ps_set_error(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&h->ev[i]);
+  *out = h;
+  return PS_OK;
+}
+
+void ps_orb_destroy(ps_orb* h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  free_device(h);
+  if (h->d_img) hipFree(h->d_img);
+  for (int i = 0; i <= ST_COUNT; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int ps_orb_get_tables(const ps_orb* h, float* s, float* is, float* s2, float* is2, int32_t* q) {
+  if (!h) return ps_set_error(PS_ERR_INVALID, "null handle");
+  for (int i = 0; i < h->cfg.nlevels; i++) {
+    if (s) s[i] = h->scale[i];
+    if (is) is[i] = h->inv_scale[i];
+    if (s2) s2[i] = h->sigma2[i];
+    if (is2) is2[i] = h->inv_sigma2[i];
+    if (q) q[i] = h->quota[i];
+  }
+  return PS_OK;
+}
+
+int ps_orb_level_size(const ps_orb* h, int w, int hgt, int level, int32_t* wl, int32_t* hl) {
+  if (!h || level < 0 || level >= h->cfg.nlevels || !wl || !hl) return ps_set_error(PS_ERR_INVALID, "bad argument");
+  level_size(h, w, hgt, level, wl, hl);
+  return PS_OK;
+}
+
+int ps_orb_extract_batch_device(ps_orb* h, const uint8_t* d_imgs, int nimg, int w, int hgt, int stride,
+                                size_t image_pitch, void* stream) {
+  if (!h || !d_imgs || nimg < 1 || w < 1 || hgt < 1 || stride < w)
+    return ps_set_error(PS_ERR_INVALID, "ps_orb_extract_batch_device: bad argument");
+  if (nimg > h->cfg.max_batch) return ps_set_error(PS_ERR_CAPACITY, "nimg %d > max_batch %d", nimg, h->cfg.max_batch);
+  PS_HIP(hipSetDevice(h->cfg.device));
+  if (!h->planned || h->plan.img_w != w || h->plan.img_h != hgt) {
+    int rc = build_plan(h, w, hgt);
+    if (rc != PS_OK) return rc;
+  }
+  return run_batch(h, d_imgs, nimg, stride, image_pitch, stream ? (hipStream_t)stream : h->stream);
+}
+
+int ps_orb_batch_device_outputs(const ps_orb* h, const ps_keypoint** d_kps, const uint8_t** d_desc,
+                                const int32_t** d_counts, int32_t* kp_capacity) {
+  if (!h || !h->planned) return ps_set_error(PS_ERR_INVALID, "no batch has been run");
+  if (d_kps) *d_kps = h->d_kps;
+  if (d_desc) *d_desc = h->d_desc;
+  if (d_counts) *d_counts = h->d_counts;
+  if (kp_capacity) *kp_capacity = h->plan.kp_cap;
+  return PS_OK;
+}
+
+int ps_orb_sync(ps_orb* h) {
+  if (!h) return ps_set_error(PS_ERR_INVALID, "null handle");
+  PS_HIP(hipSetDevice(h->cfg.device));
+  PS_HIP(hipDeviceSynchronize());
+  return PS_OK;
+}
+
+int ps_orb_batch_fetch(ps_orb* h, int image, ps_keypoint* kps, uint8_t* desc, int cap, int* n) {
+  if (!h || !h->planned || image < 0 || image >= h->last_nimg || !n)
+    return ps_set_error(PS_ERR_INVALID, "ps_orb_batch_fetch: bad argument");
+  PS_HIP(hipSetDevice(h->cfg.device));
+  PS_HIP(hipDeviceSynchronize());
+  int32_t cnt = 0;
+  PS_HIP(hipMemcpy(&cnt, h->d_counts + image, 4, hipMemcpyDeviceToHost));
+  *n = cnt;
+  if (cnt > cap) return ps_set_error(PS_ERR_CAPACITY, "%d keypoints, caller capacity %d", cnt, cap);
+  if (cnt > 0) {
+    if (!kps || !desc) return ps_set_error(PS_ERR_INVALID, "null output buffer");
+    PS_HIP(hipMemcpy(kps, h->d_kps + (size_t)image * h->plan.kp_cap, (size_t)cnt * sizeof(ps_keypoint), hipMemcpyDeviceToHost));
+    PS_HIP(hipMemcpy(desc, h->d_desc + (size_t)image * h->plan.kp_cap * 32, (size_t)cnt * 32, hipMemcpyDeviceToHost));
+  }
+  return PS_OK;
+}
+
+int ps_orb_extract(ps_orb* h, const uint8_t* img, int w, int hgt, int stride, ps_keypoint* kps, uint8_t* desc,
+                   int cap, int* n, uint8_t* const* pyramid_out) {
+  if (!h || !n) return ps_set_error(PS_ERR_INVALID, "ps_orb_extract: null argument");
+  *n = 0;
+  if (!img || w <= 0 || hgt <= 0) return PS_OK;   // empty image: silent return (ORBextractor.cc:1046-1047)
+  if (stride < w) return ps_set_error(PS_ERR_INVALID, "stride < width");
+  PS_HIP(hipSetDevice(h->cfg.device));
+  const size_t bytes = (size_t)stride * hgt;
+  if (bytes > h->d_img_bytes) {
+    if (h->d_img) hipFree(h->d_img);
+    h->d_img = nullptr;
+    PS_HIP(hipMalloc(&h->d_img, bytes));
+    h->d_img_bytes = bytes;
+  }
+  PS_HIP(hipMemcpyAsync(h->d_img, img, bytes, hipMemcpyHostToDevice, h->stream));
+  int rc = ps_orb_extract_batch_device(h, h->d_img, 1, w, hgt, stride, bytes, nullptr);
+  if (rc != PS_OK) return rc;
+  rc = ps_orb_batch_fetch(h, 0, kps, desc, cap, n);
+  if (rc != PS_OK) return rc;
+  if (pyramid_out) {
+    for (int l = 0; l < h->plan.nlevels; l++) {
+      const OrbLevel& L = h->plan.lv[l];
+      if (!pyramid_out[l]) continue;
+      PS_HIP(hipMemcpy2D(pyramid_out[l], L.w + 2 * PS_EDGE, h->d_arena + L.plane_off, L.stride, L.w + 2 * PS_EDGE,
+                         L.h + 2 * PS_EDGE, hipMemcpyDeviceToHost));
+    }
+  }
+  return PS_OK;
+}
+
+int ps_orb_debug_read(ps_orb* h, int image, int level, int what, void* out, size_t out_bytes, int* n) {
+  if (!h || !h->planned || image < 0 || image >= h->cfg.max_batch || level < 0 || level >= h->plan.nlevels || !out)
+    return ps_set_error(PS_ERR_INVALID, "ps_orb_debug_read: bad argument");
+  PS_HIP(hipSetDevice(h->cfg.device));
+  PS_HIP(hipDeviceSynchronize());
+  const OrbPlan& P = h->plan;
+  const OrbLevel& L = P.lv[level];
+  const uint8_t* base = h->d_arena + (size_t)image * P.arena_bytes;
+  if (what == 0) {
+    const size_t pw = L.w + 2 * PS_EDGE, ph = L.h + 2 * PS_EDGE;
+    if (out_bytes < pw * ph) return ps_set_error(PS_ERR_CAPACITY, "buffer too small");
+    PS_HIP(hipMemcpy2D(out, pw, base + L.plane_off, L.stride, pw, ph, hipMemcpyDeviceToHost));
+    if (n) *n = (int)(pw * ph);
+  } else if (what == 1) {
+    if (out_bytes < (size_t)L.w * L.h) return ps_set_error(PS_ERR_CAPACITY, "buffer too small");
+    PS_HIP(hipMemcpy2D(out, L.w, base + L.blur_off, L.bstride, L.w, L.h, hipMemcpyDeviceToHost));
+    if (n) *n = L.w * L.h;
+  } else if (what == 2) {
+    const int ncell = L.n_cols * L.n_rows;
+    std::vector<int32_t> cnt(ncell);
+    std::vector<uint32_t> slots((size_t)ncell * L.cell_cap);
+    PS_HIP(hipMemcpy(cnt.data(), base + P.cellcnt_off + (size_t)L.cell_base * 4, (size_t)ncell * 4, hipMemcpyDeviceToHost));
+    PS_HIP(hipMemcpy(slots.data(), base + P.cand_base + (size_t)L.cand_off * 4, slots.size() * 4, hipMemcpyDeviceToHost));
+    int32_t* o = (int32_t*)out;
+    size_t k = 0;
+    for (int c = 0; c < ncell; c++)
+      for (int i = 0; i < cnt[c]; i++) {
+        if ((k + 1) * 12 > out_bytes) return ps_set_error(PS_ERR_CAPACITY, "buffer too small");
+        const uint32_t e = slots[(size_t)c * L.cell_cap + i];
+        o[k * 3] = e & 0xFFF; o[k * 3 + 1] = (e >> 12) & 0xFFF; o[k * 3 + 2] = (int)(e >> 24) - 1;
+        k++;
+      }
+    if (n) *n = (int)k;
+  } else if (what == 3) {
+    int32_t cnts[PS_ORB_MAX_LEVELS];
+    PS_HIP(hipMemcpy(cnts, base + P.selcnt_off, sizeof(cnts), hipMemcpyDeviceToHost));
+    const int c = cnts[level];
+    if ((size_t)c * 12 > out_bytes) return ps_set_error(PS_ERR_CAPACITY, "buffer too small");
+    std::vector<uint32_t> sel(c > 0 ? c : 1);
+    if (c > 0) PS_HIP(hipMemcpy(sel.data(), base + P.sel_base + (size_t)L.sel_off * 4, (size_t)c * 4, hipMemcpyDeviceToHost));
+    int32_t* o = (int32_t*)out;
+    for (int i = 0; i < c; i++) {
+      o[i * 3] = sel[i] & 0xFFF; o[i * 3 + 1] = (sel[i] >> 12) & 0xFFF; o[i * 3 + 2] = (int)(sel[i] >> 24) - 1;
+    }
+    if (n) *n = c;
+  } else {
+    return ps_set_error(PS_ERR_INVALID, "unknown `what` %d", what);
+  }
+  return PS_OK;
+}
+
+int ps_orb_enable_stage_timing(ps_orb* h, int enable) {
+  if (!h) return ps_set_error(PS_ERR_INVALID, "null handle");
+  h->timing = enable != 0;
+  h->timed_valid = false;
+  return PS_OK;
+}
+
+int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n) {
+  if (!h || !n) return ps_set_error(PS_ERR_INVALID, "null argument");
+  if (!h->timed_valid) return ps_set_error(PS_ERR_INVALID, "stage timing was not enabled for the last batch");
+  PS_HIP(hipSetDevice(h->cfg.device));
+  PS_HIP(hipEventSynchronize(h->ev[ST_COUNT]));
+  *n = ST_COUNT;
+  for (int i = 0; i < ST_COUNT && i < cap; i++) {
+    if (names) names[i] = kStageNames[i];
+    if (ms) PS_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+  }
+  return PS_OK;
+}
+
+}  // extern "C"
