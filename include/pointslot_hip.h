@@ -106,8 +106,10 @@ int ps_orb_sync(ps_orb* h);
  *     DistributeOctTree's output order; count in *n */
 int ps_orb_debug_read(ps_orb* h, int image, int level, int what, void* out, size_t out_bytes, int* n);
 
-/* Per-kernel timing of the last ps_orb_extract_batch_device call, measured with HIP events on the
- * stream the kernels ran on.  names/ms arrays of length `cap`; *n receives the stage count. */
+/* Per-stage GPU time of ps_orb_extract_batch_device, measured with HIP events recorded on the stream
+ * the kernels run on.  After ps_orb_enable_stage_timing(h, 1) every batch records one event set (a
+ * ring of 64); ps_orb_stage_times synchronises and returns the mean over the recorded batches.
+ * names/ms arrays of length `cap`; *n receives the stage count. */
 int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n);
 int ps_orb_enable_stage_timing(ps_orb* h, int enable);
 

@@ -47,9 +47,12 @@ struct ps_orb {
   uint8_t* d_img = nullptr;       // staging for ps_orb_extract (one host image)
   size_t d_img_bytes = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[ST_COUNT + 1] = {};
+  // stage timing: a ring of event sets so that consecutive batches can be timed without a host
+  // synchronisation in between; ps_orb_stage_times() averages over the recorded batches.
+  static const int RING = 64;
+  hipEvent_t ev[RING][ST_COUNT + 1] = {};
   bool timing = false;
-  bool timed_valid = false;
+  int timed_batches = 0;
   int last_nimg = 0;
 };
 
@@ -230,20 +233,21 @@ int build_plan(ps_orb* h, int w, int hgt) {
 int run_batch(ps_orb* h, const uint8_t* d_imgs, int nimg, int stride, size_t pitch, hipStream_t st) {
   const OrbPlan* P = &h->plan;
   const bool tm = h->timing;
-  if (tm) PS_HIP(hipEventRecord(h->ev[0], st));
+  hipEvent_t* ev = h->ev[h->timed_batches % ps_orb::RING];
+  if (tm) PS_HIP(hipEventRecord(ev[0], st));
   for (int l = 0; l < P->nlevels; l++)
     psk_orb_launch_pyramid(P, l, h->d_arena, d_imgs, stride, pitch, h->d_tabs, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(h->ev[1], st));
+  if (tm) PS_HIP(hipEventRecord(ev[1], st));
   psk_orb_launch_fast(P, h->d_arena, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(h->ev[2], st));
+  if (tm) PS_HIP(hipEventRecord(ev[2], st));
   psk_orb_launch_quadtree(P, h->d_arena, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(h->ev[3], st));
+  if (tm) PS_HIP(hipEventRecord(ev[3], st));
   psk_orb_launch_blur(P, h->d_arena, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(h->ev[4], st));
+  if (tm) PS_HIP(hipEventRecord(ev[4], st));
   psk_orb_launch_describe(P, h->d_arena, h->d_kps, h->d_desc, h->d_counts, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(h->ev[5], st));
+  if (tm) PS_HIP(hipEventRecord(ev[5], st));
   PS_HIP(hipGetLastError());
-  h->timed_valid = tm;
+  if (tm) h->timed_batches++;
   h->last_nimg = nimg;
   return PS_OK;
 }
@@ -267,7 +271,8 @@ int ps_orb_create(const ps_orb_config* cfg, ps_orb** out) {
   build_tables(h);
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return ps_set_error(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
-  for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&h->ev[i]);
+  for (int r = 0; r < ps_orb::RING; r++)
+    for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&h->ev[r][i]);
   *out = h;
   return PS_OK;
 }
@@ -278,7 +283,8 @@ void ps_orb_destroy(ps_orb* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   free_device(h);
   if (h->d_img) hipFree(h->d_img);
-  for (int i = 0; i <= ST_COUNT; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  for (int r = 0; r < ps_orb::RING; r++)
+    for (int i = 0; i <= ST_COUNT; i++) if (h->ev[r][i]) hipEventDestroy(h->ev[r][i]);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -432,19 +438,28 @@ int ps_orb_debug_read(ps_orb* h, int image, int level, int what, void* out, size
 int ps_orb_enable_stage_timing(ps_orb* h, int enable) {
   if (!h) return ps_set_error(PS_ERR_INVALID, "null handle");
   h->timing = enable != 0;
-  h->timed_valid = false;
+  h->timed_batches = 0;
   return PS_OK;
 }
 
 int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n) {
   if (!h || !n) return ps_set_error(PS_ERR_INVALID, "null argument");
-  if (!h->timed_valid) return ps_set_error(PS_ERR_INVALID, "stage timing was not enabled for the last batch");
+  if (h->timed_batches <= 0) return ps_set_error(PS_ERR_INVALID, "no batch was run with stage timing enabled");
   PS_HIP(hipSetDevice(h->cfg.device));
-  PS_HIP(hipEventSynchronize(h->ev[ST_COUNT]));
+  PS_HIP(hipDeviceSynchronize());
+  const int nb = h->timed_batches < ps_orb::RING ? h->timed_batches : ps_orb::RING;
   *n = ST_COUNT;
   for (int i = 0; i < ST_COUNT && i < cap; i++) {
     if (names) names[i] = kStageNames[i];
-    if (ms) PS_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    if (ms) {
+      double acc = 0;
+      for (int r = 0; r < nb; r++) {
+        float t = 0;
+        PS_HIP(hipEventElapsedTime(&t, h->ev[r][i], h->ev[r][i + 1]));
+        acc += t;
+      }
+      ms[i] = (float)(acc / nb);
+    }
   }
   return PS_OK;
 }

@@ -1,5 +1,5 @@
-"""Seeded synthetic inputs for the BASELINE.json configs.  Pure numpy, no
-dependency on the product or the oracle, so CPU and GPU legs see identical bytes.
+"""Seeded synthetic inputs for the BASELINE.json configs.  Pure numpy and
+self-contained, so every consumer (GPU path, CPU checker, bench) sees identical bytes.
 
 RNG: xoshiro256** run as LANES independent lock-step streams (each lane seeded by splitmix64 from
 (seed, lane)); values are consumed step-major.  Deterministic for a given (seed, lanes).
