@@ -113,6 +113,99 @@ int ps_orb_debug_read(ps_orb* h, int image, int level, int what, void* out, size
 int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n);
 int ps_orb_enable_stage_timing(ps_orb* h, int enable);
 
+/* ------------------------------------------------------------------------------------------------
+ * Descriptor matching — replaces the hot members of ORB_SLAM2::ORBmatcher
+ * (/root/reference/include/ORBmatcher.h:47-118, src/ORBmatcher.cc).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ps_matcher ps_matcher;
+int ps_matcher_create(int device, ps_matcher** out);
+void ps_matcher_destroy(ps_matcher* m);
+
+/* Bulk form of ORBmatcher::DescriptorDistance (ORBmatcher.cc:2704-2720): out[i * nt + j] = Hamming
+ * distance between 32-byte descriptors q[i] and t[j] (0..256). */
+int ps_hamming_matrix(ps_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out);
+
+/* ORBmatcher::SearchByBruceMatching(LastFrame, CurrentFrame, nLastOrder, nCurrenOrder, matches)
+ * (ORBmatcher.cc:2043-2155) for a batch of independent (object) problems.
+ *   q_*   : the last frame's object features of one object: 32-byte descriptors
+ *           (mvObjPointsDescriptors), angles of mvObjKeysUn, and q_valid[i] = 1 iff
+ *           mvpMapObjectPoints[i] is non-null, not bad, and mvbObjKeysOutlier[i] is false (:2062-2063)
+ *   t_*   : the current frame's features of the same object: descriptors, angles of mvObjKeys
+ *   query_of_train[j] : out, index i of the query whose MapObjectPoint* the reference stores in
+ *           vpMapObjectPointMatches[j], or -1 (NULL)
+ *   nmatches : out, the function's return value
+ * nn_ratio / check_orientation are the ORBmatcher constructor arguments (mfNNratio, mbCheckOrientation);
+ * TH_LOW = 50 and HISTO_LENGTH = 30 are fixed as in ORBmatcher.cc:58-62. nt <= 4096. */
+typedef struct ps_bf_problem {
+  const uint8_t* q_desc; const float* q_angle; const uint8_t* q_valid; int32_t nq;
+  const uint8_t* t_desc; const float* t_angle; int32_t nt;
+  int32_t* query_of_train;
+  int32_t nmatches;
+} ps_bf_problem;
+int ps_match_bruteforce(ps_matcher* m, ps_bf_problem* probs, int nprob, float nn_ratio, int check_orientation);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser — replaces the hot static members of ORB_SLAM2::Optimizer
+ * (/root/reference/include/Optimizer.h:51-61, src/Optimizer.cc:249-1075) and the g2o solver stack they
+ * instantiate.  All arithmetic is FP64 on float32 inputs, as in the reference.
+ * SE3 poses cross this boundary either as the float 4x4 row-major matrix the reference keeps in
+ * cv::Mat (Frame::mTcw) or as 7 doubles (tx,ty,tz,qx,qy,qz,qw) = g2o::SE3Quat::toVector().
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ps_optimizer ps_optimizer;
+int ps_optimizer_create(int device, ps_optimizer** out);
+void ps_optimizer_destroy(ps_optimizer* m);
+/* GPU time of the last batch's kernel(s), from HIP events on the handle's stream. */
+int ps_optimizer_last_kernel_ms(const ps_optimizer* m, float* ms);
+/* Optional per-LM-iteration log (chi2, lambda, trials) of the next batches; for parity tests. */
+int ps_optimizer_enable_trace(ps_optimizer* m, int enable);
+int ps_optimizer_get_trace(const ps_optimizer* m, int problem, double* chi2_lambda_trials, int cap, int* n);
+
+/* Converter::toSE3Quat / Converter::toCvMat (src/Converter.cc:37-71) for callers without Eigen. */
+int ps_se3_from_mat4f(const float* m16, double* pose7);
+int ps_se3_to_mat4f(const double* pose7, float* m16);
+
+/* Optimizer::PoseOptimization(Frame*) (Optimizer.cc:249-477) for a batch of independent frames.
+ *   n          : pFrame->N
+ *   xw         : [n][3] world position of mvpMapPoints[i] (float, MapPoint::GetWorldPos)
+ *   obs        : [n][3] mvKeysUn[i].pt.x, .pt.y, mvuRight[i] (uR < 0 => monocular edge)
+ *   inv_sigma2 : [n]    mvInvLevelSigma2[mvKeysUn[i].octave]
+ *   valid      : [n]    1 iff mvpMapPoints[i] != NULL
+ *   fx..bf     : Frame::fx, fy, cx, cy, mbf
+ *   tcw        : in: pFrame->mTcw; out: the pose passed to pFrame->SetPose
+ *   outlier    : [n] in/out pFrame->mvbOutlier (entries with valid == 0 are left untouched)
+ *   result     : out, the return value: nInitialCorrespondences - nBad, 0 when < 15 correspondences */
+typedef struct ps_pose_problem {
+  int32_t n;
+  const float* xw; const float* obs; const float* inv_sigma2; const uint8_t* valid;
+  float fx, fy, cx, cy, bf;
+  float tcw[16];
+  uint8_t* outlier;
+  int32_t result;
+} ps_pose_problem;
+int ps_pose_optimize_batch(ps_optimizer* m, ps_pose_problem* probs, int nprob);
+
+/* Optimizer::CFSE3ObjStateOptimization(Frame*, vnNeedToBeOptimized, verbose) (Optimizer.cc:479-753):
+ * k objects of one frame optimised as ONE graph (k <= 16).  Object o owns the feature range
+ * [off[o], off[o+1]) of the concatenated arrays.
+ *   xo         : MapObjectPoint::GetInObjFramePosition (object-frame coordinates)
+ *   obs        : mvObjKeysUn[o][j].pt.x, .pt.y, mvuObjKeysRight[o][j]
+ *   valid      : 1 iff mvpMapObjectPoints[o][j] != NULL
+ *   poses7     : in: MapObject::GetCFInFrameObjState(frame).pose (Tco); out: the optimised vertex
+ *                estimate.  The translation of the input is also the measurement of the
+ *                EdgeTransConstraintFromDetction prior (information 50 I).
+ *   outlier    : in/out mvbObjKeysOutlier
+ *   result     : out, 1 (true) / 0 (false: no object or fewer than 15 edges) */
+typedef struct ps_cfse3_problem {
+  int32_t k;
+  const int32_t* off;
+  const float* xo; const float* obs; const float* inv_sigma2; const uint8_t* valid;
+  float fx, fy, cx, cy, bf;
+  double* poses7;
+  uint8_t* outlier;
+  int32_t result;
+} ps_cfse3_problem;
+int ps_cfse3_optimize_batch(ps_optimizer* m, ps_cfse3_problem* probs, int nprob);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,422 @@
+// CDNA4 kernel for the pose-only optimisers:
+//   Optimizer::PoseOptimization            /root/reference/src/Optimizer.cc:249-477      (mode 0)
+//   Optimizer::CFSE3ObjStateOptimization   :479-753                                      (mode 1)
+// One persistent workgroup per problem runs the reference's whole schedule on the device — 4 rounds of
+// up to 10 Levenberg–Marquardt iterations with up to 10 damping trials each, chi-square re-classification
+// between rounds — without a host round trip.  A problem has k SE3 vertices (k = 1 for PoseOptimization,
+// k = number of objects for CFSE3: g2o solves them as ONE graph, i.e. one shared lambda / gain ratio /
+// stop rule and a block-diagonal 6k x 6k system), each with its own contiguous range of unary edges.
+//
+// Per LM iteration every thread evaluates its edges (error, analytic 2x6/3x6 Jacobian, Huber weight),
+// keeps 21 + 6 + 1 FP64 partial sums in registers (upper triangle of J^T W J, J^T W e, robust chi2),
+// reduces them with wave shuffles and one LDS pass in a fixed order, and every thread then solves the
+// 6x6 system redundantly in registers (no broadcast, no divergence).
+//
+// g2o semantics reproduced (Thirdparty/g2o/g2o/...): core/optimization_algorithm_levenberg.cpp:61-189,
+// core/base_unary_edge.hpp:43-73, core/robust_kernel_impl.cpp:78-91, types/types_six_dof_expmap.cpp:266-360,
+// types/se3quat.h; include/g2o_Object.h:407-422 (translation prior with the numeric Jacobian of
+// core/base_unary_edge.hpp:83-121).  Edge errors are cached exactly where g2o caches them: the
+// classification reads the chi2 of the LAST computeActiveErrors (possibly a rejected trial).
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+#include "opt_plan.h"
+#include "se3.h"
+
+namespace {
+
+#define PO_T 256
+
+struct PoShared {
+  double red[PO_T / 64][28];
+  double out[28];
+  double pose[PS_PO_MAX_K][7];      // current estimates
+  double pose0[PS_PO_MAX_K][7];     // estimates at entry (PoseOptimization restarts every round from them)
+  double backup[PS_PO_MAX_K][7];
+  double H[PS_PO_MAX_K][21];
+  double b[PS_PO_MAX_K][6];
+  double x[PS_PO_MAX_K][6];
+  double prior_obs[PS_PO_MAX_K][3];
+  double prior_err[PS_PO_MAX_K][3];
+  uint8_t prior_robust[PS_PO_MAX_K];
+  int icount;
+};
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m);
+  hi = __shfl_xor(hi, m);
+  return __hiloint2double(hi, lo);
+}
+
+// sums acc[0..N) over the workgroup in a fixed order; the result lands in s.out[0..N) for every thread
+template <int N>
+__device__ void block_sum(double* acc, PoShared& s) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double v = acc[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += shfl_xor_d(v, d);
+    acc[i] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();   // protect s.out / s.red from the previous use
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < N; i++) s.red[wave][i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < N) {
+    double v = 0;
+#pragma unroll
+    for (int w = 0; w < PO_T / 64; w++) v += s.red[w][threadIdx.x];
+    s.out[threadIdx.x] = v;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ Se3 load_pose(const double* p) {
+  Se3 T;
+  T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2];
+  T.q[0] = p[3]; T.q[1] = p[4]; T.q[2] = p[5]; T.q[3] = p[6];
+  return T;
+}
+__device__ __forceinline__ void store_pose(double* p, const Se3& T) {
+  p[0] = T.t[0]; p[1] = T.t[1]; p[2] = T.t[2];
+  p[3] = T.q[0]; p[4] = T.q[1]; p[5] = T.q[2]; p[6] = T.q[3];
+}
+
+// RobustKernelHuber::robustify (robust_kernel_impl.cpp:78-91): rho[0] and rho[1]
+__device__ __forceinline__ void huber(double e, double delta, double& rho0, double& rho1) {
+  const double dsqr = delta * delta;
+  if (e <= dsqr) { rho0 = e; rho1 = 1.0; }
+  else { const double sq = sqrt(e); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+}
+
+// error of a projection edge at pose T (EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose)
+__device__ __forceinline__ void edge_error(const Se3& T, const PoProb& P, const float* xw, const float* ob,
+                                           bool mono, double p[3], double e[3]) {
+  const double X[3] = {(double)xw[0], (double)xw[1], (double)xw[2]};
+  se3_map(T, X, p);
+  if (mono) {
+    e[0] = (double)ob[0] - (p[0] / p[2] * (double)P.fx + (double)P.cx);
+    e[1] = (double)ob[1] - (p[1] / p[2] * (double)P.fy + (double)P.cy);
+    e[2] = 0.0;
+  } else {
+    const float invz = (float)(1.0 / p[2]);   // `const float invz = 1.0f/trans_xyz[2]` (types_six_dof_expmap.cpp:301)
+    const double u = p[0] * (double)invz * (double)P.fx + (double)P.cx;
+    const double v = p[1] * (double)invz * (double)P.fy + (double)P.cy;
+    e[0] = (double)ob[0] - u;
+    e[1] = (double)ob[1] - v;
+    e[2] = (double)ob[2] - (u - (double)P.bf * (double)invz);
+  }
+}
+
+// state byte per edge: bit0 valid, bit1 level 1 (outlier, inactive), bit2 mono
+#define ST_VALID 1
+#define ST_LVL1 2
+#define ST_MONO 4
+
+__global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVertex* verts, const float* xw,
+                                                const float* obs, const float* inv_sigma2, const uint8_t* valid,
+                                                uint8_t* outlier, double* chi2c, uint8_t* state, double* poses,
+                                                int32_t* results, double* trace) {
+  __shared__ PoShared s;
+  const PoProb P = probs[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int k = P.k;
+  const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+  double* tr = trace ? trace + (size_t)blockIdx.x * PS_PO_TRACE * 3 : nullptr;
+  int ntr = 0;
+
+  // ---- graph construction (Optimizer.cc:262-377 / :506-637) ----
+  for (int i = tid; i < k * 7; i += PO_T) {
+    const double v = poses[(size_t)P.v_off * 7 + i];
+    (&s.pose[0][0])[i] = v;
+    (&s.pose0[0][0])[i] = v;
+  }
+  if (tid < k) {
+    s.prior_robust[tid] = 1;
+    for (int c = 0; c < 3; c++) s.prior_obs[tid][c] = poses[(size_t)(P.v_off + tid) * 7 + c];
+  }
+  int cnt = 0;
+  for (int o = 0; o < k; o++) {
+    const PoVertex V = verts[P.v_off + o];
+    for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
+      uint8_t st = 0;
+      if (valid[i]) {
+        st = ST_VALID | (obs[3 * i + 2] < 0.f ? ST_MONO : 0);
+        outlier[i] = 0;          // mvbOutlier[i] = false (Optimizer.cc:299,335)
+        cnt++;
+      }
+      state[i] = st;
+      chi2c[i] = 0.0;
+    }
+  }
+  {
+    double c1[1] = {(double)cnt};
+    block_sum<1>(c1, s);
+  }
+  const int nInitial = (int)s.out[0];
+  const int nTotalEdges = nInitial + (P.mode == 1 ? k : 0);
+  if (nTotalEdges < 15) {   // Optimizer.cc:376-377 / :638-639
+    if (tid == 0) results[blockIdx.x] = 0;
+    return;
+  }
+  bool robust = true;
+  int nBadTotal = 0;
+
+  for (int it = 0; it < 4; it++) {
+    if (P.mode == 0) {   // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)) every round (Optimizer.cc:394)
+      __syncthreads();
+      for (int i = tid; i < k * 7; i += PO_T) (&s.pose[0][0])[i] = (&s.pose0[0][0])[i];
+      __syncthreads();
+    }
+    // active set = level-0 edges; a vertex without active edges is not optimised
+    int nact = 0;
+    for (int o = 0; o < k; o++) {
+      const PoVertex V = verts[P.v_off + o];
+      for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) nact += ((state[i] & (ST_VALID | ST_LVL1)) == ST_VALID) ? 1 : 0;
+    }
+    {
+      double c1[1] = {(double)nact};
+      block_sum<1>(c1, s);
+    }
+    const bool any_active = (int)s.out[0] > 0 || P.mode == 1;
+
+    if (any_active) {
+      double lambda = 0, ni = 2;
+      int nBad = 0;
+      for (int iter = 0; iter < 10; iter++) {
+        // ---- computeActiveErrors + buildSystem ----
+        double chi_total = 0;
+        for (int o = 0; o < k; o++) {
+          const PoVertex V = verts[P.v_off + o];
+          const Se3 T = load_pose(s.pose[o]);
+          double acc[28];
+#pragma unroll
+          for (int a = 0; a < 28; a++) acc[a] = 0;
+          for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
+            const uint8_t st = state[i];
+            if ((st & (ST_VALID | ST_LVL1)) != ST_VALID) continue;
+            const bool mono = st & ST_MONO;
+            double p[3], e[3];
+            edge_error(T, P, &xw[3 * i], &obs[3 * i], mono, p, e);
+            const double w = (double)inv_sigma2[i];
+            const double chi2 = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * w;
+            chi2c[i] = chi2;
+            double rho0 = chi2, rho1 = 1.0;
+            if (robust) huber(chi2, mono ? deltaMono : deltaStereo, rho0, rho1);
+            acc[27] += rho0;
+            // Jacobian (types_six_dof_expmap.cpp:266-292 / :330-360)
+            const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+            const double fx = (double)P.fx, fy = (double)P.fy, bf = (double)P.bf;
+            double J[3][6];
+            J[0][0] = x * y * invz_2 * fx; J[0][1] = -(1 + (x * x * invz_2)) * fx; J[0][2] = y * invz * fx;
+            J[0][3] = -invz * fx; J[0][4] = 0; J[0][5] = x * invz_2 * fx;
+            J[1][0] = (1 + y * y * invz_2) * fy; J[1][1] = -x * y * invz_2 * fy; J[1][2] = -x * invz * fy;
+            J[1][3] = 0; J[1][4] = -invz * fy; J[1][5] = y * invz_2 * fy;
+            if (mono) {
+#pragma unroll
+              for (int c = 0; c < 6; c++) J[2][c] = 0;
+            } else {
+              J[2][0] = J[0][0] - bf * y * invz_2; J[2][1] = J[0][1] + bf * x * invz_2; J[2][2] = J[0][2];
+              J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - bf * invz_2;
+            }
+            const double wo = rho1 * w;
+            int a = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+#pragma unroll
+              for (int c = r; c < 6; c++) { acc[a] += wo * (J[0][r] * J[0][c] + J[1][r] * J[1][c] + J[2][r] * J[2][c]); a++; }
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[21 + r] -= wo * (J[0][r] * e[0] + J[1][r] * e[1] + J[2][r] * e[2]);
+          }
+          if (P.mode == 1 && tid == 0) {
+            // EdgeTransConstraintFromDetction: error = obs - t, information 50 I, Huber(sqrt 5.991) that is never
+            // removed, Jacobian by central differences with delta = 1e-9 through oplus (base_unary_edge.hpp:83-121)
+            double e[3] = {s.prior_obs[o][0] - T.t[0], s.prior_obs[o][1] - T.t[1], s.prior_obs[o][2] - T.t[2]};
+            s.prior_err[o][0] = e[0]; s.prior_err[o][1] = e[1]; s.prior_err[o][2] = e[2];
+            const double w = 50.0;
+            const double chi2 = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * w;
+            double rho0 = chi2, rho1 = 1.0;
+            if (s.prior_robust[o]) huber(chi2, deltaMono, rho0, rho1);
+            acc[27] += rho0;
+            double J[3][6];
+            const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+            for (int d = 0; d < 6; d++) {
+              double add[6] = {0, 0, 0, 0, 0, 0};
+              add[d] = delta;
+              const Se3 Tp = se3_mul(se3_exp(add, false), T);
+              add[d] = -delta;
+              const Se3 Tm = se3_mul(se3_exp(add, false), T);
+              for (int r = 0; r < 3; r++)
+                J[r][d] = scalar * ((s.prior_obs[o][r] - Tp.t[r]) - (s.prior_obs[o][r] - Tm.t[r]));
+            }
+            const double wo = rho1 * w;
+            int a = 0;
+            for (int r = 0; r < 6; r++)
+              for (int c = r; c < 6; c++) { acc[a] += wo * (J[0][r] * J[0][c] + J[1][r] * J[1][c] + J[2][r] * J[2][c]); a++; }
+            for (int r = 0; r < 6; r++) acc[21 + r] -= wo * (J[0][r] * e[0] + J[1][r] * e[1] + J[2][r] * e[2]);
+          }
+          block_sum<28>(acc, s);
+          if (tid < 21) s.H[o][tid] = s.out[tid];
+          if (tid >= 21 && tid < 27) s.b[o][tid - 21] = s.out[tid];
+          chi_total += s.out[27];
+        }
+        __syncthreads();
+        double currentChi = chi_total;
+        const double iniChi = currentChi;
+        if (iter == 0) {   // computeLambdaInit: tau * max |H_jj| over all vertices (levenberg.cpp:166-180)
+          double maxDiag = 0;
+          for (int o = 0; o < k; o++) {
+            const int dg[6] = {0, 6, 11, 15, 18, 20};
+            for (int j = 0; j < 6; j++) maxDiag = fmax(fabs(s.H[o][dg[j]]), maxDiag);
+          }
+          lambda = 1e-5 * maxDiag;
+          ni = 2;
+          nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+          // ---- solve (H + lambda I) x = b per vertex block; x only changes when every block succeeds ----
+          bool ok2 = true;
+          double scale = 0;
+          __syncthreads();
+          for (int i = tid; i < k * 7; i += PO_T) (&s.backup[0][0])[i] = (&s.pose[0][0])[i];
+          __syncthreads();
+          if (tid == 0) {
+            double xs[PS_PO_MAX_K][6];
+            for (int o = 0; o < k && ok2; o++) {
+              // unpivoted LDL^T of the 6x6 block (LinearSolverDense uses Eigen::LDLT + isPositive())
+              double A[6][6], D[6];
+              int a = 0;
+              for (int r = 0; r < 6; r++)
+                for (int c = r; c < 6; c++) { A[r][c] = s.H[o][a]; A[c][r] = s.H[o][a]; a++; }
+              for (int j = 0; j < 6; j++) A[j][j] += lambda;
+              for (int j = 0; j < 6 && ok2; j++) {
+                double d = A[j][j];
+                for (int q = 0; q < j; q++) d -= A[j][q] * A[j][q] * D[q];
+                if (!(d > 0)) { ok2 = false; break; }
+                D[j] = d;
+                for (int i = j + 1; i < 6; i++) {
+                  double v = A[i][j];
+                  for (int q = 0; q < j; q++) v -= A[i][q] * A[j][q] * D[q];
+                  A[i][j] = v / d;
+                }
+              }
+              if (!ok2) break;
+              double y[6];
+              for (int i = 0; i < 6; i++) { double v = s.b[o][i]; for (int q = 0; q < i; q++) v -= A[i][q] * y[q]; y[i] = v; }
+              for (int i = 0; i < 6; i++) y[i] /= D[i];
+              for (int i = 5; i >= 0; i--) { double v = y[i]; for (int q = i + 1; q < 6; q++) v -= A[q][i] * xs[o][q]; xs[o][i] = v; }
+            }
+            if (ok2)
+              for (int o = 0; o < k; o++)
+                for (int j = 0; j < 6; j++) s.x[o][j] = xs[o][j];
+            s.icount = ok2 ? 1 : 0;
+            // update: estimate <- exp(x) * estimate (VertexSE3Expmap::oplusImpl), with whatever x holds
+            for (int o = 0; o < k; o++) {
+              const Se3 Tn = se3_mul(se3_exp(s.x[o], false), load_pose(s.pose[o]));
+              store_pose(s.pose[o], Tn);
+            }
+          }
+          __syncthreads();
+          ok2 = s.icount != 0;
+          for (int o = 0; o < k; o++)
+            for (int j = 0; j < 6; j++) scale += s.x[o][j] * (lambda * s.x[o][j] + s.b[o][j]);
+          // ---- computeActiveErrors at the trial estimate ----
+          double c1[1] = {0};
+          for (int o = 0; o < k; o++) {
+            const PoVertex V = verts[P.v_off + o];
+            const Se3 T = load_pose(s.pose[o]);
+            for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
+              const uint8_t st = state[i];
+              if ((st & (ST_VALID | ST_LVL1)) != ST_VALID) continue;
+              const bool mono = st & ST_MONO;
+              double p[3], e[3];
+              edge_error(T, P, &xw[3 * i], &obs[3 * i], mono, p, e);
+              const double chi2 = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * (double)inv_sigma2[i];
+              chi2c[i] = chi2;
+              double rho0 = chi2, rho1;
+              if (robust) huber(chi2, mono ? deltaMono : deltaStereo, rho0, rho1);
+              c1[0] += rho0;
+            }
+            if (P.mode == 1 && tid == 0) {
+              const double e0 = s.prior_obs[o][0] - T.t[0], e1 = s.prior_obs[o][1] - T.t[1], e2 = s.prior_obs[o][2] - T.t[2];
+              const double chi2 = (e0 * e0 + e1 * e1 + e2 * e2) * 50.0;
+              double rho0 = chi2, rho1;
+              if (s.prior_robust[o]) huber(chi2, deltaMono, rho0, rho1);
+              c1[0] += rho0;
+            }
+          }
+          block_sum<1>(c1, s);
+          double tempChi = s.out[0];
+          if (!ok2) tempChi = DBL_MAX;
+          rho = (currentChi - tempChi) / (scale + 1e-3);
+          if (rho > 0 && isfinite(tempChi)) {
+            double alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = fmin(alpha, 2. / 3.);
+            lambda *= fmax(1. / 3., alpha);
+            ni = 2;
+            currentChi = tempChi;
+          } else {
+            lambda *= ni;
+            ni *= 2;
+            __syncthreads();
+            for (int i = tid; i < k * 7; i += PO_T) (&s.pose[0][0])[i] = (&s.backup[0][0])[i];
+            __syncthreads();
+          }
+          qmax++;
+        } while (rho < 0 && qmax < 10);
+        if (tr && tid == 0 && ntr < PS_PO_TRACE) { tr[3 * ntr] = currentChi; tr[3 * ntr + 1] = lambda; tr[3 * ntr + 2] = qmax; }
+        ntr++;
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) break;
+      }
+    }
+    // ---- chi-square classification (Optimizer.cc:404-466 / :652-725) ----
+    __syncthreads();
+    int bad = 0;
+    for (int o = 0; o < k; o++) {
+      const PoVertex V = verts[P.v_off + o];
+      const Se3 T = load_pose(s.pose[o]);
+      for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
+        uint8_t st = state[i];
+        if (!(st & ST_VALID)) continue;
+        const bool mono = st & ST_MONO;
+        if (outlier[i]) {   // e->computeError() for edges that sat out the round
+          double p[3], e[3];
+          edge_error(T, P, &xw[3 * i], &obs[3 * i], mono, p, e);
+          chi2c[i] = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * (double)inv_sigma2[i];
+        }
+        const float chi2 = (float)chi2c[i];
+        if (chi2 > (mono ? 5.991f : 7.815f)) { outlier[i] = 1; st |= ST_LVL1; bad++; }
+        else { outlier[i] = 0; st &= ~ST_LVL1; }
+        state[i] = st;
+      }
+    }
+    if (it == 2) robust = false;   // e->setRobustKernel(0) on the projection edges; the prior keeps its kernel
+    double c1[1] = {(double)bad};
+    block_sum<1>(c1, s);
+    nBadTotal = (int)s.out[0];
+  }
+  __syncthreads();
+  for (int i = tid; i < k * 7; i += PO_T) poses[(size_t)P.v_off * 7 + i] = (&s.pose[0][0])[i];
+  if (tid == 0) {
+    results[blockIdx.x] = P.mode == 0 ? nInitial - nBadTotal : 1;
+    if (tr && ntr < PS_PO_TRACE) tr[3 * ntr + 2] = -1;   // terminator
+  }
+}
+
+}  // namespace
+
+extern "C" void psk_pose_lm_launch(const PoProb* probs, int nprob, const PoVertex* verts, const float* xw,
+                                   const float* obs, const float* inv_sigma2, const uint8_t* valid, uint8_t* outlier,
+                                   double* chi2c, uint8_t* state, double* poses, int32_t* results, double* trace,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(pose_lm, dim3(nprob), dim3(PO_T), 0, st, probs, verts, xw, obs, inv_sigma2, valid, outlier, chi2c,
+                     state, poses, results, trace);
+}

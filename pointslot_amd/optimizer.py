@@ -1,0 +1,129 @@
+"""Host-side mirror of the hot static members of ORB_SLAM2::Optimizer (/root/reference/include/Optimizer.h:51-61)
+on top of the C-ABI.  The reference reads its inputs out of Frame / MapObject / ObjectKeyFrame objects; here the
+same quantities are passed as arrays (see include/pointslot_hip.h for the field-by-field mapping)."""
+import ctypes
+
+import numpy as np
+
+from ._lib import lib, check
+
+
+class _PoseProblem(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("xw", ctypes.c_void_p), ("obs", ctypes.c_void_p), ("inv_sigma2", ctypes.c_void_p),
+                ("valid", ctypes.c_void_p), ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float),
+                ("cy", ctypes.c_float), ("bf", ctypes.c_float), ("tcw", ctypes.c_float * 16), ("outlier", ctypes.c_void_p),
+                ("result", ctypes.c_int32)]
+
+
+class _Cfse3Problem(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int32), ("off", ctypes.c_void_p), ("xo", ctypes.c_void_p), ("obs", ctypes.c_void_p),
+                ("inv_sigma2", ctypes.c_void_p), ("valid", ctypes.c_void_p), ("fx", ctypes.c_float), ("fy", ctypes.c_float),
+                ("cx", ctypes.c_float), ("cy", ctypes.c_float), ("bf", ctypes.c_float), ("poses7", ctypes.c_void_p),
+                ("outlier", ctypes.c_void_p), ("result", ctypes.c_int32)]
+
+
+lib.ps_optimizer_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+lib.ps_optimizer_destroy.argtypes = [ctypes.c_void_p]
+lib.ps_optimizer_destroy.restype = None
+lib.ps_optimizer_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+lib.ps_optimizer_enable_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.ps_optimizer_get_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+lib.ps_pose_optimize_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_PoseProblem), ctypes.c_int]
+lib.ps_cfse3_optimize_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Cfse3Problem), ctypes.c_int]
+lib.ps_se3_from_mat4f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+lib.ps_se3_to_mat4f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+
+
+def se3_from_mat4f(m):
+    m = np.ascontiguousarray(m, np.float32); out = np.zeros(7)
+    check(lib.ps_se3_from_mat4f(m.ctypes.data, out.ctypes.data))
+    return out
+
+
+def se3_to_mat4f(p7):
+    p7 = np.ascontiguousarray(p7, np.float64); out = np.zeros((4, 4), np.float32)
+    check(lib.ps_se3_to_mat4f(p7.ctypes.data, out.ctypes.data))
+    return out
+
+
+class Optimizer:
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        check(lib.ps_optimizer_create(device, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.ps_optimizer_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float(0)
+        check(lib.ps_optimizer_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def enable_trace(self, on=True):
+        check(lib.ps_optimizer_enable_trace(self._h, 1 if on else 0))
+
+    def get_trace(self, problem):
+        out = np.zeros((64, 3)); n = ctypes.c_int(0)
+        check(lib.ps_optimizer_get_trace(self._h, problem, out.ctypes.data, 64, ctypes.byref(n)))
+        return out[:n.value].copy()
+
+    def PoseOptimization(self, frames):
+        """frames: list of dicts {xw [n,3] f32, obs [n,3] f32 (u,v,uR), inv_sigma2 [n] f32, valid [n] u8,
+        K (fx,fy,cx,cy,bf), tcw0 4x4 f32, optional outlier0 [n] u8}.  Returns a list of
+        (ninliers, tcw float32 4x4, outlier uint8[n]) — PoseOptimization's return value, SetPose argument, mvbOutlier."""
+        n = len(frames)
+        arr = (_PoseProblem * n)()
+        keep = []
+        for i, f in enumerate(frames):
+            xw = np.ascontiguousarray(f["xw"], np.float32); obs = np.ascontiguousarray(f["obs"], np.float32)
+            is2 = np.ascontiguousarray(f["inv_sigma2"], np.float32); valid = np.ascontiguousarray(f["valid"], np.uint8)
+            outl = np.ascontiguousarray(f.get("outlier0", np.zeros(len(xw), np.uint8)), np.uint8).copy()
+            keep.append((xw, obs, is2, valid, outl))
+            K = [float(v) for v in f["K"]]
+            p = arr[i]
+            p.n = len(xw); p.xw = xw.ctypes.data; p.obs = obs.ctypes.data; p.inv_sigma2 = is2.ctypes.data
+            p.valid = valid.ctypes.data; p.fx, p.fy, p.cx, p.cy, p.bf = K
+            p.tcw = (ctypes.c_float * 16)(*np.asarray(f["tcw0"], np.float32).reshape(16))
+            p.outlier = outl.ctypes.data
+        check(lib.ps_pose_optimize_batch(self._h, arr, n))
+        return [(arr[i].result, np.array(arr[i].tcw, np.float32).reshape(4, 4), keep[i][4]) for i in range(n)]
+
+    def CFSE3ObjStateOptimization(self, frames):
+        """frames: list of dicts {objs: [ {xo, obs, inv_sigma2, valid, pose7} ... ], K}.  Returns a list of
+        (ok, poses7 [k,7], [outlier arrays])."""
+        n = len(frames)
+        arr = (_Cfse3Problem * n)()
+        keep = []
+        for i, f in enumerate(frames):
+            objs = f["objs"]; k = len(objs)
+            off = np.zeros(k + 1, np.int32)
+            for j, o in enumerate(objs):
+                off[j + 1] = off[j] + len(o["xo"])
+            def cat(key, dt, w):
+                if k == 0:
+                    return np.zeros((1, w), dt)
+                return np.ascontiguousarray(np.concatenate([np.asarray(o[key], dt).reshape(len(o["xo"]), w) for o in objs] + [np.zeros((1, w), dt)]))
+            xo, obs, is2, valid = cat("xo", np.float32, 3), cat("obs", np.float32, 3), cat("inv_sigma2", np.float32, 1), cat("valid", np.uint8, 1)
+            poses = np.ascontiguousarray(np.stack([o["pose7"] for o in objs]), np.float64).copy() if k else np.zeros((1, 7))
+            outl = np.zeros(int(off[-1]) + 1, np.uint8)
+            keep.append((off, xo, obs, is2, valid, poses, outl))
+            K = [float(v) for v in f["K"]]
+            p = arr[i]
+            p.k = k; p.off = off.ctypes.data; p.xo = xo.ctypes.data; p.obs = obs.ctypes.data; p.inv_sigma2 = is2.ctypes.data
+            p.valid = valid.ctypes.data; p.fx, p.fy, p.cx, p.cy, p.bf = K
+            p.poses7 = poses.ctypes.data; p.outlier = outl.ctypes.data
+        check(lib.ps_cfse3_optimize_batch(self._h, arr, n))
+        out = []
+        for i, f in enumerate(frames):
+            off, _, _, _, _, poses, outl = keep[i]
+            k = len(f["objs"])
+            out.append((arr[i].result, poses[:k].copy(), [outl[off[j]:off[j + 1]].copy() for j in range(k)]))
+        return out

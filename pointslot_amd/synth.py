@@ -115,3 +115,159 @@ def stereo_batch(n_pairs, seed=0x51070002, w=1242, h=375):
         l, r = stereo_pair(seed + k, w, h)
         out[2 * k], out[2 * k + 1] = l, r
     return out
+
+
+# ---- brute-force matching problems (object feature sets of two consecutive frames) ----------------------
+def bruteforce_problem(seed, nq=300, nt=320, p_same=0.7, flip_bits=18, p_valid=0.9, dup_frac=0.1):
+    """nq query descriptors; a fraction p_same of them re-appear among the nt train descriptors with
+    ~flip_bits random bit flips (so the best distance is below TH_LOW) and a consistent rotation; a
+    fraction dup_frac of the trains are near-duplicates of other trains so that the ratio test and the
+    'train already taken' rule are exercised."""
+    rng = Rng(seed)
+    qd = rng.integers(nq * 32, 0, 256).astype(np.uint8).reshape(nq, 32)
+    td = rng.integers(nt * 32, 0, 256).astype(np.uint8).reshape(nt, 32)
+    qa = rng.uniform(nq, 0.0, 360.0).astype(np.float32)
+    ta = rng.uniform(nt, 0.0, 360.0).astype(np.float32)
+    perm = np.argsort(rng.uniform(nt))
+    nsame = min(int(nq * p_same), nt)
+    src = np.argsort(rng.uniform(nq))[:nsame]
+    for k in range(nsame):
+        j, i = perm[k], src[k]
+        bits = np.unpackbits(qd[i])
+        nflip = int(rng.integers(1, 0, flip_bits + 1)[0])
+        pos = rng.integers(nflip, 0, 256)
+        bits[pos] ^= 1
+        td[j] = np.packbits(bits)
+        rot = 25.0 + rng.normal(1)[0] * (3.0 if rng.uniform(1)[0] < 0.85 else 60.0)
+        ta[j] = np.float32((qa[i] - rot) % 360.0)
+    ndup = int(nt * dup_frac)
+    a = rng.integers(ndup, 0, nt); b = rng.integers(ndup, 0, nt)
+    for k in range(ndup):
+        bits = np.unpackbits(td[a[k]])
+        bits[rng.integers(3, 0, 256)] ^= 1
+        td[b[k]] = np.packbits(bits)
+    qv = (rng.uniform(nq) < p_valid).astype(np.uint8)
+    return {"q_desc": qd, "q_angle": qa, "q_valid": qv, "t_desc": td, "t_angle": ta}
+
+
+# ---- config 3: per-frame pose optimisation problems ----------------------------------------------------
+KITTI_K = (721.5377, 721.5377, 609.5593, 172.8540)   # fx, fy, cx, cy  (Examples/Stereo/0000-0013.yaml:8-11)
+KITTI_BF = 384.38148                                  # Camera.bf (yaml:26)
+_QUOTAS = np.array([434, 362, 302, 251, 209, 175, 145, 122], np.float64)
+
+
+def _so3_exp(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def _level_sigma():
+    s = [np.float32(1.0)]
+    for _ in range(7):
+        s.append(np.float32(np.float64(s[-1]) * np.float64(np.float32(1.2))))
+    s = np.array(s, np.float32)
+    return s, (np.float32(1.0) / (s * s)).astype(np.float32)
+
+
+def pose_problem(seed, n=2000, outlier_frac=0.1, noise=1.0, mono_frac=0.0, valid_frac=1.0, w=1242, h=375):
+    """One PoseOptimization input: n map points in the frustum (z in [5,60] m), true
+    Tcw = exp(xi) with rot within +-3 deg and trans within +-0.5 m, initial guess identity, octave ~ level
+    quotas, pixel noise sigma = noise * 1.2^octave on (u, v, uR), a fraction of uniform-in-image outliers."""
+    rng = Rng(seed)
+    fx, fy, cx, cy = KITTI_K
+    R = _so3_exp(np.radians(rng.uniform(3, -3.0, 3.0)))
+    t = rng.uniform(3, -0.5, 0.5)
+    u = rng.uniform(n, 0, w); v = rng.uniform(n, 0, h); z = rng.uniform(n, 5.0, 60.0)
+    Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+    Xw = ((Xc - t) @ R).astype(np.float32)                      # R^T (Xc - t)
+    Xc = Xw.astype(np.float64) @ R.T + t                        # re-project the float32 points
+    u = fx * Xc[:, 0] / Xc[:, 2] + cx; v = fy * Xc[:, 1] / Xc[:, 2] + cy; ur = u - KITTI_BF / Xc[:, 2]
+    octave = np.searchsorted(np.cumsum(_QUOTAS) / _QUOTAS.sum(), rng.uniform(n)).clip(0, 7)
+    sig, inv_sigma2 = _level_sigma()
+    sd = noise * sig[octave].astype(np.float64)
+    obs = np.stack([u + sd * rng.normal(n), v + sd * rng.normal(n), ur + sd * rng.normal(n)], 1)
+    out = rng.uniform(n) < outlier_frac
+    no = int(out.sum())
+    obs[out, 0] = rng.uniform(no, 0, w); obs[out, 1] = rng.uniform(no, 0, h)
+    obs[out, 2] = obs[out, 0] - rng.uniform(no, 1.0, 60.0)
+    mono = rng.uniform(n) < mono_frac
+    obs[mono, 2] = -1.0
+    valid = (rng.uniform(n) < valid_frac).astype(np.uint8)
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return {"xw": Xw, "obs": obs.astype(np.float32), "inv_sigma2": inv_sigma2[octave], "valid": valid,
+            "K": (np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), np.float32(KITTI_BF)),
+            "tcw0": np.eye(4, dtype=np.float32), "tcw_true": T, "is_outlier": out, "octave": octave}
+
+
+# ---- config 4: object local bundle adjustment ------------------------------------------------------------
+def _quat_from_R(R):
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    x = (R[2, 1] - R[1, 2]) / (4 * w); y = (R[0, 2] - R[2, 0]) / (4 * w); z = (R[1, 0] - R[0, 1]) / (4 * w)
+    return np.array([x, y, z, w])
+
+
+def _Ry(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def _Rz(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def object_ba_problem(seed, n_kf=50, n_pts=300, p_vis=1.0, outlier_frac=0.05, noise=1.0, n_fixed_extra=0,
+                      perturb=(0.3, 5.0, 0.1), perturb_axis="y", mono_frac=0.0):
+    """One ObjectLocalBundleAdjustment graph: a 4.0 x 1.6 x 1.5 m cuboid with n_pts
+    points, n_kf object keyframes whose Tco follows a path (z 8 -> 30 m, x +-4 m, yaw sweep +-30 deg), every
+    (KF, point) visible with probability p_vis, pixel noise sigma = noise * 1.2^octave, outliers, KF 0 fixed,
+    the others VertexSE3Fix{roll/pitch fixed}; n_fixed_extra extra fixed observers (VertexSE3Expmap fixed).
+    perturb = (metres, degrees, metres) for pose translation / rotation / points; perturb_axis 'y' follows the
+    survey (yaw about the camera's y), 'z' perturbs the only rotation the reference's vertex can correct."""
+    rng = Rng(seed)
+    fx, fy, cx, cy = KITTI_K
+    pts = np.stack([rng.uniform(n_pts, -2.0, 2.0), rng.uniform(n_pts, -0.8, 0.8), rng.uniform(n_pts, -0.75, 0.75)], 1)
+    P = n_kf + n_fixed_extra
+    s = np.linspace(0, 1, P)
+    yaw = np.radians(-30 + 60 * s)
+    tz = 8 + 22 * s; tx = 4 * np.sin(2 * np.pi * s); ty = np.full(P, 1.0)
+    poses_true = np.zeros((P, 7)); poses_init = np.zeros((P, 7))
+    flags = np.zeros(P, np.uint8)
+    sig, inv_sigma2 = _level_sigma()
+    e_pose, e_point, e_obs, e_is2, e_out = [], [], [], [], []
+    for i in range(P):
+        R = _Ry(yaw[i]); t = np.array([tx[i], ty[i], tz[i]])
+        poses_true[i, :3] = t; poses_true[i, 3:] = _quat_from_R(R)
+        if i == 0 or i >= n_kf:
+            flags[i] = 1 | (2 if i == 0 else 0)
+            Ri, ti = R, t
+        else:
+            flags[i] = 2
+            ang = np.radians(rng.uniform(1, -perturb[1], perturb[1])[0])
+            Ri = (_Ry(ang) if perturb_axis == "y" else _Rz(ang)) @ R
+            ti = t + rng.uniform(3, -perturb[0], perturb[0])
+        poses_init[i, :3] = ti; poses_init[i, 3:] = _quat_from_R(Ri)
+        Xc = pts @ R.T + t
+        vis = rng.uniform(n_pts) < p_vis
+        octave = np.clip(np.floor(np.log(np.maximum(Xc[:, 2], 1e-3) / 8.0) / np.log(1.2)).astype(int), 0, 7)
+        sd = noise * sig[octave].astype(np.float64)
+        u = fx * Xc[:, 0] / Xc[:, 2] + cx + sd * rng.normal(n_pts)
+        v = fy * Xc[:, 1] / Xc[:, 2] + cy + sd * rng.normal(n_pts)
+        ur = fx * Xc[:, 0] / Xc[:, 2] + cx - KITTI_BF / Xc[:, 2] + sd * rng.normal(n_pts)
+        isout = rng.uniform(n_pts) < outlier_frac
+        du = rng.uniform(n_pts, -40, 40); dv = rng.uniform(n_pts, -40, 40)
+        u = np.where(isout, u + du, u); v = np.where(isout, v + dv, v)
+        mono = rng.uniform(n_pts) < mono_frac
+        ur = np.where(mono, -1.0, ur)
+        for j in np.nonzero(vis)[0]:
+            e_pose.append(i); e_point.append(j); e_obs.append((u[j], v[j], ur[j])); e_is2.append(inv_sigma2[octave[j]])
+            e_out.append(bool(isout[j]))
+    pts_init = pts + rng.uniform(3 * n_pts, -perturb[2], perturb[2]).reshape(n_pts, 3)
+    return {"poses": poses_init, "pose_flags": flags, "points": pts_init,
+            "e_pose": np.array(e_pose, np.int32), "e_point": np.array(e_point, np.int32),
+            "e_obs": np.array(e_obs, np.float32), "e_inv_sigma2": np.array(e_is2, np.float32),
+            "K": (np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), np.float32(KITTI_BF)),
+            "poses_true": poses_true, "points_true": pts, "e_is_outlier": np.array(e_out)}

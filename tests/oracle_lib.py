@@ -44,6 +44,21 @@ def lib():
         L.orc_fast_atan2.restype = ctypes.c_float
         L.orc_fast_atan2.argtypes = [ctypes.c_float, ctypes.c_float]
         L.orc_distribute.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        L.orc_descriptor_distance.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_hamming_matrix.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.orc_search_bruteforce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                            ctypes.c_int, ctypes.c_void_p]
+        L.orc_pose_optimize.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_float] * 5 + [ctypes.c_void_p] * 4
+        L.orc_cfse3_optimize.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 5 + [ctypes.c_void_p] * 2
+        L.orc_object_ba.argtypes = ([ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+                                    + [ctypes.c_void_p] * 4 + [ctypes.c_float] * 5 + [ctypes.c_void_p] * 3)
+        L.orc_se3_exp.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.orc_se3_log.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_se3_from_mat4f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_se3_to_mat4f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_edge_eval.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_double] * 5 + [ctypes.c_void_p] * 3
+        L.orc_huber.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -111,3 +126,105 @@ def distribute(keys_xyz, minX, maxX, minY, maxY, N):
     out = np.zeros((N + 16 + 64, 3), np.int32)
     n = lib().orc_distribute(keys.ctypes.data, len(keys), minX, maxX, minY, maxY, N, out.ctypes.data)
     return out[:n]
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(a.ctypes.data, b.ctypes.data)
+
+
+def hamming_matrix(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    out = np.zeros((len(q), len(t)), np.uint16)
+    lib().orc_hamming_matrix(q.ctypes.data, len(q), t.ctypes.data, len(t), out.ctypes.data)
+    return out
+
+
+def search_bruteforce(p, nnratio, check_ori):
+    qd = np.ascontiguousarray(p["q_desc"], np.uint8).reshape(-1, 32)
+    td = np.ascontiguousarray(p["t_desc"], np.uint8).reshape(-1, 32)
+    qa = np.ascontiguousarray(p["q_angle"], np.float32); ta = np.ascontiguousarray(p["t_angle"], np.float32)
+    qv = np.ascontiguousarray(p["q_valid"], np.uint8)
+    out = np.full(max(len(td), 1), -1, np.int32)
+    n = lib().orc_search_bruteforce(qd.ctypes.data, qa.ctypes.data, qv.ctypes.data, len(qd), td.ctypes.data,
+                                    ta.ctypes.data, len(td), nnratio, 1 if check_ori else 0, out.ctypes.data)
+    return n, out[:len(td)].copy()
+
+
+def pose_optimize(p, want_trace=False):
+    """p: dict from synth.pose_problem.  Returns (ninliers, tcw float32 4x4, outlier uint8[n], trace)."""
+    n = len(p["xw"])
+    xw = np.ascontiguousarray(p["xw"], np.float32); obs = np.ascontiguousarray(p["obs"], np.float32)
+    is2 = np.ascontiguousarray(p["inv_sigma2"], np.float32); valid = np.ascontiguousarray(p["valid"], np.uint8)
+    tcw = np.ascontiguousarray(p["tcw0"], np.float32).copy()
+    outlier = np.ascontiguousarray(p.get("outlier0", np.zeros(n, np.uint8)), np.uint8).copy()
+    trace = np.zeros((64, 3)); nt = ctypes.c_int(0)
+    r = lib().orc_pose_optimize(n, xw.ctypes.data, obs.ctypes.data, is2.ctypes.data, valid.ctypes.data,
+                                *[float(k) for k in p["K"]], tcw.ctypes.data, outlier.ctypes.data,
+                                trace.ctypes.data, ctypes.byref(nt))
+    return r, tcw, outlier, trace[:nt.value]
+
+
+def cfse3_optimize(objs, K):
+    """objs: list of dicts {xo [n,3], obs [n,3], inv_sigma2 [n], valid [n], pose7 [7]}.  Returns (ok, poses7, outliers)."""
+    k = len(objs)
+    off = np.zeros(k + 1, np.int32)
+    for i, o in enumerate(objs):
+        off[i + 1] = off[i] + len(o["xo"])
+    cat = lambda key, dt: np.ascontiguousarray(np.concatenate([np.asarray(o[key], dt).reshape(len(o["xo"]), -1) for o in objs]), dt) if k else np.zeros((0, 1), dt)
+    xo, obs, is2, valid = cat("xo", np.float32), cat("obs", np.float32), cat("inv_sigma2", np.float32), cat("valid", np.uint8)
+    poses = np.ascontiguousarray(np.stack([o["pose7"] for o in objs]), np.float64).copy() if k else np.zeros((0, 7))
+    outlier = np.zeros(max(int(off[-1]), 1), np.uint8)
+    r = lib().orc_cfse3_optimize(k, off.ctypes.data, xo.ctypes.data, obs.ctypes.data, is2.ctypes.data, valid.ctypes.data,
+                                 *[float(v) for v in K], poses.ctypes.data, outlier.ctypes.data)
+    return r, poses, [outlier[off[i]:off[i + 1]].copy() for i in range(k)]
+
+
+def object_ba(p):
+    poses = np.ascontiguousarray(p["poses"], np.float64).copy(); pts = np.ascontiguousarray(p["points"], np.float64).copy()
+    flags = np.ascontiguousarray(p["pose_flags"], np.uint8)
+    ep = np.ascontiguousarray(p["e_pose"], np.int32); el = np.ascontiguousarray(p["e_point"], np.int32)
+    eo = np.ascontiguousarray(p["e_obs"], np.float32); ei = np.ascontiguousarray(p["e_inv_sigma2"], np.float32)
+    erase = np.zeros(max(len(ep), 1), np.uint8); trace = np.zeros((64, 3)); nt = ctypes.c_int(0)
+    n = lib().orc_object_ba(len(poses), poses.ctypes.data, flags.ctypes.data, len(pts), pts.ctypes.data, len(ep),
+                            ep.ctypes.data, el.ctypes.data, eo.ctypes.data, ei.ctypes.data, *[float(v) for v in p["K"]],
+                            erase.ctypes.data, trace.ctypes.data, ctypes.byref(nt))
+    return n, poses, pts, erase[:len(ep)].copy(), trace[:nt.value]
+
+
+def se3_exp(u, norollpitch=False):
+    u = np.ascontiguousarray(u, np.float64); out = np.zeros(7)
+    lib().orc_se3_exp(u.ctypes.data, 1 if norollpitch else 0, out.ctypes.data)
+    return out
+
+
+def se3_log(p7):
+    p7 = np.ascontiguousarray(p7, np.float64); out = np.zeros(6)
+    lib().orc_se3_log(p7.ctypes.data, out.ctypes.data)
+    return out
+
+
+def se3_from_mat4f(m):
+    m = np.ascontiguousarray(m, np.float32); out = np.zeros(7)
+    lib().orc_se3_from_mat4f(m.ctypes.data, out.ctypes.data)
+    return out
+
+
+def se3_to_mat4f(p7):
+    p7 = np.ascontiguousarray(p7, np.float64); out = np.zeros((4, 4), np.float32)
+    lib().orc_se3_to_mat4f(p7.ctypes.data, out.ctypes.data)
+    return out
+
+
+def edge_eval(etype, pose7, X, obs, K):
+    pose7 = np.ascontiguousarray(pose7, np.float64); X = np.ascontiguousarray(X, np.float64); obs = np.ascontiguousarray(obs, np.float64)
+    err = np.zeros(3); Jp = np.zeros((3, 6)); Jx = np.zeros((3, 3))
+    lib().orc_edge_eval(etype, pose7.ctypes.data, X.ctypes.data, obs.ctypes.data, *[float(v) for v in K], err.ctypes.data,
+                        Jp.ctypes.data, Jx.ctypes.data)
+    return err, Jp, Jx
+
+
+def huber(e, delta):
+    out = np.zeros(3)
+    lib().orc_huber(float(e), float(delta), out.ctypes.data)
+    return out

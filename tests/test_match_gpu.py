@@ -1,0 +1,57 @@
+"""GPU parity of the matcher kernels against the CPU oracle: bit-exact distance matrices and match sets."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from pointslot_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    from pointslot_amd.matcher import ORBmatcher
+    m = ORBmatcher(0.9, True)
+    yield m
+    m.close()
+
+
+def test_hamming_matrix(matcher):
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, (333, 32), dtype=np.uint8); t = rng.integers(0, 256, (1001, 32), dtype=np.uint8)
+    t[5] = q[7]; t[6] = ~q[7]
+    g = matcher.DescriptorDistanceMatrix(q, t)
+    assert np.array_equal(g, oracle_lib.hamming_matrix(q, t))
+    assert g[7, 5] == 0 and g[7, 6] == 256
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+@pytest.mark.parametrize("ratio", [0.9, 0.6])
+def test_bruteforce_batch_matches_oracle(check_ori, ratio):
+    from pointslot_amd.matcher import ORBmatcher
+    m = ORBmatcher(ratio, check_ori)
+    shapes = [(300, 320), (1000, 1000), (5, 3), (64, 65), (200, 7), (1, 1), (700, 1500), (33, 4000)]
+    probs = [synth.bruteforce_problem(0x51070010 + k, nq, nt) for k, (nq, nt) in enumerate(shapes)]
+    # adversarial: many identical descriptors (exhausts the top-8 lists and forces the rescan path)
+    dup = synth.bruteforce_problem(0x51070099, 120, 100)
+    dup["t_desc"][:] = dup["t_desc"][0]
+    dup["t_desc"][50:, 0] ^= 1
+    dup["q_desc"][:] = dup["t_desc"][0]
+    dup["q_desc"][::2, 1] ^= 3
+    probs.append(dup)
+    res = m.SearchByBruceMatching(probs)
+    total = 0
+    for p, (n, out) in zip(probs, res):
+        no, oo = oracle_lib.search_bruteforce(p, ratio, check_ori)
+        assert n == no
+        assert np.array_equal(out, oo)
+        total += n
+    assert total > 300
+    m.close()
+
+
+def test_bruteforce_empty_sides(matcher):
+    p = synth.bruteforce_problem(5, 10, 10)
+    p0 = dict(p); p0["q_valid"] = np.zeros(10, np.uint8)
+    (n, out), = matcher.SearchByBruceMatching([p0])
+    assert n == 0 and np.all(out == -1)

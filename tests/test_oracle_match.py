@@ -1,0 +1,58 @@
+"""CPU pins of the matching oracle: algebraic known answers for DescriptorDistance and structural
+properties of SearchByBruceMatching."""
+import numpy as np
+
+import oracle_lib
+from pointslot_amd import synth
+
+
+def test_hamming_known_answers():
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, 32, dtype=np.uint8)
+    assert oracle_lib.descriptor_distance(a, a) == 0
+    assert oracle_lib.descriptor_distance(a, ~a) == 256
+    for _ in range(50):
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert oracle_lib.descriptor_distance(a, b) == int(np.unpackbits(a ^ b).sum())
+    one = np.zeros(32, np.uint8); one[17] = 0x10
+    assert oracle_lib.descriptor_distance(np.zeros(32, np.uint8), one) == 1
+
+
+def test_hamming_matrix_matches_numpy():
+    rng = np.random.default_rng(4)
+    q = rng.integers(0, 256, (37, 32), dtype=np.uint8); t = rng.integers(0, 256, (53, 32), dtype=np.uint8)
+    m = oracle_lib.hamming_matrix(q, t)
+    ref = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    assert np.array_equal(m, ref)
+
+
+def test_bruteforce_structure():
+    p = synth.bruteforce_problem(0x51070010)
+    n, out = oracle_lib.search_bruteforce(p, 0.9, True)
+    matched = out[out >= 0]
+    assert n == len(matched) and n > 50
+    assert len(set(matched.tolist())) == n                       # a query matches at most one train
+    assert np.all(p["q_valid"][matched] == 1)
+    d = oracle_lib.hamming_matrix(p["q_desc"], p["t_desc"])
+    for j in np.nonzero(out >= 0)[0]:
+        assert d[out[j], j] <= 50                                  # TH_LOW
+    n2, out2 = oracle_lib.search_bruteforce(p, 0.9, False)
+    assert n2 >= n                                                 # the rotation check only removes matches
+    assert np.all((out == -1) | (out == out2))
+
+
+def test_bruteforce_greedy_order_dependence():
+    """two identical queries compete for one train: the first one wins, the second must take the next best"""
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    t2 = base.copy(); t2[0] ^= 0x0F                                 # 4 bits away
+    far = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    p = {"q_desc": np.stack([base, base]), "q_angle": np.zeros(2, np.float32), "q_valid": np.ones(2, np.uint8),
+         "t_desc": np.concatenate([[base], [t2], far]), "t_angle": np.zeros(8, np.float32)}
+    n, out = oracle_lib.search_bruteforce(p, 0.9, False)
+    # query 0: best 0 (train 0), second 4 -> 0 < 0.9*4 accepted.  query 1: train 0 taken -> best 4 (train 1),
+    # second ~128 -> accepted.
+    assert n == 2 and out[0] == 0 and out[1] == 1
+    p["q_valid"] = np.array([0, 1], np.uint8)
+    n, out = oracle_lib.search_bruteforce(p, 0.9, False)
+    assert n == 1 and out[0] == 1 and out[1] == -1
