@@ -1,0 +1,245 @@
+"""CPU pins of the optimiser oracle (the reference has no tests): SE3 exp/log round trips,
+analytic Jacobians against central differences, Huber identities, recovery of the generating pose on noise-free
+data, and an independent dense numpy Levenberg-Marquardt (no Schur complement, numpy.linalg.solve) that must
+reproduce the oracle's per-iteration chi2 on the same problems — i.e. Schur solve == full dense solve."""
+import numpy as np
+
+import oracle_lib
+from pointslot_amd import synth
+
+
+def _mat(p7):
+    return oracle_lib.se3_to_mat4f(p7).astype(np.float64)
+
+
+def test_exp_log_round_trip_and_small_angle_branch():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        u = np.concatenate([rng.uniform(-1.5, 1.5, 3), rng.uniform(-5, 5, 3)])
+        assert np.allclose(oracle_lib.se3_log(oracle_lib.se3_exp(u)), u, atol=1e-9)
+    tiny = np.array([1e-7, -2e-7, 3e-7, 0.1, 0.2, 0.3])
+    p = oracle_lib.se3_exp(tiny)                       # first-order branch (theta < 1e-5): V = R = I + Omega + Omega^2
+    assert np.allclose(p[:3], [0.1, 0.2, 0.3], atol=1e-6)
+    q = oracle_lib.se3_exp(np.zeros(6))
+    assert np.allclose(q, [0, 0, 0, 0, 0, 0, 1])
+
+
+def test_norollpitch_exp_is_rz():
+    u = np.array([0.0, 0.0, 0.3, 1.0, 2.0, 3.0])
+    p = oracle_lib.se3_exp(u, norollpitch=True)
+    R = _mat(p)[:3, :3]
+    c, s = np.cos(0.3), np.sin(0.3)
+    assert np.allclose(R, [[c, -s, 0], [s, c, 0], [0, 0, 1]], atol=1e-7)
+    assert np.allclose(p, oracle_lib.se3_exp(u, False), atol=1e-12)       # identical when omega = (0,0,wz)
+    u2 = np.array([0.2, -0.1, 0.3, 1.0, 2.0, 3.0])                         # R ignores wx, wy; V does not
+    R2 = _mat(oracle_lib.se3_exp(u2, True))[:3, :3]
+    assert np.allclose(R2, R, atol=1e-7)
+
+
+def test_quaternion_sign_and_matrix_round_trip():
+    rng = np.random.default_rng(1)
+    for _ in range(30):
+        p7 = oracle_lib.se3_exp(np.concatenate([rng.uniform(-3.1, 3.1, 3), rng.uniform(-9, 9, 3)]))
+        assert p7[6] >= 0 and abs(np.linalg.norm(p7[3:]) - 1) < 1e-14
+        m = oracle_lib.se3_to_mat4f(p7)
+        q = oracle_lib.se3_from_mat4f(m)
+        assert np.allclose(_mat(q), m, atol=2e-7)
+
+
+def test_huber():
+    d = float(np.float32(np.sqrt(7.815)))
+    assert np.array_equal(oracle_lib.huber(3.0, d), [3.0, 1.0, 0.0])          # identity below delta^2
+    r = oracle_lib.huber(100.0, d)
+    assert np.isclose(r[0], 2 * 10 * d - d * d) and np.isclose(r[1], d / 10)
+
+
+def test_analytic_jacobians_match_central_differences():
+    rng = np.random.default_rng(3)
+    K = (721.5377, 721.5377, 609.5593, 172.854, 384.38148)
+    for etype in (0, 1, 3, 4):
+        for _ in range(5):
+            pose = oracle_lib.se3_exp(np.concatenate([rng.uniform(-0.3, 0.3, 3), rng.uniform(-1, 1, 3)]))
+            X = np.array([rng.uniform(-5, 5), rng.uniform(-2, 2), rng.uniform(8, 40)])
+            obs = np.array([600.0, 170.0, 580.0])
+            e0, Jp, Jx = oracle_lib.edge_eval(etype, pose, X, obs, K)
+            dim = 2 if etype in (0, 3) else 3
+            h = 1e-6
+            Tm = oracle_lib.se3_to_mat4f(pose).astype(np.float64)
+            for d in range(6):
+                du = np.zeros(6); du[d] = h
+                def moved(sign):
+                    E = _exp_mat(sign * du) @ _pose_mat(pose)
+                    return _err(etype, E, X, obs, K)
+                num = (moved(+1) - moved(-1)) / (2 * h)
+                assert np.allclose(Jp[:dim, d], num[:dim], rtol=2e-4, atol=2e-4), (etype, d)
+            if etype >= 3:
+                for d in range(3):
+                    dx = np.zeros(3); dx[d] = h
+                    num = (_err(etype, _pose_mat(pose), X + dx, obs, K) - _err(etype, _pose_mat(pose), X - dx, obs, K)) / (2 * h)
+                    assert np.allclose(Jx[:dim, d], num[:dim], rtol=2e-4, atol=2e-4), (etype, d)
+
+
+def _pose_mat(p7):
+    x, y, z, w = p7[3:]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = p7[:3]
+    return T
+
+
+def _exp_mat(u):
+    return _pose_mat(oracle_lib.se3_exp(u))
+
+
+def _err(etype, T, X, obs, K):
+    fx, fy, cx, cy, bf = K
+    p = T[:3, :3] @ X + T[:3, 3]
+    u = fx * p[0] / p[2] + cx; v = fy * p[1] / p[2] + cy
+    if etype in (0, 3):
+        return np.array([obs[0] - u, obs[1] - v, 0.0])
+    return np.array([obs[0] - u, obs[1] - v, obs[2] - (u - bf / p[2])])
+
+
+def test_pose_optimization_recovers_generating_pose_without_noise():
+    p = synth.pose_problem(0x51070003, n=500, outlier_frac=0.0, noise=0.0)
+    r, tcw, outl, tr = oracle_lib.pose_optimize(p)
+    assert r == 500 and outl.sum() == 0
+    assert np.allclose(tcw, p["tcw_true"], atol=2e-6)
+    assert tr[-1, 0] < 1e-3                                           # chi2 is float32-rounding noise only
+
+
+def test_pose_optimization_with_outliers():
+    p = synth.pose_problem(0x51070003)
+    r, tcw, outl, tr = oracle_lib.pose_optimize(p)
+    assert r == 2000 - outl.sum()
+    assert np.all(outl[p["is_outlier"]] == 1) or outl[p["is_outlier"]].mean() > 0.97
+    assert outl[~p["is_outlier"]].mean() < 0.08                       # chi2(3) tail at 7.815 is 5 %
+    assert np.linalg.norm(tcw[:3, 3] - p["tcw_true"][:3, 3]) < 0.02
+    few = synth.pose_problem(5, n=14)
+    few["outlier0"] = np.ones(14, np.uint8)
+    r, tcw, outl, _ = oracle_lib.pose_optimize(few)
+    assert r == 0 and np.array_equal(tcw, few["tcw0"]) and outl.sum() == 0   # flags are cleared before the early return
+
+
+# ---- independent dense LM ------------------------------------------------------------------------------------
+def _dense_lm(pose_list, flags, pts, edges, K, iters, robust, level):
+    """g2o's LM control flow on the FULL normal equations (no Schur), Jacobians / errors from the oracle's edge_eval.
+    edges: list of (type, pose, point, obs, info, delta).  Returns the chi2 after every iteration."""
+    poses = [p.copy() for p in pose_list]
+    pts = pts.copy()
+    act = [i for i in range(len(edges)) if level[i] == 0]
+    pidx = {}
+    lidx = {}
+    for i in act:
+        t, pi, li, *_ = edges[i]
+        if not flags[pi] & 1:
+            pidx.setdefault(pi, None)
+        lidx.setdefault(li, None)
+    for n_, k in enumerate(sorted(pidx)):
+        pidx[k] = n_
+    for n_, k in enumerate(sorted(lidx)):
+        lidx[k] = n_
+    sp = 6 * len(pidx); n = sp + 3 * len(lidx)
+
+    def hub(e, delta):
+        return oracle_lib.huber(e, delta) if robust else np.array([e, 1.0, 0.0])
+
+    def chi_all():
+        tot = 0.0
+        for i in act:
+            t, pi, li, obs, info, delta = edges[i]
+            e, _, _ = oracle_lib.edge_eval(t, poses[pi], pts[li], obs, K)
+            tot += hub(info * e @ e, delta)[0]
+        return tot
+
+    out = []
+    lam, ni, nbad = 0.0, 2.0, 0
+    for it in range(iters):
+        H = np.zeros((n, n)); b = np.zeros(n)
+        cur = 0.0
+        for i in act:
+            t, pi, li, obs, info, delta = edges[i]
+            e, Jp, Jx = oracle_lib.edge_eval(t, poses[pi], pts[li], obs, K)
+            rho = hub(info * e @ e, delta)
+            cur += rho[0]
+            J = np.zeros((3, n))
+            if pi in pidx:
+                J[:, 6 * pidx[pi]:6 * pidx[pi] + 6] = Jp
+            J[:, sp + 3 * lidx[li]:sp + 3 * lidx[li] + 3] = Jx
+            H += rho[1] * info * J.T @ J
+            b -= rho[1] * info * J.T @ e
+        ini = cur
+        if it == 0:
+            lam = 1e-5 * np.abs(np.diag(H)).max(); ni = 2.0; nbad = 0
+        rho_g, q = 0.0, 0
+        while True:
+            bp, bl = [p.copy() for p in poses], pts.copy()
+            x = np.linalg.solve(H + lam * np.eye(n), b)
+            for pi, k in pidx.items():
+                u = x[6 * k:6 * k + 6].copy()
+                nrp = bool(flags[pi] & 2)
+                if nrp:
+                    u[0] = u[1] = 0
+                E = _pose_mat(oracle_lib.se3_exp(u, nrp)) @ _pose_mat(poses[pi])
+                poses[pi] = oracle_lib.se3_from_mat4f(np.eye(4)) * 0 + _mat_to_p7(E)
+            for li, k in lidx.items():
+                pts[li] = pts[li] + x[sp + 3 * k:sp + 3 * k + 3]
+            tmp = chi_all()
+            rho_g = (cur - tmp) / (x @ (lam * x + b) + 1e-3)
+            if rho_g > 0 and np.isfinite(tmp):
+                lam *= max(1 / 3, min(1 - (2 * rho_g - 1) ** 3, 2 / 3)); ni = 2.0; cur = tmp
+            else:
+                lam *= ni; ni *= 2; poses, pts = bp, bl
+            q += 1
+            if not (rho_g < 0 and q < 10):
+                break
+        out.append(cur)
+        if q == 10 or rho_g == 0:
+            break
+        nbad = nbad + 1 if (ini - cur) * 1e3 < ini else 0
+        if nbad >= 3:
+            break
+    return np.array(out), poses, pts
+
+
+def _mat_to_p7(T):
+    R = T[:3, :3]
+    w = np.sqrt(max(0.0, 1 + np.trace(R))) / 2
+    q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+    q /= np.linalg.norm(q)
+    return np.concatenate([T[:3, 3], q])
+
+
+def test_schur_lm_equals_independent_dense_lm():
+    b = synth.object_ba_problem(0x51070044, n_kf=5, n_pts=14, p_vis=0.8, outlier_frac=0.0, mono_frac=0.2,
+                                perturb=(0.1, 2.0, 0.05), perturb_axis="z", n_fixed_extra=1)
+    n, poses, pts, erase, tr = oracle_lib.object_ba(b)
+    edges = []
+    dm, ds = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+    for k in range(len(b["e_pose"])):
+        mono = b["e_obs"][k, 2] < 0
+        edges.append((3 if mono else 4, int(b["e_pose"][k]), int(b["e_point"][k]), b["e_obs"][k].astype(np.float64),
+                      float(b["e_inv_sigma2"][k]), dm if mono else ds))
+    K = [float(v) for v in b["K"]]
+    chi, _, _ = _dense_lm(list(b["poses"]), b["pose_flags"], b["points"], edges, K, 5, True, np.zeros(len(edges), int))
+    m = len(chi)
+    assert m >= 3
+    assert np.allclose(chi, tr[:m, 0], rtol=1e-6), (chi, tr[:m, 0])
+
+
+def test_object_ba_noise_free_recovery_full_se3():
+    b = synth.object_ba_problem(0x51070004, n_kf=8, n_pts=40, p_vis=0.8, noise=0.0, outlier_frac=0.0)
+    b["pose_flags"] = np.where(b["pose_flags"] & 1, b["pose_flags"], 0).astype(np.uint8)
+    n, poses, pts, erase, tr = oracle_lib.object_ba(b)
+    assert n == 0
+    assert np.abs(poses - b["poses_true"]).max() < 5e-3 and np.abs(pts - b["points_true"]).max() < 1e-3
+    assert tr[-1, 0] < 1e-3 * tr[0, 0]
+
+
+def test_object_ba_erase_list_flags_outliers():
+    b = synth.object_ba_problem(0x51070005, n_kf=10, n_pts=50, p_vis=0.8, perturb=(0.02, 0.3, 0.01), perturb_axis="z")
+    n, poses, pts, erase, tr = oracle_lib.object_ba(b)
+    assert erase[b["e_is_outlier"]].mean() >= 0.85
+    assert erase[~b["e_is_outlier"]].mean() < 0.15
+    assert len(tr) <= 15 and np.all(np.diff(tr[:5, 0]) <= 1e-9) and np.all(np.diff(tr[5:, 0]) <= 1e-9)
