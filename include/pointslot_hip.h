@@ -206,6 +206,30 @@ typedef struct ps_cfse3_problem {
 } ps_cfse3_problem;
 int ps_cfse3_optimize_batch(ps_optimizer* m, ps_cfse3_problem* probs, int nprob);
 
+/* Optimizer::ObjectLocalBundleAdjustment(ObjectKeyFrame*, verbose) (Optimizer.cc:755-1075) on a graph the
+ * caller has already collected (:755-818, :827-951 map 1:1 onto these arrays), for a batch of objects.
+ *   poses7     : [np][7] in: Converter::toSE3Quat(pKFi->GetPose()) of the local (free) and fixed object
+ *                keyframes; out: the optimised estimates (written back with pKF->SetPose, :1033-1064)
+ *   pose_flags : [np] bit 0 = setFixed(true) (mnId == 0 or a lFixedCameras entry), bit 1 = VertexSE3Fix with
+ *                whether_fixrollpitch (every local keyframe, :834-846); at most 128 free poses
+ *   points     : [nl][3] in: MapObjectPoint::GetInObjFrameEigenPosition; out: SetInObjFramePosition (:1066-1074)
+ *   e_*        : one entry per (point, observing keyframe): vertex indices, (u, v, uR) with uR < 0 for a
+ *                monocular edge, mvInvLevelSigma2[octave]; at most one edge per (pose, point) pair
+ *   erase      : [ne] out, 1 where the reference queues (pKFi, pMP) into vToErase (:988-1012)
+ *   iterations / trials : out, LM iterations and damping trials executed (optimize(5) + optimize(10))
+ *   trace      : NULL or room for 40 x 3 doubles: (chi2, lambda, trials) per LM iteration; n_trace = count */
+typedef struct ps_ba_problem {
+  int32_t np, nl, ne;
+  double* poses7; const uint8_t* pose_flags;
+  double* points;
+  const int32_t* e_pose; const int32_t* e_point; const float* e_obs; const float* e_inv_sigma2;
+  float fx, fy, cx, cy, bf;
+  uint8_t* erase;
+  int32_t n_erased, iterations, trials, n_trace;
+  double* trace;
+} ps_ba_problem;
+int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int nprob);
+
 #ifdef __cplusplus
 }
 #endif

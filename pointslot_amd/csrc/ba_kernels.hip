@@ -1,0 +1,720 @@
+// CDNA4 kernels of the object bundle adjustment — Optimizer::ObjectLocalBundleAdjustment
+// (/root/reference/src/Optimizer.cc:755-1075): Schur-complement Levenberg–Marquardt over object keyframe
+// poses (g2o::VertexSE3Fix / fixed VertexSE3Expmap) and object-frame points (VertexSBAPointXYZ, marginalised)
+// with EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ edges.
+//
+// The LM state machine of every problem lives in device memory (BaState); the host only enqueues the same
+// kernel sequence ("global step") until every problem reports DONE.  Work is spread over the whole chip:
+//   ba_begin        per problem : stage entry — chi2/depth classification, active sets, compact pose indices
+//   ba_lin_pose     wave per pose : errors, Jacobians, Huber weights; H_pp, b_p, robust chi2, W = J_p^T w J_x
+//   ba_lin_point    thread per point : H_ll, b_l
+//   ba_post_lin     per problem : chi2 total, lambda init (tau * max diag)
+//   ba_prep         thread per point : (H_ll + lambda I)^-1 ; wave per pose : b_s = b_p - sum W D^-1 b_l
+//   ba_schur        tile per 8x8 pose blocks : S = H_pp + lambda I - (W D^-1) W^T, 48x48 FP64 tiles via LDS
+//   ba_solve        per problem : blocked unpivoted LDL^T of S, forward/backward substitution
+//   ba_update       thread per point / pose : x_l = D^-1 (b_l - W^T x_p), oplus, backups, gain-ratio scale
+//   ba_error        thread per edge : errors at the trial estimate, robust chi2
+//   ba_decide       per problem : gain ratio, lambda update, accept / restore, stop rules, stage changes
+// g2o semantics reproduced: see oracle/opt_oracle.cpp's header for the file:line list; all sums are FP64
+// and deterministic (fixed-order tree reductions, no atomics).
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+#include "ba_plan.h"
+#include "se3.h"
+
+struct BaArrays {
+  const BaProb* prob;
+  BaState* state;
+  double* poses; double* poses_bak; const uint8_t* pose_flags; int32_t* pidx; int32_t* pact;
+  double* points; double* points_bak; uint8_t* lact;
+  const int32_t* e_pose; const int32_t* e_point; const float* e_obs; const float* e_is2;
+  uint8_t* e_state; double* chi2c; uint8_t* erase;
+  const int32_t* csr_off; const int32_t* csr_edges;
+  double* Hpp; double* bp; double* Hll; double* bl; double* Dinv; double* bs; double* xp; double* xl;
+  double* W; double* S; double* part; double* trace;
+  int32_t* ndone;
+};
+
+namespace {
+
+#define ES_LVL1 1
+#define ES_MONO 2
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m);
+  hi = __shfl_xor(hi, m);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += shfl_xor_d(v, d);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, shfl_xor_d(v, d));
+  return v;
+}
+__device__ __forceinline__ Se3 load_pose(const double* p) {
+  Se3 T;
+  T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q[0] = p[3]; T.q[1] = p[4]; T.q[2] = p[5]; T.q[3] = p[6];
+  return T;
+}
+__device__ __forceinline__ void store_pose(double* p, const Se3& T) {
+  p[0] = T.t[0]; p[1] = T.t[1]; p[2] = T.t[2]; p[3] = T.q[0]; p[4] = T.q[1]; p[5] = T.q[2]; p[6] = T.q[3];
+}
+__device__ __forceinline__ void huber(double e, double delta, double& rho0, double& rho1) {
+  const double dsqr = delta * delta;
+  if (e <= dsqr) { rho0 = e; rho1 = 1.0; }
+  else { const double sq = sqrt(e); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+}
+#define DELTA_MONO ((double)(float)2.4476519361420544)    /* (float)sqrt(5.991) */
+#define DELTA_STEREO ((double)(float)2.7955321496988727)  /* (float)sqrt(7.815) */
+
+// EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ::computeError (types_six_dof_expmap.h:87-139, .cpp:141-158)
+__device__ __forceinline__ void ba_error(const Se3& T, const BaProb& P, const double X[3], const float* ob, bool mono,
+                                         double p[3], double e[3]) {
+  se3_map(T, X, p);
+  if (mono) {
+    e[0] = (double)ob[0] - (p[0] / p[2] * (double)P.fx + (double)P.cx);
+    e[1] = (double)ob[1] - (p[1] / p[2] * (double)P.fy + (double)P.cy);
+    e[2] = 0.0;
+  } else {
+    const float invz = (float)(1.0 / p[2]);
+    const double u = p[0] * (double)invz * (double)P.fx + (double)P.cx, v = p[1] * (double)invz * (double)P.fy + (double)P.cy;
+    e[0] = (double)ob[0] - u; e[1] = (double)ob[1] - v; e[2] = (double)ob[2] - (u - (double)P.bf * (double)invz);
+  }
+}
+// linearizeOplus of the two binary edges (types_six_dof_expmap.cpp:103-139, :188-232)
+__device__ __forceinline__ void ba_jacobians(const double R[9], const BaProb& P, const double p[3], bool mono,
+                                             double Jp[3][6], double Jx[3][3]) {
+  const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
+  const double fx = (double)P.fx, fy = (double)P.fy, bf = (double)P.bf;
+  if (mono) {
+    const double t0 = fx, t2 = -x / z * fx, t4 = fy, t5 = -y / z * fy;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      Jx[0][c] = -1. / z * (t0 * R[c] + t2 * R[6 + c]);
+      Jx[1][c] = -1. / z * (t4 * R[3 + c] + t5 * R[6 + c]);
+      Jx[2][c] = 0;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      Jx[0][c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+      Jx[1][c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+      Jx[2][c] = Jx[0][c] - bf * R[6 + c] / z_2;
+    }
+  }
+  Jp[0][0] = x * y / z_2 * fx; Jp[0][1] = -(1 + (x * x / z_2)) * fx; Jp[0][2] = y / z * fx;
+  Jp[0][3] = -1. / z * fx; Jp[0][4] = 0; Jp[0][5] = x / z_2 * fx;
+  Jp[1][0] = (1 + y * y / z_2) * fy; Jp[1][1] = -x * y / z_2 * fy; Jp[1][2] = -x / z * fy;
+  Jp[1][3] = 0; Jp[1][4] = -1. / z * fy; Jp[1][5] = y / z_2 * fy;
+  if (mono) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) Jp[2][c] = 0;
+  } else {
+    Jp[2][0] = Jp[0][0] - bf * y / z_2; Jp[2][1] = Jp[0][1] + bf * x / z_2; Jp[2][2] = Jp[0][2];
+    Jp[2][3] = Jp[0][3]; Jp[2][4] = 0; Jp[2][5] = Jp[0][5] - bf / z_2;
+  }
+}
+__device__ __forceinline__ bool inv3(const double M[9], double O[9]) {
+  const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+  const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+  const double id = 1.0 / det;
+  O[0] = c00 * id; O[1] = (M[2] * M[7] - M[1] * M[8]) * id; O[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+  O[3] = c01 * id; O[4] = (M[0] * M[8] - M[2] * M[6]) * id; O[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+  O[6] = c02 * id; O[7] = (M[1] * M[6] - M[0] * M[7]) * id; O[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+  return det != 0;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// Stage entry.  stage 0: all edges level 0, Huber on, 5 iterations (Optimizer.cc:955-957).
+// stage 1: chi2 > 5.991|7.815 or depth <= 0 -> level 1, Huber off, 10 iterations (:959-986).
+// stage 2: the same test fills the erase list (:988-1012) and the problem is DONE.
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_begin(BaArrays A) {
+  const BaProb P = A.prob[blockIdx.x];
+  BaState& S = A.state[blockIdx.x];
+  const int tid = threadIdx.x;
+  __shared__ int s_stage;
+  for (;;) {
+    __syncthreads();
+    if (S.phase != BA_PH_BEGIN) return;
+    const int stage = S.stage;
+    if (stage >= 1) {   // classification / erase list on the cached chi2 and the current estimate
+      for (int e = tid; e < P.ne; e += 256) {
+        const int ge = P.edge_base + e;
+        const bool mono = A.e_state[ge] & ES_MONO;
+        const Se3 T = load_pose(A.poses + (size_t)(P.pose_base + A.e_pose[ge]) * 7);
+        const double* X = A.points + (size_t)(P.point_base + A.e_point[ge]) * 3;
+        double p[3];
+        se3_map(T, X, p);
+        const bool bad = A.chi2c[ge] > (mono ? 5.991 : 7.815) || !(p[2] > 0.0);
+        if (stage == 1) { if (bad) A.e_state[ge] |= ES_LVL1; }
+        else A.erase[ge] = bad ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    if (stage == 2) {
+      if (tid == 0) { S.phase = BA_PH_DONE; atomicAdd(A.ndone, 1); }
+      return;
+    }
+    // active sets: a pose / point takes part iff it has a level-0 edge (and the pose is not fixed)
+    for (int i = tid; i < P.np; i += 256) {
+      const int b = A.csr_off[P.csr_pose_base + i], e = A.csr_off[P.csr_pose_base + i + 1];
+      bool any = false;
+      for (int k = b; k < e; k++) any |= !(A.e_state[P.edge_base + A.csr_edges[P.csr_pose_edges_base + k]] & ES_LVL1);
+      A.pidx[P.pose_base + i] = (any && !(A.pose_flags[P.pose_base + i] & 1)) ? 0 : -1;
+    }
+    for (int l = tid; l < P.nl; l += 256) {
+      const int b = A.csr_off[P.csr_point_base + l], e = A.csr_off[P.csr_point_base + l + 1];
+      bool any = false;
+      for (int k = b; k < e; k++) any |= !(A.e_state[P.edge_base + A.csr_edges[P.csr_point_edges_base + k]] & ES_LVL1);
+      A.lact[P.point_base + l] = any ? 1 : 0;
+      A.xl[(size_t)(P.point_base + l) * 3] = 0; A.xl[(size_t)(P.point_base + l) * 3 + 1] = 0; A.xl[(size_t)(P.point_base + l) * 3 + 2] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int npa = 0, nla = 0;
+      for (int i = 0; i < P.np; i++)
+        if (A.pidx[P.pose_base + i] == 0) { A.pidx[P.pose_base + i] = npa; A.pact[P.pose_base + npa] = i; npa++; }
+      for (int l = 0; l < P.nl; l++) nla += A.lact[P.point_base + l];
+      for (int i = 0; i < P.np * 6; i++) A.xp[(size_t)P.pose_base * 6 + i] = 0;
+      S.npa = npa; S.nla = nla;
+      S.robust = stage == 0 ? 1 : 0;
+      S.iter = 0; S.max_iter = stage == 0 ? 5 : 10; S.trial = 0; S.n_bad = 0;
+      if (npa + nla == 0) S.stage = stage + 1;   // "0 vertices to optimize": optimize() returns without touching anything
+      else S.phase = BA_PH_LINEARIZE;
+      s_stage = S.stage;
+    }
+    __syncthreads();
+    if (S.phase != BA_PH_BEGIN) return;
+    (void)s_stage;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// computeActiveErrors + buildSystem, pose-major: one wave per pose, lanes over the pose's edges.
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_lin_pose(BaArrays A) {
+  const BaProb P = A.prob[blockIdx.y];
+  const BaState& S = A.state[blockIdx.y];
+  if (S.phase != BA_PH_LINEARIZE) return;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= P.np) return;
+  const Se3 T = load_pose(A.poses + (size_t)(P.pose_base + i) * 7);
+  double R[9];
+  se3_quat_to_R(T.q, R);
+  const bool pose_active = A.pidx[P.pose_base + i] >= 0;
+  const bool robust = S.robust != 0;
+  double acc[28];
+#pragma unroll
+  for (int a = 0; a < 28; a++) acc[a] = 0;
+  const int b = A.csr_off[P.csr_pose_base + i], e = A.csr_off[P.csr_pose_base + i + 1];
+  for (int k = b + lane; k < e; k += 64) {
+    const int le = A.csr_edges[P.csr_pose_edges_base + k], ge = P.edge_base + le;
+    const uint8_t st = A.e_state[ge];
+    const int l = A.e_point[ge];
+    double* Wb = A.W + P.W_base + ((size_t)i * P.nl + l) * 18;
+    if (st & ES_LVL1) {
+#pragma unroll
+      for (int q = 0; q < 18; q++) Wb[q] = 0;
+      continue;
+    }
+    const bool mono = st & ES_MONO;
+    const double* X = A.points + (size_t)(P.point_base + l) * 3;
+    double p[3], er[3];
+    ba_error(T, P, X, A.e_obs + (size_t)ge * 3, mono, p, er);
+    const double w = (double)A.e_is2[ge];
+    const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * w;
+    A.chi2c[ge] = chi2;
+    double rho0 = chi2, rho1 = 1.0;
+    if (robust) huber(chi2, mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
+    acc[27] += rho0;
+    double Jp[3][6], Jx[3][3];
+    ba_jacobians(R, P, p, mono, Jp, Jx);
+    const double wo = rho1 * w;
+    if (pose_active) {
+      int a = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = r; c < 6; c++) { acc[a] += wo * (Jp[0][r] * Jp[0][c] + Jp[1][r] * Jp[1][c] + Jp[2][r] * Jp[2][c]); a++; }
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc[21 + r] -= wo * (Jp[0][r] * er[0] + Jp[1][r] * er[1] + Jp[2][r] * er[2]);
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Wb[r * 3 + c] = wo * (Jp[0][r] * Jx[0][c] + Jp[1][r] * Jx[1][c] + Jp[2][r] * Jx[2][c]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 18; q++) Wb[q] = 0;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 28; a++) acc[a] = wave_sum(acc[a]);
+  if (lane == 0) {
+    double* H = A.Hpp + (size_t)(P.pose_base + i) * 36;
+    int a = 0;
+    for (int r = 0; r < 6; r++)
+      for (int c = r; c < 6; c++) { H[r * 6 + c] = acc[a]; H[c * 6 + r] = acc[a]; a++; }
+    for (int r = 0; r < 6; r++) A.bp[(size_t)(P.pose_base + i) * 6 + r] = acc[21 + r];
+    A.part[P.part_base + i] = acc[27];
+  }
+}
+
+// point-major half of buildSystem: H_ll and b_l (one thread per point; the error cache is already fresh)
+__global__ __launch_bounds__(256) void ba_lin_point(BaArrays A) {
+  const BaProb P = A.prob[blockIdx.y];
+  const BaState& S = A.state[blockIdx.y];
+  if (S.phase != BA_PH_LINEARIZE) return;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= P.nl) return;
+  const bool robust = S.robust != 0;
+  const double* X = A.points + (size_t)(P.point_base + l) * 3;
+  double H[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
+  const int b = A.csr_off[P.csr_point_base + l], e = A.csr_off[P.csr_point_base + l + 1];
+  for (int k = b; k < e; k++) {
+    const int ge = P.edge_base + A.csr_edges[P.csr_point_edges_base + k];
+    const uint8_t st = A.e_state[ge];
+    if (st & ES_LVL1) continue;
+    const bool mono = st & ES_MONO;
+    const Se3 T = load_pose(A.poses + (size_t)(P.pose_base + A.e_pose[ge]) * 7);
+    double R[9], p[3], er[3], Jp[3][6], Jx[3][3];
+    se3_quat_to_R(T.q, R);
+    ba_error(T, P, X, A.e_obs + (size_t)ge * 3, mono, p, er);
+    ba_jacobians(R, P, p, mono, Jp, Jx);
+    const double w = (double)A.e_is2[ge];
+    double rho0, rho1 = 1.0;
+    if (robust) huber(A.chi2c[ge], mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
+    const double wo = rho1 * w;
+    H[0] += wo * (Jx[0][0] * Jx[0][0] + Jx[1][0] * Jx[1][0] + Jx[2][0] * Jx[2][0]);
+    H[1] += wo * (Jx[0][0] * Jx[0][1] + Jx[1][0] * Jx[1][1] + Jx[2][0] * Jx[2][1]);
+    H[2] += wo * (Jx[0][0] * Jx[0][2] + Jx[1][0] * Jx[1][2] + Jx[2][0] * Jx[2][2]);
+    H[3] += wo * (Jx[0][1] * Jx[0][1] + Jx[1][1] * Jx[1][1] + Jx[2][1] * Jx[2][1]);
+    H[4] += wo * (Jx[0][1] * Jx[0][2] + Jx[1][1] * Jx[1][2] + Jx[2][1] * Jx[2][2]);
+    H[5] += wo * (Jx[0][2] * Jx[0][2] + Jx[1][2] * Jx[1][2] + Jx[2][2] * Jx[2][2]);
+#pragma unroll
+    for (int r = 0; r < 3; r++) bb[r] -= wo * (Jx[0][r] * er[0] + Jx[1][r] * er[1] + Jx[2][r] * er[2]);
+  }
+  double* Ho = A.Hll + (size_t)(P.point_base + l) * 9;
+  Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
+  for (int r = 0; r < 3; r++) A.bl[(size_t)(P.point_base + l) * 3 + r] = bb[r];
+}
+
+// chi2 total, lambda init on the first iteration of a stage (levenberg.cpp:93-97,166-180)
+__global__ __launch_bounds__(256) void ba_post_lin(BaArrays A) {
+  const BaProb P = A.prob[blockIdx.x];
+  BaState& S = A.state[blockIdx.x];
+  if (S.phase != BA_PH_LINEARIZE) return;
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  double m = 0;
+  if (S.iter == 0) {
+    for (int a = tid; a < S.npa; a += 256) {
+      const double* H = A.Hpp + (size_t)(P.pose_base + A.pact[P.pose_base + a]) * 36;
+      for (int j = 0; j < 6; j++) m = fmax(m, fabs(H[j * 7]));
+    }
+    for (int l = tid; l < P.nl; l += 256)
+      if (A.lact[P.point_base + l]) {
+        const double* H = A.Hll + (size_t)(P.point_base + l) * 9;
+        m = fmax(m, fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8]))));
+      }
+  }
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double chi = 0;
+    for (int i = 0; i < P.np; i++) chi += A.part[P.part_base + i];   // fixed order
+    S.current_chi = chi;
+    S.ini_chi = chi;
+    if (S.iter == 0) {
+      S.lambda = 1e-5 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      S.ni = 2;
+      S.n_bad = 0;
+    }
+    S.trial = 0;
+    S.phase = BA_PH_TRIAL;
+  }
+}
+
+// D^-1 per point; b_s per active pose (block_solver.hpp:367-439)
+__global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
+  const BaProb P = A.prob[blockIdx.y];
+  const BaState& S = A.state[blockIdx.y];
+  if (S.phase != BA_PH_TRIAL) return;
+  const double lambda = S.lambda;
+  const int nbl = (P.nl + 255) / 256;
+  if ((int)blockIdx.x < nbl) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= P.nl || !A.lact[P.point_base + l]) return;
+    double D[9], Di[9];
+    const double* H = A.Hll + (size_t)(P.point_base + l) * 9;
+#pragma unroll
+    for (int q = 0; q < 9; q++) D[q] = H[q] + ((q % 4 == 0) ? lambda : 0.0);
+    inv3(D, Di);
+    double* o = A.Dinv + (size_t)(P.point_base + l) * 9;
+#pragma unroll
+    for (int q = 0; q < 9; q++) o[q] = Di[q];
+    return;
+  }
+  const int a = (blockIdx.x - nbl) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (a >= S.npa) return;
+  const int i = A.pact[P.pose_base + a];
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int l = lane; l < P.nl; l += 64) {
+    if (!A.lact[P.point_base + l]) continue;
+    double D[9], Di[9];
+    const double* H = A.Hll + (size_t)(P.point_base + l) * 9;
+#pragma unroll
+    for (int q = 0; q < 9; q++) D[q] = H[q] + ((q % 4 == 0) ? lambda : 0.0);
+    inv3(D, Di);
+    const double* b = A.bl + (size_t)(P.point_base + l) * 3;
+    const double db0 = Di[0] * b[0] + Di[1] * b[1] + Di[2] * b[2], db1 = Di[3] * b[0] + Di[4] * b[1] + Di[5] * b[2],
+                 db2 = Di[6] * b[0] + Di[7] * b[1] + Di[8] * b[2];
+    const double* Wb = A.W + P.W_base + ((size_t)i * P.nl + l) * 18;
+#pragma unroll
+    for (int r = 0; r < 6; r++) s[r] += Wb[r * 3] * db0 + Wb[r * 3 + 1] * db1 + Wb[r * 3 + 2] * db2;
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++) s[r] = wave_sum(s[r]);
+  if (lane == 0)
+    for (int r = 0; r < 6; r++) A.bs[(size_t)P.pose_base * 6 + a * 6 + r] = A.bp[(size_t)(P.pose_base + i) * 6 + r] - s[r];
+}
+
+// S(ta, tb) = [ta == tb] (H_pp + lambda I) - sum_l (W_a D_l^-1) W_b^T, lower-triangular tile pairs only
+#define SCH_LC 16
+__global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
+  const BaProb P = A.prob[blockIdx.y];
+  const BaState& St = A.state[blockIdx.y];
+  if (St.phase != BA_PH_TRIAL) return;
+  const int npa = St.npa, nt = (npa + PS_BA_TILE - 1) / PS_BA_TILE;
+  // blockIdx.x -> (ta, tb), tb <= ta
+  int ta = 0, rem = blockIdx.x;
+  while (ta < nt && rem > ta) { rem -= ta + 1; ta++; }
+  if (ta >= nt) return;
+  const int tb = rem;
+  __shared__ double As[48][SCH_LC * 3 + 1];
+  __shared__ double Bs[48][SCH_LC * 3 + 1];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int l0 = 0; l0 < P.nl; l0 += SCH_LC) {
+    __syncthreads();
+    for (int q = tid; q < 48 * SCH_LC * 3; q += 256) {
+      const int row = q / (SCH_LC * 3), col = q - row * (SCH_LC * 3);
+      const int lc = col / 3, k = col - lc * 3, l = l0 + lc;
+      const int pa = ta * PS_BA_TILE + row / 6, pb = tb * PS_BA_TILE + row / 6, r = row % 6;
+      double av = 0, bv = 0;
+      if (l < P.nl && A.lact[P.point_base + l]) {
+        if (pa < npa) {
+          const double* Wb = A.W + P.W_base + ((size_t)A.pact[P.pose_base + pa] * P.nl + l) * 18 + r * 3;
+          const double* Di = A.Dinv + (size_t)(P.point_base + l) * 9;
+          av = Wb[0] * Di[k] + Wb[1] * Di[3 + k] + Wb[2] * Di[6 + k];
+        }
+        if (pb < npa) bv = (A.W + P.W_base + ((size_t)A.pact[P.pose_base + pb] * P.nl + l) * 18)[r * 3 + k];
+      }
+      As[row][col] = av;
+      Bs[row][col] = bv;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < SCH_LC * 3; kk++) {
+      const double a0 = As[ty * 3][kk], a1 = As[ty * 3 + 1][kk], a2 = As[ty * 3 + 2][kk];
+      const double b0 = Bs[tx * 3][kk], b1 = Bs[tx * 3 + 1][kk], b2 = Bs[tx * 3 + 2][kk];
+      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2;
+      acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2;
+      acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2;
+    }
+  }
+  const int lda = 6 * P.np, n = 6 * npa;
+  double* Sm = A.S + P.S_base;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int gr = ta * 48 + ty * 3 + i, gc = tb * 48 + tx * 3 + j;
+      if (gr >= n || gc >= n) continue;
+      double h = 0;
+      if (gr / 6 == gc / 6) {
+        h = A.Hpp[(size_t)(P.pose_base + A.pact[P.pose_base + gr / 6]) * 36 + (gr % 6) * 6 + (gc % 6)];
+        if (gr == gc) h += St.lambda;
+      }
+      Sm[(size_t)gr * lda + gc] = h - acc[i][j];
+    }
+}
+
+// Blocked (6-wide) unpivoted LDL^T of the reduced system and the two triangular solves; x_p only changes
+// when the factorisation succeeds (linear_solver_eigen.h:94-120 returns false without touching x).
+#define SOL_T 1024
+__global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
+  const BaProb P = A.prob[blockIdx.x];
+  BaState& St = A.state[blockIdx.x];
+  if (St.phase != BA_PH_TRIAL) return;
+  const int n = 6 * St.npa, lda = 6 * P.np, tid = threadIdx.x;
+  double* Sm = A.S + P.S_base;
+  __shared__ double panel[PS_BA_MAX_POSES * 6][6];
+  __shared__ double rhs[PS_BA_MAX_POSES * 6];
+  __shared__ double Ljj[6][6];
+  __shared__ double dj[6];
+  __shared__ double dall[PS_BA_MAX_POSES * 6];
+  __shared__ int fail;
+  if (tid == 0) fail = 0;
+  for (int i = tid; i < n; i += SOL_T) rhs[i] = A.bs[(size_t)P.pose_base * 6 + i];
+  __syncthreads();
+  if (n == 0) { if (tid == 0) St.ok2 = 1; return; }
+  for (int J = 0; J < n; J += 6) {
+    if (tid == 0) {
+      double M[6][6];
+      for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) M[r][c] = Sm[(size_t)(J + r) * lda + J + c];
+      for (int j = 0; j < 6; j++) {
+        double d = M[j][j];
+        for (int q = 0; q < j; q++) d -= M[j][q] * M[j][q] * dj[q];
+        if (d == 0) fail = 1;
+        dj[j] = d;
+        for (int i = j + 1; i < 6; i++) {
+          double v = M[i][j];
+          for (int q = 0; q < j; q++) v -= M[i][q] * M[j][q] * dj[q];
+          M[i][j] = v / d;
+        }
+      }
+      for (int r = 0; r < 6; r++) {
+        for (int c = 0; c < 6; c++) Ljj[r][c] = c < r ? M[r][c] : (c == r ? 1.0 : 0.0);
+        dall[J + r] = dj[r];
+        for (int c = 0; c < r; c++) Sm[(size_t)(J + r) * lda + J + c] = M[r][c];
+      }
+    }
+    __syncthreads();
+    if (fail) break;
+    const int m0 = J + 6;
+    for (int i = m0 + tid; i < n; i += SOL_T) {
+      double Lr[6];
+      for (int c = 0; c < 6; c++) {
+        double v = Sm[(size_t)i * lda + J + c];
+        for (int q = 0; q < c; q++) v -= Lr[q] * dj[q] * Ljj[c][q];
+        Lr[c] = v / dj[c];
+      }
+      for (int c = 0; c < 6; c++) { Sm[(size_t)i * lda + J + c] = Lr[c]; panel[i][c] = Lr[c]; }
+    }
+    __syncthreads();
+    const int m = n - m0;
+    for (int q = tid; q < m * m; q += SOL_T) {
+      const int i = m0 + q / m, k = m0 + q % m;
+      if (k > i) continue;
+      double v = 0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) v += panel[i][c] * dj[c] * panel[k][c];
+      Sm[(size_t)i * lda + k] -= v;
+    }
+    __syncthreads();
+  }
+  if (fail) { if (tid == 0) St.ok2 = 0; return; }
+  // forward substitution L y = b, blocked
+  for (int J = 0; J < n; J += 6) {
+    if (tid == 0)
+      for (int r = 1; r < 6; r++) {
+        double v = rhs[J + r];
+        for (int c = 0; c < r; c++) v -= Sm[(size_t)(J + r) * lda + J + c] * rhs[J + c];
+        rhs[J + r] = v;
+      }
+    __syncthreads();
+    for (int i = J + 6 + tid; i < n; i += SOL_T) {
+      double v = rhs[i];
+#pragma unroll
+      for (int c = 0; c < 6; c++) v -= Sm[(size_t)i * lda + J + c] * rhs[J + c];
+      rhs[i] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += SOL_T) rhs[i] /= dall[i];
+  __syncthreads();
+  // backward substitution L^T x = z, blocked
+  for (int J = n - 6; J >= 0; J -= 6) {
+    if (tid == 0)
+      for (int r = 4; r >= 0; r--) {
+        double v = rhs[J + r];
+        for (int c = r + 1; c < 6; c++) v -= Sm[(size_t)(J + c) * lda + J + r] * rhs[J + c];
+        rhs[J + r] = v;
+      }
+    __syncthreads();
+    for (int k = tid; k < J; k += SOL_T) {
+      double v = rhs[k];
+#pragma unroll
+      for (int c = 0; c < 6; c++) v -= Sm[(size_t)(J + c) * lda + k] * rhs[J + c];
+      rhs[k] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += SOL_T) A.xp[(size_t)P.pose_base * 6 + i] = rhs[i];
+  if (tid == 0) St.ok2 = 1;
+}
+
+// x_l, push (backup) + oplus on every active vertex, partial sums of x . (lambda x + b)
+__global__ __launch_bounds__(256) void ba_update(BaArrays A) {
+  const BaProb P = A.prob[blockIdx.y];
+  const BaState& S = A.state[blockIdx.y];
+  if (S.phase != BA_PH_TRIAL) return;
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int nbl = (P.nl + 255) / 256;
+  const double lambda = S.lambda;
+  double sc = 0;
+  if ((int)blockIdx.x < nbl) {
+    const int l = blockIdx.x * 256 + tid;
+    if (l < P.nl) {
+      double* X = A.points + (size_t)(P.point_base + l) * 3;
+      double* Xb = A.points_bak + (size_t)(P.point_base + l) * 3;
+      Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
+      if (A.lact[P.point_base + l]) {
+        double* xl = A.xl + (size_t)(P.point_base + l) * 3;
+        const double* b = A.bl + (size_t)(P.point_base + l) * 3;
+        if (S.ok2) {
+          double c[3] = {b[0], b[1], b[2]};
+          for (int a = 0; a < S.npa; a++) {
+            const double* Wb = A.W + P.W_base + ((size_t)A.pact[P.pose_base + a] * P.nl + l) * 18;
+            const double* xp = A.xp + (size_t)P.pose_base * 6 + a * 6;
+#pragma unroll
+            for (int r = 0; r < 6; r++) { c[0] -= Wb[r * 3] * xp[r]; c[1] -= Wb[r * 3 + 1] * xp[r]; c[2] -= Wb[r * 3 + 2] * xp[r]; }
+          }
+          const double* Di = A.Dinv + (size_t)(P.point_base + l) * 9;
+          xl[0] = Di[0] * c[0] + Di[1] * c[1] + Di[2] * c[2];
+          xl[1] = Di[3] * c[0] + Di[4] * c[1] + Di[5] * c[2];
+          xl[2] = Di[6] * c[0] + Di[7] * c[1] + Di[8] * c[2];
+        }
+        X[0] += xl[0]; X[1] += xl[1]; X[2] += xl[2];
+        sc = xl[0] * (lambda * xl[0] + b[0]) + xl[1] * (lambda * xl[1] + b[1]) + xl[2] * (lambda * xl[2] + b[2]);
+      }
+    }
+  } else {
+    const int i = (blockIdx.x - nbl) * 256 + tid;
+    if (i < P.np) {
+      double* pp = A.poses + (size_t)(P.pose_base + i) * 7;
+      double* pb = A.poses_bak + (size_t)(P.pose_base + i) * 7;
+      for (int q = 0; q < 7; q++) pb[q] = pp[q];
+      const int a = A.pidx[P.pose_base + i];
+      if (a >= 0) {
+        const double* xp = A.xp + (size_t)P.pose_base * 6 + a * 6;
+        const double* b = A.bp + (size_t)(P.pose_base + i) * 6;
+        double u[6] = {xp[0], xp[1], xp[2], xp[3], xp[4], xp[5]};
+        for (int r = 0; r < 6; r++) sc += u[r] * (lambda * u[r] + b[r]);
+        const bool nrp = (A.pose_flags[P.pose_base + i] >> 1) & 1;
+        if (nrp) { u[0] = 0; u[1] = 0; }   // VertexSE3Fix::oplusImpl, whether_fixrollpitch (g2o_Object.cc:190-213)
+        store_pose(pp, se3_mul(se3_exp(u, nrp), load_pose(pp)));
+      }
+    }
+  }
+  sc = wave_sum(sc);
+  if ((tid & 63) == 0) red[tid >> 6] = sc;
+  __syncthreads();
+  if (tid == 0) A.part[P.part_base + P.np + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// computeActiveErrors + activeRobustChi2 at the trial estimate
+__global__ __launch_bounds__(256) void ba_error_k(BaArrays A, int err_part_off) {
+  const BaProb P = A.prob[blockIdx.y];
+  const BaState& S = A.state[blockIdx.y];
+  if (S.phase != BA_PH_TRIAL) return;
+  __shared__ double red[4];
+  const int tid = threadIdx.x, e = blockIdx.x * 256 + tid;
+  double chi = 0;
+  if (e < P.ne) {
+    const int ge = P.edge_base + e;
+    const uint8_t st = A.e_state[ge];
+    if (!(st & ES_LVL1)) {
+      const bool mono = st & ES_MONO;
+      const Se3 T = load_pose(A.poses + (size_t)(P.pose_base + A.e_pose[ge]) * 7);
+      double p[3], er[3];
+      ba_error(T, P, A.points + (size_t)(P.point_base + A.e_point[ge]) * 3, A.e_obs + (size_t)ge * 3, mono, p, er);
+      const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * (double)A.e_is2[ge];
+      A.chi2c[ge] = chi2;
+      double rho0 = chi2, rho1;
+      if (S.robust) huber(chi2, mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
+      chi = rho0;
+    }
+  }
+  chi = wave_sum(chi);
+  if ((tid & 63) == 0) red[tid >> 6] = chi;
+  __syncthreads();
+  if (tid == 0) A.part[P.part_base + err_part_off + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// gain ratio, lambda schedule, accept / pop, iteration and stage control (levenberg.cpp:121-161)
+__global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
+  const BaProb P = A.prob[blockIdx.x];
+  BaState& S = A.state[blockIdx.x];
+  if (S.phase != BA_PH_TRIAL) return;
+  __shared__ int s_restore;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    const int nbl = (P.nl + 255) / 256, nbp = (P.np + 255) / 256, nbe = (P.ne + 255) / 256;
+    double scale = 0, temp = 0;
+    for (int b = 0; b < nbl + nbp; b++) scale += A.part[P.part_base + P.np + b];
+    for (int b = 0; b < nbe; b++) temp += A.part[P.part_base + err_part_off + b];
+    if (!S.ok2) temp = DBL_MAX;
+    double rho = (S.current_chi - temp) / (scale + 1e-3);
+    int restore = 0;
+    if (rho > 0 && isfinite(temp)) {
+      double alpha = 1. - pow((2 * rho - 1), 3);
+      alpha = fmin(alpha, 2. / 3.);
+      S.lambda *= fmax(1. / 3., alpha);
+      S.ni = 2;
+      S.current_chi = temp;
+    } else {
+      S.lambda *= S.ni;
+      S.ni *= 2;
+      restore = 1;
+    }
+    S.rho = rho;
+    S.trial++;
+    S.trials_done++;
+    s_restore = restore;
+    if (!(rho < 0 && S.trial < 10)) {   // the iteration is over
+      if (S.ntrace < PS_BA_TRACE) {
+        double* tr = A.trace + ((size_t)blockIdx.x * PS_BA_TRACE + S.ntrace) * 3;
+        tr[0] = S.current_chi; tr[1] = S.lambda; tr[2] = S.trial;
+      }
+      S.ntrace++;
+      S.iters_done++;
+      bool terminate = (S.trial == 10 || rho == 0);
+      if (!terminate) {
+        if ((S.ini_chi - S.current_chi) * 1e3 < S.ini_chi) S.n_bad++; else S.n_bad = 0;
+        if (S.n_bad >= 3) terminate = true;
+      }
+      S.iter++;
+      if (terminate || S.iter >= S.max_iter) { S.stage++; S.phase = BA_PH_BEGIN; }
+      else S.phase = BA_PH_LINEARIZE;
+    }
+  }
+  __syncthreads();
+  if (s_restore) {   // _optimizer->pop()
+    for (int q = tid; q < P.np * 7; q += 256) A.poses[(size_t)P.pose_base * 7 + q] = A.poses_bak[(size_t)P.pose_base * 7 + q];
+    for (int q = tid; q < P.nl * 3; q += 256) A.points[(size_t)P.point_base * 3 + q] = A.points_bak[(size_t)P.point_base * 3 + q];
+  }
+}
+
+}  // namespace
+
+// one "global step": every unfinished problem advances by one LM trial (plus linearisation / stage entry
+// when it is due).  max_* are maxima over the batch.
+extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int max_nl, int max_ne, int max_tilepairs,
+                                   hipStream_t st) {
+  const int nbl = (max_nl + 255) / 256, nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
+  const int err_off = max_np + nbl + nbp;   // layout of `part`: [np chi partials][update partials][error partials]
+  hipLaunchKernelGGL(ba_begin, dim3(nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_lin_pose, dim3((max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_lin_point, dim3(nbl, nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_post_lin, dim3(nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_prep, dim3(nbl + (max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_solve, dim3(nprob), dim3(SOL_T), 0, st, *A);
+  hipLaunchKernelGGL(ba_update, dim3(nbl + nbp, nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_error_k, dim3(nbe, nprob), dim3(256), 0, st, *A, err_off);
+  hipLaunchKernelGGL(ba_decide, dim3(nprob), dim3(256), 0, st, *A, err_off);
+}
+// the stage-2 pass of ba_begin (erase list) needs one more launch once every problem left its last trial
+extern "C" void psk_ba_finalize(const BaArrays* A, int nprob, hipStream_t st) {
+  hipLaunchKernelGGL(ba_begin, dim3(nprob), dim3(256), 0, st, *A);
+}

@@ -1,0 +1,38 @@
+// Device-side descriptors of the object bundle adjustment (Optimizer::ObjectLocalBundleAdjustment,
+// /root/reference/src/Optimizer.cc:755-1075).  One BaProb per object graph; all problems of a batch
+// advance through the same kernel sequence, each according to its own BaState.
+#pragma once
+#include <stdint.h>
+
+#define PS_BA_TILE 8          // poses per Schur tile edge (48 x 48 scalars)
+#define PS_BA_TRACE 40        // LM iterations recorded per problem
+#define PS_BA_MAX_POSES 128   // FREE poses per problem (the LDL^T panel of the reduced system lives in LDS)
+
+enum { BA_PH_BEGIN = 0, BA_PH_LINEARIZE = 1, BA_PH_TRIAL = 2, BA_PH_DONE = 3 };
+
+struct BaProb {
+  int32_t np, nl, ne;               // poses (free + fixed), points, edges
+  int32_t pose_base, point_base, edge_base;   // element offsets into the batch-wide arrays
+  int32_t csr_pose_base;            // into csr_off[]: np + 1 entries; edge ids (problem-local) in csr_pose_edges
+  int32_t csr_point_base;           // nl + 1 entries
+  int32_t csr_pose_edges_base, csr_point_edges_base;   // into the int32 edge-id lists (ne entries each)
+  int64_t W_base;                   // doubles: [np][nl][18]  (6x3 blocks, row-major)
+  int64_t S_base;                   // doubles: [6 np][6 np]  (lower triangle used), lda = 6 * np
+  int32_t part_base;                // doubles: per-block partial sums, `part_cap` entries
+  int32_t part_cap;
+  float fx, fy, cx, cy, bf;
+};
+
+struct BaState {
+  int32_t stage;        // 0: optimize(5) on all edges, 1: optimize(10) on the inliers, 2: finished
+  int32_t phase;
+  int32_t iter, max_iter, trial, n_bad;
+  int32_t npa, nla;     // active poses / points of the current stage
+  int32_t robust;       // Huber on (stage 0) / off
+  int32_t ok2;
+  int32_t ntrace;
+  int32_t iters_done;   // LM iterations executed over both stages (for ms/iter reporting)
+  int32_t trials_done;
+  int32_t pad;
+  double lambda, ni, current_chi, ini_chi, rho;
+};

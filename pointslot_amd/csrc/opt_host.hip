@@ -12,7 +12,10 @@
 extern "C" void psk_pose_lm_launch(const PoProb*, int, const PoVertex*, const float*, const float*, const float*,
                                    const uint8_t*, uint8_t*, double*, uint8_t*, double*, int32_t*, double*, hipStream_t);
 
+struct BaCtx { uint8_t* d_buf = nullptr; size_t d_bytes = 0; uint8_t* h_buf = nullptr; size_t h_bytes = 0; };
+
 struct ps_optimizer {
+  BaCtx ba;
   int device = 0;
   hipStream_t stream = nullptr;
   uint8_t* d_buf = nullptr; size_t d_bytes = 0;
@@ -152,8 +155,16 @@ void ps_optimizer_destroy(ps_optimizer* m) {
   if (m->ev1) hipEventDestroy(m->ev1);
   if (m->d_buf) hipFree(m->d_buf);
   if (m->h_buf) hipHostFree(m->h_buf);
+  if (m->ba.d_buf) hipFree(m->ba.d_buf);
+  if (m->ba.h_buf) hipHostFree(m->ba.h_buf);
   delete m;
 }
+
+// accessors for ba_host.hip
+int psi_optimizer_device(ps_optimizer* m) { return m->device; }
+hipStream_t psi_optimizer_stream(ps_optimizer* m) { return m->stream; }
+BaCtx* psi_optimizer_ba_ctx(ps_optimizer* m) { return &m->ba; }
+void psi_optimizer_set_ms(ps_optimizer* m, float ms) { m->last_kernel_ms = ms; }
 
 int ps_optimizer_last_kernel_ms(const ps_optimizer* m, float* ms) {
   if (!m || !ms) return ps_set_error(PS_ERR_INVALID, "null argument");

@@ -22,6 +22,16 @@ class _Cfse3Problem(ctypes.Structure):
                 ("outlier", ctypes.c_void_p), ("result", ctypes.c_int32)]
 
 
+class _BaProblem(ctypes.Structure):
+    _fields_ = [("np", ctypes.c_int32), ("nl", ctypes.c_int32), ("ne", ctypes.c_int32), ("poses7", ctypes.c_void_p),
+                ("pose_flags", ctypes.c_void_p), ("points", ctypes.c_void_p), ("e_pose", ctypes.c_void_p),
+                ("e_point", ctypes.c_void_p), ("e_obs", ctypes.c_void_p), ("e_inv_sigma2", ctypes.c_void_p),
+                ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float),
+                ("bf", ctypes.c_float), ("erase", ctypes.c_void_p), ("n_erased", ctypes.c_int32),
+                ("iterations", ctypes.c_int32), ("trials", ctypes.c_int32), ("n_trace", ctypes.c_int32),
+                ("trace", ctypes.c_void_p)]
+
+
 lib.ps_optimizer_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
 lib.ps_optimizer_destroy.argtypes = [ctypes.c_void_p]
 lib.ps_optimizer_destroy.restype = None
@@ -30,6 +40,7 @@ lib.ps_optimizer_enable_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.ps_optimizer_get_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 lib.ps_pose_optimize_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_PoseProblem), ctypes.c_int]
 lib.ps_cfse3_optimize_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Cfse3Problem), ctypes.c_int]
+lib.ps_object_ba_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_BaProblem), ctypes.c_int]
 lib.ps_se3_from_mat4f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.ps_se3_to_mat4f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 
@@ -126,4 +137,33 @@ class Optimizer:
             off, _, _, _, _, poses, outl = keep[i]
             k = len(f["objs"])
             out.append((arr[i].result, poses[:k].copy(), [outl[off[j]:off[j + 1]].copy() for j in range(k)]))
+        return out
+
+    def ObjectLocalBundleAdjustment(self, graphs):
+        """graphs: list of dicts {poses [np,7], pose_flags [np], points [nl,3], e_pose, e_point, e_obs [ne,3],
+        e_inv_sigma2 [ne], K} (one collected graph per object).  Returns a list of dicts
+        {poses, points, erase, n_erased, iterations, trials, trace}."""
+        n = len(graphs)
+        arr = (_BaProblem * n)()
+        keep = []
+        for i, g in enumerate(graphs):
+            poses = np.ascontiguousarray(g["poses"], np.float64).copy(); pts = np.ascontiguousarray(g["points"], np.float64).copy()
+            flags = np.ascontiguousarray(g["pose_flags"], np.uint8)
+            ep = np.ascontiguousarray(g["e_pose"], np.int32); el = np.ascontiguousarray(g["e_point"], np.int32)
+            eo = np.ascontiguousarray(g["e_obs"], np.float32); ei = np.ascontiguousarray(g["e_inv_sigma2"], np.float32)
+            erase = np.zeros(max(len(ep), 1), np.uint8); trace = np.zeros((40, 3))
+            keep.append((poses, pts, flags, ep, el, eo, ei, erase, trace))
+            K = [float(v) for v in g["K"]]
+            p = arr[i]
+            p.np, p.nl, p.ne = len(poses), len(pts), len(ep)
+            p.poses7 = poses.ctypes.data; p.pose_flags = flags.ctypes.data; p.points = pts.ctypes.data
+            p.e_pose = ep.ctypes.data; p.e_point = el.ctypes.data; p.e_obs = eo.ctypes.data; p.e_inv_sigma2 = ei.ctypes.data
+            p.fx, p.fy, p.cx, p.cy, p.bf = K
+            p.erase = erase.ctypes.data; p.trace = trace.ctypes.data
+        check(lib.ps_object_ba_batch(self._h, arr, n))
+        out = []
+        for i in range(n):
+            poses, pts, _, ep, _, _, _, erase, trace = keep[i]
+            out.append({"poses": poses, "points": pts, "erase": erase[:len(ep)].copy(), "n_erased": arr[i].n_erased,
+                        "iterations": arr[i].iterations, "trials": arr[i].trials, "trace": trace[:arr[i].n_trace].copy()})
         return out

@@ -91,3 +91,42 @@ def test_cfse3_batch(opt):
         for j in range(len(f["objs"])):
             assert np.array_equal(outls[j], oo[j]), (i, j)
             assert _pose_err(_mat(poses[j]), _mat(po[j])) <= POSE_TOL, (i, j)
+
+
+def _ba_check(g, r, tag):
+    n, po, pt, er, tr = oracle_lib.object_ba(g)
+    assert len(r["trace"]) == len(tr), (tag, len(r["trace"]), len(tr))
+    assert np.array_equal(r["trace"][:, 2], tr[:, 2]), (tag, r["trace"][:, 2], tr[:, 2])      # damping trials per iteration
+    assert np.allclose(r["trace"][:, 0], tr[:, 0], rtol=1e-8), (tag, r["trace"][:, 0], tr[:, 0])
+    assert np.array_equal(r["erase"], er), (tag, int((r["erase"] != er).sum()))
+    assert r["n_erased"] == n
+    for a, b in zip(r["poses"], po):
+        assert _pose_err(_mat(a), _mat(b)) <= POSE_TOL, tag
+    scale = max(1.0, np.abs(pt).max())
+    assert np.abs(r["points"] - pt).max() <= 1e-6 * scale, tag
+
+
+def test_object_ba_small_and_realistic(opt):
+    graphs = [
+        synth.object_ba_problem(0x51070044, n_kf=5, n_pts=14, p_vis=0.8, outlier_frac=0.0, mono_frac=0.2,
+                                perturb=(0.1, 2.0, 0.05), perturb_axis="z", n_fixed_extra=1),
+        synth.object_ba_problem(0x51070045, n_kf=12, n_pts=100, p_vis=0.6, perturb=(0.05, 1.0, 0.02), perturb_axis="z", n_fixed_extra=8),
+        synth.object_ba_problem(0x51070046, n_kf=12, n_pts=60, p_vis=0.7, perturb_axis="z"),
+        synth.object_ba_problem(0x51070047, n_kf=9, n_pts=33, p_vis=0.5, perturb_axis="y", mono_frac=0.3),
+    ]
+    full = synth.object_ba_problem(0x51070048, n_kf=8, n_pts=40, p_vis=0.8, noise=0.0, outlier_frac=0.0)
+    full["pose_flags"] = np.where(full["pose_flags"] & 1, full["pose_flags"], 0).astype(np.uint8)   # plain SE3 vertices
+    graphs.append(full)
+    res = opt.ObjectLocalBundleAdjustment(graphs)
+    for i, (g, r) in enumerate(zip(graphs, res)):
+        _ba_check(g, r, "graph %d" % i)
+
+
+def test_object_ba_config4_shape(opt):
+    """BASELINE config 4: 50 object keyframes x 300 points, p = 1.0 (15 000 edges) and p = 0.6."""
+    graphs = [synth.object_ba_problem(0x51070004, perturb=(0.05, 1.0, 0.02), perturb_axis="z"),
+              synth.object_ba_problem(0x51070005, p_vis=0.6, perturb=(0.05, 1.0, 0.02), perturb_axis="z")]
+    res = opt.ObjectLocalBundleAdjustment(graphs)
+    for i, (g, r) in enumerate(zip(graphs, res)):
+        _ba_check(g, r, "config4 %d" % i)
+    print("config-4 BA: %d + %d LM iterations, %.3f ms GPU" % (res[0]["iterations"], res[1]["iterations"], opt.last_kernel_ms()))
