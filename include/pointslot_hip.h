@@ -144,6 +144,55 @@ typedef struct ps_bf_problem {
 } ps_bf_problem;
 int ps_match_bruteforce(ps_matcher* m, ps_bf_problem* probs, int nprob, float nn_ratio, int check_orientation);
 
+/* The three ORBmatcher::SearchByProjection overloads as one windowed-matching call, batched:
+ *   frame_mode = 1 : SearchByProjection(CurrentFrame, LastFrame, th, bMono)              (ORBmatcher.cc:1613-1756)
+ *   frame_mode = 0 : SearchByProjection(F, vpMapPoints, th)                              (:68-155)  and
+ *                    SearchByProjection(F, nOrder, vpMapObjectPoints, th) (use_bbox = 1) (:157-248)
+ * `train` is the frame being matched INTO (CurrentFrame / F, or one object's feature set of it):
+ *   x, y, octave, angle : mvKeysUn (mvObjKeysUn[nOrder]);  u_right : mvuRight;  desc : mDescriptors rows
+ *   occupied[j] : 1 iff mvpMapPoints[j] is non-null AND has Observations() > 0 (the reference's skip test)
+ *   in_bbox[j]  : Frame::isInBBox(nOrder, x, y) (object variant only)
+ *   cell_off / cell_idx : mGrid as CSR, cell = ix * 48 + iy (FRAME_GRID_ROWS), indices in insertion order
+ *   min_x, min_y, grid_w_inv, grid_h_inv : mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv
+ * Queries are the points being projected, in the reference's loop order:
+ *   q_valid    : frame mode: mvpMapPoints[i] && !mvbOutlier[i] of the LAST frame; else mbTrackInView && !isBad()
+ *   q_desc     : pMP->GetDescriptor();   q_observed[i] : pMP->Observations() > 0
+ *   frame mode : q_xw = GetWorldPos, q_octave = LastFrame.mvKeys[i].octave, q_angle = LastFrame.mvKeysUn[i].angle,
+ *                tcw / tlw = CurrentFrame.mTcw / LastFrame.mTcw, fx..mb, bounds = mnMinX,mnMaxX,mnMinY,mnMaxY,
+ *                scale_factors = mvScaleFactors, th, mono
+ *   otherwise  : q_u, q_v, q_ur = mTrackProjX, mTrackProjY, mTrackProjXR; q_radius = window half-size
+ *                (r * scaleFactor[level], or 5 for objects); q_radius_er = r * scaleFactor[level] (uR gate);
+ *                q_min_level / q_max_level = level-1 / level (level+1 for objects)
+ * th_dist = TH_HIGH (100) or TH_HIGH_FORDYNAMIC (130); ratio_test/nn_ratio = the same-level mfNNratio test;
+ * check_orientation = mbCheckOrientation (frame mode).
+ *   match_of_train[j] : out, index of the query assigned to slot j, -1 where the call leaves the slot alone / NULL
+ *   nmatches          : out, the return value */
+typedef struct ps_proj_train {
+  int32_t n;
+  const float* x; const float* y; const int32_t* octave; const float* angle; const float* u_right; const uint8_t* desc;
+  const uint8_t* occupied; const uint8_t* in_bbox;
+  const int32_t* cell_off; const int32_t* cell_idx;
+  float min_x, min_y, grid_w_inv, grid_h_inv;
+} ps_proj_train;
+typedef struct ps_proj_problem {
+  ps_proj_train train;
+  int32_t nq;
+  const uint8_t* q_valid; const uint8_t* q_desc; const uint8_t* q_observed; const float* q_angle;
+  const float* q_u; const float* q_v; const float* q_ur; const float* q_radius; const float* q_radius_er;
+  const int32_t* q_min_level; const int32_t* q_max_level;
+  const float* q_xw; const int32_t* q_octave;
+  int32_t frame_mode, mono;
+  float tcw[16], tlw[16];
+  float fx, fy, cx, cy, mbf, mb;
+  float bounds[4];
+  float scale_factors[8];
+  float th;
+  int32_t th_dist, ratio_test; float nn_ratio; int32_t check_orientation, use_bbox;
+  int32_t* match_of_train;
+  int32_t nmatches;
+} ps_proj_problem;
+int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser — replaces the hot static members of ORB_SLAM2::Optimizer
  * (/root/reference/include/Optimizer.h:51-61, src/Optimizer.cc:249-1075) and the g2o solver stack they

@@ -10,6 +10,7 @@
 // (Hamming(a,a)=0, Hamming(a,~a)=256, popcount identities) in tests/test_oracle_match.py.
 // Inputs are the plain arrays a caller extracts from Frame / MapPoint objects (SoA), outputs are index
 // arrays standing in for the pointer vectors the reference fills.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -94,6 +95,164 @@ int orc_search_bruteforce(const uint8_t* qd, const float* qang, const uint8_t* q
     for (int i = 0; i < HISTO_LENGTH; i++) {
       if (i == ind1 || i == ind2 || i == ind3) continue;
       for (int idx : rotHist[i]) { query_of_train[idx] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+
+// ---- grid helpers (Frame.cc:1808-1861 GetFeaturesInArea; cells hold indices in insertion order) ----
+struct OrcTrain {
+  int n; const float* x; const float* y; const int* octave; const float* angle; const float* u_right;
+  const uint8_t* desc; const uint8_t* occupied; const uint8_t* in_bbox; const int* cell_off; const int* cell_idx;
+  float min_x, min_y, gw_inv, gh_inv;
+};
+static std::vector<int> features_in_area(const OrcTrain& F, float x, float y, float r, int minLevel, int maxLevel) {
+  std::vector<int> v;
+  const int COLS = 64, ROWS = 48;
+  const int nMinCellX = std::max(0, (int)std::floor((x - F.min_x - r) * F.gw_inv));
+  if (nMinCellX >= COLS) return v;
+  const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - F.min_x + r) * F.gw_inv));
+  if (nMaxCellX < 0) return v;
+  const int nMinCellY = std::max(0, (int)std::floor((y - F.min_y - r) * F.gh_inv));
+  if (nMinCellY >= ROWS) return v;
+  const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - F.min_y + r) * F.gh_inv));
+  if (nMaxCellY < 0) return v;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+    for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+      const int c = ix * ROWS + iy;
+      for (int k = F.cell_off[c]; k < F.cell_off[c + 1]; k++) {
+        const int j = F.cell_idx[k];
+        if (bCheckLevels) {
+          if (F.octave[j] < minLevel) continue;
+          if (maxLevel >= 0 && F.octave[j] > maxLevel) continue;
+        }
+        const float distx = F.x[j] - x, disty = F.y[j] - y;
+        if (std::fabs(distx) < r && std::fabs(disty) < r) v.push_back(j);
+      }
+    }
+  return v;
+}
+
+// SearchByProjection(CurrentFrame, LastFrame, th, bMono), ORBmatcher.cc:1613-1756.
+//   last-frame side: xw [m][3] (MapPoint::GetWorldPos), valid[i] = mvpMapPoints[i] && !mvbOutlier[i],
+//   l_octave = mvKeys[i].octave, l_angle = mvKeysUn[i].angle, desc = pMP->GetDescriptor(), observed[i] = Observations()>0
+//   tcw / tlw: float 4x4 row-major poses of the current / last frame; K = fx,fy,cx,cy,mbf,mb; bounds mnMinX..mnMaxY
+// match_of_train[j] = index i of the last-frame point assigned to current keypoint j, -1 = unchanged/NULL.
+int orc_search_projection_frame(const OrcTrain* F, int m, const float* xw, const uint8_t* valid, const int* l_octave,
+                                const float* l_angle, const uint8_t* desc, const uint8_t* observed, const float* tcw,
+                                const float* tlw, const float* K6, const float* bounds4, const float* scale_factors,
+                                float th, int bMono, int check_ori, int* match_of_train) {
+  for (int j = 0; j < F->n; j++) match_of_train[j] = -1;
+  std::vector<uint8_t> blocked(F->occupied, F->occupied + F->n);
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = HISTO_LENGTH / 360.0f;
+  const float fx = K6[0], fy = K6[1], cx = K6[2], cy = K6[3], mbf = K6[4], mb = K6[5];
+  // cv::Mat float algebra: products accumulate in double (cv::gemm), results are float
+  auto mul3 = [](const float* R, const float* v, float* o) {   // R: rows of a 4x4
+    for (int r = 0; r < 3; r++) o[r] = (float)((double)R[r * 4] * v[0] + (double)R[r * 4 + 1] * v[1] + (double)R[r * 4 + 2] * v[2]);
+  };
+  float twc[3], tlc[3];
+  {  // twc = -Rcw.t()*tcw ; tlc = Rlw*twc + tlw
+    float t[3] = {tcw[3], tcw[7], tcw[11]};
+    for (int r = 0; r < 3; r++) twc[r] = (float)(-((double)tcw[r] * t[0] + (double)tcw[4 + r] * t[1] + (double)tcw[8 + r] * t[2]));
+    float o[3];
+    mul3(tlw, twc, o);
+    tlc[0] = o[0] + tlw[3]; tlc[1] = o[1] + tlw[7]; tlc[2] = o[2] + tlw[11];
+  }
+  const bool bForward = tlc[2] > mb && !bMono;
+  const bool bBackward = -tlc[2] > mb && !bMono;
+  for (int i = 0; i < m; i++) {
+    if (!valid[i]) continue;
+    float x3Dc[3];
+    mul3(tcw, xw + 3 * i, x3Dc);
+    x3Dc[0] += tcw[3]; x3Dc[1] += tcw[7]; x3Dc[2] += tcw[11];
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = (float)(1.0 / x3Dc[2]);
+    if (invzc < 0) continue;
+    float u = fx * xc * invzc + cx, v = fy * yc * invzc + cy;
+    if (u < bounds4[0] || u > bounds4[1]) continue;
+    if (v < bounds4[2] || v > bounds4[3]) continue;
+    const int nLastOctave = l_octave[i];
+    const float radius = th * scale_factors[nLastOctave];
+    std::vector<int> vIndices2;
+    if (bForward) vIndices2 = features_in_area(*F, u, v, radius, nLastOctave, -1);
+    else if (bBackward) vIndices2 = features_in_area(*F, u, v, radius, 0, nLastOctave);
+    else vIndices2 = features_in_area(*F, u, v, radius, nLastOctave - 1, nLastOctave + 1);
+    if (vIndices2.empty()) continue;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (blocked[i2]) continue;
+      if (F->u_right[i2] > 0) {
+        const float ur = u - mbf * invzc;
+        const float er = std::fabs(ur - F->u_right[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = descriptor_distance(desc + 32 * i, F->desc + 32 * i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      match_of_train[bestIdx2] = i;
+      if (observed[i]) blocked[bestIdx2] = 1;
+      nmatches++;
+      if (check_ori) {
+        float rot = l_angle[i] - F->angle[bestIdx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) { match_of_train[idx] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
+// SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:68-155) and SearchByProjection(F, nOrder, MOPs, th)
+// (:157-248, object = 1).  Query side = the fields Frame::isInFrustum leaves in each point:
+//   valid = mbTrackInView && !isBad(), proj_x/y/xr = mTrackProjX/Y/XR, level = mnTrackScaleLevel, view_cos
+int orc_search_projection_points(const OrcTrain* F, int m, const uint8_t* valid, const float* proj_x, const float* proj_y,
+                                 const float* proj_xr, const int* level, const float* view_cos, const uint8_t* desc,
+                                 const uint8_t* observed, const float* scale_factors, float th, float nnratio,
+                                 int object, int* match_of_train) {
+  for (int j = 0; j < F->n; j++) match_of_train[j] = -1;
+  std::vector<uint8_t> blocked(F->occupied, F->occupied + F->n);
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  for (int i = 0; i < m; i++) {
+    if (!valid[i]) continue;
+    const int nPredictedLevel = level[i];
+    float r = view_cos[i] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos
+    if (bFactor) r *= th;
+    const std::vector<int> vIndices = object
+        ? features_in_area(*F, proj_x[i], proj_y[i], 5, nPredictedLevel - 1, nPredictedLevel + 1)
+        : features_in_area(*F, proj_x[i], proj_y[i], r * scale_factors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+    if (vIndices.empty()) continue;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (object && !F->in_bbox[idx]) continue;
+      if (blocked[idx]) continue;
+      if (F->u_right[idx] > 0) {
+        const float er = std::fabs(proj_xr[i] - F->u_right[idx]);
+        if (er > r * scale_factors[nPredictedLevel]) continue;
+      }
+      const int dist = descriptor_distance(desc + 32 * i, F->desc + 32 * idx);
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F->octave[idx]; bestIdx = idx; }
+      else if (dist < bestDist2) { bestLevel2 = F->octave[idx]; bestDist2 = dist; }
+    }
+    if (bestDist <= (object ? 130 : TH_HIGH)) {
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      match_of_train[bestIdx] = i;
+      if (observed[i]) blocked[bestIdx] = 1;
+      nmatches++;
     }
   }
   return nmatches;

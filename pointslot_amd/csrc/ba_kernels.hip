@@ -23,18 +23,7 @@
 #include "ba_plan.h"
 #include "se3.h"
 
-struct BaArrays {
-  const BaProb* prob;
-  BaState* state;
-  double* poses; double* poses_bak; const uint8_t* pose_flags; int32_t* pidx; int32_t* pact;
-  double* points; double* points_bak; uint8_t* lact;
-  const int32_t* e_pose; const int32_t* e_point; const float* e_obs; const float* e_is2;
-  uint8_t* e_state; double* chi2c; uint8_t* erase;
-  const int32_t* csr_off; const int32_t* csr_edges;
-  double* Hpp; double* bp; double* Hll; double* bl; double* Dinv; double* bs; double* xp; double* xl;
-  double* W; double* S; double* part; double* trace;
-  int32_t* ndone;
-};
+
 
 namespace {
 

@@ -11,6 +11,7 @@ extern "C" {
 void psk_bf_launch(const BfBlock*, int, const BfProb*, int, const uint8_t*, const float*, const uint8_t*, const uint8_t*,
                    const float*, uint32_t*, int32_t*, int32_t*, float, int, hipStream_t);
 void psk_hamming_matrix_launch(const uint8_t*, int, const uint8_t*, int, uint16_t*, hipStream_t);
+void psk_pj_launch(const PjArrays*, int, int, int, hipStream_t);
 }
 
 struct ps_matcher {
@@ -145,6 +146,114 @@ int ps_match_bruteforce(ps_matcher* m, ps_bf_problem* probs, int nprob, float nn
     ps_bf_problem& P = probs[p];
     if (P.nt > 0) memcpy(P.query_of_train, H + o_out + (size_t)dp[p].t_off * 4, (size_t)P.nt * 4);
     P.nmatches = ((const int32_t*)(H + o_nm))[p];
+  }
+  return PS_OK;
+}
+
+
+// The three ORBmatcher::SearchByProjection overloads (see include/pointslot_hip.h for the field mapping).
+int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
+  if (!m || !probs || nprob < 1) return ps_set_error(PS_ERR_INVALID, "ps_search_by_projection: bad argument");
+  PS_HIP(hipSetDevice(m->device));
+  size_t NT = 0, NQ = 0;
+  int max_nq = 0, any_frame = 0;
+  const int NCELL = PS_GRID_COLS * PS_GRID_ROWS;
+  for (int p = 0; p < nprob; p++) {
+    const ps_proj_problem& P = probs[p];
+    const ps_proj_train& T = P.train;
+    if (T.n < 0 || T.n > 32767 || P.nq < 0 || (T.n > 0 && (!T.x || !T.y || !T.octave || !T.angle || !T.u_right || !T.desc ||
+        !T.occupied || !T.cell_off || !T.cell_idx || !P.match_of_train)))
+      return ps_set_error(PS_ERR_INVALID, "projection problem %d: bad train side (n <= 32767)", p);
+    if (P.nq > 0 && (!P.q_valid || !P.q_desc || !P.q_observed)) return ps_set_error(PS_ERR_INVALID, "projection problem %d: null query arrays", p);
+    if (P.frame_mode) {
+      if (P.nq > 0 && (!P.q_xw || !P.q_octave || !P.q_angle)) return ps_set_error(PS_ERR_INVALID, "projection problem %d: frame mode needs q_xw/q_octave/q_angle", p);
+      any_frame = 1;
+    } else if (P.nq > 0 && (!P.q_u || !P.q_v || !P.q_ur || !P.q_radius || !P.q_radius_er || !P.q_min_level || !P.q_max_level))
+      return ps_set_error(PS_ERR_INVALID, "projection problem %d: null pre-projected query arrays", p);
+    if (P.use_bbox && T.n > 0 && !T.in_bbox) return ps_set_error(PS_ERR_INVALID, "projection problem %d: use_bbox without in_bbox", p);
+    NT += T.n; NQ += P.nq;
+    max_nq = P.nq > max_nq ? P.nq : max_nq;
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += al(bytes + 64); return r; };
+  const size_t o_prob = take(sizeof(PjProb) * nprob);
+  const size_t o_tx = take(NT * 4), o_ty = take(NT * 4), o_toct = take(NT * 4), o_tang = take(NT * 4), o_tur = take(NT * 4);
+  const size_t o_tdesc = take(NT * 32), o_tocc = take(NT), o_tbb = take(NT), o_coff = take((size_t)nprob * (NCELL + 1) * 4), o_cidx = take(NT * 4);
+  const size_t o_qvalid = take(NQ), o_qu = take(NQ * 4), o_qv = take(NQ * 4), o_qur = take(NQ * 4), o_qrad = take(NQ * 4), o_qrer = take(NQ * 4);
+  const size_t o_qminl = take(NQ * 4), o_qmaxl = take(NQ * 4), o_qdesc = take(NQ * 32), o_qobs = take(NQ), o_qang = take(NQ * 4);
+  const size_t o_qxw = take(NQ * 12), o_qoct = take(NQ * 4);
+  const size_t in_bytes = off;
+  const size_t o_match = take(NT * 4), o_nm = take((size_t)nprob * 4), o_ovf = take(4);
+  const size_t out_end = off;
+  const size_t o_cand = take(NQ * PS_PJ_CAP * 4), o_ncand = take(NQ * 4), o_qbest = take(NQ * 4), o_qbin = take(NQ);
+  int rc = ensure(m, off);
+  if (rc != PS_OK) return rc;
+  uint8_t* H = m->h_buf;
+  memset(H, 0, in_bytes);
+  PjProb* hp = (PjProb*)(H + o_prob);
+  size_t t0 = 0, q0 = 0;
+  for (int p = 0; p < nprob; p++) {
+    const ps_proj_problem& P = probs[p];
+    const ps_proj_train& T = P.train;
+    PjProb& d = hp[p];
+    d.t_off = (int32_t)t0; d.nt = T.n; d.q_off = (int32_t)q0; d.nq = P.nq; d.grid_off = p * (NCELL + 1);
+    d.min_x = T.min_x; d.min_y = T.min_y; d.gw_inv = T.grid_w_inv; d.gh_inv = T.grid_h_inv;
+    d.th_dist = P.th_dist; d.ratio_test = P.ratio_test; d.nn_ratio = P.nn_ratio; d.check_ori = P.check_orientation;
+    d.use_bbox = P.use_bbox; d.frame_mode = P.frame_mode;
+    memcpy(d.tcw, P.tcw, 64); memcpy(d.tlw, P.tlw, 64);
+    d.fx = P.fx; d.fy = P.fy; d.cx = P.cx; d.cy = P.cy; d.mbf = P.mbf; d.mb = P.mb;
+    memcpy(d.bounds, P.bounds, 16); memcpy(d.scale, P.scale_factors, 32);
+    d.th = P.th; d.mono = P.mono;
+    if (T.n > 0) {
+      memcpy(H + o_tx + t0 * 4, T.x, (size_t)T.n * 4); memcpy(H + o_ty + t0 * 4, T.y, (size_t)T.n * 4);
+      memcpy(H + o_toct + t0 * 4, T.octave, (size_t)T.n * 4); memcpy(H + o_tang + t0 * 4, T.angle, (size_t)T.n * 4);
+      memcpy(H + o_tur + t0 * 4, T.u_right, (size_t)T.n * 4); memcpy(H + o_tdesc + t0 * 32, T.desc, (size_t)T.n * 32);
+      memcpy(H + o_tocc + t0, T.occupied, T.n);
+      if (T.in_bbox) memcpy(H + o_tbb + t0, T.in_bbox, T.n);
+      memcpy(H + o_coff + (size_t)d.grid_off * 4, T.cell_off, (size_t)(NCELL + 1) * 4);
+      memcpy(H + o_cidx + t0 * 4, T.cell_idx, (size_t)T.cell_off[NCELL] * 4);
+    }
+    if (P.nq > 0) {
+      memcpy(H + o_qvalid + q0, P.q_valid, P.nq); memcpy(H + o_qdesc + q0 * 32, P.q_desc, (size_t)P.nq * 32);
+      memcpy(H + o_qobs + q0, P.q_observed, P.nq);
+      if (P.q_angle) memcpy(H + o_qang + q0 * 4, P.q_angle, (size_t)P.nq * 4);
+      if (P.frame_mode) {
+        memcpy(H + o_qxw + q0 * 12, P.q_xw, (size_t)P.nq * 12); memcpy(H + o_qoct + q0 * 4, P.q_octave, (size_t)P.nq * 4);
+      } else {
+        memcpy(H + o_qu + q0 * 4, P.q_u, (size_t)P.nq * 4); memcpy(H + o_qv + q0 * 4, P.q_v, (size_t)P.nq * 4);
+        memcpy(H + o_qur + q0 * 4, P.q_ur, (size_t)P.nq * 4); memcpy(H + o_qrad + q0 * 4, P.q_radius, (size_t)P.nq * 4);
+        memcpy(H + o_qrer + q0 * 4, P.q_radius_er, (size_t)P.nq * 4); memcpy(H + o_qminl + q0 * 4, P.q_min_level, (size_t)P.nq * 4);
+        memcpy(H + o_qmaxl + q0 * 4, P.q_max_level, (size_t)P.nq * 4);
+      }
+    }
+    t0 += T.n; q0 += P.nq;
+  }
+  uint8_t* D = m->d_buf;
+  PS_HIP(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, m->stream));
+  PS_HIP(hipMemsetAsync(D + o_ovf, 0, 4, m->stream));
+  PjArrays A;
+  A.prob = (const PjProb*)(D + o_prob);
+  A.tx = (const float*)(D + o_tx); A.ty = (const float*)(D + o_ty); A.toct = (const int32_t*)(D + o_toct);
+  A.tang = (const float*)(D + o_tang); A.tur = (const float*)(D + o_tur); A.tdesc = D + o_tdesc; A.tocc = D + o_tocc;
+  A.tbbox = D + o_tbb; A.cell_off = (const int32_t*)(D + o_coff); A.cell_idx = (const int32_t*)(D + o_cidx);
+  A.qvalid = D + o_qvalid; A.qu = (float*)(D + o_qu); A.qv = (float*)(D + o_qv); A.qur = (float*)(D + o_qur);
+  A.qrad = (float*)(D + o_qrad); A.qrer = (float*)(D + o_qrer); A.qminl = (int32_t*)(D + o_qminl); A.qmaxl = (int32_t*)(D + o_qmaxl);
+  A.qdesc = D + o_qdesc; A.qobs = D + o_qobs; A.qang = (const float*)(D + o_qang);
+  A.qxw = (const float*)(D + o_qxw); A.qoct = (const int32_t*)(D + o_qoct);
+  A.cand = (uint32_t*)(D + o_cand); A.ncand = (int32_t*)(D + o_ncand); A.match = (int32_t*)(D + o_match);
+  A.nmatch = (int32_t*)(D + o_nm); A.overflow = (int32_t*)(D + o_ovf); A.qbest = (int32_t*)(D + o_qbest); A.qbin = D + o_qbin;
+  psk_pj_launch(&A, nprob, max_nq > 0 ? max_nq : 1, any_frame, m->stream);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipMemcpyAsync(H + o_match, D + o_match, out_end - o_match, hipMemcpyDeviceToHost, m->stream));
+  PS_HIP(hipStreamSynchronize(m->stream));
+  if (*(const int32_t*)(H + o_ovf) > 0)
+    return ps_set_error(PS_ERR_CAPACITY, "a search window held more than %d candidates", PS_PJ_CAP);
+  t0 = 0;
+  for (int p = 0; p < nprob; p++) {
+    ps_proj_problem& P = probs[p];
+    if (P.train.n > 0) memcpy(P.match_of_train, H + o_match + t0 * 4, (size_t)P.train.n * 4);
+    P.nmatches = ((const int32_t*)(H + o_nm))[p];
+    t0 += P.train.n;
   }
   return PS_OK;
 }

@@ -180,3 +180,215 @@ extern "C" void psk_bf_launch(const BfBlock* blocks, int nblocks, const BfProb* 
 extern "C" void psk_hamming_matrix_launch(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out, hipStream_t st) {
   hipLaunchKernelGGL(hamming_matrix, dim3((nt + 255) / 256, nq), dim3(256), 0, st, q, nq, t, nt, out);
 }
+
+// ================================================================================================
+// Windowed matching: the three ORBmatcher::SearchByProjection overloads
+//   (Frame&, const Frame&, th, mono)                 /root/reference/src/ORBmatcher.cc:1613-1756
+//   (Frame&, const vector<MapPoint*>&, th)           :68-155
+//   (Frame&, nOrder, const vector<MapObjectPoint*>&, th)   :157-248
+// with Frame::GetFeaturesInArea (/root/reference/src/Frame.cc:1808-1861) as the candidate generator.
+//   pj_project  : frame-to-frame variant only — float projection of the last frame's map points
+//   pj_gather   : one wave per query — grid window walk in the reference's order (ix, iy, cell order), static
+//                 filters (level, |dx|,|dy| < r, stereo uR gate, bbox), Hamming distance; candidates are
+//                 stored in traversal order as keys  dist << 23 | position << 15 | train index
+//   pj_resolve  : one wave per problem — the order-dependent part: queries in order, trains blocked by an
+//                 earlier assignment are skipped, best / second best by two wave-min reductions, ratio test,
+//                 rotation histogram
+// ================================================================================================
+namespace {
+
+
+
+__device__ __forceinline__ float dot3_f(const float* R, float x, float y, float z) {
+  // cv::Mat(float) * cv::Mat(float): cv::gemm accumulates float products in double
+  return (float)((double)R[0] * (double)x + (double)R[1] * (double)y + (double)R[2] * (double)z);
+}
+
+__global__ __launch_bounds__(256) void pj_project(PjArrays A) {
+  const PjProb P = A.prob[blockIdx.y];
+  if (!P.frame_mode) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P.nq) return;
+  const int q = P.q_off + i;
+  if (!A.qvalid[q]) return;
+  // twc = -Rcw^T tcw ; tlc = Rlw twc + tlw  (ORBmatcher.cc:1624-1633)
+  const float t0 = P.tcw[3], t1 = P.tcw[7], t2 = P.tcw[11];
+  float twc[3];
+  for (int r = 0; r < 3; r++)
+    twc[r] = (float)(-((double)P.tcw[r] * (double)t0 + (double)P.tcw[4 + r] * (double)t1 + (double)P.tcw[8 + r] * (double)t2));
+  const float tlc2 = __fadd_rn(dot3_f(&P.tlw[8], twc[0], twc[1], twc[2]), P.tlw[11]);
+  const bool fwd = tlc2 > P.mb && !P.mono, bwd = -tlc2 > P.mb && !P.mono;
+  const float X = A.qxw[3 * q], Y = A.qxw[3 * q + 1], Z = A.qxw[3 * q + 2];
+  const float xc = __fadd_rn(dot3_f(&P.tcw[0], X, Y, Z), P.tcw[3]);
+  const float yc = __fadd_rn(dot3_f(&P.tcw[4], X, Y, Z), P.tcw[7]);
+  const float zc = __fadd_rn(dot3_f(&P.tcw[8], X, Y, Z), P.tcw[11]);
+  const float invzc = (float)(1.0 / (double)zc);
+  bool ok = !(invzc < 0);
+  const float u = __fadd_rn(__fmul_rn(__fmul_rn(P.fx, xc), invzc), P.cx);
+  const float v = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, yc), invzc), P.cy);
+  if (u < P.bounds[0] || u > P.bounds[1] || v < P.bounds[2] || v > P.bounds[3]) ok = false;
+  const int oct = A.qoct[q];
+  const float radius = __fmul_rn(P.th, P.scale[oct]);
+  A.qu[q] = u; A.qv[q] = v;
+  A.qur[q] = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
+  A.qrad[q] = radius; A.qrer[q] = radius;
+  A.qminl[q] = fwd ? oct : (bwd ? 0 : oct - 1);
+  A.qmaxl[q] = fwd ? -1 : (bwd ? oct : oct + 1);
+  if (!ok) A.qvalid[q] = 0;
+}
+
+__global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
+  const PjProb P = A.prob[blockIdx.y];
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (qi >= P.nq) return;
+  const int q = P.q_off + qi;
+  if (!A.qvalid[q]) { if (lane == 0) A.ncand[q] = 0; return; }
+  const float x = A.qu[q], y = A.qv[q], r = A.qrad[q], rer = A.qrer[q], ur = A.qur[q];
+  const int minLevel = A.qminl[q], maxLevel = A.qmaxl[q];
+  // Frame::GetFeaturesInArea cell range (Frame.cc:1813-1827)
+  const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, P.min_x), r), P.gw_inv)));
+  const int nMaxCellX = min(PS_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, P.min_x), r), P.gw_inv)));
+  const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, P.min_y), r), P.gh_inv)));
+  const int nMaxCellY = min(PS_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, P.min_y), r), P.gh_inv)));
+  int count = 0;
+  if (nMinCellX < PS_GRID_COLS && nMaxCellX >= 0 && nMinCellY < PS_GRID_ROWS && nMaxCellY >= 0) {
+    const bool check = (minLevel > 0) || (maxLevel >= 0);
+    const uint4* qd = reinterpret_cast<const uint4*>(A.qdesc + (size_t)q * 32);
+    const uint4 a0 = qd[0], a1 = qd[1];
+    const int32_t* coff = A.cell_off + P.grid_off;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+      const int b = coff[ix * PS_GRID_ROWS + nMinCellY], e = coff[ix * PS_GRID_ROWS + nMaxCellY + 1];
+      for (int k0 = b; k0 < e; k0 += 64) {
+        const int k = k0 + lane;
+        bool pass = false;
+        int j = 0, dist = 0;
+        if (k < e) {
+          j = A.cell_idx[P.t_off + k];
+          const int t = P.t_off + j;
+          const int oc = A.toct[t];
+          pass = true;
+          if (check) {
+            if (oc < minLevel) pass = false;
+            if (maxLevel >= 0 && oc > maxLevel) pass = false;
+          }
+          const float dx = __fsub_rn(A.tx[t], x), dy = __fsub_rn(A.ty[t], y);
+          if (!(fabsf(dx) < r && fabsf(dy) < r)) pass = false;
+          if (pass && P.use_bbox && !A.tbbox[t]) pass = false;
+          if (pass) {
+            const float tu = A.tur[t];
+            if (tu > 0.f && fabsf(__fsub_rn(ur, tu)) > rer) pass = false;
+          }
+          if (pass) {
+            const uint4* td = reinterpret_cast<const uint4*>(A.tdesc + (size_t)t * 32);
+            dist = hamming256(a0, a1, td[0], td[1]);
+          }
+        }
+        const unsigned long long m = __ballot(pass);
+        const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+        if (pass && pos < PS_PJ_CAP)
+          A.cand[(size_t)q * PS_PJ_CAP + pos] = ((uint32_t)dist << 23) | ((uint32_t)pos << 15) | (uint32_t)j;
+        count += __popcll(m);
+      }
+    }
+  }
+  if (lane == 0) {
+    if (count > PS_PJ_CAP) { atomicAdd(A.overflow, 1); count = PS_PJ_CAP; }
+    A.ncand[q] = count;
+  }
+}
+
+__global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
+  __shared__ uint32_t blocked[1024];   // up to 32768 train features
+  __shared__ int hist[32];
+  const PjProb P = A.prob[blockIdx.x];
+  const int lane = threadIdx.x;
+  int32_t* match = A.match + P.t_off;
+  for (int w = lane; w < (P.nt + 31) / 32; w += 64) {
+    uint32_t bits = 0;
+    for (int b = 0; b < 32; b++) {
+      const int j = w * 32 + b;
+      if (j < P.nt && A.tocc[P.t_off + j]) bits |= 1u << b;
+    }
+    blocked[w] = bits;
+  }
+  if (lane < 32) hist[lane] = 0;
+  for (int j = lane; j < P.nt; j += 64) match[j] = -1;
+  __syncthreads();
+  const float factor = 30 / 360.0f;
+  int nm = 0;
+  for (int qi = 0; qi < P.nq; qi++) {
+    const int q = P.q_off + qi;
+    const int nc = A.ncand[q];
+    if (lane == 0) A.qbest[q] = -1;
+    if (nc == 0) continue;
+    uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+    for (int c = lane; c < nc; c += 64) {
+      const uint32_t k = A.cand[(size_t)q * PS_PJ_CAP + c];
+      const uint32_t j = k & 0x7FFF;
+      if ((blocked[j >> 5] >> (j & 31)) & 1u) continue;
+      if (k < m1) { m2 = m1; m1 = k; } else if (k < m2) m2 = k;
+    }
+    const uint32_t best = wave_min_u32(m1);
+    if (best == 0xFFFFFFFFu) continue;
+    const int bestDist = (int)(best >> 23), bestIdx = (int)(best & 0x7FFF);
+    if (bestDist > P.th_dist) continue;
+    if (P.ratio_test) {
+      const uint32_t second = wave_min_u32(m1 == best ? m2 : m1);
+      if (second != 0xFFFFFFFFu) {
+        const int d2 = (int)(second >> 23);
+        const int l1 = A.toct[P.t_off + bestIdx], l2 = A.toct[P.t_off + (int)(second & 0x7FFF)];
+        if (l1 == l2 && (float)bestDist > __fmul_rn(P.nn_ratio, (float)d2)) continue;
+      }
+      // no second candidate: bestLevel2 = -1 never equals an octave -> accepted
+    }
+    if (lane == 0) {
+      match[bestIdx] = qi;
+      A.qbest[q] = bestIdx;
+      if (A.qobs[q]) blocked[bestIdx >> 5] |= 1u << (bestIdx & 31);
+      if (P.check_ori) {
+        float rot = __fsub_rn(A.qang[q], A.tang[P.t_off + bestIdx]);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int bin = (int)roundf(__fmul_rn(rot, factor));
+        if (bin == 30) bin = 0;
+        hist[bin]++;
+        A.qbin[q] = (uint8_t)bin;
+      }
+    }
+    nm++;
+    __syncthreads();
+  }
+  __syncthreads();
+  if (P.check_ori) {
+    int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+    for (int i = 0; i < 30; i++) {
+      const int s = hist[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+      else if (s > max3) { max3 = s; i3 = i; }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+    else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+    int removed = 0;
+    for (int qi = lane; qi < P.nq; qi += 64) {
+      const int q = P.q_off + qi;
+      const int bi = A.qbest[q];
+      if (bi >= 0) {
+        const int b = A.qbin[q];
+        if (b != i1 && b != i2 && b != i3) { match[bi] = -1; removed++; }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
+    nm -= removed;
+  }
+  if (lane == 0) A.nmatch[blockIdx.x] = nm;
+}
+
+}  // namespace
+
+extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int any_frame_mode, hipStream_t st) {
+  const PjArrays A = *arrays;
+  if (any_frame_mode) hipLaunchKernelGGL(pj_project, dim3((max_nq + 255) / 256, nprob), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(pj_gather, dim3((max_nq + 3) / 4, nprob), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(pj_resolve, dim3(nprob), dim3(64), 0, st, A);
+}

@@ -6,3 +6,43 @@
 #define PS_BF_QPB 32           // queries per bf_topk block
 struct BfProb { int32_t q_off, nq, t_off, nt; };
 struct BfBlock { int32_t prob, q_first, q_count, pad; };
+
+// ---- windowed (projection) matching ----
+#define PS_PJ_CAP 256          // candidates kept per query (exceeding it is reported as PS_ERR_CAPACITY)
+#define PS_GRID_COLS 64        // FRAME_GRID_COLS / ROWS, /root/reference/include/Frame.h:40-41
+#define PS_GRID_ROWS 48
+struct PjProb {
+  int32_t t_off, nt;           // train features
+  int32_t q_off, nq;           // queries
+  int32_t grid_off;            // into cell_off (COLS*ROWS+1 entries per problem); cell_idx shares t_off
+  float min_x, min_y, gw_inv, gh_inv;
+  int32_t th_dist;             // TH_HIGH (100) or TH_HIGH_FORDYNAMIC (130)
+  int32_t ratio_test;          // 1: best/second-best test with nn_ratio when both are on the same level
+  float nn_ratio;
+  int32_t check_ori;           // rotation histogram (frame-to-frame variant)
+  int32_t use_bbox;
+  int32_t frame_mode;          // 1: queries are produced by pj_project (SearchByProjection(cur, last))
+  // frame_mode inputs
+  float tcw[16], tlw[16];
+  float fx, fy, cx, cy, mbf, mb;
+  float bounds[4];             // mnMinX, mnMaxX, mnMinY, mnMaxY
+  float scale[8];
+  float th;
+  int32_t mono;
+};
+
+// device pointers of one windowed-matching batch (passed by value to the kernels)
+struct PjArrays {
+  const PjProb* prob;
+  // train side
+  const float* tx; const float* ty; const int32_t* toct; const float* tang; const float* tur; const uint8_t* tdesc;
+  const uint8_t* tocc; const uint8_t* tbbox; const int32_t* cell_off; const int32_t* cell_idx;
+  // query side
+  uint8_t* qvalid; float* qu; float* qv; float* qur; float* qrad; float* qrer; int32_t* qminl; int32_t* qmaxl;
+  const uint8_t* qdesc; const uint8_t* qobs; const float* qang;
+  const float* qxw; const int32_t* qoct;     // frame mode
+  // work / outputs
+  uint32_t* cand; int32_t* ncand; int32_t* match; int32_t* nmatch; int32_t* overflow;
+  int32_t* qbest;                            // per query: matched train (or -1), for the rotation pass
+  uint8_t* qbin;
+};

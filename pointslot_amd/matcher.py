@@ -73,3 +73,119 @@ class ORBmatcher:
                                 ta.ctypes.data, len(td), out.ctypes.data, 0)
         check(lib.ps_match_bruteforce(self._h, arr, n, self.mfNNratio, 1 if self.mbCheckOrientation else 0))
         return [(arr[i].nmatches, keep[i][5][:len(keep[i][1])].copy()) for i in range(n)]
+
+
+# ---- windowed matching (the three SearchByProjection overloads) ---------------------------------------------
+FRAME_GRID_COLS, FRAME_GRID_ROWS = 64, 48      # /root/reference/include/Frame.h:40-41
+
+
+def build_grid(x, y, min_x, min_y, gw_inv, gh_inv):
+    """Frame::AssignFeaturesToGrid / PosInGrid (/root/reference/src/Frame.cc:1636-1656, 2027-2037) as CSR:
+    returns (cell_off int32[64*48+1], cell_idx int32[<=n]) with cell = ix * 48 + iy, insertion order inside a cell."""
+    x = np.asarray(x, np.float32); y = np.asarray(y, np.float32)
+    fx = (x - np.float32(min_x)) * np.float32(gw_inv); fy = (y - np.float32(min_y)) * np.float32(gh_inv)
+    px = np.where(fx >= 0, np.floor(fx + np.float32(0.5)), np.ceil(fx - np.float32(0.5))).astype(np.int64)   # C round()
+    py = np.where(fy >= 0, np.floor(fy + np.float32(0.5)), np.ceil(fy - np.float32(0.5))).astype(np.int64)
+    ok = (px >= 0) & (px < FRAME_GRID_COLS) & (py >= 0) & (py < FRAME_GRID_ROWS)
+    cell = px * FRAME_GRID_ROWS + py
+    idx = np.nonzero(ok)[0]
+    order = np.argsort(cell[idx], kind="stable")
+    cell_idx = idx[order].astype(np.int32)
+    counts = np.bincount(cell[idx], minlength=FRAME_GRID_COLS * FRAME_GRID_ROWS)
+    cell_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return cell_off, cell_idx
+
+
+class _ProjTrain(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("octave", ctypes.c_void_p),
+                ("angle", ctypes.c_void_p), ("u_right", ctypes.c_void_p), ("desc", ctypes.c_void_p),
+                ("occupied", ctypes.c_void_p), ("in_bbox", ctypes.c_void_p), ("cell_off", ctypes.c_void_p),
+                ("cell_idx", ctypes.c_void_p), ("min_x", ctypes.c_float), ("min_y", ctypes.c_float),
+                ("grid_w_inv", ctypes.c_float), ("grid_h_inv", ctypes.c_float)]
+
+
+class _ProjProblem(ctypes.Structure):
+    _fields_ = [("train", _ProjTrain), ("nq", ctypes.c_int32), ("q_valid", ctypes.c_void_p), ("q_desc", ctypes.c_void_p),
+                ("q_observed", ctypes.c_void_p), ("q_angle", ctypes.c_void_p), ("q_u", ctypes.c_void_p),
+                ("q_v", ctypes.c_void_p), ("q_ur", ctypes.c_void_p), ("q_radius", ctypes.c_void_p),
+                ("q_radius_er", ctypes.c_void_p), ("q_min_level", ctypes.c_void_p), ("q_max_level", ctypes.c_void_p),
+                ("q_xw", ctypes.c_void_p), ("q_octave", ctypes.c_void_p), ("frame_mode", ctypes.c_int32),
+                ("mono", ctypes.c_int32), ("tcw", ctypes.c_float * 16), ("tlw", ctypes.c_float * 16),
+                ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float),
+                ("mbf", ctypes.c_float), ("mb", ctypes.c_float), ("bounds", ctypes.c_float * 4),
+                ("scale_factors", ctypes.c_float * 8), ("th", ctypes.c_float), ("th_dist", ctypes.c_int32),
+                ("ratio_test", ctypes.c_int32), ("nn_ratio", ctypes.c_float), ("check_orientation", ctypes.c_int32),
+                ("use_bbox", ctypes.c_int32), ("match_of_train", ctypes.c_void_p), ("nmatches", ctypes.c_int32)]
+
+
+lib.ps_search_by_projection.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ProjProblem), ctypes.c_int]
+
+
+def _arr(a, dt):
+    return np.ascontiguousarray(a, dt)
+
+
+def _fill_train(p, F, keep):
+    n = len(F["x"])
+    a = dict(x=_arr(F["x"], np.float32), y=_arr(F["y"], np.float32), octave=_arr(F["octave"], np.int32),
+             angle=_arr(F["angle"], np.float32), u_right=_arr(F["u_right"], np.float32),
+             desc=_arr(F["desc"], np.uint8).reshape(-1, 32), occupied=_arr(F["occupied"], np.uint8),
+             in_bbox=_arr(F.get("in_bbox", np.ones(n, np.uint8)), np.uint8),
+             cell_off=_arr(F["cell_off"], np.int32), cell_idx=_arr(F["cell_idx"], np.int32))
+    keep.append(a)
+    t = p.train
+    t.n = n
+    for k, v in a.items():
+        setattr(t, k, v.ctypes.data)
+    t.min_x, t.min_y, t.grid_w_inv, t.grid_h_inv = [float(v) for v in F["grid"]]
+    return n
+
+
+def _search_by_projection(self, problems):
+    """problems: list of dicts, see SearchByProjectionFrame / SearchByProjectionPoints for the two layouts."""
+    n = len(problems)
+    arr = (_ProjProblem * n)()
+    keep, outs = [], []
+    for i, pr in enumerate(problems):
+        p = arr[i]
+        nt = _fill_train(p, pr["train"], keep)
+        q = pr["query"]
+        nq = len(q["valid"])
+        a = dict(q_valid=_arr(q["valid"], np.uint8), q_desc=_arr(q["desc"], np.uint8).reshape(-1, 32),
+                 q_observed=_arr(q["observed"], np.uint8))
+        p.frame_mode = 1 if pr["mode"] == "frame" else 0
+        if p.frame_mode:
+            a.update(q_angle=_arr(q["angle"], np.float32), q_xw=_arr(q["xw"], np.float32), q_octave=_arr(q["octave"], np.int32))
+            p.tcw = (ctypes.c_float * 16)(*np.asarray(pr["tcw"], np.float32).reshape(16))
+            p.tlw = (ctypes.c_float * 16)(*np.asarray(pr["tlw"], np.float32).reshape(16))
+            p.fx, p.fy, p.cx, p.cy, p.mbf, p.mb = [float(v) for v in pr["K6"]]
+            p.bounds = (ctypes.c_float * 4)(*[float(v) for v in pr["bounds"]])
+            p.th = float(pr["th"]); p.mono = 1 if pr.get("mono") else 0
+            p.th_dist = ORBmatcher.TH_HIGH; p.ratio_test = 0; p.nn_ratio = self.mfNNratio
+            p.check_orientation = 1 if self.mbCheckOrientation else 0; p.use_bbox = 0
+        else:
+            obj = bool(pr.get("object"))
+            th = np.float32(pr["th"])
+            lvl = np.asarray(q["level"], np.int32)
+            sf = np.asarray(pr["scale_factors"], np.float32)
+            r = np.where(np.asarray(q["view_cos"], np.float32) > np.float32(0.998), np.float32(2.5), np.float32(4.0)).astype(np.float32)
+            if float(th) != 1.0:
+                r = (r * th).astype(np.float32)
+            rer = (r * sf[lvl]).astype(np.float32)
+            a.update(q_u=_arr(q["proj_x"], np.float32), q_v=_arr(q["proj_y"], np.float32), q_ur=_arr(q["proj_xr"], np.float32),
+                     q_radius=np.full(nq, 5.0, np.float32) if obj else rer, q_radius_er=rer,
+                     q_min_level=(lvl - 1).astype(np.int32), q_max_level=(lvl + 1 if obj else lvl).astype(np.int32))
+            p.th_dist = ORBmatcher.TH_HIGH_FORDYNAMIC if obj else ORBmatcher.TH_HIGH
+            p.ratio_test = 1; p.nn_ratio = self.mfNNratio; p.check_orientation = 0; p.use_bbox = 1 if obj else 0
+        p.scale_factors = (ctypes.c_float * 8)(*np.asarray(pr["scale_factors"], np.float32))
+        p.nq = nq
+        for k, v in a.items():
+            setattr(p, k, v.ctypes.data)
+        out = np.full(max(nt, 1), -1, np.int32)
+        p.match_of_train = out.ctypes.data
+        keep.append(a); outs.append((out, nt))
+    check(lib.ps_search_by_projection(self._h, arr, n))
+    return [(arr[i].nmatches, outs[i][0][:outs[i][1]].copy()) for i in range(n)]
+
+
+ORBmatcher.SearchByProjection = _search_by_projection

@@ -271,3 +271,56 @@ def object_ba_problem(seed, n_kf=50, n_pts=300, p_vis=1.0, outlier_frac=0.05, no
             "e_obs": np.array(e_obs, np.float32), "e_inv_sigma2": np.array(e_is2, np.float32),
             "K": (np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), np.float32(KITTI_BF)),
             "poses_true": poses_true, "points_true": pts, "e_is_outlier": np.array(e_out)}
+
+
+# ---- projection-matching scenes (SearchByProjection x3) ------------------------------------------------------
+def _flip(rng, d, nmax):
+    bits = np.unpackbits(d)
+    n = int(rng.integers(1, 0, nmax + 1)[0])
+    if n:
+        bits[rng.integers(n, 0, 256)] ^= 1
+    return np.packbits(bits)
+
+
+def projection_scene(seed, n=2000, m=1500, w=1241, h=376, object_mode=False, th=7.0):
+    """A current frame with n keypoints (grid built by the caller) and m source points that project close to some of
+    them with similar descriptors.  Returns the 'train' side and both query layouts (frame-to-frame and pre-projected)."""
+    rng = Rng(seed)
+    fx, fy, cx, cy = KITTI_K
+    sig, _ = _level_sigma()
+    x = rng.uniform(n, 20, w - 20).astype(np.float32); y = rng.uniform(n, 20, h - 20).astype(np.float32)
+    octave = np.searchsorted(np.cumsum(_QUOTAS) / _QUOTAS.sum(), rng.uniform(n)).clip(0, 7).astype(np.int32)
+    angle = rng.uniform(n, 0, 360).astype(np.float32)
+    z = rng.uniform(n, 4.0, 50.0)
+    ur = np.where(rng.uniform(n) < 0.8, x - KITTI_BF / z, -1.0).astype(np.float32)
+    desc = rng.integers(n * 32, 0, 256).astype(np.uint8).reshape(n, 32)
+    occupied = (rng.uniform(n) < 0.05).astype(np.uint8)
+    in_bbox = (rng.uniform(n) < 0.9).astype(np.uint8)
+    train = {"x": x, "y": y, "octave": octave, "angle": angle, "u_right": ur, "desc": desc, "occupied": occupied,
+             "in_bbox": in_bbox, "grid": (0.0, 0.0, np.float32(64) / np.float32(w), np.float32(48) / np.float32(h))}
+    # poses: last at identity, current moved forward + small rotation
+    R = _so3_exp(np.radians(rng.uniform(3, -1.0, 1.0)))
+    t = np.array([0.05, -0.02, -0.6]) + rng.uniform(3, -0.05, 0.05)
+    tcw = np.eye(4, dtype=np.float32); tcw[:3, :3] = R; tcw[:3, 3] = t
+    tlw = np.eye(4, dtype=np.float32)
+    src = rng.integers(m, 0, n)
+    jit = rng.normal(2 * m).reshape(m, 2) * 2.0
+    u = x[src] + jit[:, 0]; v = y[src] + jit[:, 1]
+    zc = z[src]
+    Xc = np.stack([(u - cx) / fx * zc, (v - cy) / fy * zc, zc], 1)
+    xw = ((Xc - t) @ R).astype(np.float32)
+    q_desc = np.stack([_flip(rng, desc[j], 40) for j in src])
+    rand = rng.uniform(m) < 0.15
+    q_desc[rand] = rng.integers(int(rand.sum()) * 32, 0, 256).astype(np.uint8).reshape(-1, 32)
+    q_oct = np.clip(octave[src] + rng.integers(m, -1, 2), 0, 7).astype(np.int32)
+    rot = 12.0 + rng.normal(m) * np.where(rng.uniform(m) < 0.85, 2.0, 70.0)
+    q_angle = ((angle[src] + rot) % 360.0).astype(np.float32)
+    valid = (rng.uniform(m) < 0.9).astype(np.uint8)
+    observed = (rng.uniform(m) < 0.85).astype(np.uint8)
+    frame_q = {"valid": valid, "desc": q_desc, "observed": observed, "angle": q_angle, "xw": xw, "octave": q_oct}
+    pts_q = {"valid": valid, "desc": q_desc, "observed": observed, "proj_x": u.astype(np.float32), "proj_y": v.astype(np.float32),
+             "proj_xr": (u - KITTI_BF / zc).astype(np.float32), "level": q_oct,
+             "view_cos": rng.uniform(m, 0.99, 1.0).astype(np.float32)}
+    return {"train": train, "frame_query": frame_q, "points_query": pts_q, "tcw": tcw, "tlw": tlw,
+            "K6": (np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), np.float32(KITTI_BF), np.float32(KITTI_BF / fx)),
+            "bounds": (0.0, float(w), 0.0, float(h)), "scale_factors": sig, "th": th}

@@ -228,3 +228,59 @@ def huber(e, delta):
     out = np.zeros(3)
     lib().orc_huber(float(e), float(delta), out.ctypes.data)
     return out
+
+
+class _OrcTrain(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int), ("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("octave", ctypes.c_void_p),
+                ("angle", ctypes.c_void_p), ("u_right", ctypes.c_void_p), ("desc", ctypes.c_void_p),
+                ("occupied", ctypes.c_void_p), ("in_bbox", ctypes.c_void_p), ("cell_off", ctypes.c_void_p),
+                ("cell_idx", ctypes.c_void_p), ("min_x", ctypes.c_float), ("min_y", ctypes.c_float),
+                ("gw_inv", ctypes.c_float), ("gh_inv", ctypes.c_float)]
+
+
+def _orc_train(F, keep):
+    n = len(F["x"])
+    a = [np.ascontiguousarray(F["x"], np.float32), np.ascontiguousarray(F["y"], np.float32), np.ascontiguousarray(F["octave"], np.int32),
+         np.ascontiguousarray(F["angle"], np.float32), np.ascontiguousarray(F["u_right"], np.float32),
+         np.ascontiguousarray(F["desc"], np.uint8), np.ascontiguousarray(F["occupied"], np.uint8),
+         np.ascontiguousarray(F.get("in_bbox", np.ones(n, np.uint8)), np.uint8),
+         np.ascontiguousarray(F["cell_off"], np.int32), np.ascontiguousarray(F["cell_idx"], np.int32)]
+    keep.append(a)
+    g = [float(v) for v in F["grid"]]
+    return _OrcTrain(n, *[x.ctypes.data for x in a], *g)
+
+
+def search_projection_frame(pr, check_ori=True):
+    keep = []
+    T = _orc_train(pr["train"], keep)
+    q = pr["query"]
+    m = len(q["valid"])
+    c = lambda k, dt: np.ascontiguousarray(q[k], dt)
+    xw, valid, oc, ang, desc, obs = c("xw", np.float32), c("valid", np.uint8), c("octave", np.int32), c("angle", np.float32), c("desc", np.uint8), c("observed", np.uint8)
+    tcw = np.ascontiguousarray(pr["tcw"], np.float32); tlw = np.ascontiguousarray(pr["tlw"], np.float32)
+    K6 = np.ascontiguousarray(pr["K6"], np.float32); b4 = np.ascontiguousarray(pr["bounds"], np.float32)
+    sf = np.ascontiguousarray(pr["scale_factors"], np.float32)
+    out = np.full(max(T.n, 1), -1, np.int32)
+    f = lib().orc_search_projection_frame
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    n = f(ctypes.byref(T), m, xw.ctypes.data, valid.ctypes.data, oc.ctypes.data, ang.ctypes.data, desc.ctypes.data, obs.ctypes.data,
+          tcw.ctypes.data, tlw.ctypes.data, K6.ctypes.data, b4.ctypes.data, sf.ctypes.data, float(pr["th"]),
+          1 if pr.get("mono") else 0, 1 if check_ori else 0, out.ctypes.data)
+    return n, out[:T.n].copy()
+
+
+def search_projection_points(pr, nnratio):
+    keep = []
+    T = _orc_train(pr["train"], keep)
+    q = pr["query"]
+    m = len(q["valid"])
+    c = lambda k, dt: np.ascontiguousarray(q[k], dt)
+    valid, px, py, pxr, lvl, vc, desc, obs = (c("valid", np.uint8), c("proj_x", np.float32), c("proj_y", np.float32), c("proj_xr", np.float32),
+                                              c("level", np.int32), c("view_cos", np.float32), c("desc", np.uint8), c("observed", np.uint8))
+    sf = np.ascontiguousarray(pr["scale_factors"], np.float32)
+    out = np.full(max(T.n, 1), -1, np.int32)
+    f = lib().orc_search_projection_points
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+    n = f(ctypes.byref(T), m, valid.ctypes.data, px.ctypes.data, py.ctypes.data, pxr.ctypes.data, lvl.ctypes.data, vc.ctypes.data,
+          desc.ctypes.data, obs.ctypes.data, sf.ctypes.data, float(pr["th"]), float(nnratio), 1 if pr.get("object") else 0, out.ctypes.data)
+    return n, out[:T.n].copy()

@@ -55,3 +55,40 @@ def test_bruteforce_empty_sides(matcher):
     p0 = dict(p); p0["q_valid"] = np.zeros(10, np.uint8)
     (n, out), = matcher.SearchByBruceMatching([p0])
     assert n == 0 and np.all(out == -1)
+
+
+def _scene_problems(seed, **kw):
+    from pointslot_amd.matcher import build_grid
+    sc = synth.projection_scene(seed, **kw)
+    tr = dict(sc["train"])
+    tr["cell_off"], tr["cell_idx"] = build_grid(tr["x"], tr["y"], *tr["grid"])
+    base = {"train": tr, "scale_factors": sc["scale_factors"]}
+    frame = dict(base, mode="frame", query=sc["frame_query"], tcw=sc["tcw"], tlw=sc["tlw"], K6=sc["K6"], bounds=sc["bounds"], th=sc["th"])
+    pts = dict(base, mode="points", query=sc["points_query"], th=1.0)
+    pts3 = dict(pts, th=3.0)
+    obj = dict(base, mode="points", query=sc["points_query"], th=1.0, object=True)
+    return frame, pts, pts3, obj
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_projection_all_variants(check_ori):
+    from pointslot_amd.matcher import ORBmatcher
+    m = ORBmatcher(0.8, check_ori)
+    probs = []
+    for seed, kw in ((0x51070020, {}), (0x51070021, {"n": 600, "m": 900, "th": 15.0}), (0x51070022, {"n": 50, "m": 10})):
+        probs += list(_scene_problems(seed, **kw))
+    backward = dict(probs[0]); backward["tcw"] = np.linalg.inv(probs[0]["tcw"].astype(np.float64)).astype(np.float32)
+    mono = dict(probs[0]); mono["mono"] = True
+    probs += [backward, mono]
+    res = m.SearchByProjection(probs)
+    total = 0
+    for i, (pr, (n, out)) in enumerate(zip(probs, res)):
+        if pr["mode"] == "frame":
+            no, oo = oracle_lib.search_projection_frame(pr, check_ori)
+        else:
+            no, oo = oracle_lib.search_projection_points(pr, 0.8)
+        assert n == no, (i, n, no)
+        assert np.array_equal(out, oo), (i, int((out != oo).sum()))
+        total += n
+    assert total > 1500
+    m.close()

@@ -56,3 +56,27 @@ def test_bruteforce_greedy_order_dependence():
     p["q_valid"] = np.array([0, 1], np.uint8)
     n, out = oracle_lib.search_bruteforce(p, 0.9, False)
     assert n == 1 and out[0] == 1 and out[1] == -1
+
+
+def test_projection_matchers_structure():
+    from pointslot_amd.matcher import build_grid
+    sc = synth.projection_scene(0x51070020)
+    tr = dict(sc["train"])
+    tr["cell_off"], tr["cell_idx"] = build_grid(tr["x"], tr["y"], *tr["grid"])
+    assert tr["cell_off"][-1] == len(tr["x"])                     # every keypoint lands in a cell here
+    # cells hold ascending indices (insertion order)
+    for c in range(0, 64 * 48, 97):
+        seg = tr["cell_idx"][tr["cell_off"][c]:tr["cell_off"][c + 1]]
+        assert np.all(np.diff(seg) > 0)
+    pr = {"train": tr, "scale_factors": sc["scale_factors"], "query": sc["frame_query"], "tcw": sc["tcw"], "tlw": sc["tlw"],
+          "K6": sc["K6"], "bounds": sc["bounds"], "th": sc["th"]}
+    n, out = oracle_lib.search_projection_frame(pr, True)
+    n2, out2 = oracle_lib.search_projection_frame(pr, False)
+    assert 300 < n <= n2
+    assert np.all(tr["occupied"][out >= 0] == 0)                   # occupied slots are never reassigned
+    d = oracle_lib.hamming_matrix(sc["frame_query"]["desc"], tr["desc"])
+    js = np.nonzero(out >= 0)[0]
+    assert np.all(d[out[js], js] <= 100)                           # TH_HIGH
+    pp = {"train": tr, "scale_factors": sc["scale_factors"], "query": sc["points_query"], "th": 1.0}
+    n3, out3 = oracle_lib.search_projection_points(pp, 0.8)
+    assert n3 > 200 and n3 >= (out3 >= 0).sum()   # sources without observations do not block a slot: overwrites count twice
