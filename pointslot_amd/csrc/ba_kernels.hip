@@ -15,8 +15,11 @@
 //   ba_update       thread per point / pose : x_l = D^-1 (b_l - W^T x_p), oplus, backups, gain-ratio scale
 //   ba_error        thread per edge : errors at the trial estimate, robust chi2
 //   ba_decide       per problem : gain ratio, lambda update, accept / restore, stop rules, stage changes
-// g2o semantics reproduced: see oracle/opt_oracle.cpp's header for the file:line list; all sums are FP64
-// and deterministic (fixed-order tree reductions, no atomics).
+// g2o semantics reproduced (Thirdparty/g2o/g2o/...): core/optimization_algorithm_levenberg.cpp:61-189 (LM control),
+// core/block_solver.hpp:354-485,502-608 (Schur, back-substitution, setLambda), core/base_binary_edge.hpp:55-120,
+// core/robust_kernel_impl.cpp:78-91, core/sparse_optimizer.cpp:61-114,206-266,354-435, types/types_six_dof_expmap.cpp:
+// 103-232, types/types_sba.h:40-57, src/g2o_Object.cc:26-56,190-213.  All sums are FP64 and deterministic
+// (fixed-order tree reductions, no atomics).
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
