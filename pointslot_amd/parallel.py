@@ -1,0 +1,75 @@
+"""Multi-GPU plumbing.  The hot path shards with NO exchange inside the computation:
+whole sequences, frames of an offline batch and per-object BA problems are independent units, so every rank
+(one process per GPU) works on its own slice; the only collective is the gather of the results at the end
+(trajectories [frames][12] fp32, a few tens of KB — one RCCL all_gather over xGMI, latency-bound) and the
+max-over-ranks of the timing.  Works with backend "nccl" (= RCCL on ROCm) and with "gloo" (CPU tests)."""
+import os
+
+import numpy as np
+
+
+def shard_units(n_units, world, rank):
+    """Contiguous, balanced partition of units 0..n_units-1 over `world` ranks: the first n_units % world ranks
+    get one extra unit.  Returns range(begin, end) for `rank`."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank %r/%r" % (world, rank))
+    base, extra = divmod(n_units, world)
+    begin = rank * base + min(rank, extra)
+    return range(begin, begin + base + (1 if rank < extra else 0))
+
+
+def round_robin_units(n_units, world, rank):
+    """Round-robin assignment (sequence i -> GPU i % world), the throughput-run layout of SURVEY.md 8e."""
+    return range(rank, n_units, world)
+
+
+def init_from_env(backend=None):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1.  Returns (dist or None,
+    rank, world, local_rank)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return None, rank, world, local_rank
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return dist, rank, world, local_rank
+
+
+def max_over_ranks(dist, value, device="cpu"):
+    import torch
+    if dist is None:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_trajectories(dist, local, device="cpu"):
+    """local: float32 array [n_local_frames, 12] (rows of Tcw as System::SaveTrajectoryKITTI writes them,
+    /root/reference/src/System.cc:400-402).  Ranks may hold different frame counts.  Returns the list of per-rank
+    arrays on every rank (all_gather of padded buffers + counts)."""
+    import torch
+    local = np.ascontiguousarray(local, np.float32).reshape(-1, 12)
+    if dist is None:
+        return [local]
+    world = dist.get_world_size()
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    nmax = max(int(c.item()) for c in counts)
+    buf = torch.zeros((max(nmax, 1), 12), dtype=torch.float32, device=device)
+    if local.shape[0]:
+        buf[:local.shape[0]] = torch.from_numpy(local).to(device)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return [o[:int(c.item())].cpu().numpy() for o, c in zip(outs, counts)]

@@ -1,0 +1,59 @@
+"""CPU tests of the multi-GPU plumbing with the gloo backend, world_size 2 (one process per rank)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pointslot_amd import parallel  # noqa: E402
+
+
+def test_shard_units_partitions_exactly():
+    for n in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                seen += list(parallel.shard_units(n, world, r))
+            assert seen == list(range(n))
+            sizes = [len(parallel.shard_units(n, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+            rr = sorted(i for r in range(world) for i in parallel.round_robin_units(n, world, r))
+            assert rr == list(range(n))
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from pointslot_amd import parallel
+dist, rank, world, local = parallel.init_from_env("gloo")
+assert world == 2 and dist is not None
+units = list(parallel.shard_units(5, world, rank))          # 5 sequences over 2 ranks -> 3 + 2
+traj = np.stack([np.full(12, 100 * u + k, np.float32) for u in units for k in range(4 + u)]) if units else np.zeros((0, 12), np.float32)
+parts = parallel.gather_trajectories(dist, traj)
+assert len(parts) == 2
+all_rows = np.concatenate(parts)
+exp = np.stack([np.full(12, 100 * u + k, np.float32) for u in range(5) for k in range(4 + u)])
+assert np.array_equal(all_rows, exp), (all_rows.shape, exp.shape)
+t = parallel.max_over_ranks(dist, 1.5 + rank)
+assert t == 2.5
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_gloo_world2_gather_and_timing(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
