@@ -159,7 +159,10 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
   const int nInitial = (int)s.out[0];
   const int nTotalEdges = nInitial + (P.mode == 1 ? k : 0);
   if (nTotalEdges < 15) {   // Optimizer.cc:376-377 / :638-639
-    if (tid == 0) results[blockIdx.x] = 0;
+    if (tid == 0) {
+      results[blockIdx.x] = 0;
+      if (tr) tr[2] = -1;   // empty trace
+    }
     return;
   }
   bool robust = true;

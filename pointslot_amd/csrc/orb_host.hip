@@ -155,7 +155,7 @@ int build_plan(ps_orb* h, int w, int hgt) {
   for (int l = 0; l < nl; l++) {
     OrbLevel& L = P.lv[l];
     level_size(h, w, hgt, l, &L.w, &L.h);
-    if (L.w < 2 * PS_EDGE + 30 || L.h < 2 * PS_EDGE + 30 || L.w > 4000 || L.h > 4000)
+    if (L.w - 2 * PS_MINB < 30 || L.h - 2 * PS_MINB < 30 || L.w > 4000 || L.h > 4000)   // at least one 30-px FAST cell
       return ps_set_error(PS_ERR_INVALID, "image %dx%d: level %d is %dx%d, outside the supported range", w, hgt, l, L.w, L.h);
     L.stride = (int)align_up(L.w + 2 * PS_EDGE, 64);
     L.bstride = (int)align_up(L.w, 64);
