@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -16,6 +17,8 @@ void psk_orb_launch_pyramid(const OrbPlan*, int, uint8_t*, const uint8_t*, int, 
 void psk_orb_launch_fast(const OrbPlan*, uint8_t*, int, hipStream_t);
 void psk_orb_launch_quadtree(const OrbPlan*, uint8_t*, int, hipStream_t);
 void psk_orb_launch_blur(const OrbPlan*, uint8_t*, int, hipStream_t);
+void psk_orb_launch_border(const OrbPlan*, uint8_t*, int, hipStream_t);
+int psk_orb_blur_rows();
 void psk_orb_launch_describe(const OrbPlan*, uint8_t*, void*, uint8_t*, int32_t*, int, hipStream_t);
 }
 
@@ -49,8 +52,11 @@ struct ps_orb {
   hipStream_t stream = nullptr;
   // stage timing: a ring of event sets so that consecutive batches can be timed without a host
   // synchronisation in between; ps_orb_stage_times() averages over the recorded batches.
-  static const int RING = 64;
-  hipEvent_t ev[RING][ST_COUNT + 1] = {};
+  static const int RING = 32;
+  static const int MAXCHUNK = 32;
+  hipEvent_t ev[RING][MAXCHUNK][ST_COUNT + 1] = {};
+  int timed_chunks[RING] = {};
+  int chunk = 0;                  // 0 = whole batch per launch (kernels are latency-bound: fewer, larger launches win; PS_ORB_CHUNK overrides)
   bool timing = false;
   int timed_batches = 0;
   int last_nimg = 0;
@@ -202,6 +208,23 @@ int build_plan(ps_orb* h, int w, int hgt) {
     L.blur_off = (uint32_t)off;
     off += (size_t)L.bstride * L.h;
   }
+  {
+    int nb = 0;
+    const int rows_per_block = 4 * psk_orb_blur_rows();
+    for (int l = 0; l < nl; l++) {
+      P.lv[l].blur_blk_base = nb;
+      nb += ((P.lv[l].w + 255) / 256) * ((P.lv[l].h + rows_per_block - 1) / rows_per_block);
+    }
+    P.blur_blocks = nb;
+    nb = 0;
+    for (int l = 0; l < nl; l++) {
+      const OrbLevel& L = P.lv[l];
+      const int PW = L.w + 2 * PS_EDGE, ngx = (PW + 3) / 4, nleft = (PS_EDGE + 3) / 4, nright = ngx - (PS_EDGE + L.w) / 4;
+      P.lv[l].border_blk_base = nb;
+      nb += (2 * PS_EDGE * ngx + L.h * (nleft + nright) + 255) / 256;
+    }
+    P.border_blocks = nb;
+  }
   P.n_cells = cells;
   P.sel_total = sel;
   P.kp_cap = (int)align_up(sel, 64);
@@ -230,24 +253,36 @@ int build_plan(ps_orb* h, int w, int hgt) {
   return PS_OK;
 }
 
+// The batch is processed in chunks of `chunk` images: one chunk's arenas (~7 MB per image) stay resident in the
+// 256 MB Infinity Cache between the five stages instead of round-tripping through HBM.
 int run_batch(ps_orb* h, const uint8_t* d_imgs, int nimg, int stride, size_t pitch, hipStream_t st) {
   const OrbPlan* P = &h->plan;
   const bool tm = h->timing;
-  hipEvent_t* ev = h->ev[h->timed_batches % ps_orb::RING];
-  if (tm) PS_HIP(hipEventRecord(ev[0], st));
-  for (int l = 0; l < P->nlevels; l++)
-    psk_orb_launch_pyramid(P, l, h->d_arena, d_imgs, stride, pitch, h->d_tabs, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(ev[1], st));
-  psk_orb_launch_fast(P, h->d_arena, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(ev[2], st));
-  psk_orb_launch_quadtree(P, h->d_arena, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(ev[3], st));
-  psk_orb_launch_blur(P, h->d_arena, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(ev[4], st));
-  psk_orb_launch_describe(P, h->d_arena, h->d_kps, h->d_desc, h->d_counts, nimg, st);
-  if (tm) PS_HIP(hipEventRecord(ev[5], st));
+  const int chunk = h->chunk > 0 ? h->chunk : nimg;
+  const int nchunks = (nimg + chunk - 1) / chunk;
+  if (tm && nchunks > ps_orb::MAXCHUNK) return ps_set_error(PS_ERR_CAPACITY, "stage timing supports at most %d chunks", ps_orb::MAXCHUNK);
+  const int slot = h->timed_batches % ps_orb::RING;
+  for (int c = 0; c < nchunks; c++) {
+    const int i0 = c * chunk, n = nimg - i0 < chunk ? nimg - i0 : chunk;
+    uint8_t* arena = h->d_arena + (size_t)i0 * P->arena_bytes;
+    const uint8_t* imgs = d_imgs + (size_t)i0 * pitch;
+    hipEvent_t* ev = h->ev[slot][c];
+    if (tm) PS_HIP(hipEventRecord(ev[0], st));
+    for (int l = 0; l < P->nlevels; l++) psk_orb_launch_pyramid(P, l, arena, imgs, stride, pitch, h->d_tabs, n, st);
+    psk_orb_launch_border(P, arena, n, st);
+    if (tm) PS_HIP(hipEventRecord(ev[1], st));
+    psk_orb_launch_fast(P, arena, n, st);
+    if (tm) PS_HIP(hipEventRecord(ev[2], st));
+    psk_orb_launch_quadtree(P, arena, n, st);
+    if (tm) PS_HIP(hipEventRecord(ev[3], st));
+    psk_orb_launch_blur(P, arena, n, st);
+    if (tm) PS_HIP(hipEventRecord(ev[4], st));
+    psk_orb_launch_describe(P, arena, h->d_kps + (size_t)i0 * P->kp_cap, h->d_desc + (size_t)i0 * P->kp_cap * 32,
+                            h->d_counts + i0, n, st);
+    if (tm) PS_HIP(hipEventRecord(ev[5], st));
+  }
   PS_HIP(hipGetLastError());
-  if (tm) h->timed_batches++;
+  if (tm) { h->timed_chunks[slot] = nchunks; h->timed_batches++; }
   h->last_nimg = nimg;
   return PS_OK;
 }
@@ -272,7 +307,9 @@ int ps_orb_create(const ps_orb_config* cfg, ps_orb** out) {
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return ps_set_error(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
   for (int r = 0; r < ps_orb::RING; r++)
-    for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&h->ev[r][i]);
+    for (int c = 0; c < ps_orb::MAXCHUNK; c++)
+      for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&h->ev[r][c][i]);
+  if (const char* e = getenv("PS_ORB_CHUNK")) h->chunk = atoi(e);
   *out = h;
   return PS_OK;
 }
@@ -284,7 +321,8 @@ void ps_orb_destroy(ps_orb* h) {
   free_device(h);
   if (h->d_img) hipFree(h->d_img);
   for (int r = 0; r < ps_orb::RING; r++)
-    for (int i = 0; i <= ST_COUNT; i++) if (h->ev[r][i]) hipEventDestroy(h->ev[r][i]);
+    for (int c = 0; c < ps_orb::MAXCHUNK; c++)
+      for (int i = 0; i <= ST_COUNT; i++) if (h->ev[r][c][i]) hipEventDestroy(h->ev[r][c][i]);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -452,12 +490,13 @@ int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n
   for (int i = 0; i < ST_COUNT && i < cap; i++) {
     if (names) names[i] = kStageNames[i];
     if (ms) {
-      double acc = 0;
-      for (int r = 0; r < nb; r++) {
-        float t = 0;
-        PS_HIP(hipEventElapsedTime(&t, h->ev[r][i], h->ev[r][i + 1]));
-        acc += t;
-      }
+      double acc = 0;   // per batch: sum over its chunks; then the mean over the recorded batches
+      for (int r = 0; r < nb; r++)
+        for (int c = 0; c < h->timed_chunks[r]; c++) {
+          float t = 0;
+          PS_HIP(hipEventElapsedTime(&t, h->ev[r][c][i], h->ev[r][c][i + 1]));
+          acc += t;
+        }
       ms[i] = (float)(acc / nb);
     }
   }

@@ -17,6 +17,17 @@
 
 namespace {
 
+// XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MB L2; workgroup b is observed to run on XCD b % 8).
+// Kernels whose workgroups re-read one image's planes (FAST windows, keypoint patches) keep every image on ONE XCD:
+// linear block b -> xcd = b % 8, image = (b / 8 / blocks_per_image) * 8 + xcd, local block = (b / 8) % blocks_per_image.
+// Placement only affects speed (L2 hit rate), never results.
+__device__ __forceinline__ bool xcd_image_block(int blocks_per_image, int nimg, int& img, int& local_block) {
+  const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+  img = (j / blocks_per_image) * 8 + xcd;
+  local_block = j % blocks_per_image;
+  return img < nimg;
+}
+
 __device__ __forceinline__ int reflect101(int p, int len) {
   // cv::borderInterpolate(BORDER_REFLECT_101); the border (19) is smaller than any level here, but
   // loop anyway so tiny levels stay correct.
@@ -32,6 +43,40 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // xtab[dx] = {sx0, sx1, a0, a1}, ytab[dy] = {sy0, sy1, b0, b1} are built on the host exactly as
 // OpenCV builds xofs/ialpha/yofs/ibeta (float maths, saturate_cast<short>(c * 2048)).
 // ------------------------------------------------------------------------------------------------
+// Interior pixels only; the 19-px REFLECT_101 border of every level is filled afterwards by orb_border
+// (resize only reads the interior of the previous level, so the border is not on the cascade's critical path).
+// A thread produces 4 consecutive bytes (one dword store) x PYR_ROWS rows.  Source rows are fetched as aligned
+// dwords (3 per source row cover the <= 9-byte span of 4 outputs at scale 1.2) and the taps are extracted with
+// per-lane byte offsets; row r of level 0 is a shifted copy (2 aligned dwords + v_alignbyte).
+#define PYR_ROWS 4
+__device__ __forceinline__ uint32_t byte_of3(uint32_t w0, uint32_t w1, uint32_t w2, int off) {
+  const uint32_t w = off < 4 ? w0 : (off < 8 ? w1 : w2);
+  return (w >> ((off & 3) * 8)) & 0xFFu;
+}
+// OpenCV 3.4 resize(INTER_LINEAR) coefficient of destination index d for a source of `slen` samples
+// (imgproc/src/resize.cpp): f = (float)((d + 0.5) * scale - 0.5) in double, s = floor(f), f -= s, clamped at both
+// ends; weights = saturate_cast<short>(cvRound(c * 2048)).  Evaluated on the fly in IEEE double / float (no
+// contraction), which is bit-identical to the host-side table OpenCV builds.  clampx: the x axis zeroes the
+// fraction at both ends, the y axis only clips the row indices (resize.cpp's `clip`).
+struct ResizeTap { int s0, s1, a0, a1; };
+__device__ __forceinline__ ResizeTap resize_tap(int d, double scale, int slen, bool is_x) {
+  float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+  int si = (int)floorf(f);
+  f = __fsub_rn(f, (float)si);
+  ResizeTap t;
+  if (is_x) {
+    if (si < 0) { f = 0.f; si = 0; }
+    if (si >= slen - 1) { f = 0.f; si = slen - 1; }
+    t.s0 = si;
+    t.s1 = si + 1 < slen ? si + 1 : si;
+  } else {
+    t.s0 = si >= 0 ? (si < slen ? si : slen - 1) : 0;
+    t.s1 = si + 1 >= 0 ? (si + 1 < slen ? si + 1 : slen - 1) : 0;
+  }
+  t.a0 = __float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+  t.a1 = __float2int_rn(__fmul_rn(f, 2048.f));
+  return t;
+}
 template <bool LEVEL0>
 __global__ __launch_bounds__(256) void orb_pyramid_level(OrbPlan plan, int level, uint8_t* arena,
                                                         const uint8_t* imgs, int img_stride,
@@ -39,43 +84,128 @@ __global__ __launch_bounds__(256) void orb_pyramid_level(OrbPlan plan, int level
   const OrbLevel L = plan.lv[level];
   const int img = blockIdx.z;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
-  const int PW = L.w + 2 * PS_EDGE, PH = L.h + 2 * PS_EDGE;
-  const int px4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int py = blockIdx.y * 4 + threadIdx.y;
-  if (px4 >= PW || py >= PH) return;
-  const int y = reflect101(py - PS_EDGE, L.h);
-  uint32_t packed = 0;
-  if (LEVEL0) {
-    const uint8_t* src = imgs + (size_t)img * img_pitch + (size_t)y * img_stride;
+  const int px4 = PS_EDGE - 3 + (blockIdx.x * 64 + threadIdx.x) * 4;   // padded column of the group (multiple of 4)
+  const int y0 = (blockIdx.y * 4 + threadIdx.y) * PYR_ROWS;            // level row
+  const int x0 = px4 - PS_EDGE;                                        // level column of byte 0 (may be -3..)
+  if (x0 >= L.w || y0 >= L.h) return;
+  uint8_t* dst = base + L.plane_off + (size_t)PS_EDGE * L.stride + px4;
+  int xs[4];                                                           // clamped level columns of the 4 bytes
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int px = px4 + k;
-      uint32_t v = 0;
-      if (px < PW) v = src[reflect101(px - PS_EDGE, L.w)];
-      packed |= v << (8 * k);
+  for (int k = 0; k < 4; k++) xs[k] = min(max(x0 + k, 0), L.w - 1);    // out-of-range bytes are border: rewritten later
+  uint32_t packed[PYR_ROWS];
+  if (LEVEL0) {
+    const uint8_t* src = imgs + (size_t)img * img_pitch;
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; r++) {
+      const int y = min(y0 + r, L.h - 1);
+      const uint8_t* row = src + (size_t)y * img_stride;
+      if (x0 >= 0 && x0 + 7 < L.w) {
+        const uintptr_t s = reinterpret_cast<uintptr_t>(row + x0);
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(s & ~(uintptr_t)3);
+        packed[r] = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)(s & 3));
+      } else {
+        packed[r] = (uint32_t)row[xs[0]] | ((uint32_t)row[xs[1]] << 8) | ((uint32_t)row[xs[2]] << 16) | ((uint32_t)row[xs[3]] << 24);
+      }
     }
   } else {
     const OrbLevel S = plan.lv[level - 1];
-    const uint8_t* src = base + S.plane_off + (size_t)PS_EDGE * S.stride + PS_EDGE;
-    const int4 ty = tabs[L.ytab_off + y];
-    const uint8_t* r0 = src + (size_t)ty.x * S.stride;
-    const uint8_t* r1 = src + (size_t)ty.y * S.stride;
+    const uint8_t* src = base + S.plane_off + (size_t)PS_EDGE * S.stride + PS_EDGE;   // 4-byte aligned + 3
+    const double scale_x = 1. / ((double)L.w / S.w), scale_y = 1. / ((double)L.h / S.h);
+    int4 tx[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int px = px4 + k;
-      uint32_t v = 0;
-      if (px < PW) {
-        const int4 tx = tabs[L.xtab_off + reflect101(px - PS_EDGE, L.w)];
-        const int h0 = (int)r0[tx.x] * tx.z + (int)r0[tx.y] * tx.w;
-        const int h1 = (int)r1[tx.x] * tx.z + (int)r1[tx.y] * tx.w;
-        int o = (((ty.z * (h0 >> 4)) >> 16) + ((ty.w * (h1 >> 4)) >> 16) + 2) >> 2;
-        o = o < 0 ? 0 : (o > 255 ? 255 : o);
-        v = (uint32_t)o;
+      const ResizeTap t = resize_tap(xs[k], scale_x, S.w, true);
+      tx[k] = make_int4(t.s0, t.s1, t.a0, t.a1);
+    }
+    const int sx_lo = tx[0].x;
+    // aligned window start in the padded source row: source pixel sx sits at byte PS_EDGE + sx of the row
+    const int a0 = (PS_EDGE + sx_lo) & ~3;
+    int off0[4], off1[4];
+    bool fast = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      off0[k] = PS_EDGE + tx[k].x - a0;
+      off1[k] = PS_EDGE + tx[k].y - a0;
+      fast = fast && off0[k] >= 0 && off1[k] < 12;
+    }
+    const uint8_t* srow0 = base + S.plane_off + (size_t)PS_EDGE * S.stride;          // padded row start, 64-B aligned
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; r++) {
+      const ResizeTap tyy = resize_tap(min(y0 + r, L.h - 1), scale_y, S.h, false);
+      const int4 ty = make_int4(tyy.s0, tyy.s1, tyy.a0, tyy.a1);
+      uint32_t pk = 0;
+      if (fast) {
+        const uint32_t* q0 = reinterpret_cast<const uint32_t*>(srow0 + (size_t)ty.x * S.stride + a0);
+        const uint32_t* q1 = reinterpret_cast<const uint32_t*>(srow0 + (size_t)ty.y * S.stride + a0);
+        const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int h0 = (int)byte_of3(u0, u1, u2, off0[k]) * tx[k].z + (int)byte_of3(u0, u1, u2, off1[k]) * tx[k].w;
+          const int h1 = (int)byte_of3(v0, v1, v2, off0[k]) * tx[k].z + (int)byte_of3(v0, v1, v2, off1[k]) * tx[k].w;
+          int o = (((ty.z * (h0 >> 4)) >> 16) + ((ty.w * (h1 >> 4)) >> 16) + 2) >> 2;
+          o = o < 0 ? 0 : (o > 255 ? 255 : o);
+          pk |= (uint32_t)o << (8 * k);
+        }
+      } else {
+        const uint8_t* r0 = src + (size_t)ty.x * S.stride;
+        const uint8_t* r1 = src + (size_t)ty.y * S.stride;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int h0 = (int)r0[tx[k].x] * tx[k].z + (int)r0[tx[k].y] * tx[k].w;
+          const int h1 = (int)r1[tx[k].x] * tx[k].z + (int)r1[tx[k].y] * tx[k].w;
+          int o = (((ty.z * (h0 >> 4)) >> 16) + ((ty.w * (h1 >> 4)) >> 16) + 2) >> 2;
+          o = o < 0 ? 0 : (o > 255 ? 255 : o);
+          pk |= (uint32_t)o << (8 * k);
+        }
       }
-      packed |= v << (8 * k);
+      packed[r] = pk;
     }
   }
-  *reinterpret_cast<uint32_t*>(base + L.plane_off + (size_t)py * L.stride + px4) = packed;
+#pragma unroll
+  for (int r = 0; r < PYR_ROWS; r++)
+    if (y0 + r < L.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(y0 + r) * L.stride) = packed[r];
+}
+
+// copyMakeBorder(REFLECT_101) of all levels in one launch: every border dword is recomputed from the interior.
+// Work items per level: (19 + 19) full rows and, for each interior row, the dword groups that touch the left /
+// right border.  (Interior bytes inside such a group are rewritten with their own value.)
+__global__ __launch_bounds__(256) void orb_border(OrbPlan plan, uint8_t* arena) {
+  const int img = blockIdx.y;
+  int level = 0;
+#pragma unroll
+  for (int l = 1; l < PS_ORB_MAX_LEVELS; l++)
+    if (l < plan.nlevels && (int)blockIdx.x >= plan.lv[l].border_blk_base) level = l;
+  const OrbLevel L = plan.lv[level];
+  uint8_t* base = arena + (size_t)img * plan.arena_bytes;
+  const int PW = L.w + 2 * PS_EDGE, PH = L.h + 2 * PS_EDGE;
+  const int ngx = (PW + 3) >> 2;                                  // dword groups per row
+  const int nleft = (PS_EDGE + 3) >> 2;                           // groups touching the left border: 5
+  const int rstart = (PS_EDGE + L.w) >> 2;                        // first group touching the right border
+  const int nright = ngx - rstart;
+  const int n_band = 2 * PS_EDGE * ngx, n_side = L.h * (nleft + nright);
+  const int t = (blockIdx.x - L.border_blk_base) * 256 + threadIdx.x;
+  if (t >= n_band + n_side) return;
+  int py, gx;
+  if (t < n_band) {
+    const int rr = t / ngx;
+    gx = t - rr * ngx;
+    py = rr < PS_EDGE ? rr : (L.h + rr);                          // top rows 0..18, bottom rows h+19..h+37
+  } else {
+    const int u = t - n_band, per = nleft + nright;
+    const int rr = u / per, c = u - rr * per;
+    py = PS_EDGE + rr;
+    gx = c < nleft ? c : rstart + (c - nleft);
+  }
+  const int sy = reflect101(py - PS_EDGE, L.h);
+  const uint8_t* srow = base + L.plane_off + (size_t)(PS_EDGE + sy) * L.stride + PS_EDGE;
+  uint32_t pk = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int px = min(gx * 4 + k, PW - 1);
+    pk |= (uint32_t)srow[reflect101(px - PS_EDGE, L.w)] << (8 * k);
+  }
+  (void)PH;
+  *reinterpret_cast<uint32_t*>(base + L.plane_off + (size_t)py * L.stride + gx * 4) = pk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -89,64 +219,57 @@ __global__ __launch_bounds__(256) void orb_pyramid_level(OrbPlan plan, int level
 //   keypoint_t(p) = s(p) > t  AND  s(p) > s(n) for all in-cell neighbours n,
 // the cell uses t = iniThFAST unless that yields no keypoint, then minThFAST (ORBextractor.cc:809-816).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_score(const uint8_t* c, int ts, int min_th) {
-  // ring in OpenCV's makeOffsets order
+// Exact score of a pixel that is known to be a corner at min_th: s = max over the 16 nine-pixel arcs of
+// min |signed diff| (see above).  c points at the pixel inside the LDS tile.
+__device__ __forceinline__ int fast_score_exact(const uint8_t* c, int ts) {
   const int v = c[0];
   int d[16];
   d[0] = v - c[3 * ts];      d[1] = v - c[3 * ts + 1];  d[2] = v - c[2 * ts + 2];  d[3] = v - c[ts + 3];
   d[4] = v - c[3];           d[5] = v - c[-ts + 3];     d[6] = v - c[-2 * ts + 2]; d[7] = v - c[-3 * ts + 1];
   d[8] = v - c[-3 * ts];     d[9] = v - c[-3 * ts - 1]; d[10] = v - c[-2 * ts - 2]; d[11] = v - c[-ts - 3];
   d[12] = v - c[-3];         d[13] = v - c[ts - 3];     d[14] = v - c[2 * ts - 2]; d[15] = v - c[3 * ts - 1];
-  uint32_t md = 0, mb = 0;
+  int lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    md |= (uint32_t)(d[k] > min_th) << k;
-    mb |= (uint32_t)(d[k] < -min_th) << k;
-  }
-  auto arc9 = [](uint32_t m16) {
-    uint32_t m = m16 | (m16 << 16);
-    uint32_t r = m & (m >> 1);
-    r &= r >> 2;
-    r &= r >> 4;
-    r &= m >> 8;
-    return r & 0xFFFFu;
-  };
-  const uint32_t rd = arc9(md), rb = arc9(mb);
-  if ((rd | rb) == 0) return 0;
-  // exact: A = max_i min(d[i..i+8]), B = max_i min(-d[i..i+8]) = -min_i max(d[i..i+8])
-  int lo2[16], hi2[16];
+  for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo2[i] = min(d[i], d[(i + 1) & 15]);
-    hi2[i] = max(d[i], d[(i + 1) & 15]);
-  }
-  int lo4[16], hi4[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo4[i] = min(lo2[i], lo2[(i + 2) & 15]);
-    hi4[i] = max(hi2[i], hi2[(i + 2) & 15]);
-  }
+  for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
   int A = -256, Bn = 256;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    const int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
-    const int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
-    A = max(A, lo9);
-    Bn = min(Bn, hi9);
+    A = max(A, min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]));
+    Bn = min(Bn, max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]));
   }
   return max(A, -Bn);
 }
 
-#define FAST_T 256
-__global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena) {
-  __shared__ uint8_t tile[PS_FAST_WIN * PS_FAST_WIN];
-  __shared__ uint8_t smap[(PS_FAST_WIN - 4) * (PS_FAST_WIN - 4)];   // (cw+2) x (ch+2), zero ring
-  __shared__ uint8_t flag[(PS_FAST_WIN - 6) * (PS_FAST_WIN - 6)];
-  __shared__ int wsum[FAST_T / 64];
-  __shared__ int tcount[FAST_T];
-  __shared__ int n20;
+// wave-level phase separator: LDS traffic of one wave is processed in order, the fence only keeps the
+// compiler from moving accesses across it (no workgroup barrier anywhere in this kernel)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-  const int cell = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+// One WAVE per FAST cell, four independent cells per workgroup, no workgroup barriers.
+//   A  the cell window (cell + 6) is copied to LDS with aligned dword loads
+//   B  every lane takes 4 horizontally adjacent pixels at a time: 7 rows x 12 bytes from LDS, ring pixels are
+//      compared against v -/+ min_th and the 32 results are kept TRANSPOSED as 64-bit lane masks
+//      (__ballot), so the "9 contiguous of 16" test is 2 x 79 scalar AND/ORs shared by 64 pixels
+//   C  the few pixels that pass are compacted (raster order) and scored exactly
+//   D  strict 3x3 NMS on the LDS score map, threshold fallback, raster-ordered emission into the cell's slots
+#define FAST_T 256
+__global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int nimg, int bpi) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int img, lb;
+  if (!xcd_image_block(bpi, nimg, img, lb)) return;
+  const int cell = lb * 4 + wave;
+  if (cell >= plan.n_cells) return;
+  const int per_wave = TR * TS + SS * (TR - 4) + 3 * LCAP + 16;
+  uint8_t* tile = fast_smem + (size_t)wave * ((per_wave + 15) & ~15);
+  uint8_t* smap = tile + TR * TS;
+  uint16_t* list = reinterpret_cast<uint16_t*>(smap + ((SS * (TR - 4) + 1) & ~1));
+  uint8_t* lflag = reinterpret_cast<uint8_t*>(list + LCAP);
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
   int level = 0;
 #pragma unroll
@@ -159,82 +282,133 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   const int maxBX = L.w - PS_MINB, maxBY = L.h - PS_MINB;
   const int iniX = PS_MINB + ci_x * L.w_cell, iniY = PS_MINB + ci_y * L.h_cell;
   const int maxX = min(iniX + L.w_cell + 6, maxBX), maxY = min(iniY + L.h_cell + 6, maxBY);
-  const int ww = maxX - iniX, wh = maxY - iniY;   // FAST ROI
-  const int cw = ww - 6, ch = wh - 6;             // candidate area
+  const int ww = maxX - iniX, wh = maxY - iniY, cw = ww - 6, ch = wh - 6;
   if (iniX >= maxBX - 3 || iniY >= maxBY - 3 || cw <= 0 || ch <= 0) {
-    if (tid == 0) cellcnt[cell] = 0;
+    if (lane == 0) cellcnt[cell] = 0;
     return;
   }
-  const int ts = PS_FAST_WIN, ss = cw + 2;
-  const uint8_t* plane = base + L.plane_off + (size_t)(PS_EDGE + iniY) * L.stride + PS_EDGE + iniX;
-  for (int i = tid; i < ww * wh; i += FAST_T) {
-    const int y = i / ww, x = i - y * ww;
-    tile[y * ts + x] = plane[(size_t)y * L.stride + x];
+  // ---- A: window -> LDS (aligned dwords), score map cleared ----
+  const int shift = (PS_EDGE + iniX) & 3;   // plane origins are 256-B aligned, strides multiples of 64
+  const uint8_t* ga = base + L.plane_off + (size_t)(PS_EDGE + iniY) * L.stride + (PS_EDGE + iniX - shift);
+  const int nd = (shift + ww + 3) >> 2;
+  for (int t = lane; t < wh * nd; t += 64) {
+    const int y = t / nd, dd = t - y * nd;
+    *reinterpret_cast<uint32_t*>(tile + y * TS + 4 * dd) = *reinterpret_cast<const uint32_t*>(ga + (size_t)y * L.stride + 4 * dd);
   }
-  for (int i = tid; i < ss * (ch + 2); i += FAST_T) smap[i] = 0;
-  if (tid == 0) n20 = 0;
-  __syncthreads();
-  const int npx = cw * ch;
-  for (int p = tid; p < npx; p += FAST_T) {
-    const int y = p / cw, x = p - y * cw;
-    const int s = fast_score(&tile[(y + 3) * ts + x + 3], ts, plan.min_th);
-    smap[(y + 1) * ss + x + 1] = (uint8_t)s;
-  }
-  __syncthreads();
-  int my20 = 0;
-  for (int p = tid; p < npx; p += FAST_T) {
-    const int y = p / cw, x = p - y * cw;
-    const uint8_t* m = &smap[(y + 1) * ss + x + 1];
-    const int s = m[0];
-    uint8_t f = 0;
-    if (s > 0) {
-      const bool lmax = s > m[-1] && s > m[1] && s > m[-ss - 1] && s > m[-ss] && s > m[-ss + 1] &&
-                        s > m[ss - 1] && s > m[ss] && s > m[ss + 1];
-      if (lmax) {
-        f = 1;
-        if (s > plan.ini_th) { f = 3; my20++; }
+  for (int t = lane; t < (SS * (ch + 2) + 3) / 4; t += 64) reinterpret_cast<uint32_t*>(smap)[t] = 0;
+  wave_sync();
+  // ---- B: candidate test, 4 pixels per lane and step ----
+  const int ng = (cw + 3) >> 2, ntask = ch * ng;
+  const int th = plan.min_th;
+  const unsigned long long ltmask = (1ull << lane) - 1ull;
+  int ncand = 0;
+  for (int t0 = 0; t0 < ntask; t0 += 64) {
+    const int t = t0 + lane;
+    const bool tv = t < ntask;
+    const int y = tv ? t / ng : 0, g = tv ? t - y * ng : 0;
+    uint32_t w[7][3];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(tile + (y + r) * TS + 4 * g);
+      const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+      w[r][0] = __builtin_amdgcn_alignbyte(a1, a0, shift);
+      w[r][1] = __builtin_amdgcn_alignbyte(a2, a1, shift);
+      w[r][2] = __builtin_amdgcn_alignbyte(a3, a2, shift);
+    }
+    unsigned long long C[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bool valid = tv && (4 * g + i) < cw;
+#define PXB(r, b) ((int)((w[r][(b) >> 2] >> (((b) & 3) * 8)) & 0xFFu))
+      const int v = PXB(3, 3 + i);
+      const int vlo = v - th, vhi = v + th;
+      // ring in OpenCV's order: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+      const int p0 = PXB(6, 3 + i), p1 = PXB(6, 4 + i), p2 = PXB(5, 5 + i), p3 = PXB(4, 6 + i);
+      const int p4 = PXB(3, 6 + i), p5 = PXB(2, 6 + i), p6 = PXB(1, 5 + i), p7 = PXB(0, 4 + i);
+      const int p8 = PXB(0, 3 + i), p9 = PXB(0, 2 + i), p10 = PXB(1, 1 + i), p11 = PXB(2, 0 + i);
+      const int p12 = PXB(3, 0 + i), p13 = PXB(4, 0 + i), p14 = PXB(5, 1 + i), p15 = PXB(6, 2 + i);
+#undef PXB
+      const int pr[16] = {p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, p13, p14, p15};
+      // per-lane 16-bit ring masks: the sign bit of (p - (v - th)) / ((v + th) - p) is shifted in with ONE
+      // v_alignbit per ring pixel (the compiler folds the byte extraction into the SDWA subtract).  [A transposed
+      // variant that kept the 32 compare results as 64-bit lane masks and reduced them with scalar ANDs was
+      // measured 4.7x slower: the CU has ONE scalar ALU for its four SIMDs.]
+      uint32_t md = 0, mb = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        md = __builtin_amdgcn_alignbit(md, (uint32_t)(pr[k] - vlo), 31);
+        mb = __builtin_amdgcn_alignbit(mb, (uint32_t)(vhi - pr[k]), 31);
+      }
+      auto arc9 = [](uint32_t m16) {
+        const uint32_t m = (m16 & 0xFFFFu) | (m16 << 16);
+        uint32_t r = m & (m >> 1);
+        r &= r >> 2;
+        r &= r >> 4;
+        r &= m >> 8;
+        return r & 0xFFFFu;
+      };
+      const bool cand = valid && ((arc9(md) | arc9(mb)) != 0);
+      C[i] = __builtin_amdgcn_ballot_w64(cand);
+    }
+    // raster-ordered compaction: order (lane, slot)
+    const int lower = __popcll(C[0] & ltmask) + __popcll(C[1] & ltmask) + __popcll(C[2] & ltmask) + __popcll(C[3] & ltmask);
+    int own = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if ((C[i] >> lane) & 1ull) {
+        const int pos = ncand + lower + own;
+        if (pos < LCAP) list[pos] = (uint16_t)(y * cw + 4 * g + i);
+        own++;
       }
     }
-    flag[p] = f;
+    ncand += __popcll(C[0]) + __popcll(C[1]) + __popcll(C[2]) + __popcll(C[3]);
   }
-  if (my20) atomicAdd(&n20, my20);
-  __syncthreads();
-  const uint8_t want = n20 > 0 ? 2 : 1;
-  // raster-ordered compaction: thread t owns pixels [t*per, (t+1)*per)
-  const int per = (npx + FAST_T - 1) / FAST_T;
-  const int b = tid * per, e = min(b + per, npx);
-  int mine = 0;
-  for (int p = b; p < e; p++) mine += (flag[p] & want) ? 1 : 0;
-  // block exclusive scan of `mine`
-  int incl = mine;
-  const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-  for (int dlt = 1; dlt < 64; dlt <<= 1) {
-    const int o = __shfl_up(incl, dlt);
-    if (lane >= dlt) incl += o;
+  ncand = min(ncand, LCAP);
+  wave_sync();
+  // ---- C: exact scores of the candidates ----
+  for (int idx = lane; idx < ncand; idx += 64) {
+    const int p = list[idx];
+    const int y = p / cw, x = p - y * cw;
+    smap[(y + 1) * SS + x + 1] = (uint8_t)fast_score_exact(tile + (y + 3) * TS + shift + x + 3, TS);
   }
-  if (lane == 63) wsum[wv] = incl;
-  __syncthreads();
-  int woff = 0, total = 0;
-#pragma unroll
-  for (int k = 0; k < FAST_T / 64; k++) {
-    if (k < wv) woff += wsum[k];
-    total += wsum[k];
-  }
-  int pos = woff + incl - mine;
-  (void)tcount;
-  uint32_t* slots = reinterpret_cast<uint32_t*>(base + plan.cand_base) + L.cand_off + (size_t)ci * L.cell_cap;
-  for (int p = b; p < e; p++) {
-    if (flag[p] & want) {
+  wave_sync();
+  // ---- D: per-cell NMS, threshold choice, emission ----
+  unsigned long long any20 = 0;
+  for (int i0 = 0; i0 < ncand; i0 += 64) {
+    const int idx = i0 + lane;
+    uint8_t f = 0;
+    if (idx < ncand) {
+      const int p = list[idx];
       const int y = p / cw, x = p - y * cw;
-      const int s = smap[(y + 1) * ss + x + 1];
+      const uint8_t* m = smap + (y + 1) * SS + x + 1;
+      const int s = m[0];
+      const bool lmax = s > m[-1] && s > m[1] && s > m[-SS - 1] && s > m[-SS] && s > m[-SS + 1] &&
+                        s > m[SS - 1] && s > m[SS] && s > m[SS + 1];
+      f = lmax ? (s > plan.ini_th ? 3 : 1) : 0;
+      lflag[idx] = f;
+    }
+    any20 |= __ballot(f == 3);
+  }
+  wave_sync();
+  const uint8_t want = any20 ? 2 : 1;
+  uint32_t* slots = reinterpret_cast<uint32_t*>(base + plan.cand_base) + L.cand_off + (size_t)ci * L.cell_cap;
+  int total = 0;
+  for (int i0 = 0; i0 < ncand; i0 += 64) {
+    const int idx = i0 + lane;
+    const bool keep = idx < ncand && (lflag[idx] & want);
+    const unsigned long long km = __ballot(keep);
+    if (keep) {
+      const int pos = total + __popcll(km & ltmask);
+      const int p = list[idx];
+      const int y = p / cw, x = p - y * cw;
+      const int s = smap[(y + 1) * SS + x + 1];
       // coordinates relative to (minBorderX, minBorderY): local + j*wCell (ORBextractor.cc:822-824)
       const uint32_t xr = (uint32_t)(x + 3 + ci_x * L.w_cell), yr = (uint32_t)(y + 3 + ci_y * L.h_cell);
       if (pos < L.cell_cap) slots[pos] = xr | (yr << 12) | ((uint32_t)s << 24);
-      pos++;
     }
+    total += __popcll(km);
   }
-  if (tid == 0) cellcnt[cell] = min(total, L.cell_cap);
+  if (lane == 0) cellcnt[cell] = min(total, L.cell_cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -548,27 +722,53 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
 // REFLECT_101 of the level, so reading the padded plane reproduces the border handling.
 // One wave = a strip of 64 columns; each lane slides a 7-deep window of horizontal sums down ROWS.
 // ------------------------------------------------------------------------------------------------
-#define BLUR_ROWS 32
-__global__ __launch_bounds__(256) void orb_blur(OrbPlan plan, uint8_t* arena, int level) {
+// One launch for all levels.  A lane owns 4 adjacent columns (3 aligned dword loads per row: pixel x0-3 sits at
+// byte 16 + x0 of the padded row because the border is 19) and BLUR_ROWS output rows; all BLUR_ROWS + 6 row loads
+// are issued before any arithmetic (memory-level parallelism), the 7x7 is evaluated separably in registers.
+#define BLUR_ROWS 8
+__global__ __launch_bounds__(256) void orb_blur(OrbPlan plan, uint8_t* arena) {
+  const int img = blockIdx.y;
+  int level = 0;
+#pragma unroll
+  for (int l = 1; l < PS_ORB_MAX_LEVELS; l++)
+    if (l < plan.nlevels && (int)blockIdx.x >= plan.lv[l].blur_blk_base) level = l;
   const OrbLevel L = plan.lv[level];
-  const int img = blockIdx.z;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  const int y0 = (blockIdx.y * 4 + threadIdx.y) * BLUR_ROWS;
-  if (x >= L.w || y0 >= L.h) return;
-  const uint8_t* src = base + L.plane_off + (size_t)PS_EDGE * L.stride + PS_EDGE + x;
-  uint8_t* dst = base + L.blur_off + x;
-  const int rows = min(BLUR_ROWS, L.h - y0);
-  uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0;
-  for (int r = -3; r < rows + 3; r++) {
-    const uint8_t* p = src + (ptrdiff_t)(y0 + r) * L.stride;
-    const uint32_t hs = 18u * (p[-3] + p[3]) + 34u * (p[-2] + p[2]) + 49u * (p[-1] + p[1]) + 55u * p[0];
-    h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = h5; h5 = h6; h6 = hs;
-    if (r >= 3) {
-      const uint32_t v = 18u * (h0 + h6) + 34u * (h1 + h5) + 49u * (h2 + h4) + 55u * h3;
-      const uint32_t o = (v + 32768u) >> 16;
-      dst[(size_t)(y0 + r - 3) * L.bstride] = (uint8_t)(o > 255u ? 255u : o);
+  const int nsx = (L.w + 255) >> 8;
+  const int bidx = blockIdx.x - L.blur_blk_base;
+  const int gy = bidx / nsx, sxi = bidx - gy * nsx;
+  const int x0 = sxi * 256 + (threadIdx.x & 63) * 4;
+  const int y0 = (gy * 4 + (threadIdx.x >> 6)) * BLUR_ROWS;
+  if (x0 >= L.w || y0 >= L.h) return;
+  const uint8_t* src = base + L.plane_off + (size_t)PS_EDGE * L.stride + 16 + x0;   // pixel (x0 - 3, 0)
+  uint32_t a[BLUR_ROWS + 6][3];
+#pragma unroll
+  for (int r = 0; r < BLUR_ROWS + 6; r++) {
+    const int y = min(y0 + r - 3, L.h + 2);   // rows past the level's bottom border are never used
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(src + (ptrdiff_t)y * L.stride);
+    a[r][0] = p[0]; a[r][1] = p[1]; a[r][2] = p[2];
+  }
+  uint32_t hs[BLUR_ROWS + 6][4];
+#pragma unroll
+  for (int r = 0; r < BLUR_ROWS + 6; r++) {
+#define BB(i) ((a[r][(i) >> 2] >> (((i) & 3) * 8)) & 0xFFu)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      hs[r][j] = 18u * (BB(j) + BB(j + 6)) + 34u * (BB(j + 1) + BB(j + 5)) + 49u * (BB(j + 2) + BB(j + 4)) + 55u * BB(j + 3);
+#undef BB
+  }
+  uint8_t* dst = base + L.blur_off + x0;
+#pragma unroll
+  for (int o = 0; o < BLUR_ROWS; o++) {
+    if (y0 + o >= L.h) break;
+    uint32_t pk = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t v = 18u * (hs[o][j] + hs[o + 6][j]) + 34u * (hs[o + 1][j] + hs[o + 5][j]) + 49u * (hs[o + 2][j] + hs[o + 4][j]) + 55u * hs[o + 3][j];
+      const uint32_t q = (v + 32768u) >> 16;
+      pk |= (q > 255u ? 255u : q) << (8 * j);
     }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)(y0 + o) * L.bstride) = pk;
   }
 }
 
@@ -576,11 +776,9 @@ __global__ __launch_bounds__(256) void orb_blur(OrbPlan plan, uint8_t* arena, in
 // Orientation + descriptor: ORBextractor.cc:77-104 (IC_Angle, cv::fastAtan2), :108-147
 // (computeOrbDescriptor), :1095-1101 (scaling), one wave per selected keypoint.
 // ------------------------------------------------------------------------------------------------
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
-// circular patch of radius 15: row v has half-width umax[v] (ORBextractor.cc:451-469)
-__constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   // OpenCV 3.4 atan_f32 (mathfuncs_core.simd.hpp), evaluated without FMA contraction
@@ -608,9 +806,10 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 struct PsKeyPoint { float x, y, size, angle, response; int32_t octave, class_id; };
 
 __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena, PsKeyPoint* out_kps,
-                                                   uint8_t* out_desc, int32_t* out_counts) {
-  const int img = blockIdx.y;
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                   uint8_t* out_desc, int32_t* out_counts, int nimg, int bpi) {
+  int img, lb;
+  if (!xcd_image_block(bpi, nimg, img, lb)) return;
+  const int slot = lb * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
   const int32_t* selcnt = reinterpret_cast<const int32_t*>(base + plan.selcnt_off);
@@ -640,19 +839,29 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
   // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the disc ----
   const uint8_t* center = base + L.plane_off + (size_t)(PS_EDGE + ky) * L.stride + PS_EDGE + kx;
   int m10 = 0, m01 = 0;
-  // 31 rows x up to 31 columns: lanes 0..30 take column u = lane - 15 of two rows per step
+  // 31 rows x up to 31 columns: lanes 0..30 take column u = lane - 15 of the even rows, lanes 32..62 of the odd rows.
+  // All 16 loads are issued unconditionally first (the patch lies inside the padded plane), then masked: a load
+  // inside a data-dependent branch would serialise 16 memory round trips.
   {
     const int u = (lane & 31) - 15;
     const int half = lane >> 5;
-    if ((lane & 31) < 31) {
-      for (int vv = -15 + half; vv <= 15; vv += 2) {
-        const int av = vv < 0 ? -vv : vv;
-        if (u >= -c_umax[av] && u <= c_umax[av]) {
-          const int val = center[(ptrdiff_t)vv * L.stride + u];
-          m10 += u * val;
-          m01 += vv * val;
-        }
-      }
+    const bool col_ok = (lane & 31) < 31;
+    int val[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int vv = min(-15 + half + 2 * it, 15);
+      val[it] = center[(ptrdiff_t)vv * L.stride + (col_ok ? u : 0)];
+    }
+    constexpr int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    const int au = u < 0 ? -u : u;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      // row of this lane: vv = -15 + half + 2*it ; |vv| is 15-2it (half 0) or |2it-14| (half 1)
+      const int ve = -15 + 2 * it, vo = -14 + 2 * it;
+      const int ume = kUmax[ve < 0 ? -ve : ve], umo = vo <= 15 ? kUmax[vo < 0 ? -vo : vo] : -1;
+      const int vv = half ? vo : ve;
+      const int um = half ? umo : ume;
+      if (col_ok && au <= um && vv <= 15) { m10 += u * val[it]; m01 += vv * val[it]; }
     }
   }
 #pragma unroll
@@ -668,9 +877,12 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
   const float a = (float)cos((double)arad), b = (float)sin((double)arad);
   const uint8_t* bc = base + L.blur_off + (size_t)ky * L.bstride + kx;
   uint32_t nib = 0;
+  const int4 pw = reinterpret_cast<const int4*>(c_pattern)[lane];   // this lane's 4 tests x (x0,y0,x1,y1) int8
+  const int pws[4] = {pw.x, pw.y, pw.z, pw.w};
 #pragma unroll
   for (int tst = 0; tst < 4; tst++) {
-    const int8_t* pp = &c_pattern[(lane * 4 + tst) * 4];
+    const int8_t pp[4] = {(int8_t)(pws[tst] & 0xFF), (int8_t)((pws[tst] >> 8) & 0xFF), (int8_t)((pws[tst] >> 16) & 0xFF),
+                          (int8_t)((pws[tst] >> 24) & 0xFF)};
     const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
     const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
     const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
@@ -707,28 +919,40 @@ extern "C" void psk_orb_launch_pyramid(const OrbPlan* plan, int level, uint8_t* 
                                        int img_stride, size_t img_pitch, const int4* tabs, int nimg,
                                        hipStream_t st) {
   const OrbLevel& L = plan->lv[level];
-  const int PW = L.w + 2 * PS_EDGE, PH = L.h + 2 * PS_EDGE;
-  dim3 blk(64, 4), grd((PW + 255) / 256, (PH + 3) / 4, nimg);
+  const int groups = (L.w + 3 + 3) / 4;   // dword groups from padded column 16 to the last interior byte
+  dim3 blk(64, 4), grd((groups + 63) / 64, (L.h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), nimg);
   if (level == 0)
     hipLaunchKernelGGL(orb_pyramid_level<true>, grd, blk, 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
   else
     hipLaunchKernelGGL(orb_pyramid_level<false>, grd, blk, 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
 }
+extern "C" void psk_orb_launch_border(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
+  hipLaunchKernelGGL(orb_border, dim3(plan->border_blocks, nimg), dim3(256), 0, st, *plan, arena);
+}
 extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
-  hipLaunchKernelGGL(orb_fast_cells, dim3(plan->n_cells, nimg), dim3(FAST_T), 0, st, *plan, arena);
+  // LDS geometry from the largest cell window of the plan
+  int mw = 0, mh = 0;
+  for (int l = 0; l < plan->nlevels; l++) {
+    mw = plan->lv[l].w_cell + 6 > mw ? plan->lv[l].w_cell + 6 : mw;
+    mh = plan->lv[l].h_cell + 6 > mh ? plan->lv[l].h_cell + 6 : mh;
+  }
+  const int TS = (mw + 16 + 3) & ~3, TR = mh, SS = (mw - 6 + 2 + 3) & ~3;
+  const int LCAP = (mw - 6) * (mh - 6);
+  const int per_wave = (TR * TS + SS * (TR - 4) + 3 * LCAP + 16 + 15) & ~15;
+  const int bpi = (plan->n_cells + 3) / 4;
+  hipLaunchKernelGGL(orb_fast_cells, dim3(bpi * ((nimg + 7) / 8) * 8), dim3(FAST_T), (size_t)per_wave * 4, st, *plan, arena,
+                     TS, TR, SS, LCAP, nimg, bpi);
 }
 extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   hipLaunchKernelGGL(orb_quadtree, dim3(plan->nlevels, nimg), dim3(QT_T), 0, st, *plan, arena);
 }
 extern "C" void psk_orb_launch_blur(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
-  for (int l = 0; l < plan->nlevels; l++) {
-    const OrbLevel& L = plan->lv[l];
-    dim3 blk(64, 4), grd((L.w + 63) / 64, (L.h + BLUR_ROWS * 4 - 1) / (BLUR_ROWS * 4), nimg);
-    hipLaunchKernelGGL(orb_blur, grd, blk, 0, st, *plan, arena, l);
-  }
+  hipLaunchKernelGGL(orb_blur, dim3(plan->blur_blocks, nimg), dim3(256), 0, st, *plan, arena);
 }
+extern "C" int psk_orb_blur_rows() { return BLUR_ROWS; }
 extern "C" void psk_orb_launch_describe(const OrbPlan* plan, uint8_t* arena, void* kps, uint8_t* desc,
                                         int32_t* counts, int nimg, hipStream_t st) {
-  hipLaunchKernelGGL(orb_describe, dim3((plan->sel_total + 3) / 4, nimg), dim3(256), 0, st, *plan, arena,
-                     (PsKeyPoint*)kps, desc, counts);
+  const int bpi = (plan->sel_total + 3) / 4;
+  hipLaunchKernelGGL(orb_describe, dim3(bpi * ((nimg + 7) / 8) * 8), dim3(256), 0, st, *plan, arena,
+                     (PsKeyPoint*)kps, desc, counts, nimg, bpi);
 }

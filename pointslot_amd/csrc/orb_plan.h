@@ -31,6 +31,8 @@ struct OrbLevel {
   float scale;              // mvScaleFactor[level]
   float kp_size;            // (float)(int)(31 * scale), ORBextractor.cc:839
   uint32_t xtab_off, ytab_off;  // element offsets into the resize tables (level >= 1)
+  int32_t blur_blk_base;        // first block of this level in the single orb_blur launch
+  int32_t border_blk_base;      // same for orb_border
 };
 
 struct OrbPlan {
@@ -41,6 +43,8 @@ struct OrbPlan {
   int32_t sel_total;        // selected-keypoint slots per image, all levels
   int32_t kp_cap;           // output keypoints per image
   int32_t ini_th, min_th;
+  int32_t blur_blocks;      // grid.x of orb_blur
+  int32_t border_blocks;    // grid.x of orb_border
   uint64_t arena_bytes;     // per image
   uint64_t cellcnt_off;     // int32[n_cells]
   uint64_t cand_base;       // u32 slots
