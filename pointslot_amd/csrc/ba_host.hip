@@ -11,7 +11,7 @@
 #include "ps_common.h"
 
 
-extern "C" void psk_ba_global_step(const BaArrays*, int, int, int, int, int, hipStream_t);
+extern "C" void psk_ba_global_step(const BaArrays*, int, int, int, int, int, int, hipStream_t);
 
 struct ps_optimizer;   // defined in opt_host.hip; BA keeps its own arena inside this small side struct
 struct BaCtx {
@@ -165,7 +165,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   int steps = 0;
   const int max_steps = 15 * 10 + 8;   // 15 iterations x 10 trials + stage transitions
   for (;;) {
-    psk_ba_global_step(&A, nprob, max_np, max_nl, max_ne, max_tilepairs, st);
+    psk_ba_global_step(&A, nprob, max_np, max_nl, max_ne, max_tilepairs, max_free, st);
     PS_HIP(hipGetLastError());
     PS_HIP(hipMemcpyAsync(h_done, A.ndone, 4, hipMemcpyDeviceToHost, st));
     PS_HIP(hipStreamSynchronize(st));

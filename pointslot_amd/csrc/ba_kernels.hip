@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "ba_plan.h"
 #include "se3.h"
 
@@ -37,6 +38,13 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __shfl_xor(lo, m);
   hi = __shfl_xor(hi, m);
+  return __hiloint2double(hi, lo);
+}
+// broadcast lane `src` (wave-uniform index) of a double: v_readlane_b32 x 2, a few cycles — not the LDS-routed
+// ds_bpermute a general __shfl costs
+__device__ __forceinline__ double shfl_d(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double v) {
@@ -439,109 +447,217 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
     }
 }
 
-// Blocked (6-wide) unpivoted LDL^T of the reduced system and the two triangular solves; x_p only changes
-// when the factorisation succeeds (linear_solver_eigen.h:94-120 returns false without touching x).
+// Blocked unpivoted LDL^T of the reduced system S (n = 6 * active poses) and the two triangular solves, one
+// workgroup per problem.  Block width NB (48 for n <= 312): per block column
+//   (1) ONE wave factors the NB x NB diagonal block with its rows in registers (lane = row, broadcasts by shuffle,
+//       no workgroup barrier), (2) every other row solves its NB-wide panel against it (thread per row, panel kept
+//       in LDS), (3) the trailing matrix gets the rank-NB update from the LDS panel, 1 x 4 register blocking.
+// Global traffic is n^3 / (3 NB) instead of n^3 / 18 with 6-wide blocks.  x_p only changes when the factorisation
+// succeeds (linear_solver_eigen.h:94-120 returns false without touching x); a zero pivot = failure, like
+// SimplicialLDLT.
 #define SOL_T 1024
+#ifdef PS_BA_PROFILE   // developer build: per-phase wall-clock ticks (100 MHz) of problem 0, printed by the kernel
+#define SOLP_DECL long long T0 = wall_clock64(), tph[6] = {0, 0, 0, 0, 0, 0}, tt = T0
+#define SOLP_MARK(k) do { const long long _n = wall_clock64(); tph[k] += _n - tt; tt = _n; } while (0)
+#define SOLP_PRINT() do { if (tid == 0 && blockIdx.x == 0) printf("solve n=%d NB=%d ticks: diag %lld panel %lld trail %lld fwd %lld bwd %lld total %lld\n", n, NB, tph[0], tph[1], tph[2], tph[3], tph[4], wall_clock64() - T0); } while (0)
+#else
+#define SOLP_DECL
+#define SOLP_MARK(k)
+#define SOLP_PRINT()
+#endif
+template <int NB>
 __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   const BaProb P = A.prob[blockIdx.x];
   BaState& St = A.state[blockIdx.x];
   if (St.phase != BA_PH_TRIAL) return;
-  const int n = 6 * St.npa, lda = 6 * P.np, tid = threadIdx.x;
+  const int n = 6 * St.npa, lda = 6 * P.np, tid = threadIdx.x, lane = tid & 63;
   double* Sm = A.S + P.S_base;
-  __shared__ double panel[PS_BA_MAX_POSES * 6][6];
-  __shared__ double rhs[PS_BA_MAX_POSES * 6];
-  __shared__ double Ljj[6][6];
-  __shared__ double dj[6];
-  __shared__ double dall[PS_BA_MAX_POSES * 6];
+  extern __shared__ __attribute__((aligned(16))) double sol_smem[];
+  double* Ljj = sol_smem;                       // [NB][NB + 1]
+  double* dj = Ljj + NB * (NB + 1);             // [NB]
+  double* rhs = dj + NB;                        // [n]
+  double* dall = rhs + 6 * PS_BA_MAX_POSES;     // [n]
+  double* lcol = dall + 6 * PS_BA_MAX_POSES;    // [2][64] multipliers of the current elimination step
+  double* panel = lcol + 128;                   // [rows below][NB + 1]
   __shared__ int fail;
   if (tid == 0) fail = 0;
   for (int i = tid; i < n; i += SOL_T) rhs[i] = A.bs[(size_t)P.pose_base * 6 + i];
   __syncthreads();
   if (n == 0) { if (tid == 0) St.ok2 = 1; return; }
-  for (int J = 0; J < n; J += 6) {
-    if (tid == 0) {
-      double M[6][6];
-      for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) M[r][c] = Sm[(size_t)(J + r) * lda + J + c];
-      for (int j = 0; j < 6; j++) {
-        double d = M[j][j];
-        for (int q = 0; q < j; q++) d -= M[j][q] * M[j][q] * dj[q];
-        if (d == 0) fail = 1;
-        dj[j] = d;
-        for (int i = j + 1; i < 6; i++) {
-          double v = M[i][j];
-          for (int q = 0; q < j; q++) v -= M[i][q] * M[j][q] * dj[q];
-          M[i][j] = v / d;
+  SOLP_DECL;
+  for (int J = 0; J < n; J += NB) {
+    const int jb = min(NB, n - J);
+    SOLP_MARK(5);
+    // ---- (1) diagonal block, wave 0: lane = row, rows in registers.  Step j: every lane forms its multiplier
+    // l = a[j] / d_j and publishes it in LDS; the rank-1 update reads the other rows' multipliers back as LDS
+    // BROADCASTS (all lanes read the same address).  Entries above the diagonal are never consumed, so the update
+    // needs no masking.
+    if (tid < 64) {
+      double a[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) a[c] = (lane < jb && c <= lane) ? Sm[(size_t)(J + lane) * lda + J + c] : 0.0;
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        if (j < jb) {
+          const double d = shfl_d(a[j], j);
+          if (d == 0) bad = true;
+          const double l = lane > j ? a[j] / d : 0.0;
+          double* lc = lcol + (j & 1) * 64;
+          lc[lane] = l;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const double ld = l * d;
+#pragma unroll
+          for (int k = j + 1; k < NB; k++) a[k] -= ld * lc[k];
+          if (lane > j) a[j] = l;
         }
       }
-      for (int r = 0; r < 6; r++) {
-        for (int c = 0; c < 6; c++) Ljj[r][c] = c < r ? M[r][c] : (c == r ? 1.0 : 0.0);
-        dall[J + r] = dj[r];
-        for (int c = 0; c < r; c++) Sm[(size_t)(J + r) * lda + J + c] = M[r][c];
-      }
-    }
-    __syncthreads();
-    if (fail) break;
-    const int m0 = J + 6;
-    for (int i = m0 + tid; i < n; i += SOL_T) {
-      double Lr[6];
-      for (int c = 0; c < 6; c++) {
-        double v = Sm[(size_t)i * lda + J + c];
-        for (int q = 0; q < c; q++) v -= Lr[q] * dj[q] * Ljj[c][q];
-        Lr[c] = v / dj[c];
-      }
-      for (int c = 0; c < 6; c++) { Sm[(size_t)i * lda + J + c] = Lr[c]; panel[i][c] = Lr[c]; }
-    }
-    __syncthreads();
-    const int m = n - m0;
-    for (int q = tid; q < m * m; q += SOL_T) {
-      const int i = m0 + q / m, k = m0 + q % m;
-      if (k > i) continue;
-      double v = 0;
+      if (lane < jb) {
 #pragma unroll
-      for (int c = 0; c < 6; c++) v += panel[i][c] * dj[c] * panel[k][c];
-      Sm[(size_t)i * lda + k] -= v;
+        for (int c = 0; c < NB; c++) {
+          if (c < lane) { Ljj[lane * (NB + 1) + c] = a[c]; Sm[(size_t)(J + lane) * lda + J + c] = a[c]; }
+          else if (c == lane) { dj[lane] = a[c]; dall[J + lane] = a[c]; }
+        }
+      }
+      if (bad && lane == 0) fail = 1;
     }
     __syncthreads();
+    SOLP_MARK(0);
+    if (fail) break;
+    // ---- (2) panel rows below the block: coalesced load into LDS, thread-per-row solve in LDS, coalesced store ----
+    const int m0 = J + jb, m = n - m0;
+    for (int q = tid; q < m * jb; q += SOL_T) {
+      const int i = q / jb, c = q - i * jb;
+      panel[(size_t)i * (NB + 1) + c] = Sm[(size_t)(m0 + i) * lda + J + c];
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += SOL_T) {
+      double* prow = panel + (size_t)i * (NB + 1);
+      double xd[NB];   // x[q] * d_q = the un-divided value of column q
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        if (c < jb) {
+          double v = prow[c];
+#pragma unroll
+          for (int q = 0; q < c; q++) v -= xd[q] * Ljj[c * (NB + 1) + q];
+          xd[c] = v;
+          prow[c] = v / dj[c];
+        } else {
+          xd[c] = 0.0;
+          prow[c] = 0.0;
+        }
+      }
+    }
+    __syncthreads();
+    for (int q = tid; q < m * jb; q += SOL_T) {
+      const int i = q / jb, c = q - i * jb;
+      Sm[(size_t)(m0 + i) * lda + J + c] = panel[(size_t)i * (NB + 1) + c];
+    }
+    // forward substitution of this block column while its panel is still in LDS: y_J = L_JJ^-1 b_J (wave 0, after
+    // which the rows below subtract L_panel y_J) — no extra pass over L in global memory
+    if (tid < 64) {
+      double y = lane < jb ? rhs[J + lane] : 0.0;
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        if (j < jb) {
+          const double yj = shfl_d(y, j);
+          if (lane > j && lane < jb) y -= Ljj[lane * (NB + 1) + j] * yj;
+        }
+      }
+      if (lane < jb) rhs[J + lane] = y;
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += SOL_T) {
+      double v = rhs[m0 + i];
+      const double* prow = panel + (size_t)i * (NB + 1);
+#pragma unroll
+      for (int c = 0; c < NB; c++) if (c < jb) v -= prow[c] * rhs[J + c];
+      rhs[m0 + i] = v;
+    }
+    SOLP_MARK(1);
+    // ---- (3) trailing update, lower triangle, 1 x 4 register blocking ----
+    // 4 x 4 register blocking with lanes along the COLUMN index (row-major S: consecutive lanes write consecutive
+    // doubles): a thread owns 4 consecutive rows and columns k, k+64, k+128, k+192 of a 256-column slab.  The
+    // column-side panel reads have stride (NB + 1) doubles (conflict-free), the row-side reads are LDS broadcasts.
+    const int iq = (m + 3) >> 2, ncs = (m + 255) >> 8;
+    for (int q = tid; q < ncs * iq * 64; q += SOL_T) {
+      const int kl = q & 63, i4 = ((q >> 6) % iq) * 4, cs = (q >> 6) / iq;
+      const int c0 = cs * 256 + kl;
+      if (c0 > min(i4 + 3, m - 1)) continue;
+      double acc[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) acc[r][c4] = 0;
+      const double* pr = panel + (size_t)i4 * (NB + 1);
+      const double* q0 = panel + (size_t)min(c0, m - 1) * (NB + 1);
+      const double* q1 = panel + (size_t)min(c0 + 64, m - 1) * (NB + 1);
+      const double* q2 = panel + (size_t)min(c0 + 128, m - 1) * (NB + 1);
+      const double* q3 = panel + (size_t)min(c0 + 192, m - 1) * (NB + 1);
+#pragma unroll 4
+      for (int c = 0; c < NB; c++) {
+        const double dc = dj[c];
+        const double a0 = pr[c] * dc, a1 = pr[(NB + 1) + c] * dc, a2 = pr[2 * (NB + 1) + c] * dc, a3 = pr[3 * (NB + 1) + c] * dc;
+        const double k0 = q0[c], k1 = q1[c], k2 = q2[c], k3 = q3[c];
+        acc[0][0] += a0 * k0; acc[0][1] += a0 * k1; acc[0][2] += a0 * k2; acc[0][3] += a0 * k3;
+        acc[1][0] += a1 * k0; acc[1][1] += a1 * k1; acc[1][2] += a1 * k2; acc[1][3] += a1 * k3;
+        acc[2][0] += a2 * k0; acc[2][1] += a2 * k1; acc[2][2] += a2 * k2; acc[2][3] += a2 * k3;
+        acc[3][0] += a3 * k0; acc[3][1] += a3 * k1; acc[3][2] += a3 * k2; acc[3][3] += a3 * k3;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = i4 + r;
+        if (i >= m) continue;
+        double* dst = Sm + (size_t)(m0 + i) * lda + m0;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) {
+          const int k = c0 + 64 * c4;
+          if (k <= i) dst[k] -= acc[r][c4];
+        }
+      }
+    }
+    __syncthreads();
+    SOLP_MARK(2);
   }
   if (fail) { if (tid == 0) St.ok2 = 0; return; }
-  // forward substitution L y = b, blocked
-  for (int J = 0; J < n; J += 6) {
-    if (tid == 0)
-      for (int r = 1; r < 6; r++) {
-        double v = rhs[J + r];
-        for (int c = 0; c < r; c++) v -= Sm[(size_t)(J + r) * lda + J + c] * rhs[J + c];
-        rhs[J + r] = v;
-      }
-    __syncthreads();
-    for (int i = J + 6 + tid; i < n; i += SOL_T) {
-      double v = rhs[i];
-#pragma unroll
-      for (int c = 0; c < 6; c++) v -= Sm[(size_t)i * lda + J + c] * rhs[J + c];
-      rhs[i] = v;
-    }
-    __syncthreads();
-  }
   for (int i = tid; i < n; i += SOL_T) rhs[i] /= dall[i];
   __syncthreads();
-  // backward substitution L^T x = z, blocked
-  for (int J = n - 6; J >= 0; J -= 6) {
-    if (tid == 0)
-      for (int r = 4; r >= 0; r--) {
-        double v = rhs[J + r];
-        for (int c = r + 1; c < 6; c++) v -= Sm[(size_t)(J + c) * lda + J + r] * rhs[J + c];
-        rhs[J + r] = v;
+  SOLP_MARK(3);
+  // ---- backward substitution L^T x = z ----
+  for (int J = ((n - 1) / NB) * NB; J >= 0; J -= NB) {
+    const int jb = min(NB, n - J);
+    if (tid < 64) {   // lane = column r of the block: x_r -= sum_{c > r} L[J+c][J+r] x_c (column fetched up front)
+      double Lc[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) Lc[c] = (c < jb && lane < c) ? Sm[(size_t)(J + c) * lda + J + lane] : 0.0;
+      double x = lane < jb ? rhs[J + lane] : 0.0;
+#pragma unroll
+      for (int c = NB - 1; c >= 1; c--) {
+        if (c < jb) {
+          const double xc = shfl_d(x, c);
+          if (lane < c) x -= Lc[c] * xc;
+        }
       }
+      if (lane < jb) rhs[J + lane] = x;
+    }
     __syncthreads();
     for (int k = tid; k < J; k += SOL_T) {
       double v = rhs[k];
+      double lc[NB];
 #pragma unroll
-      for (int c = 0; c < 6; c++) v -= Sm[(size_t)(J + c) * lda + k] * rhs[J + c];
+      for (int c = 0; c < NB; c++) lc[c] = c < jb ? Sm[(size_t)(J + c) * lda + k] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NB; c++) v -= lc[c] * rhs[J + c];
       rhs[k] = v;
     }
     __syncthreads();
   }
+  SOLP_MARK(4);
   for (int i = tid; i < n; i += SOL_T) A.xp[(size_t)P.pose_base * 6 + i] = rhs[i];
   if (tid == 0) St.ok2 = 1;
+  SOLP_PRINT();
 }
 
 // x_l, push (backup) + oplus on every active vertex, partial sums of x . (lambda x + b)
@@ -692,7 +808,7 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
 // one "global step": every unfinished problem advances by one LM trial (plus linearisation / stage entry
 // when it is due).  max_* are maxima over the batch.
 extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int max_nl, int max_ne, int max_tilepairs,
-                                   hipStream_t st) {
+                                   int max_free, hipStream_t st) {
   const int nbl = (max_nl + 255) / 256, nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
   const int err_off = max_np + nbl + nbp;   // layout of `part`: [np chi partials][update partials][error partials]
   hipLaunchKernelGGL(ba_begin, dim3(nprob), dim3(256), 0, st, *A);
@@ -701,7 +817,22 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   hipLaunchKernelGGL(ba_post_lin, dim3(nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_prep, dim3(nbl + (max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), 0, st, *A);
-  hipLaunchKernelGGL(ba_solve, dim3(nprob), dim3(SOL_T), 0, st, *A);
+  {
+    const int n_max = 6 * max_free;
+    auto lds = [&](int nb) { return (size_t)(nb * (nb + 1) + nb + 128 + 12 * PS_BA_MAX_POSES + (size_t)(n_max > nb ? n_max - nb + 4 : 4) * (nb + 1) + 8) * sizeof(double); };
+    // > 64 KB of dynamic LDS has to be requested per kernel
+    static const int force_nb = getenv("PS_BA_NB") ? atoi(getenv("PS_BA_NB")) : 0;
+    if (force_nb == 48 && lds(48) <= 150 * 1024) {   // measured slower than 24 at n = 294 (single-wave diagonal factor)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(48));
+      hipLaunchKernelGGL(ba_solve<48>, dim3(nprob), dim3(SOL_T), lds(48), st, *A);
+    } else if (force_nb != 12 && lds(24) <= 150 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(24));
+      hipLaunchKernelGGL(ba_solve<24>, dim3(nprob), dim3(SOL_T), lds(24), st, *A);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(12));
+      hipLaunchKernelGGL(ba_solve<12>, dim3(nprob), dim3(SOL_T), lds(12), st, *A);
+    }
+  }
   hipLaunchKernelGGL(ba_update, dim3(nbl + nbp, nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_error_k, dim3(nbe, nprob), dim3(256), 0, st, *A, err_off);
   hipLaunchKernelGGL(ba_decide, dim3(nprob), dim3(256), 0, st, *A, err_off);

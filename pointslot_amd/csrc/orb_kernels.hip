@@ -429,16 +429,20 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
 #define QT_T 512
 #define QT_INV 0x80000000u
 
+#define QT_KCAP 4096              // keys kept in LDS (levels with more candidates use the global scratch)
+template <int NCAP>
 struct QtShared {
-  uint32_t boxa[2][PS_QT_NCAP];   // x0 | y0 << 16
-  uint32_t boxb[2][PS_QT_NCAP];   // x1 | y1 << 16
-  uint32_t cnt[2][PS_QT_NCAP];    // key count | QT_INV (member of vSizeAndPointerToNode)
-  uint32_t seq[2][PS_QT_NCAP];    // creation order
-  uint32_t child[PS_QT_NCAP * 4];
-  int32_t rank[PS_QT_NCAP];       // node -> rank in processing order, -1 = not a candidate
-  int32_t ord[PS_QT_NCAP];        // rank -> node
-  int32_t cpre[PS_QT_NCAP + 1];   // exclusive prefix (rank order) of non-empty child counts
-  int32_t surv[PS_QT_NCAP];       // node -> new index when it survives unprocessed
+  uint32_t boxa[2][NCAP];   // x0 | y0 << 16
+  uint32_t boxb[2][NCAP];   // x1 | y1 << 16
+  uint32_t cnt[2][NCAP];    // key count | QT_INV (member of vSizeAndPointerToNode)
+  uint32_t seq[2][NCAP];    // creation order
+  uint32_t child[NCAP * 4];
+  int32_t rank[NCAP];       // node -> rank in processing order, -1 = not a candidate
+  int32_t ord[NCAP];        // rank -> node
+  int32_t cpre[NCAP + 1];   // exclusive prefix (rank order) of non-empty child counts
+  uint32_t kxy[QT_KCAP];    // key position x | y << 16
+  uint32_t kns[QT_KCAP];    // key node | score << 16
+  int32_t surv[NCAP + 1];   // node -> new index when it survives unprocessed (also: cell offsets during the gather)
   int32_t tmp[QT_T];
   int32_t total;
   int32_t cut;
@@ -446,7 +450,8 @@ struct QtShared {
 };
 
 // exclusive in-place scan of a[0..n) (n <= capacity of a), returns the total to every thread.
-__device__ int qt_exscan(int32_t* a, int n, QtShared& s) {
+template <int NCAP>
+__device__ int qt_exscan(int32_t* a, int n, QtShared<NCAP>& s) {
   const int t = threadIdx.x;
   const int chunk = (n + QT_T - 1) / QT_T;
   const int b = min(t * chunk, n), e = min(b + chunk, n);
@@ -485,16 +490,15 @@ __device__ __forceinline__ int qt_quadrant(uint32_t kxy, uint32_t ba, uint32_t b
   return (kx < mx ? 0 : 1) + (ky < my ? 0 : 2);
 }
 
+template <int NCAP>
 __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* arena) {
-  __shared__ QtShared s;
+  __shared__ QtShared<NCAP> s;
   const int level = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
   const OrbLevel L = plan.lv[level];
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
   const int32_t* cellcnt = reinterpret_cast<const int32_t*>(base + plan.cellcnt_off) + L.cell_base;
   const uint32_t* slots = reinterpret_cast<const uint32_t*>(base + plan.cand_base) + L.cand_off;
-  uint32_t* kxy = reinterpret_cast<uint32_t*>(base + plan.key_base) + L.key_off;
-  uint32_t* kns = kxy + L.key_cap;   // node | score << 16
+  uint32_t* gkxy = reinterpret_cast<uint32_t*>(base + plan.key_base) + L.key_off;   // global scratch (large levels)
   uint32_t* sel = reinterpret_cast<uint32_t*>(base + plan.sel_base) + L.sel_off;
   int32_t* selcnt = reinterpret_cast<int32_t*>(base + plan.selcnt_off);
   int32_t* ncand_out = reinterpret_cast<int32_t*>(base + plan.ncand_off);
@@ -511,17 +515,26 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
     if (t == 0) selcnt[level] = 0;
     return;
   }
-  for (int c = wave; c < ncell; c += QT_T / 64) {
-    const int cn = cellcnt[c], off = s.surv[c];
-    for (int k = lane; k < cn; k += 64) {
-      const uint32_t e = slots[(size_t)c * L.cell_cap + k];
-      const uint32_t x = e & 0xFFF, y = (e >> 12) & 0xFFF, sc = e >> 24;
-      // vpIniNodes[kp.pt.x / hX] (ORBextractor.cc:569): float division, truncation
-      const int ni = (int)__fdiv_rn((float)x, L.h_x);
-      kxy[off + k] = x | (y << 16);
-      kns[off + k] = (uint32_t)ni | (sc << 16);
-      atomicAdd(&s.child[ni], 1u);
+  // flattened gather: key j lives in cell c with off[c] <= j < off[c+1] (binary search in LDS), so every thread
+  // issues independent slot loads instead of walking the cells one dependent global round trip at a time
+  // keys live in LDS when they fit (generic pointers: the same code serves both cases)
+  uint32_t* kxy = n <= QT_KCAP ? s.kxy : gkxy;
+  uint32_t* kns = n <= QT_KCAP ? s.kns : gkxy + L.key_cap;   // node | score << 16
+  if (t == 0) s.surv[ncell] = n;
+  __syncthreads();
+  for (int j = t; j < n; j += QT_T) {
+    int lo = 0, hi = ncell;          // invariant: off[lo] <= j < off[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s.surv[mid] <= j) lo = mid; else hi = mid;
     }
+    const uint32_t e = slots[(size_t)lo * L.cell_cap + (j - s.surv[lo])];
+    const uint32_t x = e & 0xFFF, y = (e >> 12) & 0xFFF, sc = e >> 24;
+    // vpIniNodes[kp.pt.x / hX] (ORBextractor.cc:569): float division, truncation
+    const int ni = (int)__fdiv_rn((float)x, L.h_x);
+    kxy[j] = x | (y << 16);
+    kns[j] = (uint32_t)ni | (sc << 16);
+    atomicAdd(&s.child[ni], 1u);
   }
   __syncthreads();
   // ---- initial nodes (ORBextractor.cc:543-586); empty ones stay in the array with count 0 and
@@ -944,7 +957,13 @@ extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nim
                      TS, TR, SS, LCAP, nimg, bpi);
 }
 extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
-  hipLaunchKernelGGL(orb_quadtree, dim3(plan->nlevels, nimg), dim3(QT_T), 0, st, *plan, arena);
+  bool small = true;
+  for (int l = 0; l < plan->nlevels; l++) {
+    const OrbLevel& L = plan->lv[l];
+    small = small && L.quota + 4 <= 512 && 4 * L.n_ini <= 512 && L.n_cols * L.n_rows <= 512;
+  }
+  if (small) hipLaunchKernelGGL(orb_quadtree<512>, dim3(plan->nlevels, nimg), dim3(QT_T), 0, st, *plan, arena);
+  else hipLaunchKernelGGL(orb_quadtree<PS_QT_NCAP>, dim3(plan->nlevels, nimg), dim3(QT_T), 0, st, *plan, arena);
 }
 extern "C" void psk_orb_launch_blur(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   hipLaunchKernelGGL(orb_blur, dim3(plan->blur_blocks, nimg), dim3(256), 0, st, *plan, arena);
