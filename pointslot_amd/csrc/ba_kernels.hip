@@ -266,43 +266,72 @@ __global__ __launch_bounds__(256) void ba_lin_pose(BaArrays A) {
   }
 }
 
-// point-major half of buildSystem: H_ll and b_l (one thread per point; the error cache is already fresh)
+// point-major half of buildSystem: H_ll and b_l.  16 lanes share one point (its edges are strided over them and the
+// 6 + 3 sums are combined with a fixed-order butterfly over the 16 lanes); the error cache is already fresh.
+__device__ __forceinline__ void ba_jx(const double R[9], const BaProb& P, const double p[3], bool mono, double Jx[3][3]) {
+  const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
+  const double fx = (double)P.fx, fy = (double)P.fy, bf = (double)P.bf;
+  if (mono) {
+    const double t0 = fx, t2 = -x / z * fx, t4 = fy, t5 = -y / z * fy;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      Jx[0][c] = -1. / z * (t0 * R[c] + t2 * R[6 + c]);
+      Jx[1][c] = -1. / z * (t4 * R[3 + c] + t5 * R[6 + c]);
+      Jx[2][c] = 0;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      Jx[0][c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+      Jx[1][c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+      Jx[2][c] = Jx[0][c] - bf * R[6 + c] / z_2;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void ba_lin_point(BaArrays A) {
   const BaProb P = A.prob[blockIdx.y];
   const BaState& S = A.state[blockIdx.y];
   if (S.phase != BA_PH_LINEARIZE) return;
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= P.nl) return;
+  const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const bool lv = l < P.nl;
   const bool robust = S.robust != 0;
-  const double* X = A.points + (size_t)(P.point_base + l) * 3;
-  double H[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
-  const int b = A.csr_off[P.csr_point_base + l], e = A.csr_off[P.csr_point_base + l + 1];
-  for (int k = b; k < e; k++) {
-    const int ge = P.edge_base + A.csr_edges[P.csr_point_edges_base + k];
-    const uint8_t st = A.e_state[ge];
-    if (st & ES_LVL1) continue;
-    const bool mono = st & ES_MONO;
-    const Se3 T = load_pose(A.poses + (size_t)(P.pose_base + A.e_pose[ge]) * 7);
-    double R[9], p[3], er[3], Jp[3][6], Jx[3][3];
-    se3_quat_to_R(T.q, R);
-    ba_error(T, P, X, A.e_obs + (size_t)ge * 3, mono, p, er);
-    ba_jacobians(R, P, p, mono, Jp, Jx);
-    const double w = (double)A.e_is2[ge];
-    double rho0, rho1 = 1.0;
-    if (robust) huber(A.chi2c[ge], mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
-    const double wo = rho1 * w;
-    H[0] += wo * (Jx[0][0] * Jx[0][0] + Jx[1][0] * Jx[1][0] + Jx[2][0] * Jx[2][0]);
-    H[1] += wo * (Jx[0][0] * Jx[0][1] + Jx[1][0] * Jx[1][1] + Jx[2][0] * Jx[2][1]);
-    H[2] += wo * (Jx[0][0] * Jx[0][2] + Jx[1][0] * Jx[1][2] + Jx[2][0] * Jx[2][2]);
-    H[3] += wo * (Jx[0][1] * Jx[0][1] + Jx[1][1] * Jx[1][1] + Jx[2][1] * Jx[2][1]);
-    H[4] += wo * (Jx[0][1] * Jx[0][2] + Jx[1][1] * Jx[1][2] + Jx[2][1] * Jx[2][2]);
-    H[5] += wo * (Jx[0][2] * Jx[0][2] + Jx[1][2] * Jx[1][2] + Jx[2][2] * Jx[2][2]);
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // H00 H01 H02 H11 H12 H22 b0 b1 b2
+  if (lv) {
+    const double* X = A.points + (size_t)(P.point_base + l) * 3;
+    const int b = A.csr_off[P.csr_point_base + l], e = A.csr_off[P.csr_point_base + l + 1];
+    for (int k = b + sub; k < e; k += 16) {
+      const int ge = P.edge_base + A.csr_edges[P.csr_point_edges_base + k];
+      const uint8_t st = A.e_state[ge];
+      if (st & ES_LVL1) continue;
+      const bool mono = st & ES_MONO;
+      const Se3 T = load_pose(A.poses + (size_t)(P.pose_base + A.e_pose[ge]) * 7);
+      double R[9], p[3], er[3], Jx[3][3];
+      se3_quat_to_R(T.q, R);
+      ba_error(T, P, X, A.e_obs + (size_t)ge * 3, mono, p, er);
+      ba_jx(R, P, p, mono, Jx);
+      const double w = (double)A.e_is2[ge];
+      double rho0, rho1 = 1.0;
+      if (robust) huber(A.chi2c[ge], mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
+      const double wo = rho1 * w;
+      acc[0] += wo * (Jx[0][0] * Jx[0][0] + Jx[1][0] * Jx[1][0] + Jx[2][0] * Jx[2][0]);
+      acc[1] += wo * (Jx[0][0] * Jx[0][1] + Jx[1][0] * Jx[1][1] + Jx[2][0] * Jx[2][1]);
+      acc[2] += wo * (Jx[0][0] * Jx[0][2] + Jx[1][0] * Jx[1][2] + Jx[2][0] * Jx[2][2]);
+      acc[3] += wo * (Jx[0][1] * Jx[0][1] + Jx[1][1] * Jx[1][1] + Jx[2][1] * Jx[2][1]);
+      acc[4] += wo * (Jx[0][1] * Jx[0][2] + Jx[1][1] * Jx[1][2] + Jx[2][1] * Jx[2][2]);
+      acc[5] += wo * (Jx[0][2] * Jx[0][2] + Jx[1][2] * Jx[1][2] + Jx[2][2] * Jx[2][2]);
 #pragma unroll
-    for (int r = 0; r < 3; r++) bb[r] -= wo * (Jx[0][r] * er[0] + Jx[1][r] * er[1] + Jx[2][r] * er[2]);
+      for (int r = 0; r < 3; r++) acc[6 + r] -= wo * (Jx[0][r] * er[0] + Jx[1][r] * er[1] + Jx[2][r] * er[2]);
+    }
   }
-  double* Ho = A.Hll + (size_t)(P.point_base + l) * 9;
-  Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
-  for (int r = 0; r < 3; r++) A.bl[(size_t)(P.point_base + l) * 3 + r] = bb[r];
+#pragma unroll
+  for (int q = 0; q < 9; q++)
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) acc[q] += shfl_xor_d(acc[q], d);
+  if (lv && sub == 0) {
+    double* Ho = A.Hll + (size_t)(P.point_base + l) * 9;
+    Ho[0] = acc[0]; Ho[1] = acc[1]; Ho[2] = acc[2]; Ho[3] = acc[1]; Ho[4] = acc[3]; Ho[5] = acc[4]; Ho[6] = acc[2]; Ho[7] = acc[4]; Ho[8] = acc[5];
+    for (int r = 0; r < 3; r++) A.bl[(size_t)(P.point_base + l) * 3 + r] = acc[6 + r];
+  }
 }
 
 // chi2 total, lambda init on the first iteration of a stage (levenberg.cpp:93-97,166-180)
@@ -386,40 +415,60 @@ __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
     for (int r = 0; r < 6; r++) A.bs[(size_t)P.pose_base * 6 + a * 6 + r] = A.bp[(size_t)(P.pose_base + i) * 6 + r] - s[r];
 }
 
-// S(ta, tb) = [ta == tb] (H_pp + lambda I) - sum_l (W_a D_l^-1) W_b^T, lower-triangular tile pairs only
+// S(ta, tb) = [ta == tb] (H_pp + lambda I) - sum_l (W_a D_l^-1) W_b^T, lower-triangular tile pairs only.
+// One workgroup = one 48 x 48 tile (8 x 8 poses); the points are streamed in chunks of 16.  Staging: thread t takes
+// ONE (pose, point) pair of one side — its 6x3 W block is 18 contiguous doubles — the A side multiplies by D_l^-1 on
+// the fly; then every thread accumulates a 3 x 3 register block from the two LDS tiles.
 #define SCH_LC 16
 __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
   const BaProb P = A.prob[blockIdx.y];
   const BaState& St = A.state[blockIdx.y];
   if (St.phase != BA_PH_TRIAL) return;
   const int npa = St.npa, nt = (npa + PS_BA_TILE - 1) / PS_BA_TILE;
-  // blockIdx.x -> (ta, tb), tb <= ta
-  int ta = 0, rem = blockIdx.x;
+  int ta = 0, rem = blockIdx.x;   // blockIdx.x -> (ta, tb), tb <= ta
   while (ta < nt && rem > ta) { rem -= ta + 1; ta++; }
   if (ta >= nt) return;
   const int tb = rem;
   __shared__ double As[48][SCH_LC * 3 + 1];
   __shared__ double Bs[48][SCH_LC * 3 + 1];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  // staging role of this thread
+  const int side = tid >> 7, pl = (tid & 127) >> 4, lc = tid & 15;
+  const int pc = (side == 0 ? ta : tb) * PS_BA_TILE + pl;               // compact pose index
+  const bool pose_ok = pc < npa;
+  const double* Wrow = pose_ok ? A.W + P.W_base + (size_t)A.pact[P.pose_base + pc] * P.nl * 18 : nullptr;
+  double (*dstT)[SCH_LC * 3 + 1] = side == 0 ? As : Bs;
   double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   for (int l0 = 0; l0 < P.nl; l0 += SCH_LC) {
-    __syncthreads();
-    for (int q = tid; q < 48 * SCH_LC * 3; q += 256) {
-      const int row = q / (SCH_LC * 3), col = q - row * (SCH_LC * 3);
-      const int lc = col / 3, k = col - lc * 3, l = l0 + lc;
-      const int pa = ta * PS_BA_TILE + row / 6, pb = tb * PS_BA_TILE + row / 6, r = row % 6;
-      double av = 0, bv = 0;
-      if (l < P.nl && A.lact[P.point_base + l]) {
-        if (pa < npa) {
-          const double* Wb = A.W + P.W_base + ((size_t)A.pact[P.pose_base + pa] * P.nl + l) * 18 + r * 3;
-          const double* Di = A.Dinv + (size_t)(P.point_base + l) * 9;
-          av = Wb[0] * Di[k] + Wb[1] * Di[3 + k] + Wb[2] * Di[6 + k];
+    const int l = l0 + lc;
+    double w[18];
+    const bool ok = pose_ok && l < P.nl && A.lact[P.point_base + l];
+    if (ok) {
+      const double2* src = reinterpret_cast<const double2*>(Wrow + (size_t)l * 18);
+#pragma unroll
+      for (int q = 0; q < 9; q++) { const double2 v = src[q]; w[2 * q] = v.x; w[2 * q + 1] = v.y; }
+      if (side == 0) {
+        const double* Di = A.Dinv + (size_t)(P.point_base + l) * 9;
+        double d[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) d[q] = Di[q];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const double w0 = w[r * 3], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
+          w[r * 3] = w0 * d[0] + w1 * d[3] + w2 * d[6];
+          w[r * 3 + 1] = w0 * d[1] + w1 * d[4] + w2 * d[7];
+          w[r * 3 + 2] = w0 * d[2] + w1 * d[5] + w2 * d[8];
         }
-        if (pb < npa) bv = (A.W + P.W_base + ((size_t)A.pact[P.pose_base + pb] * P.nl + l) * 18)[r * 3 + k];
       }
-      As[row][col] = av;
-      Bs[row][col] = bv;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 18; q++) w[q] = 0.0;
     }
+    __syncthreads();   // the previous chunk's tiles are no longer being read
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) dstT[pl * 6 + r][lc * 3 + k] = w[r * 3 + k];
     __syncthreads();
 #pragma unroll 4
     for (int kk = 0; kk < SCH_LC * 3; kk++) {
@@ -586,11 +635,18 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       const int kl = q & 63, i4 = ((q >> 6) % iq) * 4, cs = (q >> 6) / iq;
       const int c0 = cs * 256 + kl;
       if (c0 > min(i4 + 3, m - 1)) continue;
+      // the 16 old values of S are fetched first: their L2 latency hides behind the NB-deep accumulation
       double acc[4][4];
 #pragma unroll
-      for (int r = 0; r < 4; r++)
+      for (int r = 0; r < 4; r++) {
+        const int i = min(i4 + r, m - 1);
+        const double* srow = Sm + (size_t)(m0 + i) * lda + m0;
 #pragma unroll
-        for (int c4 = 0; c4 < 4; c4++) acc[r][c4] = 0;
+        for (int c4 = 0; c4 < 4; c4++) {
+          const int k = c0 + 64 * c4;
+          acc[r][c4] = k <= i ? srow[k] : 0.0;
+        }
+      }
       const double* pr = panel + (size_t)i4 * (NB + 1);
       const double* q0 = panel + (size_t)min(c0, m - 1) * (NB + 1);
       const double* q1 = panel + (size_t)min(c0 + 64, m - 1) * (NB + 1);
@@ -598,7 +654,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       const double* q3 = panel + (size_t)min(c0 + 192, m - 1) * (NB + 1);
 #pragma unroll 4
       for (int c = 0; c < NB; c++) {
-        const double dc = dj[c];
+        const double dc = -dj[c];
         const double a0 = pr[c] * dc, a1 = pr[(NB + 1) + c] * dc, a2 = pr[2 * (NB + 1) + c] * dc, a3 = pr[3 * (NB + 1) + c] * dc;
         const double k0 = q0[c], k1 = q1[c], k2 = q2[c], k3 = q3[c];
         acc[0][0] += a0 * k0; acc[0][1] += a0 * k1; acc[0][2] += a0 * k2; acc[0][3] += a0 * k3;
@@ -614,7 +670,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
 #pragma unroll
         for (int c4 = 0; c4 < 4; c4++) {
           const int k = c0 + 64 * c4;
-          if (k <= i) dst[k] -= acc[r][c4];
+          if (k <= i) dst[k] = acc[r][c4];
         }
       }
     }
@@ -813,7 +869,7 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   const int err_off = max_np + nbl + nbp;   // layout of `part`: [np chi partials][update partials][error partials]
   hipLaunchKernelGGL(ba_begin, dim3(nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_lin_pose, dim3((max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
-  hipLaunchKernelGGL(ba_lin_point, dim3(nbl, nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_lin_point, dim3((max_nl + 15) / 16, nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_post_lin, dim3(nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_prep, dim3(nbl + (max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), 0, st, *A);
