@@ -252,10 +252,10 @@ __device__ __forceinline__ void wave_sync() {
 
 // One WAVE per FAST cell, four independent cells per workgroup, no workgroup barriers.
 //   A  the cell window (cell + 6) is copied to LDS with aligned dword loads
-//   B  every lane takes 4 horizontally adjacent pixels at a time: 7 rows x 12 bytes from LDS, ring pixels are
-//      compared against v -/+ min_th and the 32 results are kept TRANSPOSED as 64-bit lane masks
-//      (__ballot), so the "9 contiguous of 16" test is 2 x 79 scalar AND/ORs shared by 64 pixels
-//   C  the few pixels that pass are compacted (raster order) and scored exactly
+//   B  every lane takes 4 horizontally adjacent pixels at a time (rows x 12 bytes from LDS, v_alignbyte) and applies
+//      a cheap necessary condition on the 8 even ring positions; survivors are compacted in raster order (__ballot +
+//      popcount prefix)
+//   C  survivors are scored exactly (s > min_th <=> corner) and compacted again
 //   D  strict 3x3 NMS on the LDS score map, threshold fallback, raster-ordered emission into the cell's slots
 #define FAST_T 256
 __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int nimg, int bpi) {
@@ -297,11 +297,19 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   }
   for (int t = lane; t < (SS * (ch + 2) + 3) / 4; t += 64) reinterpret_cast<uint32_t*>(smap)[t] = 0;
   wave_sync();
-  // ---- B: candidate test, 4 pixels per lane and step ----
+  // ---- B: cheap NECESSARY test on the 8 even ring positions, 4 pixels per lane and step.  Nine contiguous ring
+  // pixels always contain four consecutive even positions, so a pixel without 4 consecutive dark (or bright) even
+  // positions cannot be a corner at min_th; this rejects most pixels for ~1/3 of the full test's work. ----
   const int ng = (cw + 3) >> 2, ntask = ch * ng;
-  const int th = plan.min_th;
   const unsigned long long ltmask = (1ull << lane) - 1ull;
-  int ncand = 0;
+  uint32_t* slots = reinterpret_cast<uint32_t*>(base + plan.cand_base) + L.cand_off + (size_t)ci * L.cell_cap;
+  int total = 0;
+  // Two passes at most: first with iniThFAST — a keypoint at threshold t only competes with neighbours that are corners
+  // at t, so when the cell has a keypoint at iniThFAST (the common case) the many weak corners between minThFAST and
+  // iniThFAST never need a score.  Only a cell without one repeats the pipeline at minThFAST (ORBextractor.cc:809-816).
+  for (int pass = 0; pass < 2; pass++) {
+  const int th = pass == 0 ? plan.ini_th : plan.min_th;
+  int nsurv = 0;
   for (int t0 = 0; t0 < ntask; t0 += 64) {
     const int t = t0 + lane;
     const bool tv = t < ntask;
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     uint32_t w[7][3];
 #pragma unroll
     for (int r = 0; r < 7; r++) {
+      if (r == 2 || r == 4) continue;   // rows +-1 hold odd ring positions only
       const uint32_t* p = reinterpret_cast<const uint32_t*>(tile + (y + r) * TS + 4 * g);
       const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
       w[r][0] = __builtin_amdgcn_alignbyte(a1, a0, shift);
@@ -322,33 +331,23 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
 #define PXB(r, b) ((int)((w[r][(b) >> 2] >> (((b) & 3) * 8)) & 0xFFu))
       const int v = PXB(3, 3 + i);
       const int vlo = v - th, vhi = v + th;
-      // ring in OpenCV's order: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-      const int p0 = PXB(6, 3 + i), p1 = PXB(6, 4 + i), p2 = PXB(5, 5 + i), p3 = PXB(4, 6 + i);
-      const int p4 = PXB(3, 6 + i), p5 = PXB(2, 6 + i), p6 = PXB(1, 5 + i), p7 = PXB(0, 4 + i);
-      const int p8 = PXB(0, 3 + i), p9 = PXB(0, 2 + i), p10 = PXB(1, 1 + i), p11 = PXB(2, 0 + i);
-      const int p12 = PXB(3, 0 + i), p13 = PXB(4, 0 + i), p14 = PXB(5, 1 + i), p15 = PXB(6, 2 + i);
+      // even ring positions in OpenCV's order: (0,3) (2,2) (3,0) (2,-2) (0,-3) (-2,-2) (-3,0) (-2,2)
+      const int pr[8] = {PXB(6, 3 + i), PXB(5, 5 + i), PXB(3, 6 + i), PXB(1, 5 + i),
+                         PXB(0, 3 + i), PXB(1, 1 + i), PXB(3, 0 + i), PXB(5, 1 + i)};
 #undef PXB
-      const int pr[16] = {p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, p13, p14, p15};
-      // per-lane 16-bit ring masks: the sign bit of (p - (v - th)) / ((v + th) - p) is shifted in with ONE
-      // v_alignbit per ring pixel (the compiler folds the byte extraction into the SDWA subtract).  [A transposed
-      // variant that kept the 32 compare results as 64-bit lane masks and reduced them with scalar ANDs was
-      // measured 4.7x slower: the CU has ONE scalar ALU for its four SIMDs.]
       uint32_t md = 0, mb = 0;
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
+      for (int k = 0; k < 8; k++) {
         md = __builtin_amdgcn_alignbit(md, (uint32_t)(pr[k] - vlo), 31);
         mb = __builtin_amdgcn_alignbit(mb, (uint32_t)(vhi - pr[k]), 31);
       }
-      auto arc9 = [](uint32_t m16) {
-        const uint32_t m = (m16 & 0xFFFFu) | (m16 << 16);
+      auto run4 = [](uint32_t m8) {   // 4 consecutive set bits in a circular 8-bit mask
+        const uint32_t m = (m8 & 0xFFu) | (m8 << 8);
         uint32_t r = m & (m >> 1);
         r &= r >> 2;
-        r &= r >> 4;
-        r &= m >> 8;
-        return r & 0xFFFFu;
+        return r & 0xFFu;
       };
-      const bool cand = valid && ((arc9(md) | arc9(mb)) != 0);
-      C[i] = __builtin_amdgcn_ballot_w64(cand);
+      C[i] = __builtin_amdgcn_ballot_w64(valid && ((run4(md) | run4(mb)) != 0));
     }
     // raster-ordered compaction: order (lane, slot)
     const int lower = __popcll(C[0] & ltmask) + __popcll(C[1] & ltmask) + __popcll(C[2] & ltmask) + __popcll(C[3] & ltmask);
@@ -356,24 +355,35 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if ((C[i] >> lane) & 1ull) {
-        const int pos = ncand + lower + own;
+        const int pos = nsurv + lower + own;
         if (pos < LCAP) list[pos] = (uint16_t)(y * cw + 4 * g + i);
         own++;
       }
     }
-    ncand += __popcll(C[0]) + __popcll(C[1]) + __popcll(C[2]) + __popcll(C[3]);
+    nsurv += __popcll(C[0]) + __popcll(C[1]) + __popcll(C[2]) + __popcll(C[3]);
   }
-  ncand = min(ncand, LCAP);
+  nsurv = min(nsurv, LCAP);
   wave_sync();
-  // ---- C: exact scores of the candidates ----
-  for (int idx = lane; idx < ncand; idx += 64) {
-    const int p = list[idx];
-    const int y = p / cw, x = p - y * cw;
-    smap[(y + 1) * SS + x + 1] = (uint8_t)fast_score_exact(tile + (y + 3) * TS + shift + x + 3, TS);
+  // ---- C: exact score of the survivors; s > min_th <=> corner.  The list is compacted in place (a chunk is read
+  // before anything is written, and writes never run ahead of the reads). ----
+  int ncand = 0;
+  for (int i0 = 0; i0 < nsurv; i0 += 64) {
+    const int idx = i0 + lane;
+    int p = 0, sc = 0;
+    if (idx < nsurv) {
+      p = list[idx];
+      const int y = p / cw, x = p - y * cw;
+      sc = fast_score_exact(tile + (y + 3) * TS + shift + x + 3, TS);
+      if (sc > th) smap[(y + 1) * SS + x + 1] = (uint8_t)sc;
+    }
+    const unsigned long long cm = __builtin_amdgcn_ballot_w64(sc > th);
+    wave_sync();
+    if (sc > th) list[ncand + __popcll(cm & ltmask)] = (uint16_t)p;
+    ncand += __popcll(cm);
   }
   wave_sync();
-  // ---- D: per-cell NMS, threshold choice, emission ----
-  unsigned long long any20 = 0;
+  // ---- D: per-cell NMS and emission (every listed pixel is a corner at th) ----
+  unsigned long long anykp = 0;
   for (int i0 = 0; i0 < ncand; i0 += 64) {
     const int idx = i0 + lane;
     uint8_t f = 0;
@@ -384,18 +394,16 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
       const int s = m[0];
       const bool lmax = s > m[-1] && s > m[1] && s > m[-SS - 1] && s > m[-SS] && s > m[-SS + 1] &&
                         s > m[SS - 1] && s > m[SS] && s > m[SS + 1];
-      f = lmax ? (s > plan.ini_th ? 3 : 1) : 0;
+      f = lmax ? 1 : 0;
       lflag[idx] = f;
     }
-    any20 |= __ballot(f == 3);
+    anykp |= __builtin_amdgcn_ballot_w64(f != 0);
   }
   wave_sync();
-  const uint8_t want = any20 ? 2 : 1;
-  uint32_t* slots = reinterpret_cast<uint32_t*>(base + plan.cand_base) + L.cand_off + (size_t)ci * L.cell_cap;
-  int total = 0;
+  if (!anykp && pass == 0) continue;   // no keypoint at iniThFAST: run the cell again at minThFAST
   for (int i0 = 0; i0 < ncand; i0 += 64) {
     const int idx = i0 + lane;
-    const bool keep = idx < ncand && (lflag[idx] & want);
+    const bool keep = idx < ncand && lflag[idx];
     const unsigned long long km = __ballot(keep);
     if (keep) {
       const int pos = total + __popcll(km & ltmask);
@@ -408,6 +416,8 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     }
     total += __popcll(km);
   }
+  break;
+  }   // pass
   if (lane == 0) cellcnt[cell] = min(total, L.cell_cap);
 }
 
