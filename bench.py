@@ -35,6 +35,24 @@ ALGO_BYTES_PER_IMAGE = {
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def pmc_traffic(kernel, nimg):
+    """HBM bytes per launch of `kernel` from the committed PMC measurement (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate passes, same workload).  On gfx950 FETCH_SIZE tallies 64 B per 128-B request of a coalesced
+    stream, so it is doubled as MI355X_MICROARCH.md prescribes; WRITE_SIZE is taken as reported (uncalibrated).  Returns None
+    when no measurement for this launch shape is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if t.get("images_per_launch") != nimg:
+        return None
+    for name, v in t.get("kernels", {}).items():
+        if name.split("<")[0] == kernel:
+            return v.get("hbm_bytes_per_launch_fetch_doubled")
+    return None
+
+
 def cpu_baseline(batch, pairs_sample):
     """Times the CPU restatement (oracle/, kind "port") on a bounded sample of the same workload, using the
     reference's thread model: left and right image on two threads (/root/reference/src/Frame.cc:709-710)."""
@@ -202,7 +220,7 @@ def main():
                        "pairs_per_step_per_gpu": args.pairs, "images_per_step_per_gpu": nimg,
                        "parallelism": "images sharded over %d GPU(s), no collective in the data path" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, nimg),
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms},
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         }
