@@ -68,6 +68,11 @@ __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint
   __shared__ int hist[32];
   const BfProb P = probs[blockIdx.x];
   const int lane = threadIdx.x;
+  if (P.nt == 0 || P.nq == 0) {   // nothing to match (bf_topk was not run for this problem)
+    for (int j = lane; j < P.nt; j += 64) query_of_train[P.t_off + j] = -1;
+    if (lane == 0) nmatch[blockIdx.x] = 0;
+    return;
+  }
   int32_t* out = query_of_train + P.t_off;
   for (int j = lane; j < PS_BF_MAX_TRAIN / 32; j += 64) taken[j] = 0;
   if (lane < 32) hist[lane] = 0;

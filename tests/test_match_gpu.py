@@ -92,3 +92,18 @@ def test_search_by_projection_all_variants(check_ori):
         total += n
     assert total > 1500
     m.close()
+
+
+def test_matchers_with_empty_inputs(matcher):
+    from pointslot_amd.matcher import build_grid
+    p = synth.bruteforce_problem(3, 0, 12)                      # no queries
+    (n, out), = matcher.SearchByBruceMatching([p])
+    assert n == 0 and np.all(out == -1) and len(out) == 12
+    p = synth.bruteforce_problem(4, 9, 0)                       # no trains
+    (n, out), = matcher.SearchByBruceMatching([p])
+    assert n == 0 and len(out) == 0
+    sc = synth.projection_scene(0x51070030, n=40, m=0)
+    tr = dict(sc["train"]); tr["cell_off"], tr["cell_idx"] = build_grid(tr["x"], tr["y"], *tr["grid"])
+    pr = {"train": tr, "scale_factors": sc["scale_factors"], "mode": "points", "query": sc["points_query"], "th": 1.0}
+    (n, out), = matcher.SearchByProjection([pr])
+    assert n == 0 and np.all(out == -1)
