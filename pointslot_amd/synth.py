@@ -309,7 +309,7 @@ def projection_scene(seed, n=2000, m=1500, w=1241, h=376, object_mode=False, th=
     zc = z[src]
     Xc = np.stack([(u - cx) / fx * zc, (v - cy) / fy * zc, zc], 1)
     xw = ((Xc - t) @ R).astype(np.float32)
-    q_desc = np.stack([_flip(rng, desc[j], 40) for j in src])
+    q_desc = np.stack([_flip(rng, desc[j], 40) for j in src]) if m else np.zeros((0, 32), np.uint8)
     rand = rng.uniform(m) < 0.15
     q_desc[rand] = rng.integers(int(rand.sum()) * 32, 0, 256).astype(np.uint8).reshape(-1, 32)
     q_oct = np.clip(octave[src] + rng.integers(m, -1, 2), 0, 7).astype(np.int32)
