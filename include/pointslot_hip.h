@@ -98,6 +98,17 @@ int ps_orb_batch_fetch(ps_orb* h, int image, ps_keypoint* kps, uint8_t* desc, in
 /* Waits for all work queued on the handle. */
 int ps_orb_sync(ps_orb* h);
 
+/* Frame::ComputeStereoMatches (/root/reference/src/Frame.cc:2142-2316) on extraction results that
+ * are still in HBM: both padded pyramids (mvImagePyramid of the left and the right extractor), keypoints and descriptors.
+ * mb = Frame::mb (baseline in metres), mbf = Frame::mbf.  Outputs are indexed like the LEFT image's keypoints:
+ * u_right = mvuRight, depth = mvDepth, -1 where the keypoint has no stereo match.
+ *   ps_orb_stereo_match_batch : the last batch of `h` holds left/right interleaved (image 2k = left, 2k+1 = right)
+ *   ps_orb_stereo_match_pair  : the reference's layout — two extractor objects, one image each (Frame.cc:709-722) */
+int ps_orb_stereo_match_batch(ps_orb* h, int npairs, float mb, float mbf);
+int ps_orb_stereo_device_outputs(const ps_orb* h, const float** d_uright, const float** d_depth, const int32_t** d_kept);
+int ps_orb_stereo_fetch(ps_orb* h, int pair, float* u_right, float* depth, int cap, int* n_left, int* kept);
+int ps_orb_stereo_match_pair(ps_orb* left, ps_orb* right, float mb, float mbf, float* u_right, float* depth, int cap, int* n_left);
+
 /* Test/diagnostic access to intermediates of the last call (blocking).  `what`:
  *   0 padded plane (tight, (w_l+38) x (h_l+38) bytes)      1 blurred plane (tight, w_l x h_l)
  *   2 FAST candidates in reference emission order, int32 triples (x, y, score) relative to

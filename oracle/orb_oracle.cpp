@@ -28,6 +28,7 @@
 #include <vector>
 #include <cfloat>
 #include <cstddef>
+#include <climits>
 using std::ptrdiff_t;
 
 namespace {
@@ -689,6 +690,109 @@ void orc_orb_level_kps(void* h, int level, void* kps28) {
 void orc_gaussian_kernel_q8(int* k7) { gaussian_kernel_q8(k7); }
 float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 int orc_pattern(int i) { return kPattern[i]; }
+
+// Frame::ComputeStereoMatches (/root/reference/src/Frame.cc:2142-2316) on the keypoints / descriptors / pyramids the two
+// extractors hold after orc_orb_run (left = hl, right = hr).  u_right / depth: N_left floats (-1 where unmatched).
+// Restated literally, including the quirks: `int bestDist` receives the float SAD, the window test uses
+// scaleduR0 + L - w, the parabola division is unguarded, and the cut is 1.5f * 1.4f * median of the SADs.
+int orc_stereo_match(void* hl, void* hr, float mb, float mbf, float* u_right, float* depth) {
+  Extractor& EL = *(Extractor*)hl;
+  Extractor& ER = *(Extractor*)hr;
+  const int N = (int)EL.out_kps.size(), Nr = (int)ER.out_kps.size();
+  for (int i = 0; i < N; i++) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+  if (N == 0) return 0;
+  const int TH_HIGH = 100, TH_LOW = 50;
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  const int nRows = EL.pyr[0].h;
+  std::vector<std::vector<size_t>> vRowIndices(nRows);
+  for (int iR = 0; iR < Nr; iR++) {
+    const KeyPoint& kp = ER.out_kps[iR];
+    const float kpY = kp.y;
+    const float r = 2.0f * ER.mvScaleFactor[kp.octave];
+    const int maxr = (int)std::ceil(kpY + r), minr = (int)std::floor(kpY - r);
+    for (int yi = minr; yi <= maxr; yi++)
+      if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);   // (the reference does not guard; out-of-range rows are UB there)
+  }
+  const float minZ = mb, minD = 0, maxD = mbf / minZ;
+  std::vector<std::pair<int, int>> vDistIdx;
+  auto desc_dist = [](const uint8_t* a, const uint8_t* b) {
+    int d = 0;
+    for (int i = 0; i < 32; i++) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return d;
+  };
+  for (int iL = 0; iL < N; iL++) {
+    const KeyPoint& kpL = EL.out_kps[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+    if (vCandidates.empty()) continue;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH;
+    size_t bestIdxR = 0;
+    for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+      const size_t iR = vCandidates[iC];
+      const KeyPoint& kpR = ER.out_kps[iR];
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      const float uR = kpR.x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = desc_dist(&EL.out_desc[(size_t)iL * 32], &ER.out_desc[iR * 32]);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      const float uR0 = ER.out_kps[bestIdxR].x;
+      const float scaleFactor = EL.mvInvScaleFactor[kpL.octave];
+      const float scaleduL = std::round(kpL.x * scaleFactor);
+      const float scaledvL = std::round(kpL.y * scaleFactor);
+      const float scaleduR0 = std::round(uR0 * scaleFactor);
+      const int w = 5, L = 5;
+      const Plane& PL = EL.pyr[kpL.octave];
+      const Plane& PR = ER.pyr[kpL.octave];
+      auto pix = [](const Plane& P, int y, int x) { return (float)P.roi()[(ptrdiff_t)y * P.stride + x]; };
+      const int cy = (int)scaledvL, cxl = (int)scaleduL;
+      const float ILc = pix(PL, cy, cxl);
+      int bestDistS = INT32_MAX, bestincR = 0;
+      float vDists[2 * 5 + 1];
+      const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+      if (iniu < 0 || endu >= PR.w) continue;
+      for (int incR = -L; incR <= +L; incR++) {
+        const int cxr = (int)(scaleduR0 + incR);
+        const float IRc = pix(PR, cy, cxr);
+        float dist = 0;
+        for (int dy = -w; dy <= w; dy++)
+          for (int dx = -w; dx <= w; dx++)
+            dist += std::fabs((pix(PL, cy + dy, cxl + dx) - ILc) - (pix(PR, cy + dy, cxr + dx) - IRc));
+        if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+      }
+      if (bestincR == -L || bestincR == L) continue;
+      const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = EL.mvScaleFactor[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+        depth[iL] = mbf / disparity;
+        u_right[iL] = bestuR;
+        vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+      }
+    }
+  }
+  if (vDistIdx.empty()) return 0;   // (the reference indexes an empty vector here)
+  std::sort(vDistIdx.begin(), vDistIdx.end());
+  const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  int kept = (int)vDistIdx.size();
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+    if (vDistIdx[i].first < thDist) break;
+    u_right[vDistIdx[i].second] = -1;
+    depth[vDistIdx[i].second] = -1;
+    kept--;
+  }
+  return kept;
+}
 
 // standalone quadtree for unit tests: keys as int triples (x,y,response)
 int orc_distribute(const int* keys, int n, int minX, int maxX, int minY, int maxY, int N, int* out_xyz) {

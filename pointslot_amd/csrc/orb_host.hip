@@ -20,6 +20,7 @@ void psk_orb_launch_blur(const OrbPlan*, uint8_t*, int, hipStream_t);
 void psk_orb_launch_border(const OrbPlan*, uint8_t*, int, hipStream_t);
 int psk_orb_blur_rows();
 void psk_orb_launch_describe(const OrbPlan*, uint8_t*, void*, uint8_t*, int32_t*, int, hipStream_t);
+void psk_stereo_launch(const OrbPlan*, const StPair*, int, float, float, hipStream_t);
 }
 
 namespace {
@@ -47,6 +48,10 @@ struct ps_orb {
   ps_keypoint* d_kps = nullptr;
   uint8_t* d_desc = nullptr;
   int32_t* d_counts = nullptr;
+  // stereo matcher outputs, indexed like the keypoints of the LEFT image: [max_batch][kp_cap]
+  float* d_uright = nullptr; float* d_depth = nullptr; int32_t* d_sad = nullptr; int32_t* d_kept = nullptr;
+  StPair* d_pairs = nullptr;
+  int last_npairs = 0;
   uint8_t* d_img = nullptr;       // staging for ps_orb_extract (one host image)
   size_t d_img_bytes = 0;
   hipStream_t stream = nullptr;
@@ -141,6 +146,12 @@ int free_device(ps_orb* h) {
   if (h->d_kps) hipFree(h->d_kps);
   if (h->d_desc) hipFree(h->d_desc);
   if (h->d_counts) hipFree(h->d_counts);
+  if (h->d_uright) hipFree(h->d_uright);
+  if (h->d_depth) hipFree(h->d_depth);
+  if (h->d_sad) hipFree(h->d_sad);
+  if (h->d_kept) hipFree(h->d_kept);
+  if (h->d_pairs) hipFree(h->d_pairs);
+  h->d_uright = nullptr; h->d_depth = nullptr; h->d_sad = nullptr; h->d_kept = nullptr; h->d_pairs = nullptr;
   h->d_arena = nullptr; h->d_tabs = nullptr; h->d_kps = nullptr; h->d_desc = nullptr; h->d_counts = nullptr;
   return 0;
 }
@@ -199,6 +210,7 @@ int build_plan(ps_orb* h, int w, int hgt) {
     L.sel_cap = (L.quota + 3 > 4 * L.n_ini ? L.quota + 3 : 4 * L.n_ini) + 1;
     sel += L.sel_cap;
     L.scale = h->scale[l];
+    L.inv_scale = h->inv_scale[l];
     L.kp_size = (float)(int)(31 * h->scale[l]);   // ORBextractor.cc:839: const int scaledPatchSize
     if (l > 0) resize_tables(P.lv[l - 1].w, P.lv[l - 1].h, L.w, L.h, h->tabs_host, &L.xtab_off, &L.ytab_off);
   }
@@ -247,6 +259,11 @@ int build_plan(ps_orb* h, int w, int hgt) {
   PS_HIP(hipMalloc(&h->d_kps, (size_t)B * P.kp_cap * sizeof(ps_keypoint)));
   PS_HIP(hipMalloc(&h->d_desc, (size_t)B * P.kp_cap * 32));
   PS_HIP(hipMalloc(&h->d_counts, (size_t)B * 4));
+  PS_HIP(hipMalloc(&h->d_uright, (size_t)B * P.kp_cap * 4));
+  PS_HIP(hipMalloc(&h->d_depth, (size_t)B * P.kp_cap * 4));
+  PS_HIP(hipMalloc(&h->d_sad, (size_t)B * P.kp_cap * 4));
+  PS_HIP(hipMalloc(&h->d_kept, (size_t)B * 4));
+  PS_HIP(hipMalloc(&h->d_pairs, (size_t)B * sizeof(StPair)));
   PS_HIP(hipMemsetAsync(h->d_counts, 0, (size_t)B * 4, h->stream));
   PS_HIP(hipStreamSynchronize(h->stream));
   h->planned = true;
@@ -501,6 +518,86 @@ int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n
     }
   }
   return PS_OK;
+}
+
+
+// ---- Frame::ComputeStereoMatches (Frame.cc:2142-2316) on device-resident extraction results ----
+static int stereo_run(ps_orb* out_h, const std::vector<StPair>& pairs, float mb, float mbf) {
+  PS_HIP(hipMemcpyAsync(out_h->d_pairs, pairs.data(), pairs.size() * sizeof(StPair), hipMemcpyHostToDevice, out_h->stream));
+  psk_stereo_launch(&out_h->plan, out_h->d_pairs, (int)pairs.size(), mb, mbf, out_h->stream);
+  PS_HIP(hipGetLastError());
+  out_h->last_npairs = (int)pairs.size();
+  return PS_OK;
+}
+
+int ps_orb_stereo_match_batch(ps_orb* h, int npairs, float mb, float mbf) {
+  if (!h || !h->planned || npairs < 1 || 2 * npairs > h->last_nimg || !(mb > 0) || !(mbf > 0))
+    return ps_set_error(PS_ERR_INVALID, "ps_orb_stereo_match_batch: needs a batch with 2 * npairs images (left, right interleaved)");
+  if (h->plan.kp_cap > 4096) return ps_set_error(PS_ERR_CAPACITY, "stereo matcher supports at most 4096 keypoints per image");
+  PS_HIP(hipSetDevice(h->cfg.device));
+  PS_HIP(hipDeviceSynchronize());   // the extraction may have run on a caller stream
+  const OrbPlan& P = h->plan;
+  std::vector<StPair> pairs(npairs);
+  for (int k = 0; k < npairs; k++) {
+    const size_t l = 2 * (size_t)k, r = l + 1;
+    StPair& s = pairs[k];
+    s.arena_l = h->d_arena + l * P.arena_bytes; s.arena_r = h->d_arena + r * P.arena_bytes;
+    s.kps_l = h->d_kps + l * P.kp_cap; s.desc_l = h->d_desc + l * P.kp_cap * 32; s.cnt_l = h->d_counts + l;
+    s.kps_r = h->d_kps + r * P.kp_cap; s.desc_r = h->d_desc + r * P.kp_cap * 32; s.cnt_r = h->d_counts + r;
+    s.u_right = h->d_uright + (size_t)k * P.kp_cap; s.depth = h->d_depth + (size_t)k * P.kp_cap;
+    s.sad = h->d_sad + (size_t)k * P.kp_cap; s.kept = h->d_kept + k;
+  }
+  return stereo_run(h, pairs, mb, mbf);
+}
+
+int ps_orb_stereo_device_outputs(const ps_orb* h, const float** d_uright, const float** d_depth, const int32_t** d_kept) {
+  if (!h || !h->planned) return ps_set_error(PS_ERR_INVALID, "no batch has been run");
+  if (d_uright) *d_uright = h->d_uright;
+  if (d_depth) *d_depth = h->d_depth;
+  if (d_kept) *d_kept = h->d_kept;
+  return PS_OK;
+}
+
+int ps_orb_stereo_fetch(ps_orb* h, int pair, float* u_right, float* depth, int cap, int* n_left, int* kept) {
+  if (!h || !h->planned || pair < 0 || pair >= h->last_npairs || !n_left)
+    return ps_set_error(PS_ERR_INVALID, "ps_orb_stereo_fetch: bad argument");
+  PS_HIP(hipSetDevice(h->cfg.device));
+  PS_HIP(hipDeviceSynchronize());
+  // the left image of pair k is image 2k of a batch, image 0 of a two-handle call
+  int32_t n = 0, kp = 0;
+  const int limg = h->last_npairs == 1 && h->last_nimg == 1 ? 0 : 2 * pair;
+  PS_HIP(hipMemcpy(&n, h->d_counts + limg, 4, hipMemcpyDeviceToHost));
+  PS_HIP(hipMemcpy(&kp, h->d_kept + pair, 4, hipMemcpyDeviceToHost));
+  *n_left = n;
+  if (kept) *kept = kp;
+  if (n > cap) return ps_set_error(PS_ERR_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
+  if (n > 0) {
+    if (!u_right || !depth) return ps_set_error(PS_ERR_INVALID, "null output buffer");
+    PS_HIP(hipMemcpy(u_right, h->d_uright + (size_t)pair * h->plan.kp_cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    PS_HIP(hipMemcpy(depth, h->d_depth + (size_t)pair * h->plan.kp_cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  return PS_OK;
+}
+
+int ps_orb_stereo_match_pair(ps_orb* left, ps_orb* right, float mb, float mbf, float* u_right, float* depth, int cap, int* n_left) {
+  if (!left || !right || !left->planned || !right->planned || !n_left || !(mb > 0) || !(mbf > 0))
+    return ps_set_error(PS_ERR_INVALID, "ps_orb_stereo_match_pair: both extractors must have processed an image");
+  if (left->cfg.device != right->cfg.device || left->plan.img_w != right->plan.img_w || left->plan.img_h != right->plan.img_h ||
+      left->plan.nlevels != right->plan.nlevels)
+    return ps_set_error(PS_ERR_INVALID, "left and right extractor differ in device, image size or level count");
+  if (left->plan.kp_cap > 4096) return ps_set_error(PS_ERR_CAPACITY, "stereo matcher supports at most 4096 keypoints per image");
+  PS_HIP(hipSetDevice(left->cfg.device));
+  PS_HIP(hipDeviceSynchronize());
+  std::vector<StPair> pairs(1);
+  StPair& s = pairs[0];
+  s.arena_l = left->d_arena; s.arena_r = right->d_arena;
+  s.kps_l = left->d_kps; s.desc_l = left->d_desc; s.cnt_l = left->d_counts;
+  s.kps_r = right->d_kps; s.desc_r = right->d_desc; s.cnt_r = right->d_counts;
+  s.u_right = left->d_uright; s.depth = left->d_depth; s.sad = left->d_sad; s.kept = left->d_kept;
+  int rc = stereo_run(left, pairs, mb, mbf);
+  if (rc != PS_OK) return rc;
+  left->last_nimg = 1;
+  return ps_orb_stereo_fetch(left, 0, u_right, depth, cap, n_left, nullptr);
 }
 
 }  // extern "C"

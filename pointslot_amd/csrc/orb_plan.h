@@ -29,6 +29,7 @@ struct OrbLevel {
   int32_t sel_off;          // element offset of the level's selected-keypoint slots
   int32_t sel_cap;
   float scale;              // mvScaleFactor[level]
+  float inv_scale;          // mvInvScaleFactor[level]
   float kp_size;            // (float)(int)(31 * scale), ORBextractor.cc:839
   uint32_t xtab_off, ytab_off;  // element offsets into the resize tables (level >= 1)
   int32_t blur_blk_base;        // first block of this level in the single orb_blur launch
@@ -52,4 +53,13 @@ struct OrbPlan {
   uint64_t sel_base;        // u32[sel_total]
   uint64_t selcnt_off;      // int32[PS_ORB_MAX_LEVELS]
   uint64_t ncand_off;       // int32[PS_ORB_MAX_LEVELS] (diagnostic: candidates per level)
+};
+
+// one stereo pair for the stereo matcher (orb_stereo.hip): raw device pointers so that the left and the right image may
+// live in the same batch (images 2k / 2k+1 of one handle) or in two handles (the reference's two ORBextractor objects)
+struct StPair {
+  const uint8_t* arena_l; const uint8_t* arena_r;
+  const void* kps_l; const uint8_t* desc_l; const int32_t* cnt_l;
+  const void* kps_r; const uint8_t* desc_r; const int32_t* cnt_r;
+  float* u_right; float* depth; int32_t* sad; int32_t* kept;
 };

@@ -37,6 +37,11 @@ lib.ps_orb_batch_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_
 lib.ps_orb_sync.argtypes = [ctypes.c_void_p]
 lib.ps_orb_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                   ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+lib.ps_orb_stereo_match_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float]
+lib.ps_orb_stereo_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+lib.ps_orb_stereo_match_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 lib.ps_orb_enable_stage_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.ps_orb_stage_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.POINTER(ctypes.c_int)]
@@ -153,3 +158,23 @@ class ORBextractor:
         n = ctypes.c_int(0)
         check(lib.ps_orb_stage_times(self._h, names, ms, 16, ctypes.byref(n)))
         return {names[i].decode(): ms[i] for i in range(n.value)}
+
+    # ---- Frame::ComputeStereoMatches on the device-resident results ----
+    def stereo_match_batch(self, npairs, mb, mbf):
+        """left/right interleaved in the last batch (image 2k = left, 2k+1 = right)"""
+        check(lib.ps_orb_stereo_match_batch(self._h, npairs, mb, mbf))
+
+    def stereo_fetch(self, pair):
+        ur = np.zeros(self.capacity, np.float32); dp = np.zeros(self.capacity, np.float32)
+        n = ctypes.c_int(0); kept = ctypes.c_int(0)
+        check(lib.ps_orb_stereo_fetch(self._h, pair, ur.ctypes.data, dp.ctypes.data, self.capacity, ctypes.byref(n), ctypes.byref(kept)))
+        return ur[:n.value].copy(), dp[:n.value].copy(), kept.value
+
+
+def ComputeStereoMatches(left, right, mb, mbf):
+    """Frame::ComputeStereoMatches for two ORBextractor objects that have each processed one image.
+    Returns (mvuRight, mvDepth) indexed like the left keypoints."""
+    ur = np.zeros(left.capacity, np.float32); dp = np.zeros(left.capacity, np.float32)
+    n = ctypes.c_int(0)
+    check(lib.ps_orb_stereo_match_pair(left._h, right._h, mb, mbf, ur.ctypes.data, dp.ctypes.data, left.capacity, ctypes.byref(n)))
+    return ur[:n.value].copy(), dp[:n.value].copy()

@@ -86,6 +86,7 @@ class OracleORB:
     def run(self, img):
         img = np.ascontiguousarray(img)
         n = self.L.orc_orb_run(self.h, img.ctypes.data, img.shape[1], img.shape[0], img.strides[0])
+        self.last_n = n
         kps = np.zeros(max(n, 1), KEYPOINT_DTYPE)
         desc = np.zeros((max(n, 1), 32), np.uint8)
         self.L.orc_orb_result(self.h, kps.ctypes.data, desc.ctypes.data)
@@ -119,6 +120,17 @@ class OracleORB:
         out = np.zeros(max(n, 1), KEYPOINT_DTYPE)
         self.L.orc_orb_level_kps(self.h, l, out.ctypes.data)
         return out[:n]
+
+
+def stereo_match(left, right, mb, mbf):
+    """left / right: OracleORB objects after run().  Returns (kept, u_right, depth)."""
+    L = lib()
+    L.orc_stereo_match.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    n = L.orc_orb_run  # noqa
+    nl = left.last_n
+    ur = np.zeros(max(nl, 1), np.float32); dp = np.zeros(max(nl, 1), np.float32)
+    kept = L.orc_stereo_match(left.h, right.h, mb, mbf, ur.ctypes.data, dp.ctypes.data)
+    return kept, ur[:nl], dp[:nl]
 
 
 def distribute(keys_xyz, minX, maxX, minY, maxY, N):
