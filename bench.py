@@ -189,6 +189,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # SURVEY 8f-1 (next row): stereo matching of the batch's pairs on the device-resident pyramids / descriptors
+    bf, fxc = 384.38148, 721.5377
+    ex.stereo_match_batch(args.pairs, bf / fxc, bf)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        ex.stereo_match_batch(args.pairs, bf / fxc, bf)
+    barrier()
+    stereo_ms = (time.perf_counter() - t1) / 5 * 1e3
+    ur, dp, kept = ex.stereo_fetch(0)
+    assert kept > 200 and (ur >= 0).sum() == kept
+
     # sanity: the timed work produced keypoints (outputs stay in HBM; fetch one image)
     kps, desc = ex.fetch(0)
     assert len(kps) >= NFEAT // 2 and desc.shape == (len(kps), 32)
@@ -225,6 +237,9 @@ def main():
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         }
         if secondary is not None:
+            secondary["stereo_matching"] = {"workload": "Frame::ComputeStereoMatches on the step's %d pairs (SURVEY 8f-1), device-resident" % args.pairs,
+                                            "wall_ms_per_batch": stereo_ms, "pairs_per_s": args.pairs / (stereo_ms * 1e-3),
+                                            "matches_pair0": int(kept)}
             out["secondary_metrics"] = secondary
             out["metric_ba"] = {"metric": "ms/iter 50-KF object BA (8 objects)", "value": secondary["object_ba"]["ms_per_iter"],
                                 "unit": "ms", "higher_is_better": False}

@@ -289,6 +289,10 @@ typedef struct ps_ba_problem {
   double* trace;
 } ps_ba_problem;
 int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int nprob);
+/* Optimizer::LocalBundleAdjustment(KeyFrame*, pbStopFlag, Map*) (Optimizer.cc:1077-1417) on a collected
+ * graph: same edge types and LM schedule with plain VertexSE3Expmap keyframes (pose_flags bit 1 = 0; bit 0 = fixed for
+ * mnId == 0 and the fixed cameras) and world-frame map points.  The abort flag of the reference is not modelled. */
+int ps_local_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int nprob);
 
 #ifdef __cplusplus
 }

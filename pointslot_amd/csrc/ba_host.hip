@@ -208,3 +208,8 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   }
   return PS_OK;
 }
+
+// Optimizer::LocalBundleAdjustment (/root/reference/src/Optimizer.cc:1077-1417): the static-map BA runs the same
+// graph (EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ, marginalised points, LM 5 + outlier pass + 10) with plain
+// VertexSE3Expmap keyframes (pose_flags bit 1 clear) and world-frame points, so it is the same solver.
+extern "C" int ps_local_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int nprob) { return ps_object_ba_batch(m, probs, nprob); }

@@ -130,3 +130,14 @@ def test_object_ba_config4_shape(opt):
     for i, (g, r) in enumerate(zip(graphs, res)):
         _ba_check(g, r, "config4 %d" % i)
     print("config-4 BA: %d + %d LM iterations, %.3f ms GPU" % (res[0]["iterations"], res[1]["iterations"], opt.last_kernel_ms()))
+
+
+def test_local_ba_shape(opt):
+    """SURVEY 8f-3: Optimizer::LocalBundleAdjustment's graph — plain SE3 keyframes (no roll/pitch lock), fixed cameras,
+    many more points than poses — through the same kernels."""
+    g = synth.object_ba_problem(0x51070060, n_kf=10, n_pts=1200, p_vis=0.35, perturb=(0.05, 1.0, 0.03), perturb_axis="y",
+                                n_fixed_extra=6, mono_frac=0.15)
+    g["pose_flags"] = (g["pose_flags"] & 1).astype(np.uint8)          # VertexSE3Expmap everywhere
+    r, = opt.ObjectLocalBundleAdjustment([g])
+    _ba_check(g, r, "local BA")
+    assert r["n_erased"] < 0.2 * len(g["e_pose"])
