@@ -147,6 +147,11 @@ int ps_hamming_matrix(ps_matcher* m, const uint8_t* q, int nq, const uint8_t* t,
  *   nmatches : out, the function's return value
  * nn_ratio / check_orientation are the ORBmatcher constructor arguments (mfNNratio, mbCheckOrientation);
  * TH_LOW = 50 and HISTO_LENGTH = 30 are fixed as in ORBmatcher.cc:58-62. nt <= 4096. */
+/* MapPoint / MapObjectPoint::ComputeDistinctiveDescriptors (src/MapObjectPoint.cc:379-436, src/MapPoint.cc:366; SURVEY.md
+ * 8f-4) for a batch of points: point p owns the descriptor rows [off[p], off[p+1]) (its observations, <= 128);
+ * best[p] = row index (relative to off[p]) of the descriptor with the least median distance to the others, -1 if none. */
+int ps_distinctive_descriptors(ps_matcher* m, const uint8_t* desc, const int32_t* off, int npoints, int32_t* best);
+
 typedef struct ps_bf_problem {
   const uint8_t* q_desc; const float* q_angle; const uint8_t* q_valid; int32_t nq;
   const uint8_t* t_desc; const float* t_angle; int32_t nt;

@@ -258,4 +258,31 @@ int orc_search_projection_points(const OrcTrain* F, int m, const uint8_t* valid,
   return nmatches;
 }
 
+
+// MapPoint / MapObjectPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapObjectPoint.cc:379-436, src/MapPoint.cc:366):
+// for every point, the index of the observation whose descriptor has the least median Hamming distance to the others.
+// desc: concatenated 32-byte rows, point p owns rows [off[p], off[p+1]).  best[p] = -1 for a point without observations.
+void orc_distinctive_descriptors(const uint8_t* desc, const int* off, int npoints, int* best) {
+  for (int p = 0; p < npoints; p++) {
+    const int N = off[p + 1] - off[p];
+    if (N <= 0) { best[p] = -1; continue; }
+    const uint8_t* D = desc + (size_t)off[p] * 32;
+    std::vector<std::vector<int>> Distances(N, std::vector<int>(N, 0));
+    for (int i = 0; i < N; i++)
+      for (int j = i + 1; j < N; j++) {
+        const int d = descriptor_distance(D + 32 * i, D + 32 * j);
+        Distances[i][j] = d;
+        Distances[j][i] = d;
+      }
+    int BestMedian = 2147483647, BestIdx = 0;
+    for (int i = 0; i < N; i++) {
+      std::vector<int> vDists(Distances[i]);
+      std::sort(vDists.begin(), vDists.end());
+      const int median = vDists[(size_t)(0.5 * (N - 1))];
+      if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+    }
+    best[p] = BestIdx;
+  }
+}
+
 }  // extern "C"

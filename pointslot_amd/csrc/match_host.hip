@@ -12,6 +12,7 @@ void psk_bf_launch(const BfBlock*, int, const BfProb*, int, const uint8_t*, cons
                    const float*, uint32_t*, int32_t*, int32_t*, float, int, hipStream_t);
 void psk_hamming_matrix_launch(const uint8_t*, int, const uint8_t*, int, uint16_t*, hipStream_t);
 void psk_pj_launch(const PjArrays*, int, int, int, hipStream_t);
+void psk_distinctive_launch(const uint8_t*, const int32_t*, int32_t*, int, hipStream_t);
 }
 
 struct ps_matcher {
@@ -255,6 +256,28 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
     P.nmatches = ((const int32_t*)(H + o_nm))[p];
     t0 += P.train.n;
   }
+  return PS_OK;
+}
+
+
+int ps_distinctive_descriptors(ps_matcher* m, const uint8_t* desc, const int32_t* off, int npoints, int32_t* best) {
+  if (!m || !off || !best || npoints < 1) return ps_set_error(PS_ERR_INVALID, "ps_distinctive_descriptors: bad argument");
+  const int total = off[npoints];
+  if (total > 0 && !desc) return ps_set_error(PS_ERR_INVALID, "null descriptors");
+  for (int p = 0; p < npoints; p++)
+    if (off[p + 1] < off[p] || off[p + 1] - off[p] > 128) return ps_set_error(PS_ERR_CAPACITY, "point %d: 0..128 observations supported", p);
+  PS_HIP(hipSetDevice(m->device));
+  const size_t o_desc = 0, o_off = al((size_t)total * 32 + 32), o_best = o_off + al((size_t)(npoints + 1) * 4), end = o_best + al((size_t)npoints * 4);
+  int rc = ensure(m, end);
+  if (rc != PS_OK) return rc;
+  if (total > 0) memcpy(m->h_buf + o_desc, desc, (size_t)total * 32);
+  memcpy(m->h_buf + o_off, off, (size_t)(npoints + 1) * 4);
+  PS_HIP(hipMemcpyAsync(m->d_buf, m->h_buf, o_best, hipMemcpyHostToDevice, m->stream));
+  psk_distinctive_launch(m->d_buf + o_desc, (const int32_t*)(m->d_buf + o_off), (int32_t*)(m->d_buf + o_best), npoints, m->stream);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipMemcpyAsync(m->h_buf + o_best, m->d_buf + o_best, (size_t)npoints * 4, hipMemcpyDeviceToHost, m->stream));
+  PS_HIP(hipStreamSynchronize(m->stream));
+  memcpy(best, m->h_buf + o_best, (size_t)npoints * 4);
   return PS_OK;
 }
 

@@ -397,3 +397,44 @@ extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int
   hipLaunchKernelGGL(pj_gather, dim3((max_nq + 3) / 4, nprob), dim3(256), 0, st, A);
   hipLaunchKernelGGL(pj_resolve, dim3(nprob), dim3(64), 0, st, A);
 }
+
+// ================================================================================================
+// MapPoint / MapObjectPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapObjectPoint.cc:379-436, MapPoint.cc:366;
+// SURVEY.md 8f-4): the observation whose descriptor has the least median Hamming distance to the others.  One wave per
+// point: lane = row of the distance matrix (kept in LDS), median by rank counting, smallest (median, index) by a wave-min.
+// ================================================================================================
+namespace {
+#define DD_MAX 128   // observations per point
+__global__ __launch_bounds__(64) void distinctive_desc(const uint8_t* desc, const int32_t* off, int32_t* best) {
+  __shared__ uint16_t rows[64][DD_MAX + 2];
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int o = off[p], N = off[p + 1] - o;
+  if (N <= 0) { if (lane == 0) best[p] = -1; return; }
+  const uint4* D = reinterpret_cast<const uint4*>(desc + (size_t)o * 32);
+  const int k = (int)(0.5 * (N - 1));   // vDists[0.5*(N-1)]
+  uint32_t bestkey = 0xFFFFFFFFu;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < N) {
+      const uint4 a0 = D[2 * i], a1 = D[2 * i + 1];
+      for (int j = 0; j < N; j++) rows[lane][j] = (uint16_t)hamming256(a0, a1, D[2 * j], D[2 * j + 1]);
+      int median = 0;
+      for (int j = 0; j < N; j++) {
+        const int dj = rows[lane][j];
+        int rank = 0;
+        for (int m = 0; m < N; m++) {
+          const int dm = rows[lane][m];
+          rank += (dm < dj || (dm == dj && m < j)) ? 1 : 0;
+        }
+        if (rank == k) median = dj;
+      }
+      bestkey = min(bestkey, ((uint32_t)median << 16) | (uint32_t)i);
+    }
+  }
+  bestkey = wave_min_u32(bestkey);
+  if (lane == 0) best[p] = (int32_t)(bestkey & 0xFFFF);
+}
+}  // namespace
+extern "C" void psk_distinctive_launch(const uint8_t* desc, const int32_t* off, int32_t* best, int npoints, hipStream_t st) {
+  hipLaunchKernelGGL(distinctive_desc, dim3(npoints), dim3(64), 0, st, desc, off, best);
+}

@@ -23,6 +23,9 @@ lib.ps_match_bruteforce.argtypes = [ctypes.c_void_p, ctypes.POINTER(_BfProblem),
                                     ctypes.c_int]
 
 
+lib.ps_distinctive_descriptors.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+
+
 class ORBmatcher:
     TH_HIGH = 100
     TH_LOW = 50
@@ -54,6 +57,17 @@ class ORBmatcher:
         out = np.zeros((len(q), len(t)), np.uint16)
         check(lib.ps_hamming_matrix(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), out.ctypes.data))
         return out
+
+    def ComputeDistinctiveDescriptors(self, desc_lists):
+        """desc_lists: one uint8 [n_i, 32] array per map point (its observations).  Returns int32 best index per point."""
+        n = len(desc_lists)
+        off = np.zeros(n + 1, np.int32)
+        for i, d in enumerate(desc_lists):
+            off[i + 1] = off[i] + len(d)
+        cat = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint8).reshape(-1, 32) for d in desc_lists] + [np.zeros((1, 32), np.uint8)]))
+        best = np.zeros(n, np.int32)
+        check(lib.ps_distinctive_descriptors(self._h, cat.ctypes.data, off.ctypes.data, n, best.ctypes.data))
+        return best
 
     def SearchByBruceMatching(self, problems):
         """problems: list of dicts {q_desc [nq,32], q_angle [nq], q_valid [nq], t_desc [nt,32], t_angle [nt]}

@@ -296,3 +296,16 @@ def search_projection_points(pr, nnratio):
     n = f(ctypes.byref(T), m, valid.ctypes.data, px.ctypes.data, py.ctypes.data, pxr.ctypes.data, lvl.ctypes.data, vc.ctypes.data,
           desc.ctypes.data, obs.ctypes.data, sf.ctypes.data, float(pr["th"]), float(nnratio), 1 if pr.get("object") else 0, out.ctypes.data)
     return n, out[:T.n].copy()
+
+
+def distinctive_descriptors(desc_lists):
+    n = len(desc_lists)
+    off = np.zeros(n + 1, np.int32)
+    for i, d in enumerate(desc_lists):
+        off[i + 1] = off[i] + len(d)
+    cat = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint8).reshape(-1, 32) for d in desc_lists] + [np.zeros((1, 32), np.uint8)]))
+    best = np.zeros(n, np.int32)
+    f = lib().orc_distinctive_descriptors
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    f(cat.ctypes.data, off.ctypes.data, n, best.ctypes.data)
+    return best

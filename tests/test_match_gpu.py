@@ -107,3 +107,22 @@ def test_matchers_with_empty_inputs(matcher):
     pr = {"train": tr, "scale_factors": sc["scale_factors"], "mode": "points", "query": sc["points_query"], "th": 1.0}
     (n, out), = matcher.SearchByProjection([pr])
     assert n == 0 and np.all(out == -1)
+
+
+def test_distinctive_descriptors(matcher):
+    rng = np.random.default_rng(12)
+    lists = []
+    for n in [1, 2, 3, 7, 50, 64, 65, 128, 0, 31]:
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        obs = []
+        for _ in range(n):
+            bits = np.unpackbits(base)
+            flips = rng.integers(0, 256, rng.integers(0, 60))
+            bits[flips] ^= 1
+            obs.append(np.packbits(bits))
+        lists.append(np.array(obs, np.uint8).reshape(-1, 32))
+    lists.append(np.tile(rng.integers(0, 256, 32, dtype=np.uint8), (9, 1)))      # all identical: first index wins
+    g = matcher.ComputeDistinctiveDescriptors(lists)
+    o = oracle_lib.distinctive_descriptors(lists)
+    assert np.array_equal(g, o), (g, o)
+    assert g[8] == -1 and g[-1] == 0

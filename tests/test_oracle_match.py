@@ -80,3 +80,16 @@ def test_projection_matchers_structure():
     pp = {"train": tr, "scale_factors": sc["scale_factors"], "query": sc["points_query"], "th": 1.0}
     n3, out3 = oracle_lib.search_projection_points(pp, 0.8)
     assert n3 > 200 and n3 >= (out3 >= 0).sum()   # sources without observations do not block a slot: overwrites count twice
+
+
+def test_distinctive_descriptor_is_the_medoid_like_choice():
+    rng = np.random.default_rng(2)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    obs = [base.copy() for _ in range(5)]
+    obs[3] = ~base                                                   # one wild outlier never wins
+    obs[1][0] ^= 1
+    best = oracle_lib.distinctive_descriptors([np.array(obs)])[0]
+    assert best != 3
+    d = oracle_lib.hamming_matrix(np.array(obs), np.array(obs)).astype(int)
+    med = [sorted(r)[int(0.5 * 4)] for r in d]
+    assert best == int(np.argmin(med))
