@@ -1,0 +1,146 @@
+"""A generated stereo mini-sequence in the on-disk layout the reference's stereo_kitti driver reads (SURVEY.md 8d,
+config 1):  <seq>/image_02/%06d.png, <seq>/image_03/%06d.png (/root/reference/Examples/Stereo/stereo_kitti.cc:79-80,
+213-225), timestamp.txt (:179-206), ObjectTracking.txt in KITTI-tracking label format (src/Tracking.cc:485-640),
+poses.txt with 12 floats per frame (row-major 3x4 Twc, the layout of the reference's 0011.txt, Tracking.cc:449-479) and
+Segmentation/%06d.png 16-bit instance ids 1000+inst (src/Frame.cc:1023-1043).
+
+The scene is geometrically exact: a static surface whose depth depends on the image row only, z(y) linear 60 m (top) ..
+6 m (bottom), seen by a camera that translates along +x; a translation t moves the row y by fx*t/z(y) pixels and the
+right camera sees it a further bf/z(y) to the left.  Every image is ONE bilinear resampling of a wide base texture, so
+errors do not accumulate over frames.  Two textured boxes at constant depth move with their own velocity (dynamic
+objects: outliers for the static tracker, the objects of ObjectTracking.txt).
+"""
+import os
+
+import numpy as np
+
+from .synth import Rng, _value_noise, KITTI_K, KITTI_BF
+
+
+def _texture(rng, w, h, n_rect):
+    img = np.full((h, w), 128.0)
+    for cell, amp in ((32, 64.0), (16, 32.0), (8, 16.0), (3, 14.0)):
+        img += _value_noise(rng, w, h, cell, amp)
+    rw = rng.integers(n_rect, 8, 65); rh = rng.integers(n_rect, 8, 65)
+    rx = rng.integers(n_rect, 0, w); ry = rng.integers(n_rect, 0, h)
+    rg = rng.integers(n_rect, 0, 256)
+    for i in range(n_rect):
+        img[ry[i]:ry[i] + rh[i], rx[i]:rx[i] + rw[i]] = rg[i]
+    return np.clip(np.rint(img), 0, 255)
+
+
+def _resample_rows(base, shift, w):
+    """out[y, x] = base[y, x + shift[y]] (bilinear), for x in [0, w)"""
+    h = base.shape[0]
+    xs = np.arange(w)[None, :] + shift[:, None]
+    x0 = np.floor(xs).astype(np.int64)
+    fx = xs - x0
+    x0 = np.clip(x0, 0, base.shape[1] - 2)
+    rows = np.arange(h)[:, None]
+    return base[rows, x0] * (1 - fx) + base[rows, x0 + 1] * fx
+
+
+def generate(n_frames=20, seed=4, w=1242, h=375, step=0.08, n_boxes=2, K=KITTI_K, bf=KITTI_BF):
+    """Returns a dict: left/right uint8 [n, h, w], twc float64 [n, 3, 4] (ground truth), boxes (per frame, per box:
+    x1 y1 x2 y2 in the left image, depth), seg uint16 [n, h, w], K, bf."""
+    rng = Rng(0x51070000 + seed)
+    fx, fy, cx, cy = [float(v) for v in K]
+    z = 60.0 + (6.0 - 60.0) * (np.arange(h) / (h - 1))
+    # camera x positions: nominal step with a seeded +-25 % variation so that the constant-velocity prediction is never exact
+    steps = step * (1.0 + rng.uniform(n_frames, -0.25, 0.25))
+    steps[0] = 0.0
+    tx = np.cumsum(steps)
+    margin = int(np.ceil(fx * tx[-1] / z.min() + bf / z.min())) + 8
+    base = _texture(rng, w + margin, h, int(400 * (w + margin) / 1242))
+    box_tex, box_geo = [], []
+    for b in range(n_boxes):
+        bw, bh = int(rng.integers(1, 90, 140)[0]), int(rng.integers(1, 50, 80)[0])
+        zb = float(rng.uniform(1, 9.0, 16.0)[0])
+        v0 = int(rng.integers(1, h // 3, h - bh - 20)[0])
+        x0 = float(rng.uniform(1, -3.0, 3.0)[0])           # metres, world
+        vel = float(rng.uniform(1, 0.05, 0.25)[0]) * (1 if b % 2 == 0 else -1)
+        box_tex.append(_texture(rng, bw, bh, 12))
+        box_geo.append((bw, bh, zb, v0, x0, vel))
+    left = np.zeros((n_frames, h, w), np.uint8); right = np.zeros_like(left)
+    seg = np.zeros((n_frames, h, w), np.uint16)
+    twc = np.zeros((n_frames, 3, 4))
+    boxes = []
+    for k in range(n_frames):
+        sh = fx * tx[k] / z
+        L = _resample_rows(base, sh, w)
+        R = _resample_rows(base, sh + bf / z, w)
+        fb = []
+        for b, (bw, bh, zb, v0, x0, vel) in enumerate(box_geo):
+            u = int(round(fx * (x0 + vel * k - tx[k]) / zb + cx))
+            d = int(round(bf / zb))
+            for img, uu, is_left in ((L, u, True), (R, u - d, False)):
+                a0, a1 = max(uu, 0), min(uu + bw, w)
+                if a1 > a0:
+                    img[v0:v0 + bh, a0:a1] = box_tex[b][:, a0 - uu:a1 - uu]
+                    if is_left:
+                        seg[k, v0:v0 + bh, a0:a1] = 1000 + b
+            fb.append((u, v0, u + bw, v0 + bh, zb, x0 + vel * k))
+        boxes.append(fb)
+        left[k] = np.clip(np.rint(L), 0, 255).astype(np.uint8)
+        right[k] = np.clip(np.rint(R), 0, 255).astype(np.uint8)
+        twc[k, :3, :3] = np.eye(3); twc[k, 0, 3] = tx[k]
+    return {"left": left, "right": right, "twc": twc, "boxes": boxes, "seg": seg, "K": (fx, fy, cx, cy), "bf": float(bf)}
+
+
+def write(seq_dir, seq, dt=0.1):
+    """Writes `seq` (from generate()) in the reference's on-disk layout."""
+    from PIL import Image
+    for d in ("image_02", "image_03", "Segmentation"):
+        os.makedirs(os.path.join(seq_dir, d), exist_ok=True)
+    n = len(seq["left"])
+    for k in range(n):
+        Image.fromarray(seq["left"][k]).save(os.path.join(seq_dir, "image_02", "%06d.png" % k))
+        Image.fromarray(seq["right"][k]).save(os.path.join(seq_dir, "image_03", "%06d.png" % k))
+        Image.fromarray(seq["seg"][k]).save(os.path.join(seq_dir, "Segmentation", "%06d.png" % k))
+    with open(os.path.join(seq_dir, "timestamp.txt"), "w") as f:
+        for k in range(n):
+            f.write("%.6f\n" % (k * dt))
+    with open(os.path.join(seq_dir, "poses.txt"), "w") as f:
+        for k in range(n):
+            f.write(" ".join("%.9g" % v for v in seq["twc"][k].reshape(12)) + "\n")
+    fx, fy, cx, cy = seq["K"]
+    with open(os.path.join(seq_dir, "ObjectTracking.txt"), "w") as f:
+        # frame track type trunc occl alpha x1 y1 x2 y2 h w l X Y Z ry   (camera-frame X Y Z of the box bottom centre)
+        for k, fb in enumerate(seq["boxes"]):
+            for b, (x1, y1, x2, y2, zb, xw) in enumerate(fb):
+                hm, wm = (y2 - y1) * zb / fy, (x2 - x1) * zb / fx
+                X = (0.5 * (x1 + x2) - cx) * zb / fx; Y = (y2 - cy) * zb / fy
+                f.write("%d %d Car 0 0 0 %.2f %.2f %.2f %.2f %.3f %.3f %.3f %.3f %.3f %.3f 0\n"
+                        % (k, b, x1, y1, x2, y2, hm, wm, 0.5, X, Y, zb))
+    with open(os.path.join(seq_dir, "calib.txt"), "w") as f:
+        f.write("Camera.fx: %.9g\nCamera.fy: %.9g\nCamera.cx: %.9g\nCamera.cy: %.9g\nCamera.bf: %.9g\nThDepth: 35\n" % (fx, fy, cx, cy, seq["bf"]))
+
+
+def _to_gray(a, rgb_order=True):
+    """cv::cvtColor RGB2GRAY / BGR2GRAY of OpenCV 3.4 on 8-bit data: (R*4899 + G*9617 + B*1868 + 8192) >> 14
+    (Tracking.cc:1016-1037; `Camera.RGB` picks which channel gets the R weight)."""
+    a = a.astype(np.int64)
+    r, g, b = (a[..., 0], a[..., 1], a[..., 2]) if rgb_order else (a[..., 2], a[..., 1], a[..., 0])
+    return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+
+
+def load(seq_dir, max_frames=None):
+    """LoadImages of stereo_kitti.cc:170-230: timestamps decide the frame count; images are %06d.png in image_02 / image_03."""
+    from PIL import Image
+    with open(os.path.join(seq_dir, "timestamp.txt")) as f:
+        stamps = [float(s.split()[0]) for s in f if s.strip()]
+    if max_frames is not None:
+        stamps = stamps[:max_frames]
+    left, right = [], []
+    for k in range(len(stamps)):
+        for lst, d in ((left, "image_02"), (right, "image_03")):
+            a = np.asarray(Image.open(os.path.join(seq_dir, d, "%06d.png" % k)))
+            lst.append(_to_gray(a) if a.ndim == 3 else a.astype(np.uint8))
+    calib = {}
+    p = os.path.join(seq_dir, "calib.txt")
+    if os.path.exists(p):
+        with open(p) as f:
+            for line in f:
+                k, v = line.split(":")
+                calib[k.strip()] = float(v)
+    return {"left": left, "right": right, "timestamps": stamps, "calib": calib}

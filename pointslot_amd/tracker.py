@@ -1,0 +1,303 @@
+"""The caller either side of the hot path: a stereo visual-odometry loop that chains the kernels the way the reference's
+tracking thread does in localisation mode (`mbOnlyTracking`), so that the path can be exercised and measured end to end on a
+sequence:
+
+    Frame::Frame            ExtractORB x2 (a2-a8)  ->  ComputeStereoMatches (8f-1)           src/Frame.cc:709-722
+    StereoInitialization    map points from every keypoint with depth                        src/Tracking.cc:2840-2910
+    UpdateLastFrame         temporal "visual odometry" points, closest first                 src/Tracking.cc:2971-3026
+    TrackWithMotionModel    SearchByProjection(cur, last, th=7) (a11) -> PoseOptimization (a14)   src/Tracking.cc:3028-3095
+    TrackLocalMap           isInFrustum + SearchByProjection(F, points, th) (a12) -> PoseOptimization   src/Tracking.cc:3097-3160
+    motion model            mVelocity = Tcw * LastTwc                                        src/Tracking.cc:1260-1272
+
+Only this data flow is kept; keyframes, local mapping, relocalisation, loop closing and the object pipeline are the
+reference's control plane and are not rebuilt.  The loop is backend-agnostic: the product backend below drives
+libpointslot_hip.so; the tests plug the CPU checker in through the same five calls and compare trajectories.
+"""
+import numpy as np
+
+from .matcher import build_grid, FRAME_GRID_COLS, FRAME_GRID_ROWS
+
+
+class HipBackend:
+    """The five hot-path calls on the GPU (ORBextractor x2, ComputeStereoMatches, two SearchByProjection overloads,
+    PoseOptimization)."""
+
+    def __init__(self, nfeatures=2000, scale=1.2, nlevels=8, ini_th=20, min_th=5, device=0):
+        from .extractor import ORBextractor
+        from .matcher import ORBmatcher
+        from .optimizer import Optimizer
+        self.left = ORBextractor(nfeatures, scale, nlevels, ini_th, min_th, device=device)
+        self.right = ORBextractor(nfeatures, scale, nlevels, ini_th, min_th, device=device)
+        self.matcher_mm = ORBmatcher(0.9, True, device=device)     # Tracking.cc:3030
+        self.matcher_lm = ORBmatcher(0.8, True, device=device)     # Tracking.cc SearchLocalPoints
+        self.optimizer = Optimizer(device=device)
+        self.scale_factors = self.left.GetScaleFactors()
+        self.inv_level_sigma2 = self.left.GetInverseScaleSigmaSquares()
+
+    def extract_stereo(self, left, right, mb, mbf):
+        from .extractor import ComputeStereoMatches
+        kps, desc = self.left(left)
+        self.right(right)
+        ur, dp = ComputeStereoMatches(self.left, self.right, mb, mbf)
+        return kps, desc, ur, dp
+
+    def search_frame(self, problem):
+        return self.matcher_mm.SearchByProjection([problem])[0]
+
+    def search_points(self, problem):
+        return self.matcher_lm.SearchByProjection([problem])[0]
+
+    def pose_optimization(self, frame):
+        return self.optimizer.PoseOptimization([frame])[0]
+
+    def close(self):
+        for o in (self.left, self.right, self.matcher_mm, self.matcher_lm, self.optimizer):
+            o.close()
+
+
+class _Frame:
+    pass
+
+
+def _f32(x):
+    return np.asarray(x, np.float32)
+
+
+class StereoOdometry:
+    """State of the tracking thread that the hot path needs: last frame, motion model, the initial keyframe's map points."""
+
+    def __init__(self, backend, K, bf, width, height, th_depth=35.0, track_local_map=True):
+        self.be = backend
+        self.fx, self.fy, self.cx, self.cy = [np.float32(v) for v in K]
+        self.bf = np.float32(bf)
+        self.mb = np.float32(self.bf / self.fx)                         # Frame.cc: mb = mbf / fx
+        self.th_depth = np.float32(self.bf * np.float32(th_depth) / self.fx)   # Tracking.cc:402
+        self.w, self.h = width, height
+        self.grid = (np.float32(0), np.float32(0), np.float32(FRAME_GRID_COLS) / np.float32(width),
+                     np.float32(FRAME_GRID_ROWS) / np.float32(height))    # Frame.cc:1636-1640 without distortion
+        self.sf = _f32(backend.scale_factors)
+        self.log_sf = np.float32(np.log(self.sf[1]))
+        self.last = None
+        self.velocity = None
+        self.local_map = None
+        self.track_local_map = track_local_map
+        self.state = "NOT_INITIALIZED"
+        self.trajectory = []            # Tcw per frame (float32 4x4), None when lost
+        self.stats = []
+
+    # ---- Frame::Frame (stereo) ----
+    def _make_frame(self, left, right):
+        F = _Frame()
+        F.kps, F.desc, F.u_right, F.depth = self.be.extract_stereo(left, right, self.mb, self.bf)
+        F.N = len(F.kps)
+        F.x, F.y = _f32(F.kps["x"]), _f32(F.kps["y"])
+        F.octave = np.asarray(F.kps["octave"], np.int32)
+        F.angle = _f32(F.kps["angle"])
+        F.cell_off, F.cell_idx = build_grid(F.x, F.y, *self.grid)
+        F.mp_xw = np.zeros((F.N, 3), np.float32)      # mvpMapPoints[i]->GetWorldPos()
+        F.mp_valid = np.zeros(F.N, bool)              # mvpMapPoints[i] != NULL
+        F.mp_observed = np.zeros(F.N, bool)           # Observations() > 0 (false for temporal points)
+        F.mp_id = np.full(F.N, -1, np.int64)          # index into the local map (the initial keyframe's points)
+        F.outlier = np.zeros(F.N, np.uint8)
+        F.tcw = None
+        return F
+
+    def _unproject(self, F, idx):
+        """Frame::UnprojectStereo (Frame.cc:2505-2519), float arithmetic"""
+        z = F.depth[idx]
+        x = (F.x[idx] - self.cx) * z * (np.float32(1) / self.fx)
+        y = (F.y[idx] - self.cy) * z * (np.float32(1) / self.fy)
+        Xc = np.stack([x, y, z], 1).astype(np.float32)
+        Rwc = F.tcw[:3, :3].T
+        Ow = -(Rwc @ F.tcw[:3, 3])
+        return (Xc @ Rwc.T + Ow).astype(np.float32)
+
+    def _train(self, F):
+        return {"x": F.x, "y": F.y, "octave": F.octave, "angle": F.angle, "u_right": F.u_right, "desc": F.desc,
+                "occupied": (F.mp_valid & F.mp_observed).astype(np.uint8), "grid": self.grid,
+                "cell_off": F.cell_off, "cell_idx": F.cell_idx}
+
+    def _K6(self):
+        return (self.fx, self.fy, self.cx, self.cy, self.bf, self.mb)
+
+    # ---- Tracking::StereoInitialization ----
+    def _initialize(self, F):
+        if F.N <= 500:
+            return False
+        F.tcw = np.eye(4, dtype=np.float32)
+        idx = np.nonzero(F.depth > 0)[0]
+        F.mp_xw[idx] = self._unproject(F, idx)
+        F.mp_valid[idx] = True
+        F.mp_observed[idx] = True
+        F.mp_id[idx] = np.arange(len(idx))
+        # MapPoint::UpdateNormalAndDepth for one observation (MapPoint.cc:470-497)
+        PO = F.mp_xw[idx]                              # camera centre of the initial keyframe is the origin
+        dist = np.sqrt((PO.astype(np.float32) ** 2).sum(1, dtype=np.float32)).astype(np.float32)
+        maxd = (dist * self.sf[F.octave[idx]]).astype(np.float32)
+        self.local_map = {"xw": F.mp_xw[idx].copy(), "desc": F.desc[idx].copy(), "normal": (PO / dist[:, None]).astype(np.float32),
+                          "max_dist": maxd, "min_dist": (maxd / self.sf[-1]).astype(np.float32)}
+        self.state = "OK"
+        return True
+
+    # ---- Tracking::UpdateLastFrame (localisation mode) ----
+    def _update_last_frame(self):
+        L = self.last
+        idx = np.nonzero(L.depth > 0)[0]
+        if len(idx) == 0:
+            return
+        order = idx[np.lexsort((idx, L.depth[idx]))]           # sort(pair<float,int>)
+        create = []
+        npoints = 0
+        for i in order:
+            if not L.mp_valid[i] or not L.mp_observed[i]:
+                create.append(i)
+            npoints += 1
+            if L.depth[i] > 2 * self.th_depth and npoints > 100:
+                break
+        if create:
+            create = np.asarray(create)
+            L.mp_xw[create] = self._unproject(L, create)
+            L.mp_valid[create] = True
+            L.mp_observed[create] = False
+            L.mp_id[create] = -1
+
+    # ---- Tracking::TrackWithMotionModel ----
+    def _track_motion_model(self, F):
+        L = self.last
+        self._update_last_frame()
+        F.tcw = (self.velocity @ L.tcw).astype(np.float32)
+        query = {"valid": (L.mp_valid & (L.outlier == 0)).astype(np.uint8), "desc": L.desc,
+                 "observed": np.ones(L.N, np.uint8), "angle": L.angle, "xw": L.mp_xw, "octave": L.octave}
+        nm = 0
+        for th in (7.0, 14.0):                                  # th = 7 (stereo), then 2 * th
+            F.mp_valid[:] = False
+            pr = {"mode": "frame", "train": self._train(F), "query": query, "tcw": F.tcw, "tlw": L.tcw, "K6": self._K6(),
+                  "bounds": (0.0, float(self.w), 0.0, float(self.h)), "scale_factors": self.sf, "th": th, "mono": False}
+            nm, match = self.be.search_frame(pr)
+            if nm >= 20:
+                break
+        if nm < 20:
+            return False, nm, 0
+        m = match >= 0
+        F.mp_valid[:] = m
+        F.mp_xw[m] = L.mp_xw[match[m]]
+        F.mp_observed[m] = L.mp_observed[match[m]]
+        F.mp_id[m] = L.mp_id[match[m]]
+        self._pose_optimization(F)
+        # discard outliers (Tracking.cc:3062-3082)
+        out = F.mp_valid & (F.outlier != 0)
+        F.mp_valid[out] = False
+        F.outlier[out] = 0
+        nmatches = int(F.mp_valid.sum())
+        nmatches_map = int((F.mp_valid & F.mp_observed).sum())
+        self.vo = nmatches_map < 10
+        return nmatches > 20, nmatches, nmatches_map
+
+    def _pose_optimization(self, F):
+        obs = np.stack([F.x, F.y, F.u_right], 1).astype(np.float32)
+        frame = {"xw": F.mp_xw, "obs": obs, "inv_sigma2": _f32(self.be.inv_level_sigma2)[F.octave], "valid": F.mp_valid.astype(np.uint8),
+                 "K": (self.fx, self.fy, self.cx, self.cy, self.bf), "tcw0": F.tcw, "outlier0": F.outlier}
+        ninl, tcw, outlier = self.be.pose_optimization(frame)
+        F.outlier = np.asarray(outlier, np.uint8).copy()
+        if int(F.mp_valid.sum()) >= 15:       # Optimizer.cc:376-377: fewer than 15 edges -> return 0 before SetPose
+            F.tcw = _f32(tcw).copy()
+        return ninl
+
+    # ---- Tracking::SearchLocalPoints + TrackLocalMap ----
+    def _track_local_map(self, F):
+        M = self.local_map
+        n = len(M["xw"])
+        already = np.zeros(n, bool)
+        ids = F.mp_id[F.mp_valid & (F.mp_id >= 0)]
+        already[ids] = True
+        # Frame::isInFrustum (Frame.cc:1686-1743), float arithmetic, viewingCosLimit 0.5
+        Rcw, tcw = F.tcw[:3, :3], F.tcw[:3, 3]
+        Pc = (M["xw"] @ Rcw.T + tcw).astype(np.float32)
+        z = Pc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            invz = (np.float32(1) / z).astype(np.float32)
+            u = (self.fx * Pc[:, 0] * invz + self.cx).astype(np.float32)
+            v = (self.fy * Pc[:, 1] * invz + self.cy).astype(np.float32)
+        Ow = -(Rcw.T @ tcw)
+        PO = (M["xw"] - Ow).astype(np.float32)
+        dist = np.sqrt((PO * PO).sum(1, dtype=np.float32)).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            view_cos = ((PO * M["normal"]).sum(1, dtype=np.float32) / dist).astype(np.float32)
+            ratio = (M["max_dist"] / dist).astype(np.float32)
+            level = np.ceil(np.log(ratio) / self.log_sf)
+        ok = ~already & ~(z < 0) & ~(u < 0) & ~(u > self.w) & ~(v < 0) & ~(v > self.h)
+        ok &= ~(dist < np.float32(0.8) * M["min_dist"]) & ~(dist > np.float32(1.2) * M["max_dist"]) & ~(view_cos < np.float32(0.5))
+        level = np.clip(np.nan_to_num(level, nan=0.0, posinf=7.0, neginf=0.0), 0, len(self.sf) - 1).astype(np.int32)
+        nto = int(ok.sum())
+        nfound = 0
+        if nto > 0:
+            query = {"valid": ok.astype(np.uint8), "desc": M["desc"], "observed": np.ones(n, np.uint8), "proj_x": np.where(ok, u, 0).astype(np.float32),
+                     "proj_y": np.where(ok, v, 0).astype(np.float32), "proj_xr": np.where(ok, u - self.bf * invz, 0).astype(np.float32),
+                     "level": level, "view_cos": np.where(ok, view_cos, 0).astype(np.float32)}
+            pr = {"mode": "points", "train": self._train(F), "query": query, "scale_factors": self.sf, "th": 1.0}
+            nfound, match = self.be.search_points(pr)
+            m = match >= 0                 # occupied slots are never matched; temporal matches are overwritten (ORBmatcher.cc:146)
+            F.mp_valid[m] = True
+            F.mp_xw[m] = M["xw"][match[m]]
+            F.mp_observed[m] = True
+            F.mp_id[m] = match[m]
+        self._pose_optimization(F)
+        inl = F.mp_valid & (F.outlier == 0)
+        # stereo: outliers lose their map point (Tracking.cc:3141-3142)
+        drop = F.mp_valid & (F.outlier != 0)
+        F.mp_valid[drop] = False
+        return int(inl.sum()) >= 30, int(inl.sum()), nfound
+
+    # ---- Tracking::Track for one stereo frame ----
+    def track(self, left, right):
+        F = self._make_frame(left, right)
+        st = {"N": F.N, "stereo": int((F.depth > 0).sum())}
+        if self.state == "NOT_INITIALIZED":
+            if self._initialize(F):
+                self.last = F
+                self.velocity = None
+            self.trajectory.append(None if F.tcw is None else F.tcw.copy())
+            self.stats.append(st)
+            return F.tcw
+        if self.velocity is None:
+            # the reference takes TrackReferenceKeyFrame (BoW matching against ORBvoc) for the frame right after
+            # initialisation (Tracking.cc:1141-1145); without the vocabulary blob this slice substitutes the motion model
+            # with an identity velocity, as SURVEY.md 8d config 1 prescribes
+            self.velocity = np.eye(4, dtype=np.float32)
+        ok, nm, nmap = self._track_motion_model(F)
+        st.update(matches=nm, map_matches=nmap)
+        if ok and self.track_local_map and not self.vo:
+            ok, ninl, nfound = self._track_local_map(F)
+            st.update(local_inliers=ninl, local_found=nfound)
+        if not ok:
+            self.state = "LOST"
+            self.trajectory.append(None)
+            self.stats.append(st)
+            self.velocity = None
+            return None
+        # motion model (Tracking.cc:1260-1270)
+        L = self.last
+        last_twc = np.eye(4, dtype=np.float32)
+        last_twc[:3, :3] = L.tcw[:3, :3].T
+        last_twc[:3, 3] = -(L.tcw[:3, :3].T @ L.tcw[:3, 3])
+        self.velocity = (F.tcw @ last_twc).astype(np.float32)
+        # clean VO matches (Tracking.cc:1274-1286): matches to temporal points do not outlive the frame
+        tmp = F.mp_valid & ~F.mp_observed
+        F.mp_valid[tmp] = False
+        F.outlier[tmp] = 0
+        self.last = F
+        self.trajectory.append(F.tcw.copy())
+        self.stats.append(st)
+        return F.tcw
+
+
+def save_trajectory_kitti(path, trajectory):
+    """System::SaveTrajectoryKITTI line format (src/System.cc:395-402): row-major 3x4 [Rwc | twc], setprecision(9)."""
+    with open(path, "w") as f:
+        for tcw in trajectory:
+            if tcw is None:
+                continue
+            Rwc = tcw[:3, :3].T
+            twc = -(Rwc @ tcw[:3, 3])
+            M = np.concatenate([Rwc, twc[:, None]], 1).astype(np.float32)
+            f.write(" ".join("%.9g" % float(v) for v in M.reshape(12)) + "\n")

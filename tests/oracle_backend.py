@@ -1,0 +1,32 @@
+"""The CPU checker behind the five calls of pointslot_amd.tracker.StereoOdometry (test infrastructure only)."""
+import numpy as np
+
+import oracle_lib
+from oracle_lib import OracleORB
+
+
+class OracleBackend:
+    def __init__(self, nfeatures=2000, scale=1.2, nlevels=8, ini_th=20, min_th=5):
+        self.left = OracleORB(nfeatures, scale, nlevels, ini_th, min_th)
+        self.right = OracleORB(nfeatures, scale, nlevels, ini_th, min_th)
+        f, _, _ = self.left.tables()
+        self.scale_factors, self.inv_level_sigma2 = f[0], f[3]
+
+    def extract_stereo(self, left, right, mb, mbf):
+        kps, desc = self.left.run(left)
+        self.right.run(right)
+        _, ur, dp = oracle_lib.stereo_match(self.left, self.right, mb, mbf)
+        return kps, desc, ur, dp
+
+    def search_frame(self, problem):
+        return oracle_lib.search_projection_frame(problem, check_ori=True)
+
+    def search_points(self, problem):
+        return oracle_lib.search_projection_points(problem, 0.8)
+
+    def pose_optimization(self, frame):
+        r, tcw, outlier, _ = oracle_lib.pose_optimize(frame)
+        return r, tcw, outlier
+
+    def close(self):
+        pass
