@@ -125,6 +125,55 @@ def secondary_metrics(rank, world, local_rank, dist, with_cpu):
         dt = time.perf_counter() - t0
         out["object_ba"]["cpu_port_ms_per_iter_1core_1object"] = dt * 1e3 / max(len(tr), 1)
     opt.close()
+    out["sequence_tracking"] = sequence_leg(rank, world, local_rank, dist, with_cpu)
+    return out
+
+
+def sequence_leg(rank, world, local_rank, dist, with_cpu, n_frames=12):
+    """BASELINE configs[0] / [4]: every rank tracks its own generated stereo sequence (seed = rank) through the chained hot
+    path (extraction -> stereo -> projection matching -> pose optimisation, pointslot_amd.tracker), then one gather of
+    the [frames][12] float32 trajectories (the only collective of the workflow)."""
+    import torch
+    from pointslot_amd import parallel, sequence
+    from pointslot_amd.tracker import HipBackend, StereoOdometry
+    seq = sequence.generate(n_frames=n_frames, seed=4 + rank)
+    h, w = seq["left"][0].shape
+    be = HipBackend(device=local_rank)
+    vo = StereoOdometry(be, seq["K"], seq["bf"], w, h)
+    vo.track(seq["left"][0], seq["right"][0])
+    times = []
+    for k in range(1, n_frames):
+        t0 = time.perf_counter()
+        vo.track(seq["left"][k], seq["right"][k])
+        times.append(time.perf_counter() - t0)
+    be.close()
+    traj = np.zeros((n_frames, 12), np.float32)
+    err = 0.0
+    for k, t in enumerate(vo.trajectory):
+        if t is not None:
+            Rwc = t[:3, :3].T
+            twc = -(Rwc @ t[:3, 3])
+            traj[k] = np.concatenate([Rwc, twc[:, None]], 1).reshape(12)
+            err = max(err, float(np.abs(twc - seq["twc"][k][:, 3]).max()))
+    t0 = time.perf_counter()
+    allt = parallel.gather_trajectories(dist, traj, "cuda")
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t0) * 1e3
+    ms = parallel.max_over_ranks(dist, float(np.median(times)) * 1e3, "cuda")
+    out = {"workload": "BASELINE configs[0]/[4]: %d generated 1242x375 stereo sequence(s) x %d frames, one per GPU, host-driven "
+                       "tracking loop over the C-ABI (single frame in flight per sequence)" % (world, n_frames),
+           "median_ms_per_frame": ms, "frames_per_s_all_sequences": world * 1e3 / ms, "tracked": int(sum(t is not None for t in vo.trajectory)),
+           "max_abs_position_error_m": parallel.max_over_ranks(dist, err, "cuda"), "trajectory_gather_ms": gather_ms,
+           "gathered": [list(a.shape) for a in allt]}
+    if with_cpu and rank == 0 and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_backend import OracleBackend
+        voc = StereoOdometry(OracleBackend(), seq["K"], seq["bf"], w, h)
+        t0 = time.perf_counter()
+        for k in range(4):
+            voc.track(seq["left"][k], seq["right"][k])
+        out["cpu_port_ms_per_frame_1core"] = (time.perf_counter() - t0) * 1e3 / 4
     return out
 
 
