@@ -108,6 +108,13 @@ int ps_orb_stereo_match_batch(ps_orb* h, int npairs, float mb, float mbf);
 int ps_orb_stereo_device_outputs(const ps_orb* h, const float** d_uright, const float** d_depth, const int32_t** d_kept);
 int ps_orb_stereo_fetch(ps_orb* h, int pair, float* u_right, float* depth, int cap, int* n_left, int* kept);
 int ps_orb_stereo_match_pair(ps_orb* left, ps_orb* right, float mb, float mbf, float* u_right, float* depth, int cap, int* n_left);
+/* Frame::ComputeObjStereoMatches (src/Frame.cc:2318-2503): the same matcher on caller-provided key sets (the frame's object
+ * features, mvTempObjKeys / mvTempObjKeysRight + descriptors, <= 4096 each) against the two extractors' device-resident
+ * pyramids.  u_right / depth: n_left floats (-1 where unmatched); *kept (nullable) = matches that survive the median cut.
+ * Keypoints must lie where the reference's 11x11 window + slide stays inside the level image (cv::ORB's edge threshold). */
+int ps_orb_stereo_match_keys(ps_orb* left, ps_orb* right, const ps_keypoint* kps_l, const uint8_t* desc_l, int n_left,
+                             const ps_keypoint* kps_r, const uint8_t* desc_r, int n_right, float mb, float mbf,
+                             float* u_right, float* depth, int* kept);
 
 /* Test/diagnostic access to intermediates of the last call (blocking).  `what`:
  *   0 padded plane (tight, (w_l+38) x (h_l+38) bytes)      1 blurred plane (tight, w_l x h_l)

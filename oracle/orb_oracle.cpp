@@ -695,10 +695,8 @@ int orc_pattern(int i) { return kPattern[i]; }
 // extractors hold after orc_orb_run (left = hl, right = hr).  u_right / depth: N_left floats (-1 where unmatched).
 // Restated literally, including the quirks: `int bestDist` receives the float SAD, the window test uses
 // scaleduR0 + L - w, the parabola division is unguarded, and the cut is 1.5f * 1.4f * median of the SADs.
-int orc_stereo_match(void* hl, void* hr, float mb, float mbf, float* u_right, float* depth) {
-  Extractor& EL = *(Extractor*)hl;
-  Extractor& ER = *(Extractor*)hr;
-  const int N = (int)EL.out_kps.size(), Nr = (int)ER.out_kps.size();
+static int stereo_match_keys(Extractor& EL, Extractor& ER, const KeyPoint* KL, const uint8_t* DL, int N, const KeyPoint* KR,
+                             const uint8_t* DR, int Nr, float mb, float mbf, float* u_right, float* depth) {
   for (int i = 0; i < N; i++) { u_right[i] = -1.0f; depth[i] = -1.0f; }
   if (N == 0) return 0;
   const int TH_HIGH = 100, TH_LOW = 50;
@@ -706,7 +704,7 @@ int orc_stereo_match(void* hl, void* hr, float mb, float mbf, float* u_right, fl
   const int nRows = EL.pyr[0].h;
   std::vector<std::vector<size_t>> vRowIndices(nRows);
   for (int iR = 0; iR < Nr; iR++) {
-    const KeyPoint& kp = ER.out_kps[iR];
+    const KeyPoint& kp = KR[iR];
     const float kpY = kp.y;
     const float r = 2.0f * ER.mvScaleFactor[kp.octave];
     const int maxr = (int)std::ceil(kpY + r), minr = (int)std::floor(kpY - r);
@@ -721,7 +719,7 @@ int orc_stereo_match(void* hl, void* hr, float mb, float mbf, float* u_right, fl
     return d;
   };
   for (int iL = 0; iL < N; iL++) {
-    const KeyPoint& kpL = EL.out_kps[iL];
+    const KeyPoint& kpL = KL[iL];
     const int levelL = kpL.octave;
     const float vL = kpL.y, uL = kpL.x;
     const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
@@ -732,16 +730,16 @@ int orc_stereo_match(void* hl, void* hr, float mb, float mbf, float* u_right, fl
     size_t bestIdxR = 0;
     for (size_t iC = 0; iC < vCandidates.size(); iC++) {
       const size_t iR = vCandidates[iC];
-      const KeyPoint& kpR = ER.out_kps[iR];
+      const KeyPoint& kpR = KR[iR];
       if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
       const float uR = kpR.x;
       if (uR >= minU && uR <= maxU) {
-        const int dist = desc_dist(&EL.out_desc[(size_t)iL * 32], &ER.out_desc[iR * 32]);
+        const int dist = desc_dist(DL + (size_t)iL * 32, DR + iR * 32);
         if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
       }
     }
     if (bestDist < thOrbDist) {
-      const float uR0 = ER.out_kps[bestIdxR].x;
+      const float uR0 = KR[bestIdxR].x;
       const float scaleFactor = EL.mvInvScaleFactor[kpL.octave];
       const float scaleduL = std::round(kpL.x * scaleFactor);
       const float scaledvL = std::round(kpL.y * scaleFactor);
@@ -792,6 +790,22 @@ int orc_stereo_match(void* hl, void* hr, float mb, float mbf, float* u_right, fl
     kept--;
   }
   return kept;
+}
+
+int orc_stereo_match(void* hl, void* hr, float mb, float mbf, float* u_right, float* depth) {
+  Extractor& EL = *(Extractor*)hl;
+  Extractor& ER = *(Extractor*)hr;
+  return stereo_match_keys(EL, ER, EL.out_kps.data(), EL.out_desc.data(), (int)EL.out_kps.size(), ER.out_kps.data(), ER.out_desc.data(),
+                           (int)ER.out_kps.size(), mb, mbf, u_right, depth);
+}
+
+// Frame::ComputeObjStereoMatches (/root/reference/src/Frame.cc:2318-2503): the same algorithm on the object key sets
+// (mvTempObjKeys / mvTempObjKeysRight with their descriptors) against the SAME two image pyramids.
+int orc_stereo_match_keys(void* hl, void* hr, const void* kps_l, const uint8_t* desc_l, int nl, const void* kps_r, const uint8_t* desc_r,
+                          int nr, float mb, float mbf, float* u_right, float* depth) {
+  if (nl <= 0) return 0;                                   // Frame.cc:2320
+  return stereo_match_keys(*(Extractor*)hl, *(Extractor*)hr, (const KeyPoint*)kps_l, desc_l, nl, (const KeyPoint*)kps_r, desc_r, nr, mb, mbf,
+                           u_right, depth);
 }
 
 // standalone quadtree for unit tests: keys as int triples (x,y,response)

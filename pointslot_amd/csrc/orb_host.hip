@@ -20,7 +20,7 @@ void psk_orb_launch_blur(const OrbPlan*, uint8_t*, int, hipStream_t);
 void psk_orb_launch_border(const OrbPlan*, uint8_t*, int, hipStream_t);
 int psk_orb_blur_rows();
 void psk_orb_launch_describe(const OrbPlan*, uint8_t*, void*, uint8_t*, int32_t*, int, hipStream_t);
-void psk_stereo_launch(const OrbPlan*, const StPair*, int, float, float, hipStream_t);
+void psk_stereo_launch(const OrbPlan*, const StPair*, int, int, float, float, hipStream_t);
 }
 
 namespace {
@@ -52,6 +52,8 @@ struct ps_orb {
   float* d_uright = nullptr; float* d_depth = nullptr; int32_t* d_sad = nullptr; int32_t* d_kept = nullptr;
   StPair* d_pairs = nullptr;
   int last_npairs = 0;
+  uint8_t* d_objkeys = nullptr;   // scratch of ps_orb_stereo_match_keys (caller-provided key sets + their outputs)
+  uint8_t* h_objkeys = nullptr;
   uint8_t* d_img = nullptr;       // staging for ps_orb_extract (one host image)
   size_t d_img_bytes = 0;
   hipStream_t stream = nullptr;
@@ -151,6 +153,9 @@ int free_device(ps_orb* h) {
   if (h->d_sad) hipFree(h->d_sad);
   if (h->d_kept) hipFree(h->d_kept);
   if (h->d_pairs) hipFree(h->d_pairs);
+  if (h->d_objkeys) hipFree(h->d_objkeys);
+  if (h->h_objkeys) hipHostFree(h->h_objkeys);
+  h->d_objkeys = nullptr; h->h_objkeys = nullptr;
   h->d_uright = nullptr; h->d_depth = nullptr; h->d_sad = nullptr; h->d_kept = nullptr; h->d_pairs = nullptr;
   h->d_arena = nullptr; h->d_tabs = nullptr; h->d_kps = nullptr; h->d_desc = nullptr; h->d_counts = nullptr;
   return 0;
@@ -522,9 +527,9 @@ int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n
 
 
 // ---- Frame::ComputeStereoMatches (Frame.cc:2142-2316) on device-resident extraction results ----
-static int stereo_run(ps_orb* out_h, const std::vector<StPair>& pairs, float mb, float mbf) {
+static int stereo_run(ps_orb* out_h, const std::vector<StPair>& pairs, float mb, float mbf, int max_left = 0) {
   PS_HIP(hipMemcpyAsync(out_h->d_pairs, pairs.data(), pairs.size() * sizeof(StPair), hipMemcpyHostToDevice, out_h->stream));
-  psk_stereo_launch(&out_h->plan, out_h->d_pairs, (int)pairs.size(), mb, mbf, out_h->stream);
+  psk_stereo_launch(&out_h->plan, out_h->d_pairs, (int)pairs.size(), max_left > 0 ? max_left : out_h->plan.kp_cap, mb, mbf, out_h->stream);
   PS_HIP(hipGetLastError());
   out_h->last_npairs = (int)pairs.size();
   return PS_OK;
@@ -598,6 +603,61 @@ int ps_orb_stereo_match_pair(ps_orb* left, ps_orb* right, float mb, float mbf, f
   if (rc != PS_OK) return rc;
   left->last_nimg = 1;
   return ps_orb_stereo_fetch(left, 0, u_right, depth, cap, n_left, nullptr);
+}
+
+
+// Frame::ComputeObjStereoMatches (Frame.cc:2318-2503): the same matcher on caller-provided key sets (the object features of the
+// frame, mvTempObjKeys / mvTempObjKeysRight) against the two handles' device-resident pyramids.
+int ps_orb_stereo_match_keys(ps_orb* left, ps_orb* right, const ps_keypoint* kps_l, const uint8_t* desc_l, int n_left,
+                             const ps_keypoint* kps_r, const uint8_t* desc_r, int n_right, float mb, float mbf, float* u_right, float* depth,
+                             int* kept) {
+  if (!left || !right || !left->planned || !right->planned || n_left < 0 || n_right < 0 || !(mb > 0) || !(mbf > 0))
+    return ps_set_error(PS_ERR_INVALID, "ps_orb_stereo_match_keys: both extractors must have processed an image");
+  if (left->cfg.device != right->cfg.device || left->plan.img_w != right->plan.img_w || left->plan.img_h != right->plan.img_h ||
+      left->plan.nlevels != right->plan.nlevels)
+    return ps_set_error(PS_ERR_INVALID, "left and right extractor differ in device, image size or level count");
+  if (kept) *kept = 0;
+  if (n_left == 0) return PS_OK;                       // Frame.cc:2320
+  const int CAP = 4096;
+  if (n_left > CAP || n_right > CAP) return ps_set_error(PS_ERR_CAPACITY, "stereo matcher supports at most 4096 keypoints per image");
+  if (!kps_l || !desc_l || !u_right || !depth || (n_right > 0 && (!kps_r || !desc_r))) return ps_set_error(PS_ERR_INVALID, "null buffer");
+  for (int i = 0; i < n_left + n_right; i++) {
+    const ps_keypoint& k = i < n_left ? kps_l[i] : kps_r[i - n_left];
+    if (k.octave < 0 || k.octave >= left->plan.nlevels) return ps_set_error(PS_ERR_INVALID, "keypoint %d: octave %d", i, k.octave);
+  }
+  PS_HIP(hipSetDevice(left->cfg.device));
+  PS_HIP(hipDeviceSynchronize());
+  // scratch layout: [kpsL][kpsR][descL][descR][cntL, cntR, kept, pad][uright][depth][sad]
+  const size_t o_kl = 0, o_kr = o_kl + (size_t)CAP * 28, o_dl = o_kr + (size_t)CAP * 28, o_dr = o_dl + (size_t)CAP * 32,
+               o_cnt = o_dr + (size_t)CAP * 32, o_ur = o_cnt + 64, o_dp = o_ur + (size_t)CAP * 4, o_sad = o_dp + (size_t)CAP * 4,
+               total = o_sad + (size_t)CAP * 4;
+  if (!left->d_objkeys) {
+    PS_HIP(hipMalloc(&left->d_objkeys, total));
+    PS_HIP(hipHostMalloc(&left->h_objkeys, total));
+  }
+  uint8_t* hb = left->h_objkeys; uint8_t* db = left->d_objkeys;
+  memcpy(hb + o_kl, kps_l, (size_t)n_left * 28);
+  memcpy(hb + o_dl, desc_l, (size_t)n_left * 32);
+  if (n_right > 0) { memcpy(hb + o_kr, kps_r, (size_t)n_right * 28); memcpy(hb + o_dr, desc_r, (size_t)n_right * 32); }
+  int32_t* cnt = (int32_t*)(hb + o_cnt);
+  cnt[0] = n_left; cnt[1] = n_right; cnt[2] = 0;
+  PS_HIP(hipMemcpyAsync(db, hb, o_ur, hipMemcpyHostToDevice, left->stream));
+  std::vector<StPair> pairs(1);
+  StPair& s = pairs[0];
+  s.arena_l = left->d_arena; s.arena_r = right->d_arena;
+  s.kps_l = db + o_kl; s.desc_l = db + o_dl; s.cnt_l = (const int32_t*)(db + o_cnt);
+  s.kps_r = db + o_kr; s.desc_r = db + o_dr; s.cnt_r = (const int32_t*)(db + o_cnt) + 1;
+  s.u_right = (float*)(db + o_ur); s.depth = (float*)(db + o_dp); s.sad = (int32_t*)(db + o_sad); s.kept = (int32_t*)(db + o_cnt) + 2;
+  const int keep_npairs = left->last_npairs;
+  int rc = stereo_run(left, pairs, mb, mbf, n_left);
+  left->last_npairs = keep_npairs;                     // the frame's own ComputeStereoMatches results stay fetchable
+  if (rc != PS_OK) return rc;
+  PS_HIP(hipMemcpyAsync(hb + o_cnt, db + o_cnt, total - o_cnt, hipMemcpyDeviceToHost, left->stream));
+  PS_HIP(hipStreamSynchronize(left->stream));
+  memcpy(u_right, hb + o_ur, (size_t)n_left * 4);
+  memcpy(depth, hb + o_dp, (size_t)n_left * 4);
+  if (kept) *kept = cnt[2];
+  return PS_OK;
 }
 
 }  // extern "C"

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void st_median(OrbPlan plan, const StPair* pai
 
 }  // namespace
 
-extern "C" void psk_stereo_launch(const OrbPlan* plan, const StPair* d_pairs, int npairs, float mb, float mbf, hipStream_t st) {
-  hipLaunchKernelGGL(st_match, dim3((plan->kp_cap + 3) / 4, npairs), dim3(256), 0, st, *plan, d_pairs, mb, mbf);
+extern "C" void psk_stereo_launch(const OrbPlan* plan, const StPair* d_pairs, int npairs, int max_left, float mb, float mbf, hipStream_t st) {
+  hipLaunchKernelGGL(st_match, dim3((max_left + 3) / 4, npairs), dim3(256), 0, st, *plan, d_pairs, mb, mbf);
   hipLaunchKernelGGL(st_median, dim3(npairs), dim3(256), 0, st, *plan, d_pairs);
 }

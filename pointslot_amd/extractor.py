@@ -40,6 +40,8 @@ lib.ps_orb_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c
 lib.ps_orb_stereo_match_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float]
 lib.ps_orb_stereo_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+lib.ps_orb_stereo_match_keys.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                         ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 lib.ps_orb_stereo_match_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 lib.ps_orb_enable_stage_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -178,3 +180,15 @@ def ComputeStereoMatches(left, right, mb, mbf):
     n = ctypes.c_int(0)
     check(lib.ps_orb_stereo_match_pair(left._h, right._h, mb, mbf, ur.ctypes.data, dp.ctypes.data, left.capacity, ctypes.byref(n)))
     return ur[:n.value].copy(), dp[:n.value].copy()
+
+
+def ComputeObjStereoMatches(left, right, kps_l, desc_l, kps_r, desc_r, mb, mbf):
+    """Frame::ComputeObjStereoMatches (Frame.cc:2318-2503): object key sets against the two extractors' pyramids.
+    Returns (mvuTempObjKeysRight, mvTempObjDepth, kept)."""
+    kl = np.ascontiguousarray(kps_l, KEYPOINT_DTYPE); kr = np.ascontiguousarray(kps_r, KEYPOINT_DTYPE)
+    dl = np.ascontiguousarray(desc_l, np.uint8).reshape(-1, 32); dr = np.ascontiguousarray(desc_r, np.uint8).reshape(-1, 32)
+    ur = np.full(max(len(kl), 1), -1.0, np.float32); dp = np.full(max(len(kl), 1), -1.0, np.float32)
+    kept = ctypes.c_int(0)
+    check(lib.ps_orb_stereo_match_keys(left._h, right._h, kl.ctypes.data, dl.ctypes.data, len(kl), kr.ctypes.data, dr.ctypes.data, len(kr),
+                                       mb, mbf, ur.ctypes.data, dp.ctypes.data, ctypes.byref(kept)))
+    return ur[:len(kl)], dp[:len(kl)], kept.value

@@ -309,3 +309,15 @@ def distinctive_descriptors(desc_lists):
     f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     f(cat.ctypes.data, off.ctypes.data, n, best.ctypes.data)
     return best
+
+
+def stereo_match_keys(left, right, kps_l, desc_l, kps_r, desc_r, mb, mbf):
+    """Frame::ComputeObjStereoMatches on caller key sets; left / right: OracleORB objects after run()."""
+    L = lib()
+    f = L.orc_stereo_match_keys
+    f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    kl = np.ascontiguousarray(kps_l, KEYPOINT_DTYPE); kr = np.ascontiguousarray(kps_r, KEYPOINT_DTYPE)
+    dl = np.ascontiguousarray(desc_l, np.uint8).reshape(-1, 32); dr = np.ascontiguousarray(desc_r, np.uint8).reshape(-1, 32)
+    ur = np.full(max(len(kl), 1), -1.0, np.float32); dp = np.full(max(len(kl), 1), -1.0, np.float32)
+    kept = f(left.h, right.h, kl.ctypes.data, dl.ctypes.data, len(kl), kr.ctypes.data, dr.ctypes.data, len(kr), mb, mbf, ur.ctypes.data, dp.ctypes.data)
+    return kept, ur[:len(kl)], dp[:len(kl)]

@@ -241,3 +241,33 @@ def test_stereo_matches_bit_exact(images):
     ztrue = 60 + (6 - 60) * (kl["y"][m] / 374.0)
     assert np.median(np.abs(dp[m] - ztrue) / ztrue) < 0.1
     exl.close(); exr.close(); exb.close()
+
+
+def test_object_stereo_matches_bit_exact(images):
+    """Frame::ComputeObjStereoMatches (Frame.cc:2318-2503): caller-provided object key sets (here: the frame's keypoints inside
+    a detection box, in shuffled order) matched against the device-resident pyramids; bit-exact against the checker."""
+    from oracle_lib import stereo_match_keys
+    from pointslot_amd.extractor import ORBextractor, ComputeObjStereoMatches, ComputeStereoMatches
+    bf, fx = 384.38148, 721.5377
+    mb, mbf = np.float32(bf / fx), np.float32(bf)
+    L, R = images["synth_left"], images["synth_right"]
+    exl, exr = ORBextractor(2000, 1.2, 8, 20, 5), ORBextractor(2000, 1.2, 8, 20, 5)
+    kl, dl = exl(L); kr, dr = exr(R)
+    ol, orr = OracleORB(2000), OracleORB(2000)
+    ol.run(L); orr.run(R)
+    ur_frame, dp_frame = ComputeStereoMatches(exl, exr, mb, mbf)
+    rng = np.random.default_rng(5)
+    for box in [(300, 60, 900, 330), (0, 0, 1242, 375), (500, 150, 560, 200), (2000, 0, 2100, 10)]:
+        sl = np.nonzero((kl["x"] >= box[0]) & (kl["x"] < box[2]) & (kl["y"] >= box[1]) & (kl["y"] < box[3]))[0]
+        sr = np.nonzero((kr["x"] >= box[0] - 80) & (kr["x"] < box[2]) & (kr["y"] >= box[1] - 3) & (kr["y"] < box[3] + 3))[0]
+        sl, sr = rng.permutation(sl), rng.permutation(sr)
+        ur, dp, kept = ComputeObjStereoMatches(exl, exr, kl[sl], dl[sl], kr[sr], dr[sr], mb, mbf)
+        ko, uro, dpo = stereo_match_keys(ol, orr, kl[sl], dl[sl], kr[sr], dr[sr], mb, mbf)
+        assert kept == ko and len(ur) == len(sl)
+        assert np.array_equal(ur.view(np.uint32), uro.view(np.uint32)) and np.array_equal(dp.view(np.uint32), dpo.view(np.uint32))
+        if box == (300, 60, 900, 330):
+            assert kept > 100
+    # the object call leaves the frame's own results fetchable and unchanged
+    ur2, dp2 = ComputeStereoMatches(exl, exr, mb, mbf)
+    assert np.array_equal(ur2.view(np.uint32), ur_frame.view(np.uint32))
+    exl.close(); exr.close()
