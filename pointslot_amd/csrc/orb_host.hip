@@ -20,6 +20,7 @@ void psk_orb_launch_blur(const OrbPlan*, uint8_t*, int, hipStream_t);
 void psk_orb_launch_border(const OrbPlan*, uint8_t*, int, hipStream_t);
 int psk_orb_blur_rows();
 void psk_orb_launch_describe(const OrbPlan*, uint8_t*, void*, uint8_t*, int32_t*, int, hipStream_t);
+void psk_orb_launch_level_fused(const OrbPlan*, int, uint8_t*, const uint8_t*, int, size_t, const int4*, int, hipStream_t);
 void psk_stereo_launch(const OrbPlan*, const StPair*, int, int, float, float, hipStream_t);
 }
 
@@ -63,6 +64,7 @@ struct ps_orb {
   static const int MAXCHUNK = 32;
   hipEvent_t ev[RING][MAXCHUNK][ST_COUNT + 1] = {};
   int timed_chunks[RING] = {};
+  bool fused = true;              // one launch per level writes plane + border + blur (PS_ORB_FUSED=0: separate kernels)
   int chunk = 0;                  // 0 = whole batch per launch (kernels are latency-bound: fewer, larger launches win; PS_ORB_CHUNK overrides)
   bool timing = false;
   int timed_batches = 0;
@@ -290,14 +292,18 @@ int run_batch(ps_orb* h, const uint8_t* d_imgs, int nimg, int stride, size_t pit
     const uint8_t* imgs = d_imgs + (size_t)i0 * pitch;
     hipEvent_t* ev = h->ev[slot][c];
     if (tm) PS_HIP(hipEventRecord(ev[0], st));
-    for (int l = 0; l < P->nlevels; l++) psk_orb_launch_pyramid(P, l, arena, imgs, stride, pitch, h->d_tabs, n, st);
-    psk_orb_launch_border(P, arena, n, st);
+    if (h->fused) {
+      for (int l = 0; l < P->nlevels; l++) psk_orb_launch_level_fused(P, l, arena, imgs, stride, pitch, h->d_tabs, n, st);
+    } else {
+      for (int l = 0; l < P->nlevels; l++) psk_orb_launch_pyramid(P, l, arena, imgs, stride, pitch, h->d_tabs, n, st);
+      psk_orb_launch_border(P, arena, n, st);
+    }
     if (tm) PS_HIP(hipEventRecord(ev[1], st));
     psk_orb_launch_fast(P, arena, n, st);
     if (tm) PS_HIP(hipEventRecord(ev[2], st));
     psk_orb_launch_quadtree(P, arena, n, st);
     if (tm) PS_HIP(hipEventRecord(ev[3], st));
-    psk_orb_launch_blur(P, arena, n, st);
+    if (!h->fused) psk_orb_launch_blur(P, arena, n, st);
     if (tm) PS_HIP(hipEventRecord(ev[4], st));
     psk_orb_launch_describe(P, arena, h->d_kps + (size_t)i0 * P->kp_cap, h->d_desc + (size_t)i0 * P->kp_cap * 32,
                             h->d_counts + i0, n, st);
@@ -332,6 +338,7 @@ int ps_orb_create(const ps_orb_config* cfg, ps_orb** out) {
     for (int c = 0; c < ps_orb::MAXCHUNK; c++)
       for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&h->ev[r][c][i]);
   if (const char* e = getenv("PS_ORB_CHUNK")) h->chunk = atoi(e);
+  if (const char* e = getenv("PS_ORB_FUSED")) h->fused = atoi(e) != 0;
   *out = h;
   return PS_OK;
 }

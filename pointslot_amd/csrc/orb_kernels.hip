@@ -166,6 +166,199 @@ __global__ __launch_bounds__(256) void orb_pyramid_level(OrbPlan plan, int level
     if (y0 + r < L.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(y0 + r) * L.stride) = packed[r];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused level kernel: one launch per level produces the PADDED plane (interior + 19-px REFLECT_101 border) and the
+// level's GaussianBlur plane (ORBextractor.cc:1107-1132 + :1085-1086), replacing orb_pyramid_level + orb_border + orb_blur.
+//   * The output domain is the padded plane; a padded pixel (px, py) is the level pixel (reflect101(px - 19),
+//     reflect101(py - 19)), so the border is just more resize evaluations - no second pass, no read-back.
+//   * A workgroup owns 248 x 34 padded pixels and evaluates a 256 x 40 region (4 / 3 pixels of halo) into LDS;
+//     the 7x7 blur of the owned in-image pixels is then taken from LDS, so the plane is never re-read from HBM.
+//   * Arithmetic: the 8 source bytes that the 4 pixels of a lane can touch are brought into two registers
+//     (3 aligned dword loads + v_alignbyte); v_perm_b32 extracts each pixel's (b0, b1) pair as packed u16 and
+//     v_dot2_u32_u16 forms b0*a0 + b1*a1 in one instruction; the vertical step is two v_mul_hi_u32 (the
+//     weights are pre-shifted by 16) and one add3.  No saturation is needed: a0 + a1 = 2048 bounds the result by 255.
+// ------------------------------------------------------------------------------------------------
+#define LV_RPT 10                 // region rows per thread
+#define LV_R (4 * LV_RPT)         // region rows per workgroup
+#define LV_OWN_R (LV_R - 6)       // owned rows
+#define LV_OWN_C 248              // owned columns (62 dword groups; lanes 0 and 63 are halo)
+#define LV_BLUR_ROWS 9            // 4 row chunks of <= 9 cover the 34 owned rows
+typedef unsigned short lv_us2 __attribute__((ext_vector_type(2)));
+
+template <bool LEVEL0>
+__global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, uint8_t* arena, const uint8_t* imgs,
+                                                      int img_stride, size_t img_pitch, const int4* tabs) {
+  __shared__ uint32_t tile[LV_R][64];
+  const OrbLevel L = plan.lv[level];
+  const int img = blockIdx.z;
+  uint8_t* base = arena + (size_t)img * plan.arena_bytes;
+  const int lane = threadIdx.x & 63;
+  const int tyq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int PW = L.w + 2 * PS_EDGE, PH = L.h + 2 * PS_EDGE;
+  const int P0 = blockIdx.x * LV_OWN_C - 4;      // padded column of region column 0 (multiple of 4)
+  const int Q0 = blockIdx.y * LV_OWN_R - 3;      // padded row of region row 0
+
+  // ---- phase 1: resize (or copy) the region into LDS, store the owned part of the padded plane ----
+  int s0[4], s1[4];
+  uint32_t coef[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int px = min(max(P0 + 4 * lane + k, 0), PW - 1);
+    const int lx = reflect101(px - PS_EDGE, L.w);
+    if (LEVEL0) { s0[k] = lx; s1[k] = lx; coef[k] = 2048u; }
+    else {
+      const int4 t = tabs[L.xtab_off + lx];
+      s0[k] = t.x; s1[k] = t.y; coef[k] = (uint32_t)t.z | ((uint32_t)t.w << 16);
+    }
+  }
+  const int sb = min(min(s0[0], s0[1]), min(s0[2], s0[3]));
+  uint32_t sel[4];
+  bool fast = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i0 = s0[k] - sb, i1 = s1[k] - sb;
+    fast = fast && i0 < 8 && i1 < 8;
+    sel[k] = (uint32_t)i0 | (0x0cu << 8) | ((uint32_t)i1 << 16) | (0x0cu << 24);
+  }
+  const uint32_t sel_copy = (uint32_t)(s0[0] - sb) | ((uint32_t)(s0[1] - sb) << 8) | ((uint32_t)(s0[2] - sb) << 16) | ((uint32_t)(s0[3] - sb) << 24);
+  const uint8_t* src_rows;       // pointer to source pixel (0, 0)
+  int src_stride;
+  if (LEVEL0) {
+    src_rows = imgs + (size_t)img * img_pitch; src_stride = img_stride;
+    fast = fast && sb >= 4 && sb + 12 <= L.w;        // the aligned 12-byte window must stay inside the caller's row
+  } else {
+    const OrbLevel S = plan.lv[level - 1];
+    src_rows = base + S.plane_off + (size_t)PS_EDGE * S.stride + PS_EDGE; src_stride = S.stride;
+  }
+  const bool own_x = lane >= 1 && lane <= 62 && P0 + 4 * lane < PW;
+  uint8_t* plane = base + L.plane_off;
+  // Consecutive output rows share a source row four times out of five at scale 1.2 (s0 of row r is s1 of row r - 1), so
+  // the horizontally interpolated row is carried over instead of being recomputed; the row indices are wave-uniform.
+  uint32_t hc[4] = {0, 0, 0, 0};
+  int hc_row = -1;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    uint32_t wl[LV_RPT / 2][2], wh[LV_RPT / 2][2];
+    int4 ty[LV_RPT / 2];
+    bool need0[LV_RPT / 2];
+#pragma unroll
+    for (int r = 0; r < LV_RPT / 2; r++) {
+      const int rr = tyq * LV_RPT + half * (LV_RPT / 2) + r;
+      const int py = min(max(Q0 + rr, 0), PH - 1);
+      const int ly = reflect101(py - PS_EDGE, L.h);
+      if (LEVEL0) ty[r] = make_int4(ly, ly, 0, 0);
+      else ty[r] = tabs[L.ytab_off + ly];
+      const int prev_s1 = r > 0 ? ty[r - 1].y : hc_row;
+      need0[r] = LEVEL0 || ty[r].x != prev_s1;
+#pragma unroll
+      for (int v = 0; v < (LEVEL0 ? 1 : 2); v++) {
+        if (v == 0 && !need0[r]) continue;
+        const uint8_t* row = src_rows + (size_t)(v == 0 ? ty[r].x : ty[r].y) * src_stride;
+        if (fast) {
+          const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(row + sb) & 3);
+          const uint32_t* q = reinterpret_cast<const uint32_t*>(row + sb - sh);
+          const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+          wl[r][v] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+          wh[r][v] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        } else {
+          // generic gather (image edges of level 0, scale factors above 2): byte k <- s0[k], byte 4 + k <- s1[k]
+          wl[r][v] = (uint32_t)row[s0[0]] | ((uint32_t)row[s0[1]] << 8) | ((uint32_t)row[s0[2]] << 16) | ((uint32_t)row[s0[3]] << 24);
+          wh[r][v] = (uint32_t)row[s1[0]] | ((uint32_t)row[s1[1]] << 8) | ((uint32_t)row[s1[2]] << 16) | ((uint32_t)row[s1[3]] << 24);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < LV_RPT / 2; r++) {
+      const int rr = tyq * LV_RPT + half * (LV_RPT / 2) + r;
+      uint32_t pk;
+      if (LEVEL0) {
+        pk = fast ? __builtin_amdgcn_perm(wh[r][0], wl[r][0], sel_copy) : wl[r][0];
+      } else {
+        const uint32_t bz = (uint32_t)ty[r].z << 16, bw = (uint32_t)ty[r].w << 16;
+        pk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t sk = fast ? sel[k] : ((uint32_t)k | (0x0cu << 8) | ((uint32_t)(4 + k) << 16) | (0x0cu << 24));
+          uint32_t h0 = hc[k];
+          if (need0[r]) {
+            const uint32_t p0 = __builtin_amdgcn_perm(wh[r][0], wl[r][0], sk);
+            h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, p0), __builtin_bit_cast(lv_us2, coef[k]), 0u, false) >> 4;
+          }
+          const uint32_t p1 = __builtin_amdgcn_perm(wh[r][1], wl[r][1], sk);
+          const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, p1), __builtin_bit_cast(lv_us2, coef[k]), 0u, false) >> 4;
+          hc[k] = h1;
+          // ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2, weights pre-shifted by 16 for mul_hi
+          const uint32_t o = (__umulhi(h0, bz) + __umulhi(h1, bw) + 2u) >> 2;
+          pk |= o << (8 * k);
+        }
+      }
+      tile[rr][lane] = pk;
+      const int py = Q0 + rr;
+      if (own_x && rr >= 3 && rr < 3 + LV_OWN_R && py < PH)
+        *reinterpret_cast<uint32_t*>(plane + (size_t)py * L.stride + P0 + 4 * lane) = pk;
+    }
+    hc_row = ty[LV_RPT / 2 - 1].y;
+  }
+  __syncthreads();
+
+  // ---- phase 2: GaussianBlur 7x7 of the owned in-image pixels from LDS (fixed point, see orb_blur) ----
+  const int tid = threadIdx.x;
+  if (tid >= 4 * 62) return;
+  const int c = tid % 62, q = tid / 62;
+  const int x0 = P0 + 4 * c + 3 - PS_EDGE;                 // level column of the blur group (multiple of 4)
+  if (x0 < 0 || x0 >= L.w) return;
+  const int o0 = q * LV_BLUR_ROWS;                         // first owned row of the chunk
+  const int nrows = min(LV_BLUR_ROWS, LV_OWN_R - o0);
+  const int y0 = Q0 + 3 + o0 - PS_EDGE;                    // level row of the chunk's first output
+  if (y0 >= L.h || y0 + nrows <= 0) return;
+  // horizontal 7-tap sums (exact in 16 bits: the taps add up to 257) with two v_dot4_u32_u8 per pixel; two consecutive
+  // rows are packed into one register so that the vertical pass is four v_dot2_u32_u16 per pixel
+  const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24), KHI = 49u | (34u << 8) | (18u << 16);
+  uint32_t E[(LV_BLUR_ROWS + 7) / 2][4];     // E[i][j] = hs(row 2i)[j] | hs(row 2i + 1)[j] << 16
+#pragma unroll
+  for (int r = 0; r < LV_BLUR_ROWS + 6; r++) {
+    const int rr = min(o0 + r, LV_R - 1);
+    const uint32_t a0 = tile[rr][c], a1 = tile[rr][c + 1], a2 = tile[rr][c + 2];
+    uint32_t w[8];
+    w[0] = a0; w[4] = a1;
+#pragma unroll
+    for (int k = 1; k < 4; k++) { w[k] = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)k); w[4 + k] = __builtin_amdgcn_alignbyte(a2, a1, (uint32_t)k); }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t hsum = __builtin_amdgcn_udot4(w[j + 4], KHI, __builtin_amdgcn_udot4(w[j], KLO, 0u, false), false);
+      if (r & 1) E[r >> 1][j] |= hsum << 16; else E[r >> 1][j] = hsum;
+    }
+  }
+  const uint32_t C01 = 18u | (34u << 16), C23 = 49u | (55u << 16), C45 = 49u | (34u << 16), C6 = 18u;           // even output rows
+  const uint32_t D0 = 18u << 16, D12 = 34u | (49u << 16), D34 = 55u | (49u << 16), D56 = 34u | (18u << 16);      // odd output rows
+  uint8_t* dst = base + L.blur_off + x0;
+#pragma unroll
+  for (int o = 0; o < LV_BLUR_ROWS; o++) {
+    const int y = y0 + o;
+    if (o >= nrows || y < 0 || y >= L.h) continue;
+    const int m = o >> 1;
+    uint32_t pk = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t v = 32768u;
+      if (o & 1) {
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m][j]), __builtin_bit_cast(lv_us2, D0), v, false);
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 1][j]), __builtin_bit_cast(lv_us2, D12), v, false);
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 2][j]), __builtin_bit_cast(lv_us2, D34), v, false);
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 3][j]), __builtin_bit_cast(lv_us2, D56), v, false);
+      } else {
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m][j]), __builtin_bit_cast(lv_us2, C01), v, false);
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 1][j]), __builtin_bit_cast(lv_us2, C23), v, false);
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 2][j]), __builtin_bit_cast(lv_us2, C45), v, false);
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 3][j]), __builtin_bit_cast(lv_us2, C6), v, false);
+      }
+      const uint32_t qv = v >> 16;
+      pk |= (qv > 255u ? 255u : qv) << (8 * j);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.bstride) = pk;
+  }
+}
+
 // copyMakeBorder(REFLECT_101) of all levels in one launch: every border dword is recomputed from the interior.
 // Work items per level: (19 + 19) full rows and, for each interior row, the dword groups that touch the left /
 // right border.  (Interior bytes inside such a group are rewritten with their own value.)
@@ -948,6 +1141,17 @@ extern "C" void psk_orb_launch_pyramid(const OrbPlan* plan, int level, uint8_t* 
     hipLaunchKernelGGL(orb_pyramid_level<true>, grd, blk, 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
   else
     hipLaunchKernelGGL(orb_pyramid_level<false>, grd, blk, 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
+}
+// fused path: padded plane + blurred plane of one level in one launch
+extern "C" void psk_orb_launch_level_fused(const OrbPlan* plan, int level, uint8_t* arena, const uint8_t* imgs,
+                                           int img_stride, size_t img_pitch, const int4* tabs, int nimg, hipStream_t st) {
+  const OrbLevel& L = plan->lv[level];
+  const int PW = L.w + 2 * PS_EDGE, PH = L.h + 2 * PS_EDGE;
+  dim3 grd((PW + LV_OWN_C - 1) / LV_OWN_C, (PH + LV_OWN_R - 1) / LV_OWN_R, nimg);
+  if (level == 0)
+    hipLaunchKernelGGL(orb_level_fused<true>, grd, dim3(256), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
+  else
+    hipLaunchKernelGGL(orb_level_fused<false>, grd, dim3(256), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
 }
 extern "C" void psk_orb_launch_border(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   hipLaunchKernelGGL(orb_border, dim3(plan->border_blocks, nimg), dim3(256), 0, st, *plan, arena);
