@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpointslot_hip.so")
+LIB_PATH = os.environ.get("PS_LIB_PATH") or os.path.join(_HERE, "libpointslot_hip.so")   # PS_LIB_PATH: developer builds of the same library
 
 PS_OK = 0
 PS_ERR_INVALID = -1

@@ -1021,11 +1021,46 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 struct PsKeyPoint { float x, y, size, angle, response; int32_t octave, class_id; };
 
+// IC_Angle item table: item t = lane + 64 i covers row v = (t >> 3) - 15, columns u0 .. u0 + 3 with u0 = 4 (t & 7) - 15 of
+// the 31 x 31 patch; x = byte mask of the columns inside the disc (|u| <= umax[|v|], ORBextractor.cc:452-468), y = the same
+// bytes times (u + 15).
+struct IcTab { uint2 v[4][64]; };
+constexpr IcTab make_ictab() {
+  IcTab tb{};
+  const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  for (int i = 0; i < 4; i++)
+    for (int lane = 0; lane < 64; lane++) {
+      const int t = lane + 64 * i;
+      uint32_t m = 0, um = 0;
+      if (t < 248) {
+        const int v = (t >> 3) - 15, u0 = 4 * (t & 7) - 15;
+        const int um_row = umax[v < 0 ? -v : v];
+        for (int k = 0; k < 4; k++) {
+          const int u = u0 + k, au = u < 0 ? -u : u;
+          if (au <= um_row) { m |= 1u << (8 * k); um |= (uint32_t)(u + 15) << (8 * k); }
+        }
+      }
+      tb.v[i][lane].x = m; tb.v[i][lane].y = um;
+    }
+  return tb;
+}
+__constant__ IcTab c_ictab = make_ictab();
+
+// wave-wide integer sum with DPP (no LDS round trips): xor-1, xor-2, half-row mirror, row mirror, then the four rows
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena, PsKeyPoint* out_kps,
                                                    uint8_t* out_desc, int32_t* out_counts, int nimg, int bpi) {
   int img, lb;
   if (!xcd_image_block(bpi, nimg, img, lb)) return;
-  const int slot = lb * 4 + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the level lookup on the scalar unit
+  const int slot = lb * 4 + wv;
   const int lane = threadIdx.x & 63;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
   const int32_t* selcnt = reinterpret_cast<const int32_t*>(base + plan.selcnt_off);
@@ -1052,46 +1087,58 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
   const uint32_t e = (reinterpret_cast<const uint32_t*>(base + plan.sel_base) + L.sel_off)[k];
   const int kx = e & 0xFFF, ky = (e >> 12) & 0xFFF, sc = e >> 24;
 
+  // ---- the 39 x 39 neighbourhood of the blurred level that the steered pattern can reach (|coordinate| <= 18.4 before
+  // rounding) goes to LDS with row-coalesced dword loads: the 512 byte gathers of the tests would otherwise touch ~30
+  // cache lines per load instruction and the kernel is bound by the L1 tag rate.  Issued first, consumed last. ----
+  __shared__ uint32_t patch_all[4][40 * 12];
+  uint32_t* patch = patch_all[wv];
+  const int pshift = (kx - 19) & 3;
+  {
+    // 16 lanes per row (11 dwords used), 4 rows per step, 10 steps
+    const int pr = lane >> 4, pd = min(lane & 15, 10);
+    const uint8_t* prow = base + L.blur_off + (size_t)(ky - 19 + pr) * L.bstride + (kx - 19 - pshift) + 4 * pd;
+    uint32_t tmp[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) tmp[i] = *reinterpret_cast<const uint32_t*>(prow + (size_t)min(4 * i, 38 - pr) * L.bstride);
+#pragma unroll
+    for (int i = 0; i < 10; i++) patch[(4 * i + pr) * 12 + pd] = tmp[i];   // rows 39 (i = 9, pr = 3) is a duplicate of row 38 and never read
+  }
   // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the disc ----
   const uint8_t* center = base + L.plane_off + (size_t)(PS_EDGE + ky) * L.stride + PS_EDGE + kx;
   int m10 = 0, m01 = 0;
-  // 31 rows x up to 31 columns: lanes 0..30 take column u = lane - 15 of the even rows, lanes 32..62 of the odd rows.
-  // All 16 loads are issued unconditionally first (the patch lies inside the padded plane), then masked: a load
-  // inside a data-dependent branch would serialise 16 memory round trips.
+  // 31 rows x 8 groups of 4 columns = 248 items, 4 per lane: one (unaligned) dword load per item; the disc mask and the
+  // column weights (u + 15, as bytes) come from a per-lane table so that an item costs three v_dot4_u32_u8 and a mad:
+  //   m10 = sum (u + 15) I - 15 sum I,   m01 = sum_rows v * (row sum)
   {
-    const int u = (lane & 31) - 15;
-    const int half = lane >> 5;
-    const bool col_ok = (lane & 31) < 31;
-    int val[16];
+    uint32_t pix[4];
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const int vv = min(-15 + half + 2 * it, 15);
-      val[it] = center[(ptrdiff_t)vv * L.stride + (col_ok ? u : 0)];
+    for (int i = 0; i < 4; i++) {
+      const int t = min(lane + 64 * i, 247);
+      pix[i] = *reinterpret_cast<const uint32_t*>(center + (ptrdiff_t)((t >> 3) - 15) * L.stride + (4 * (t & 7) - 15));
     }
-    constexpr int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-    const int au = u < 0 ? -u : u;
+    int s0 = 0;
+    uint32_t acc = 0;
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-      // row of this lane: vv = -15 + half + 2*it ; |vv| is 15-2it (half 0) or |2it-14| (half 1)
-      const int ve = -15 + 2 * it, vo = -14 + 2 * it;
-      const int ume = kUmax[ve < 0 ? -ve : ve], umo = vo <= 15 ? kUmax[vo < 0 ? -vo : vo] : -1;
-      const int vv = half ? vo : ve;
-      const int um = half ? umo : ume;
-      if (col_ok && au <= um && vv <= 15) { m10 += u * val[it]; m01 += vv * val[it]; }
+    for (int i = 0; i < 4; i++) {
+      const uint2 mk = c_ictab.v[i][lane];
+      const int t = min(lane + 64 * i, 247);
+      const uint32_t sr = __builtin_amdgcn_udot4(pix[i], mk.x, 0u, false);
+      acc = __builtin_amdgcn_udot4(pix[i], mk.y, acc, false);
+      s0 += (int)sr;
+      m01 += ((t >> 3) - 15) * (int)sr;
     }
+    m10 = (int)acc - 15 * s0;
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    m10 += __shfl_xor(m10, d);
-    m01 += __shfl_xor(m01, d);
-  }
+  m10 = wave_sum_i32(m10);
+  m01 = wave_sum_i32(m01);
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
   // ---- steered BRIEF on the blurred level: lane handles tests 4*lane .. 4*lane+3 ----
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float arad = __fmul_rn(angle, factorPI);
   const float a = (float)cos((double)arad), b = (float)sin((double)arad);
-  const uint8_t* bc = base + L.blur_off + (size_t)ky * L.bstride + kx;
+  wave_sync();
+  const uint8_t* bc = reinterpret_cast<const uint8_t*>(patch) + 19 * 48 + 19 + pshift;
   uint32_t nib = 0;
   const int4 pw = reinterpret_cast<const int4*>(c_pattern)[lane];   // this lane's 4 tests x (x0,y0,x1,y1) int8
   const int pws[4] = {pw.x, pw.y, pw.z, pw.w};
@@ -1104,7 +1151,7 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
     const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
     const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
     const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = bc[(ptrdiff_t)r0 * L.bstride + q0], t1 = bc[(ptrdiff_t)r1 * L.bstride + q1];
+    const int t0 = bc[r0 * 48 + q0], t1 = bc[r1 * 48 + q1];
     nib |= (uint32_t)(t0 < t1) << tst;
   }
   // assemble 8 lanes (32 bits) into one dword on lanes 0,8,16,...
