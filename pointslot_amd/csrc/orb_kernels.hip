@@ -453,7 +453,7 @@ __device__ __forceinline__ void wave_sync() {
 #define FAST_T 256
 __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int nimg, int bpi) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform geometry stays on the scalar unit
   int img, lb;
   if (!xcd_image_block(bpi, nimg, img, lb)) return;
   const int cell = lb * 4 + wave;
@@ -484,12 +484,33 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   const int shift = (PS_EDGE + iniX) & 3;   // plane origins are 256-B aligned, strides multiples of 64
   const uint8_t* ga = base + L.plane_off + (size_t)(PS_EDGE + iniY) * L.stride + (PS_EDGE + iniX - shift);
   const int nd = (shift + ww + 3) >> 2;
-  for (int t = lane; t < wh * nd; t += 64) {
-    const int y = t / nd, dd = t - y * nd;
-    *reinterpret_cast<uint32_t*>(tile + y * TS + 4 * dd) = *reinterpret_cast<const uint32_t*>(ga + (size_t)y * L.stride + 4 * dd);
+  if (TR <= 40 && nd <= 16) {
+    // 16 lanes per row, 4 rows per step; every load is issued before the first LDS store so that the window costs one
+    // memory round trip instead of one per step (windows of the usual 30-px cells: <= 40 rows, <= 16 dwords)
+    const int wr = lane >> 4, wd = lane & 15;
+    const bool wact = wd < nd;
+    const uint8_t* gp = ga + (size_t)wr * L.stride + 4 * (wact ? wd : 0);
+    uint32_t tmp[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+      const int y = min(4 * i + wr, wh - 1) - wr;
+      tmp[i] = *reinterpret_cast<const uint32_t*>(gp + (ptrdiff_t)y * L.stride);
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+      if (wact && 4 * i + wr < wh) *reinterpret_cast<uint32_t*>(tile + (4 * i + wr) * TS + 4 * wd) = tmp[i];
+  } else {
+    for (int t = lane; t < wh * nd; t += 64) {
+      const int y = t / nd, dd = t - y * nd;
+      *reinterpret_cast<uint32_t*>(tile + y * TS + 4 * dd) = *reinterpret_cast<const uint32_t*>(ga + (size_t)y * L.stride + 4 * dd);
+    }
   }
   for (int t = lane; t < (SS * (ch + 2) + 3) / 4; t += 64) reinterpret_cast<uint32_t*>(smap)[t] = 0;
   wave_sync();
+#if defined(PS_EXP) && (PS_EXP & 16)
+  if (lane == 0) cellcnt[cell] = tile[7];
+  return;
+#endif
   // ---- B: cheap NECESSARY test on the 8 even ring positions, 4 pixels per lane and step.  Nine contiguous ring
   // pixels always contain four consecutive even positions, so a pixel without 4 consecutive dark (or bright) even
   // positions cannot be a corner at min_th; this rejects most pixels for ~1/3 of the full test's work. ----
@@ -556,6 +577,9 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     nsurv += __popcll(C[0]) + __popcll(C[1]) + __popcll(C[2]) + __popcll(C[3]);
   }
   nsurv = min(nsurv, LCAP);
+#if defined(PS_EXP) && (PS_EXP & 32)
+  nsurv = min(nsurv, 0);
+#endif
   wave_sync();
   // ---- C: exact score of the survivors; s > min_th <=> corner.  The list is compacted in place (a chunk is read
   // before anything is written, and writes never run ahead of the reads). ----
@@ -1071,6 +1095,8 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
     if (l < plan.nlevels && slot >= plan.lv[l].sel_off) level = l;
   const OrbLevel L = plan.lv[level];
   const int k = slot - L.sel_off;
+  // the slot is read before the counts are known (it always exists), so the two round trips overlap
+  const uint32_t e = (reinterpret_cast<const uint32_t*>(base + plan.sel_base) + L.sel_off)[min(k, L.sel_cap - 1)];
   int offset = 0, total = 0;
 #pragma unroll
   for (int l = 0; l < PS_ORB_MAX_LEVELS; l++) {
@@ -1084,7 +1110,6 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
   if (k >= selcnt[level]) return;
   const int oi = offset + k;
   if (oi >= plan.kp_cap) return;
-  const uint32_t e = (reinterpret_cast<const uint32_t*>(base + plan.sel_base) + L.sel_off)[k];
   const int kx = e & 0xFFF, ky = (e >> 12) & 0xFFF, sc = e >> 24;
 
   // ---- the 39 x 39 neighbourhood of the blurred level that the steered pattern can reach (|coordinate| <= 18.4 before
@@ -1099,7 +1124,11 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
     const uint8_t* prow = base + L.blur_off + (size_t)(ky - 19 + pr) * L.bstride + (kx - 19 - pshift) + 4 * pd;
     uint32_t tmp[10];
 #pragma unroll
+#if defined(PS_EXP) && (PS_EXP & 2)
+    for (int i = 0; i < 10; i++) tmp[i] = i * lane;
+#else
     for (int i = 0; i < 10; i++) tmp[i] = *reinterpret_cast<const uint32_t*>(prow + (size_t)min(4 * i, 38 - pr) * L.bstride);
+#endif
 #pragma unroll
     for (int i = 0; i < 10; i++) patch[(4 * i + pr) * 12 + pd] = tmp[i];   // rows 39 (i = 9, pr = 3) is a duplicate of row 38 and never read
   }
@@ -1114,7 +1143,11 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int t = min(lane + 64 * i, 247);
+#if defined(PS_EXP) && (PS_EXP & 4)
+      pix[i] = t * kx;
+#else
       pix[i] = *reinterpret_cast<const uint32_t*>(center + (ptrdiff_t)((t >> 3) - 15) * L.stride + (4 * (t & 7) - 15));
+#endif
     }
     int s0 = 0;
     uint32_t acc = 0;
@@ -1136,7 +1169,11 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
   // ---- steered BRIEF on the blurred level: lane handles tests 4*lane .. 4*lane+3 ----
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float arad = __fmul_rn(angle, factorPI);
+#if defined(PS_EXP) && (PS_EXP & 1)
+  const float a = __cosf(arad), b = __sinf(arad);
+#else
   const float a = (float)cos((double)arad), b = (float)sin((double)arad);
+#endif
   wave_sync();
   const uint8_t* bc = reinterpret_cast<const uint8_t*>(patch) + 19 * 48 + 19 + pshift;
   uint32_t nib = 0;
