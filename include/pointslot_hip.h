@@ -216,6 +216,38 @@ typedef struct ps_proj_problem {
 } ps_proj_problem;
 int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob);
 
+/* The search half of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:982-1136) and
+ * Fuse(ObjectKeyFrame*, const vector<MapObjectPoint*>&, th) (:1138-1260), SURVEY.md 8f-4: for every candidate point the
+ * projection into the keyframe, the depth / image-or-box / scale-invariance / viewing-angle gates, PredictScale,
+ * KeyFrame::GetFeaturesInArea(u, v, th * scale[level]) and the chi-square-gated (7.8 stereo / 5.99 mono) best Hamming match.
+ * best_idx[i] = keyframe feature to fuse with (bestDist <= TH_LOW), -1 otherwise; best_dist[i] = bestDist (256 if none).
+ * What the reference does next (Replace / AddObservation, :1113-1131 / :1239-1255) is map surgery and stays with the caller,
+ * in candidate order.  train: the keyframe's mvKeysUn / mvObjKeysUn (x, y, octave), mvuRight, descriptors and feature grid
+ * (angle / occupied / in_bbox unused).  q_valid[i] = pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF); q_pos = GetWorldPos()
+ * or GetInObjFramePosition(); q_min_dist / q_max_dist = mfMinDistance / mfMaxDistance (the 0.8 / 1.2 factors are applied
+ * inside).  bounds = {minX, maxX, minY, maxY}: IsInImage's mnMin/MaxX/Y or IsInBBox's detection box (doubles, as there). */
+typedef struct ps_fuse_problem {
+  ps_proj_train train;
+  int32_t nq;
+  const uint8_t* q_valid;
+  const float* q_pos;        /* [nq][3] */
+  const float* q_normal;     /* [nq][3] GetNormal() */
+  const float* q_min_dist;
+  const float* q_max_dist;
+  const uint8_t* q_desc;     /* [nq][32] GetDescriptor() */
+  float rcw[9], tcw[3], ow[3];   /* GetRotation() row-major, GetTranslation(), GetCameraCenter() */
+  float fx, fy, cx, cy, bf;
+  double bounds[4];
+  float scale_factors[8], inv_level_sigma2[8];
+  float log_scale_factor;    /* mfLogScaleFactor */
+  int32_t n_levels;          /* mnScaleLevels */
+  float th;
+  int32_t* best_idx;         /* out [nq] */
+  int32_t* best_dist;        /* out [nq] */
+} ps_fuse_problem;
+int ps_fuse_search(ps_matcher* m, ps_fuse_problem* problems, int nproblems);
+
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser — replaces the hot static members of ORB_SLAM2::Optimizer
  * (/root/reference/include/Optimizer.h:51-61, src/Optimizer.cc:249-1075) and the g2o solver stack they

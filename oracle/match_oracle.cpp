@@ -285,4 +285,68 @@ void orc_distinctive_descriptors(const uint8_t* desc, const int* off, int npoint
   }
 }
 
+
+// The search half of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (/root/reference/src/ORBmatcher.cc:982-1136) and
+// Fuse(ObjectKeyFrame*, vpMapObjectPoints, th) (:1138-1260): per candidate point the projection, the frustum / scale /
+// viewing-angle gates, KeyFrame::GetFeaturesInArea and the chi-square-gated best Hamming match.  What the reference does
+// with (bestIdx, bestDist) afterwards - Replace / AddObservation on the map - is pointer surgery and stays with the caller.
+//   valid[i] = pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF);  pos = GetWorldPos() / GetInObjFramePosition();
+//   min_dist / max_dist = mfMinDistance / mfMaxDistance (the 0.8f / 1.2f of Get*DistanceInvariance are applied here);
+//   R (row-major 3x3), t, ow = GetRotation(), GetTranslation(), GetCameraCenter();  bounds = {minX, maxX, minY, maxY} as doubles
+//   (IsInImage: mnMinX.. ; IsInBBox: the detection box);  K5 = fx, fy, cx, cy, mbf.
+// cv::Mat float products accumulate in double (cv::gemm, Mat::dot, cv::norm), everything else is float as written.
+void orc_fuse_search(const OrcTrain* F, int m, const uint8_t* valid, const float* pos, const float* normal, const float* min_dist,
+                     const float* max_dist, const uint8_t* desc, const float* R, const float* t, const float* ow, const float* K5,
+                     const double* bounds, const float* scale_factors, const float* inv_level_sigma2, float log_scale_factor, int n_levels,
+                     float th, int* best_idx, int* best_dist) {
+  const float fx = K5[0], fy = K5[1], cx = K5[2], cy = K5[3], bf = K5[4];
+  for (int i = 0; i < m; i++) {
+    best_idx[i] = -1; best_dist[i] = 256;
+    if (!valid[i]) continue;
+    const float* P = pos + 3 * i;
+    float Pc[3];
+    for (int r = 0; r < 3; r++)
+      Pc[r] = (float)((double)R[3 * r] * P[0] + (double)R[3 * r + 1] * P[1] + (double)R[3 * r + 2] * P[2]) + t[r];
+    if (Pc[2] < 0.0f) continue;
+    const float invz = 1 / Pc[2];
+    const float x = Pc[0] * invz, y = Pc[1] * invz;
+    const float u = fx * x + cx, v = fy * y + cy;
+    const float ur = u - bf * invz;
+    if (!(u >= bounds[0] && u < bounds[1] && v >= bounds[2] && v < bounds[3])) continue;
+    const float PO[3] = {P[0] - ow[0], P[1] - ow[1], P[2] - ow[2]};
+    const float dist3D = (float)std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float* Pn = normal + 3 * i;
+    const double dotn = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+    if (dotn < 0.5 * dist3D) continue;
+    // PredictScale (MapPoint.cc:515-530): ceil(log(ratio) / mfLogScaleFactor), ::log(double)
+    const float ratio = max_dist[i] / dist3D;
+    int nPredictedLevel = (int)std::ceil(std::log((double)ratio) / log_scale_factor);
+    if (nPredictedLevel < 0) nPredictedLevel = 0;
+    else if (nPredictedLevel >= n_levels) nPredictedLevel = n_levels - 1;
+    const float radius = th * scale_factors[nPredictedLevel];
+    const std::vector<int> vIndices = features_in_area(*F, u, v, radius, -1, -1);
+    if (vIndices.empty()) continue;
+    int bestDist = 256, bestIdx = -1;
+    for (int idx : vIndices) {
+      const int kpLevel = F->octave[idx];
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const float ex = u - F->x[idx], ey = v - F->y[idx];
+      if (F->u_right[idx] >= 0) {
+        const float er = ur - F->u_right[idx];
+        const float e2 = ex * ex + ey * ey + er * er;
+        if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+      } else {
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+      }
+      const int dist = descriptor_distance(desc + 32 * i, F->desc + 32 * idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    best_dist[i] = bestDist;
+    if (bestDist <= TH_LOW) best_idx[i] = bestIdx;
+  }
+}
+
 }  // extern "C"

@@ -12,6 +12,7 @@ void psk_bf_launch(const BfBlock*, int, const BfProb*, int, const uint8_t*, cons
                    const float*, uint32_t*, int32_t*, int32_t*, float, int, hipStream_t);
 void psk_hamming_matrix_launch(const uint8_t*, int, const uint8_t*, int, uint16_t*, hipStream_t);
 void psk_pj_launch(const PjArrays*, int, int, int, hipStream_t);
+void psk_fuse_launch(const FuArrays*, int, int, hipStream_t);
 void psk_distinctive_launch(const uint8_t*, const int32_t*, int32_t*, int, hipStream_t);
 }
 
@@ -278,6 +279,87 @@ int ps_distinctive_descriptors(ps_matcher* m, const uint8_t* desc, const int32_t
   PS_HIP(hipMemcpyAsync(m->h_buf + o_best, m->d_buf + o_best, (size_t)npoints * 4, hipMemcpyDeviceToHost, m->stream));
   PS_HIP(hipStreamSynchronize(m->stream));
   memcpy(best, m->h_buf + o_best, (size_t)npoints * 4);
+  return PS_OK;
+}
+
+
+int ps_fuse_search(ps_matcher* m, ps_fuse_problem* probs, int nprob) {
+  if (!m || !probs || nprob < 1) return ps_set_error(PS_ERR_INVALID, "ps_fuse_search: bad argument");
+  PS_HIP(hipSetDevice(m->device));
+  size_t NT = 0, NQ = 0;
+  int max_nq = 0;
+  const int NCELL = PS_GRID_COLS * PS_GRID_ROWS;
+  for (int p = 0; p < nprob; p++) {
+    const ps_fuse_problem& P = probs[p];
+    const ps_proj_train& T = P.train;
+    if (T.n < 0 || P.nq < 0 || (T.n > 0 && (!T.x || !T.y || !T.octave || !T.u_right || !T.desc || !T.cell_off || !T.cell_idx)))
+      return ps_set_error(PS_ERR_INVALID, "fuse problem %d: bad keyframe side", p);
+    if (P.nq > 0 && (!P.q_valid || !P.q_pos || !P.q_normal || !P.q_min_dist || !P.q_max_dist || !P.q_desc || !P.best_idx || !P.best_dist))
+      return ps_set_error(PS_ERR_INVALID, "fuse problem %d: null query arrays", p);
+    if (P.n_levels < 1 || P.n_levels > 8) return ps_set_error(PS_ERR_INVALID, "fuse problem %d: n_levels must be 1..8", p);
+    NT += T.n; NQ += P.nq;
+    max_nq = P.nq > max_nq ? P.nq : max_nq;
+  }
+  if (NQ == 0) return PS_OK;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += al(bytes + 64); return r; };
+  const size_t o_prob = take(sizeof(FuProb) * nprob);
+  const size_t o_tx = take(NT * 4), o_ty = take(NT * 4), o_toct = take(NT * 4), o_tur = take(NT * 4), o_tdesc = take(NT * 32);
+  const size_t o_coff = take((size_t)nprob * (NCELL + 1) * 4), o_cidx = take(NT * 4);
+  const size_t o_qvalid = take(NQ), o_qpos = take(NQ * 12), o_qnor = take(NQ * 12), o_qmin = take(NQ * 4), o_qmax = take(NQ * 4), o_qdesc = take(NQ * 32);
+  const size_t in_bytes = off;
+  const size_t o_bi = take(NQ * 4), o_bd = take(NQ * 4);
+  int rc = ensure(m, off);
+  if (rc != PS_OK) return rc;
+  uint8_t* H = m->h_buf;
+  memset(H, 0, in_bytes);
+  FuProb* hp = (FuProb*)(H + o_prob);
+  size_t t0 = 0, q0 = 0;
+  for (int p = 0; p < nprob; p++) {
+    const ps_fuse_problem& P = probs[p];
+    const ps_proj_train& T = P.train;
+    FuProb& d = hp[p];
+    d.t_off = (int32_t)t0; d.nt = T.n; d.q_off = (int32_t)q0; d.nq = P.nq; d.grid_off = p * (NCELL + 1);
+    d.min_x = T.min_x; d.min_y = T.min_y; d.gw_inv = T.grid_w_inv; d.gh_inv = T.grid_h_inv;
+    memcpy(d.R, P.rcw, 36); memcpy(d.t, P.tcw, 12); memcpy(d.ow, P.ow, 12);
+    d.fx = P.fx; d.fy = P.fy; d.cx = P.cx; d.cy = P.cy; d.bf = P.bf;
+    memcpy(d.bounds, P.bounds, 32); memcpy(d.scale, P.scale_factors, 32); memcpy(d.inv_sigma2, P.inv_level_sigma2, 32);
+    d.log_scale = P.log_scale_factor; d.n_levels = P.n_levels; d.th = P.th;
+    if (T.n > 0) {
+      memcpy(H + o_tx + t0 * 4, T.x, (size_t)T.n * 4); memcpy(H + o_ty + t0 * 4, T.y, (size_t)T.n * 4);
+      memcpy(H + o_toct + t0 * 4, T.octave, (size_t)T.n * 4); memcpy(H + o_tur + t0 * 4, T.u_right, (size_t)T.n * 4);
+      memcpy(H + o_tdesc + t0 * 32, T.desc, (size_t)T.n * 32);
+      memcpy(H + o_cidx + t0 * 4, T.cell_idx, (size_t)T.cell_off[NCELL] * 4);
+    }
+    if (T.cell_off) memcpy(H + o_coff + (size_t)d.grid_off * 4, T.cell_off, (size_t)(NCELL + 1) * 4);
+    if (P.nq > 0) {
+      memcpy(H + o_qvalid + q0, P.q_valid, P.nq); memcpy(H + o_qpos + q0 * 12, P.q_pos, (size_t)P.nq * 12);
+      memcpy(H + o_qnor + q0 * 12, P.q_normal, (size_t)P.nq * 12); memcpy(H + o_qmin + q0 * 4, P.q_min_dist, (size_t)P.nq * 4);
+      memcpy(H + o_qmax + q0 * 4, P.q_max_dist, (size_t)P.nq * 4); memcpy(H + o_qdesc + q0 * 32, P.q_desc, (size_t)P.nq * 32);
+    }
+    t0 += T.n; q0 += P.nq;
+  }
+  uint8_t* D = m->d_buf;
+  PS_HIP(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, m->stream));
+  FuArrays A;
+  A.prob = (const FuProb*)(D + o_prob);
+  A.tx = (const float*)(D + o_tx); A.ty = (const float*)(D + o_ty); A.toct = (const int32_t*)(D + o_toct); A.tur = (const float*)(D + o_tur);
+  A.tdesc = D + o_tdesc; A.cell_off = (const int32_t*)(D + o_coff); A.cell_idx = (const int32_t*)(D + o_cidx);
+  A.qvalid = D + o_qvalid; A.qpos = (const float*)(D + o_qpos); A.qnormal = (const float*)(D + o_qnor); A.qmin = (const float*)(D + o_qmin);
+  A.qmax = (const float*)(D + o_qmax); A.qdesc = D + o_qdesc; A.best_idx = (int32_t*)(D + o_bi); A.best_dist = (int32_t*)(D + o_bd);
+  psk_fuse_launch(&A, nprob, max_nq, m->stream);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipMemcpyAsync(H + o_bi, D + o_bi, off - o_bi, hipMemcpyDeviceToHost, m->stream));
+  PS_HIP(hipStreamSynchronize(m->stream));
+  q0 = 0;
+  for (int p = 0; p < nprob; p++) {
+    ps_fuse_problem& P = probs[p];
+    if (P.nq > 0) {
+      memcpy(P.best_idx, H + o_bi + q0 * 4, (size_t)P.nq * 4);
+      memcpy(P.best_dist, H + o_bd + q0 * 4, (size_t)P.nq * 4);
+    }
+    q0 += P.nq;
+  }
   return PS_OK;
 }
 

@@ -438,3 +438,97 @@ __global__ __launch_bounds__(64) void distinctive_desc(const uint8_t* desc, cons
 extern "C" void psk_distinctive_launch(const uint8_t* desc, const int32_t* off, int32_t* best, int npoints, hipStream_t st) {
   hipLaunchKernelGGL(distinctive_desc, dim3(npoints), dim3(64), 0, st, desc, off, best);
 }
+
+// ================================================================================================
+// The search half of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (/root/reference/src/ORBmatcher.cc:982-1136) and
+// Fuse(ObjectKeyFrame*, vpMapObjectPoints, th) (:1138-1260), SURVEY.md 8f-4.  One wave per candidate point: the float
+// projection and the gates are evaluated by every lane (they are wave-uniform), then the lanes walk the grid window of
+// KeyFrame::GetFeaturesInArea in the reference's order; "first strict minimum" = wave-min of (distance, traversal position).
+// ================================================================================================
+namespace {
+__global__ __launch_bounds__(256) void fuse_search(FuArrays A) {
+  const FuProb P = A.prob[blockIdx.y];
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (qi >= P.nq) return;
+  const int q = P.q_off + qi;
+  int out_idx = -1, out_dist = 256;
+  bool ok = A.qvalid[q] != 0;
+  const float X = A.qpos[3 * q], Y = A.qpos[3 * q + 1], Z = A.qpos[3 * q + 2];
+  const float xc = __fadd_rn(dot3_f(&P.R[0], X, Y, Z), P.t[0]);
+  const float yc = __fadd_rn(dot3_f(&P.R[3], X, Y, Z), P.t[1]);
+  const float zc = __fadd_rn(dot3_f(&P.R[6], X, Y, Z), P.t[2]);
+  if (zc < 0.0f) ok = false;
+  const float invz = __fdiv_rn(1.0f, zc);
+  const float u = __fadd_rn(__fmul_rn(P.fx, __fmul_rn(xc, invz)), P.cx);
+  const float v = __fadd_rn(__fmul_rn(P.fy, __fmul_rn(yc, invz)), P.cy);
+  const float ur = __fsub_rn(u, __fmul_rn(P.bf, invz));
+  if (!((double)u >= P.bounds[0] && (double)u < P.bounds[1] && (double)v >= P.bounds[2] && (double)v < P.bounds[3])) ok = false;
+  const float p0 = __fsub_rn(X, P.ow[0]), p1 = __fsub_rn(Y, P.ow[1]), p2 = __fsub_rn(Z, P.ow[2]);
+  const float dist3D = (float)sqrt(__dadd_rn(__dadd_rn(__dmul_rn((double)p0, (double)p0), __dmul_rn((double)p1, (double)p1)), __dmul_rn((double)p2, (double)p2)));
+  const float maxd = A.qmax[q], mind = A.qmin[q];
+  if (dist3D < __fmul_rn(0.8f, mind) || dist3D > __fmul_rn(1.2f, maxd)) ok = false;
+  const double dotn = __dadd_rn(__dadd_rn(__dmul_rn((double)p0, (double)A.qnormal[3 * q]), __dmul_rn((double)p1, (double)A.qnormal[3 * q + 1])),
+                                __dmul_rn((double)p2, (double)A.qnormal[3 * q + 2]));
+  if (dotn < __dmul_rn(0.5, (double)dist3D)) ok = false;
+  if (ok) {
+    const float ratio = __fdiv_rn(maxd, dist3D);
+    int lvl = (int)ceil(__ddiv_rn(log((double)ratio), (double)P.log_scale));
+    lvl = lvl < 0 ? 0 : (lvl >= P.n_levels ? P.n_levels - 1 : lvl);
+    const float r = __fmul_rn(P.th, P.scale[lvl]);
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(u, P.min_x), r), P.gw_inv)));
+    const int nMaxCellX = min(PS_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, P.min_x), r), P.gw_inv)));
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, P.min_y), r), P.gh_inv)));
+    const int nMaxCellY = min(PS_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(v, P.min_y), r), P.gh_inv)));
+    uint32_t best = 0xFFFFFFFFu;   // distance << 20 | traversal position (unique per candidate)
+    int bestj = -1;
+    if (nMinCellX < PS_GRID_COLS && nMaxCellX >= 0 && nMinCellY < PS_GRID_ROWS && nMaxCellY >= 0) {
+      const uint4* qd = reinterpret_cast<const uint4*>(A.qdesc + (size_t)q * 32);
+      const uint4 a0 = qd[0], a1 = qd[1];
+      const int32_t* coff = A.cell_off + P.grid_off;
+      int scanned = 0;
+      for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        const int b = coff[ix * PS_GRID_ROWS + nMinCellY], e = coff[ix * PS_GRID_ROWS + nMaxCellY + 1];
+        for (int k0 = b; k0 < e; k0 += 64) {
+          const int k = k0 + lane;
+          if (k < e) {
+            const int j = A.cell_idx[P.t_off + k];
+            const int t = P.t_off + j;
+            const float ex = __fsub_rn(u, A.tx[t]), ey = __fsub_rn(v, A.ty[t]);
+            const int oc = A.toct[t];
+            bool pass = fabsf(ex) < r && fabsf(ey) < r;            // KeyFrame::GetFeaturesInArea
+            if (oc < lvl - 1 || oc > lvl) pass = false;
+            const float tu = A.tur[t];
+            const float is2 = P.inv_sigma2[oc & 7];
+            const float e2m = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+            if (tu >= 0.f) {
+              const float er = __fsub_rn(ur, tu);
+              if ((double)__fmul_rn(__fadd_rn(e2m, __fmul_rn(er, er)), is2) > 7.8) pass = false;
+            } else {
+              if ((double)__fmul_rn(e2m, is2) > 5.99) pass = false;
+            }
+            if (pass) {
+              const uint4* td = reinterpret_cast<const uint4*>(A.tdesc + (size_t)t * 32);
+              const uint32_t dist = (uint32_t)hamming256(a0, a1, td[0], td[1]);
+              const uint32_t key = (dist << 20) | (uint32_t)min(scanned + (k - k0), 0xFFFFF);
+              if (key < best) { best = key; bestj = j; }
+            }
+          }
+          scanned += 64;
+        }
+      }
+    }
+    const uint32_t bk = wave_min_u32(best);
+    if (bk != 0xFFFFFFFFu) {
+      out_dist = (int)(bk >> 20);
+      const unsigned long long holder = __builtin_amdgcn_ballot_w64(best == bk);
+      const int src = __ffsll((long long)holder) - 1;
+      const int bj = __builtin_amdgcn_readlane(bestj, src);
+      if (out_dist <= 50) out_idx = bj;                              // TH_LOW
+    }
+  }
+  if (lane == 0) { A.best_idx[q] = out_idx; A.best_dist[q] = out_dist; }
+}
+}  // namespace
+extern "C" void psk_fuse_launch(const FuArrays* arrays, int nprob, int max_nq, hipStream_t st) {
+  hipLaunchKernelGGL(fuse_search, dim3((max_nq + 3) / 4, nprob), dim3(256), 0, st, *arrays);
+}

@@ -46,3 +46,23 @@ struct PjArrays {
   int32_t* qbest;                            // per query: matched train (or -1), for the rotation pass
   uint8_t* qbin;
 };
+
+// ---- ORBmatcher::Fuse search (projection + gates + chi-square-gated best match per candidate point) ----
+struct FuProb {
+  int32_t t_off, nt, q_off, nq, grid_off;
+  float min_x, min_y, gw_inv, gh_inv;
+  float R[9], t[3], ow[3];
+  float fx, fy, cx, cy, bf;
+  double bounds[4];
+  float scale[8], inv_sigma2[8];
+  float log_scale;
+  int32_t n_levels;
+  float th;
+};
+struct FuArrays {
+  const FuProb* prob;
+  const float* tx; const float* ty; const int32_t* toct; const float* tur; const uint8_t* tdesc;
+  const int32_t* cell_off; const int32_t* cell_idx;
+  const uint8_t* qvalid; const float* qpos; const float* qnormal; const float* qmin; const float* qmax; const uint8_t* qdesc;
+  int32_t* best_idx; int32_t* best_dist;
+};

@@ -203,3 +203,55 @@ def _search_by_projection(self, problems):
 
 
 ORBmatcher.SearchByProjection = _search_by_projection
+
+
+class _FuseProblem(ctypes.Structure):
+    _fields_ = [("train", _ProjTrain), ("nq", ctypes.c_int32), ("q_valid", ctypes.c_void_p), ("q_pos", ctypes.c_void_p),
+                ("q_normal", ctypes.c_void_p), ("q_min_dist", ctypes.c_void_p), ("q_max_dist", ctypes.c_void_p), ("q_desc", ctypes.c_void_p),
+                ("rcw", ctypes.c_float * 9), ("tcw", ctypes.c_float * 3), ("ow", ctypes.c_float * 3),
+                ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float), ("bf", ctypes.c_float),
+                ("bounds", ctypes.c_double * 4), ("scale_factors", ctypes.c_float * 8), ("inv_level_sigma2", ctypes.c_float * 8),
+                ("log_scale_factor", ctypes.c_float), ("n_levels", ctypes.c_int32), ("th", ctypes.c_float),
+                ("best_idx", ctypes.c_void_p), ("best_dist", ctypes.c_void_p)]
+
+
+lib.ps_fuse_search.argtypes = [ctypes.c_void_p, ctypes.POINTER(_FuseProblem), ctypes.c_int]
+
+
+def _fuse_search(self, problems):
+    """The search half of ORBmatcher::Fuse (KeyFrame / ObjectKeyFrame variants).  problems: list of dicts
+    {train (keyframe features + grid, as for SearchByProjection), query {valid, pos [m,3], normal [m,3], min_dist, max_dist, desc},
+     R 3x3, t 3, ow 3, K5 (fx, fy, cx, cy, bf), bounds (minX, maxX, minY, maxY), scale_factors, inv_level_sigma2,
+     log_scale_factor, n_levels, th}.  Returns a list of (best_idx int32[m], best_dist int32[m])."""
+    n = len(problems)
+    arr = (_FuseProblem * n)()
+    keep, outs = [], []
+    for i, pr in enumerate(problems):
+        p = arr[i]
+        F = dict(pr["train"])
+        nt = len(F["x"])
+        F.setdefault("angle", np.zeros(nt, np.float32)); F.setdefault("occupied", np.zeros(nt, np.uint8))
+        _fill_train(p, F, keep)
+        q = pr["query"]
+        m = len(q["valid"])
+        a = dict(q_valid=_arr(q["valid"], np.uint8), q_pos=_arr(q["pos"], np.float32).reshape(-1, 3), q_normal=_arr(q["normal"], np.float32).reshape(-1, 3),
+                 q_min_dist=_arr(q["min_dist"], np.float32), q_max_dist=_arr(q["max_dist"], np.float32), q_desc=_arr(q["desc"], np.uint8).reshape(-1, 32))
+        for k, v in a.items():
+            setattr(p, k, v.ctypes.data)
+        p.nq = m
+        p.rcw = (ctypes.c_float * 9)(*np.asarray(pr["R"], np.float32).reshape(9))
+        p.tcw = (ctypes.c_float * 3)(*np.asarray(pr["t"], np.float32).reshape(3))
+        p.ow = (ctypes.c_float * 3)(*np.asarray(pr["ow"], np.float32).reshape(3))
+        p.fx, p.fy, p.cx, p.cy, p.bf = [float(v) for v in pr["K5"]]
+        p.bounds = (ctypes.c_double * 4)(*[float(v) for v in pr["bounds"]])
+        p.scale_factors = (ctypes.c_float * 8)(*np.asarray(pr["scale_factors"], np.float32))
+        p.inv_level_sigma2 = (ctypes.c_float * 8)(*np.asarray(pr["inv_level_sigma2"], np.float32))
+        p.log_scale_factor = float(pr["log_scale_factor"]); p.n_levels = int(pr["n_levels"]); p.th = float(pr["th"])
+        bi = np.full(max(m, 1), -1, np.int32); bd = np.full(max(m, 1), 256, np.int32)
+        p.best_idx = bi.ctypes.data; p.best_dist = bd.ctypes.data
+        keep.append(a); outs.append((bi, bd, m))
+    check(lib.ps_fuse_search(self._h, arr, n))
+    return [(bi[:m].copy(), bd[:m].copy()) for bi, bd, m in outs]
+
+
+ORBmatcher.FuseSearch = _fuse_search

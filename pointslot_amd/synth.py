@@ -324,3 +324,49 @@ def projection_scene(seed, n=2000, m=1500, w=1241, h=376, object_mode=False, th=
     return {"train": train, "frame_query": frame_q, "points_query": pts_q, "tcw": tcw, "tlw": tlw,
             "K6": (np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), np.float32(KITTI_BF), np.float32(KITTI_BF / fx)),
             "bounds": (0.0, float(w), 0.0, float(h)), "scale_factors": sig, "th": th}
+
+
+def fuse_scene(seed, n=1500, m=800, w=1241, h=376, th=3.0, box=None):
+    """A keyframe with n features and m candidate points for ORBmatcher::Fuse: most candidates re-project onto a feature with a
+    similar descriptor and a consistent depth; the rest exercise every gate (behind the camera, outside the image / box, outside
+    the scale-invariance range, viewing angle above 60 degrees, wrong level, stereo chi-square, far descriptor)."""
+    rng = Rng(seed)
+    fx, fy, cx, cy = KITTI_K
+    sig, inv_sigma2 = _level_sigma()
+    x = rng.uniform(n, 20, w - 20).astype(np.float32); y = rng.uniform(n, 20, h - 20).astype(np.float32)
+    octave = np.searchsorted(np.cumsum(_QUOTAS) / _QUOTAS.sum(), rng.uniform(n)).clip(0, 7).astype(np.int32)
+    z = rng.uniform(n, 4.0, 50.0)
+    ur = np.where(rng.uniform(n) < 0.8, x - KITTI_BF / z, -1.0).astype(np.float32)
+    desc = rng.integers(n * 32, 0, 256).astype(np.uint8).reshape(n, 32)
+    train = {"x": x, "y": y, "octave": octave, "u_right": ur, "desc": desc,
+             "grid": (0.0, 0.0, np.float32(64) / np.float32(w), np.float32(48) / np.float32(h))}
+    R = _so3_exp(np.radians(rng.uniform(3, -4.0, 4.0))).astype(np.float32)
+    t = rng.uniform(3, -1.0, 1.0).astype(np.float32)
+    ow = (-(R.T.astype(np.float64) @ t)).astype(np.float32)
+    src = rng.integers(m, 0, n)
+    jit = rng.normal(2 * m).reshape(m, 2) * 0.7 * sig[octave[src]][:, None]
+    zc = z[src] * np.where(rng.uniform(m) < 0.9, 1.0, rng.uniform(m, 0.6, 1.6))          # some with an inconsistent depth
+    zc = np.where(rng.uniform(m) < 0.03, -zc, zc)                                          # behind the camera
+    u = x[src] + jit[:, 0] + np.where(rng.uniform(m) < 0.04, 3000.0, 0.0)                 # outside the image
+    v = y[src] + jit[:, 1]
+    Pc = np.stack([(u - cx) / fx * zc, (v - cy) / fy * zc, zc], 1)
+    pos = ((Pc - t) @ R).astype(np.float32)
+    PO = pos.astype(np.float64) - ow
+    dist = np.linalg.norm(PO, axis=1)
+    nrm = PO / dist[:, None]
+    tilt = rng.uniform(m) < 0.08
+    nrm[tilt] = np.roll(nrm[tilt], 1, axis=1) * np.array([1.0, -1.0, 1.0])                 # viewing angle far off
+    lvl = np.clip(octave[src] + rng.integers(m, 0, 2) + np.where(rng.uniform(m) < 0.1, 3, 0), 0, 7)
+    max_dist = (dist * sig[lvl] * rng.uniform(m, 0.86, 0.99)).astype(np.float32)          # ceil(log(ratio)/log 1.2) == lvl
+    far = rng.uniform(m) < 0.05
+    max_dist[far] *= np.float32(0.3)                                                      # outside the invariance range
+    min_dist = (max_dist / sig[7]).astype(np.float32)
+    qd = np.stack([_flip(rng, desc[j], 30) for j in src]) if m else np.zeros((0, 32), np.uint8)
+    rand = rng.uniform(m) < 0.1
+    qd[rand] = rng.integers(int(rand.sum()) * 32, 0, 256).astype(np.uint8).reshape(-1, 32)
+    valid = (rng.uniform(m) < 0.93).astype(np.uint8)
+    query = {"valid": valid, "pos": pos, "normal": nrm.astype(np.float32), "min_dist": min_dist, "max_dist": max_dist, "desc": qd}
+    bounds = (0.0, float(w), 0.0, float(h)) if box is None else tuple(float(b) for b in box)
+    return {"train": train, "query": query, "R": R, "t": t, "ow": ow, "K5": (np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), np.float32(KITTI_BF)),
+            "bounds": bounds, "scale_factors": sig, "inv_level_sigma2": inv_sigma2, "log_scale_factor": np.float32(np.log(np.float32(1.2))),
+            "n_levels": 8, "th": th, "src": src}

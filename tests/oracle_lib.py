@@ -321,3 +321,26 @@ def stereo_match_keys(left, right, kps_l, desc_l, kps_r, desc_r, mb, mbf):
     ur = np.full(max(len(kl), 1), -1.0, np.float32); dp = np.full(max(len(kl), 1), -1.0, np.float32)
     kept = f(left.h, right.h, kl.ctypes.data, dl.ctypes.data, len(kl), kr.ctypes.data, dr.ctypes.data, len(kr), mb, mbf, ur.ctypes.data, dp.ctypes.data)
     return kept, ur[:len(kl)], dp[:len(kl)]
+
+
+def fuse_search(pr):
+    keep = []
+    F = dict(pr["train"])
+    nt = len(F["x"])
+    F.setdefault("angle", np.zeros(nt, np.float32)); F.setdefault("occupied", np.zeros(nt, np.uint8))
+    T = _orc_train(F, keep)
+    q = pr["query"]
+    m = len(q["valid"])
+    c = lambda k, dt: np.ascontiguousarray(q[k], dt)
+    valid, pos, nor, mind, maxd, desc = c("valid", np.uint8), c("pos", np.float32), c("normal", np.float32), c("min_dist", np.float32), c("max_dist", np.float32), c("desc", np.uint8)
+    f32 = lambda v: np.ascontiguousarray(v, np.float32)
+    R, t, ow, K5, sf, is2 = f32(pr["R"]), f32(pr["t"]), f32(pr["ow"]), f32(pr["K5"]), f32(pr["scale_factors"]), f32(pr["inv_level_sigma2"])
+    b = np.ascontiguousarray(pr["bounds"], np.float64)
+    bi = np.full(max(m, 1), -1, np.int32); bd = np.full(max(m, 1), 256, np.int32)
+    f = lib().orc_fuse_search
+    f.restype = None
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 13 + [ctypes.c_float, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    f(ctypes.byref(T), m, valid.ctypes.data, pos.ctypes.data, nor.ctypes.data, mind.ctypes.data, maxd.ctypes.data, desc.ctypes.data,
+      R.ctypes.data, t.ctypes.data, ow.ctypes.data, K5.ctypes.data, b.ctypes.data, sf.ctypes.data, is2.ctypes.data,
+      float(np.float32(pr["log_scale_factor"])), int(pr["n_levels"]), float(np.float32(pr["th"])), bi.ctypes.data, bd.ctypes.data)
+    return bi[:m].copy(), bd[:m].copy()

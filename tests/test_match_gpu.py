@@ -126,3 +126,31 @@ def test_distinctive_descriptors(matcher):
     o = oracle_lib.distinctive_descriptors(lists)
     assert np.array_equal(g, o), (g, o)
     assert g[8] == -1 and g[-1] == 0
+
+
+@pytest.mark.parametrize("seed,kw", [(41, {}), (42, {"th": 5.0}), (43, {"box": (300, 600, 100, 300)}), (44, {"n": 3000, "m": 2500}),
+                                     (45, {"m": 1}), (46, {"n": 40, "m": 300})])
+def test_fuse_search_bit_exact(matcher, seed, kw):
+    """ORBmatcher::Fuse search half (KeyFrame and ObjectKeyFrame variants): best feature and distance per candidate."""
+    from pointslot_amd.matcher import build_grid
+    pr = synth.fuse_scene(seed, **kw)
+    T = pr["train"]
+    T["cell_off"], T["cell_idx"] = build_grid(T["x"], T["y"], *T["grid"])
+    (gi, gd), = matcher.FuseSearch([pr])
+    oi, od = oracle_lib.fuse_search(pr)
+    assert np.array_equal(gi, oi), np.nonzero(gi != oi)[0][:10]
+    assert np.array_equal(gd, od)
+
+
+def test_fuse_search_batch(matcher):
+    from pointslot_amd.matcher import build_grid
+    prs = []
+    for s in range(50, 56):
+        pr = synth.fuse_scene(s, n=500 + 100 * (s - 50), m=200 + 50 * (s - 50))
+        T = pr["train"]
+        T["cell_off"], T["cell_idx"] = build_grid(T["x"], T["y"], *T["grid"])
+        prs.append(pr)
+    res = matcher.FuseSearch(prs)
+    for pr, (gi, gd) in zip(prs, res):
+        oi, od = oracle_lib.fuse_search(pr)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)

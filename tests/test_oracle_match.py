@@ -93,3 +93,32 @@ def test_distinctive_descriptor_is_the_medoid_like_choice():
     d = oracle_lib.hamming_matrix(np.array(obs), np.array(obs)).astype(int)
     med = [sorted(r)[int(0.5 * 4)] for r in d]
     assert best == int(np.argmin(med))
+
+
+def _fuse_problem(seed, **kw):
+    from pointslot_amd import synth
+    from pointslot_amd.matcher import build_grid
+    pr = synth.fuse_scene(seed, **kw)
+    T = pr["train"]
+    T["cell_off"], T["cell_idx"] = build_grid(T["x"], T["y"], *T["grid"])
+    return pr
+
+
+def test_fuse_search_gates_and_matches():
+    pr = _fuse_problem(41)
+    bi, bd = oracle_lib.fuse_search(pr)
+    q, src = pr["query"], pr["src"]
+    hit = bi >= 0
+    assert hit.sum() > 0.4 * len(bi)                                  # most consistent candidates find their feature
+    assert np.all(bd[hit] <= 50) and np.all(bi[~q["valid"].astype(bool)] == -1)
+    assert (bi[hit] == src[hit]).mean() > 0.95                         # ... and it is the generating feature
+    # gates: behind the camera / outside the image never match
+    Pc = q["pos"].astype(np.float64) @ pr["R"].T.astype(np.float64) + pr["t"]
+    assert np.all(bi[Pc[:, 2] < 0] == -1)
+    # restricting the bounds to a box (IsInBBox) only removes matches
+    prb = _fuse_problem(41, box=(300, 600, 100, 300))
+    bib, _ = oracle_lib.fuse_search(prb)
+    assert np.all((bib == -1) | (bib == bi)) and (bib >= 0).sum() < hit.sum()
+    fx, fy, cx, cy, _ = [float(k) for k in pr["K5"]]
+    ub = fx * Pc[:, 0] / Pc[:, 2] + cx
+    assert np.all(bib[(ub < 299) | (ub > 601)] == -1)
