@@ -333,6 +333,27 @@ typedef struct ps_ba_problem {
   double* trace;
 } ps_ba_problem;
 int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int nprob);
+/* The reprojection test of Tracking::DynamicStaticDiscrimination (src/Tracking.cc:2099-2181) for a batch of
+ * tracked detections: every object point is moved as if the object were static, Pc = Tcw_cur * Tcw_last^-1 * (Tco_last * Po),
+ * and its chi-square against the current observation is collected per kind (monocular: u_right < 0 / stereo); each list is
+ * sorted, values above 5 x median dropped, the rest averaged in sorted order (FP64, bit-identical to the CPU statement).
+ * The caller keeps the gates around it (depth range, image prior, :2082-2097) and feeds the averages to
+ * DetectionObject::SetDynamicFlag(mono_avg, stereo_avg).  Poses are (tx, ty, tz, qx, qy, qz, qw). */
+typedef struct ps_dyn_problem {
+  int32_t n;                      /* mvpMapObjectPoints[order].size(), <= 2048 */
+  const uint8_t* valid;           /* vMOPs[j] != NULL */
+  const double* po;               /* [n][3] GetInObjFrameEigenPosition() */
+  const float* obs;               /* [n][3] mvObjKeysUn[order][j].pt.x, .pt.y, mvuObjKeysRight[order][j] */
+  const float* inv_sigma2;        /* [n] mvInvLevelSigma2[octave] */
+  double last_tco[7];             /* pMO->GetCFInFrameObjState(mLastFrame.mnId).pose */
+  double last_tcw[7], cur_tcw[7]; /* mLastFrame.mSETcw, mCurrentFrame.mSETcw */
+  double fx, fy, cx, cy;          /* mdCamProjMatrix */
+  float mbf;
+  double mono_avg, stereo_avg;    /* out: monoDynaValAvg, stereoDynaValAvg (0 with fewer than 5 points of the kind) */
+  int32_t mono_n, stereo_n;       /* out: monoPointNum, stereoPointNum after the rejection */
+} ps_dyn_problem;
+int ps_dynamic_discrimination_batch(ps_optimizer* h, ps_dyn_problem* problems, int nproblems);
+
 /* Optimizer::LocalBundleAdjustment(KeyFrame*, pbStopFlag, Map*) (Optimizer.cc:1077-1417) on a collected
  * graph: same edge types and LM schedule with plain VertexSE3Expmap keyframes (pose_flags bit 1 = 0; bit 0 = fixed for
  * mnId == 0 and the fixed cameras) and world-frame map points.  The abort flag of the reference is not modelled. */

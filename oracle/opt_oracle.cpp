@@ -744,4 +744,62 @@ void orc_edge_eval(int type, const double* pose7, const double* X, const double*
 }
 void orc_huber(double e, double delta, double* rho3) { huber(e, delta, rho3); }
 
+
+// The reprojection test of Tracking::DynamicStaticDiscrimination (/root/reference/src/Tracking.cc:2099-2181) for one detection:
+// every object point is moved as if it were static (Pc = Tcw_cur * Tcw_last^-1 * Tco_last * Po), projected, and its chi-square
+// against the current observation collected per kind (monocular / stereo); each list is sorted, values above 5 x median
+// (element int(size / 2 + 0.5)) are dropped and the rest averaged.  Lists with fewer than 5 points keep the average 0.
+// poses: (tx, ty, tz, qx, qy, qz, qw).  out4 = {monoDynaValAvg, stereoDynaValAvg}, outn = {monoPointNum, stereoPointNum}.
+void orc_dynamic_discrimination(int n, const uint8_t* valid, const double* po, const float* obs, const float* inv_sigma2,
+                                const double* last_tco7, const double* last_tcw7, const double* cur_tcw7, double fx, double fy,
+                                double cx, double cy, float mbf, double* out_avg2, int* out_n2) {
+  auto from7 = [](const double* v) { SE3 T; for (int i = 0; i < 3; i++) T.t[i] = v[i]; for (int i = 0; i < 4; i++) T.q[i] = v[3 + i]; return T; };
+  const SE3 Tco = from7(last_tco7), Tl = from7(last_tcw7), Tc = from7(cur_tcw7);
+  // SE3Quat::inverse (se3quat.h:112-117): r = conj, t = r * (t * -1)
+  SE3 Tli;
+  Tli.q[0] = -Tl.q[0]; Tli.q[1] = -Tl.q[1]; Tli.q[2] = -Tl.q[2]; Tli.q[3] = Tl.q[3];
+  const double nt[3] = {Tl.t[0] * -1., Tl.t[1] * -1., Tl.t[2] * -1.};
+  quat_rotate(Tli.q, nt, Tli.t);
+  const SE3 Trel = se3_mul(Tc, Tli);                       // current_pose * last_pose.inverse()
+  std::vector<double> monoDynaVal, stereoDynaVal;
+  int monoPointNum = 0, stereoPointNum = 0;
+  for (int j = 0; j < n; j++) {
+    if (!valid[j]) continue;
+    double Plc[3], Pc[3];
+    se3_map(Tco, po + 3 * j, Plc);
+    se3_map(Trel, Plc, Pc);
+    const double invz = 1.0 / Pc[2];
+    const double s = (double)inv_sigma2[j];
+    const double z0 = cx + Pc[0] * invz * fx, z1 = cy + Pc[1] * invz * fy;
+    const double e0 = (double)obs[3 * j] - z0, e1 = (double)obs[3 * j + 1] - z1;
+    if (obs[3 * j + 2] < 0) {
+      monoDynaVal.push_back(e0 * (s * e0) + e1 * (s * e1));
+      monoPointNum++;
+    } else {
+      const double z2 = z0 - (double)mbf * invz;
+      const double e2 = (double)obs[3 * j + 2] - z2;
+      stereoDynaVal.push_back(e0 * (s * e0) + e1 * (s * e1) + e2 * (s * e2));
+      stereoPointNum++;
+    }
+  }
+  auto reject_and_average = [](std::vector<double>& v, int& num) {
+    double avg = 0;
+    if (num >= 5) {
+      std::sort(v.begin(), v.end());
+      const double median = v[int(v.size() / 2 + 0.5)];
+      for (auto it = v.begin(); it != v.end();) {
+        if ((*it) > 5 * median) { it = v.erase(it); num--; }   // (the reference relies on erase leaving `it` at the next element)
+        else it++;
+      }
+      double sum = 0.0;
+      for (double x : v) sum += x;                              // std::accumulate
+      avg = sum / num;
+    }
+    return avg;
+  };
+  out_avg2[0] = reject_and_average(monoDynaVal, monoPointNum);
+  out_avg2[1] = reject_and_average(stereoDynaVal, stereoPointNum);
+  out_n2[0] = monoPointNum; out_n2[1] = stereoPointNum;
+}
+
 }  // extern "C"

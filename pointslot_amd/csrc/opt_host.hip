@@ -8,6 +8,7 @@
 #include "opt_plan.h"
 #include "ps_common.h"
 #include "se3.h"
+#include "dyn_plan.h"
 
 extern "C" void psk_pose_lm_launch(const PoProb*, int, const PoVertex*, const float*, const float*, const float*,
                                    const uint8_t*, uint8_t*, double*, uint8_t*, double*, int32_t*, double*, hipStream_t);
@@ -266,6 +267,62 @@ int ps_se3_to_mat4f(const double* pose7, float* m16) {
   Se3 T;
   T.t[0] = pose7[0]; T.t[1] = pose7[1]; T.t[2] = pose7[2]; T.q[0] = pose7[3]; T.q[1] = pose7[4]; T.q[2] = pose7[5]; T.q[3] = pose7[6];
   se3_to_mat4f(T, m16);
+  return PS_OK;
+}
+
+
+extern "C" void psk_dyn_launch(const DynProb*, int, const uint8_t*, const double*, const float*, const float*, double*, int32_t*, hipStream_t);
+
+int ps_dynamic_discrimination_batch(ps_optimizer* h, ps_dyn_problem* probs, int nprob) {
+  if (!h || !probs || nprob < 1) return ps_set_error(PS_ERR_INVALID, "ps_dynamic_discrimination_batch: bad argument");
+  size_t N = 0;
+  for (int p = 0; p < nprob; p++) {
+    const ps_dyn_problem& P = probs[p];
+    if (P.n < 0 || P.n > PS_DYN_MAX) return ps_set_error(PS_ERR_CAPACITY, "problem %d: 0..%d object points supported", p, PS_DYN_MAX);
+    if (P.n > 0 && (!P.valid || !P.po || !P.obs || !P.inv_sigma2)) return ps_set_error(PS_ERR_INVALID, "problem %d: null array", p);
+    N += P.n;
+  }
+  PS_HIP(hipSetDevice(h->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += al(bytes + 64); return r; };
+  const size_t o_prob = take(sizeof(DynProb) * nprob), o_valid = take(N), o_po = take(N * 24), o_obs = take(N * 12), o_is2 = take(N * 4);
+  const size_t in_bytes = off;
+  const size_t o_avg = take((size_t)nprob * 16), o_n = take((size_t)nprob * 8);
+  int rc = ensure(h, off);
+  if (rc != PS_OK) return rc;
+  uint8_t* H = h->h_buf;
+  DynProb* hp = (DynProb*)(H + o_prob);
+  size_t n0 = 0;
+  auto from7 = [](const double* v) { Se3 T; for (int i = 0; i < 3; i++) T.t[i] = v[i]; for (int i = 0; i < 4; i++) T.q[i] = v[3 + i]; return T; };
+  for (int p = 0; p < nprob; p++) {
+    const ps_dyn_problem& P = probs[p];
+    DynProb& d = hp[p];
+    d.off = (int32_t)n0; d.n = P.n;
+    d.tco = from7(P.last_tco);
+    const Se3 Tl = from7(P.last_tcw), Tc = from7(P.cur_tcw);
+    Se3 Tli;   // SE3Quat::inverse (se3quat.h:112-117)
+    Tli.q[0] = -Tl.q[0]; Tli.q[1] = -Tl.q[1]; Tli.q[2] = -Tl.q[2]; Tli.q[3] = Tl.q[3];
+    const double nt[3] = {Tl.t[0] * -1., Tl.t[1] * -1., Tl.t[2] * -1.};
+    se3_rotate(Tli.q, nt, Tli.t);
+    d.trel = se3_mul(Tc, Tli);
+    d.fx = P.fx; d.fy = P.fy; d.cx = P.cx; d.cy = P.cy; d.mbf = P.mbf;
+    if (P.n > 0) {
+      memcpy(H + o_valid + n0, P.valid, P.n); memcpy(H + o_po + n0 * 24, P.po, (size_t)P.n * 24);
+      memcpy(H + o_obs + n0 * 12, P.obs, (size_t)P.n * 12); memcpy(H + o_is2 + n0 * 4, P.inv_sigma2, (size_t)P.n * 4);
+    }
+    n0 += P.n;
+  }
+  uint8_t* D = h->d_buf;
+  PS_HIP(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, h->stream));
+  psk_dyn_launch((const DynProb*)(D + o_prob), nprob, D + o_valid, (const double*)(D + o_po), (const float*)(D + o_obs),
+                 (const float*)(D + o_is2), (double*)(D + o_avg), (int32_t*)(D + o_n), h->stream);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipMemcpyAsync(H + o_avg, D + o_avg, off - o_avg, hipMemcpyDeviceToHost, h->stream));
+  PS_HIP(hipStreamSynchronize(h->stream));
+  for (int p = 0; p < nprob; p++) {
+    probs[p].mono_avg = ((const double*)(H + o_avg))[2 * p]; probs[p].stereo_avg = ((const double*)(H + o_avg))[2 * p + 1];
+    probs[p].mono_n = ((const int32_t*)(H + o_n))[2 * p]; probs[p].stereo_n = ((const int32_t*)(H + o_n))[2 * p + 1];
+  }
   return PS_OK;
 }
 

@@ -507,10 +507,6 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   }
   for (int t = lane; t < (SS * (ch + 2) + 3) / 4; t += 64) reinterpret_cast<uint32_t*>(smap)[t] = 0;
   wave_sync();
-#if defined(PS_EXP) && (PS_EXP & 16)
-  if (lane == 0) cellcnt[cell] = tile[7];
-  return;
-#endif
   // ---- B: cheap NECESSARY test on the 8 even ring positions, 4 pixels per lane and step.  Nine contiguous ring
   // pixels always contain four consecutive even positions, so a pixel without 4 consecutive dark (or bright) even
   // positions cannot be a corner at min_th; this rejects most pixels for ~1/3 of the full test's work. ----
@@ -577,9 +573,6 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     nsurv += __popcll(C[0]) + __popcll(C[1]) + __popcll(C[2]) + __popcll(C[3]);
   }
   nsurv = min(nsurv, LCAP);
-#if defined(PS_EXP) && (PS_EXP & 32)
-  nsurv = min(nsurv, 0);
-#endif
   wave_sync();
   // ---- C: exact score of the survivors; s > min_th <=> corner.  The list is compacted in place (a chunk is read
   // before anything is written, and writes never run ahead of the reads). ----
@@ -1124,11 +1117,7 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
     const uint8_t* prow = base + L.blur_off + (size_t)(ky - 19 + pr) * L.bstride + (kx - 19 - pshift) + 4 * pd;
     uint32_t tmp[10];
 #pragma unroll
-#if defined(PS_EXP) && (PS_EXP & 2)
-    for (int i = 0; i < 10; i++) tmp[i] = i * lane;
-#else
     for (int i = 0; i < 10; i++) tmp[i] = *reinterpret_cast<const uint32_t*>(prow + (size_t)min(4 * i, 38 - pr) * L.bstride);
-#endif
 #pragma unroll
     for (int i = 0; i < 10; i++) patch[(4 * i + pr) * 12 + pd] = tmp[i];   // rows 39 (i = 9, pr = 3) is a duplicate of row 38 and never read
   }
@@ -1143,11 +1132,7 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int t = min(lane + 64 * i, 247);
-#if defined(PS_EXP) && (PS_EXP & 4)
-      pix[i] = t * kx;
-#else
       pix[i] = *reinterpret_cast<const uint32_t*>(center + (ptrdiff_t)((t >> 3) - 15) * L.stride + (4 * (t & 7) - 15));
-#endif
     }
     int s0 = 0;
     uint32_t acc = 0;
@@ -1169,11 +1154,7 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
   // ---- steered BRIEF on the blurred level: lane handles tests 4*lane .. 4*lane+3 ----
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float arad = __fmul_rn(angle, factorPI);
-#if defined(PS_EXP) && (PS_EXP & 1)
-  const float a = __cosf(arad), b = __sinf(arad);
-#else
   const float a = (float)cos((double)arad), b = (float)sin((double)arad);
-#endif
   wave_sync();
   const uint8_t* bc = reinterpret_cast<const uint8_t*>(patch) + 19 * 48 + 19 + pshift;
   uint32_t nib = 0;

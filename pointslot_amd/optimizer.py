@@ -45,6 +45,17 @@ lib.ps_se3_from_mat4f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.ps_se3_to_mat4f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 
 
+class _DynProblem(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("valid", ctypes.c_void_p), ("po", ctypes.c_void_p), ("obs", ctypes.c_void_p),
+                ("inv_sigma2", ctypes.c_void_p), ("last_tco", ctypes.c_double * 7), ("last_tcw", ctypes.c_double * 7),
+                ("cur_tcw", ctypes.c_double * 7), ("fx", ctypes.c_double), ("fy", ctypes.c_double), ("cx", ctypes.c_double),
+                ("cy", ctypes.c_double), ("mbf", ctypes.c_float), ("mono_avg", ctypes.c_double), ("stereo_avg", ctypes.c_double),
+                ("mono_n", ctypes.c_int32), ("stereo_n", ctypes.c_int32)]
+
+
+lib.ps_dynamic_discrimination_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_DynProblem), ctypes.c_int]
+
+
 def se3_from_mat4f(m):
     m = np.ascontiguousarray(m, np.float32); out = np.zeros(7)
     check(lib.ps_se3_from_mat4f(m.ctypes.data, out.ctypes.data))
@@ -167,3 +178,27 @@ class Optimizer:
             out.append({"poses": poses, "points": pts, "erase": erase[:len(ep)].copy(), "n_erased": arr[i].n_erased,
                         "iterations": arr[i].iterations, "trials": arr[i].trials, "trace": trace[:arr[i].n_trace].copy()})
         return out
+
+
+def _dynamic_static_discrimination(self, objects):
+    """Reprojection test of Tracking::DynamicStaticDiscrimination.  objects: list of dicts {valid [n] u8, po [n,3] f64, obs [n,3] f32
+    (x, y, uR), inv_sigma2 [n] f32, last_tco, last_tcw, cur_tcw (7 doubles each), K (fx, fy, cx, cy), mbf}.
+    Returns a list of (mono_avg, stereo_avg, mono_n, stereo_n)."""
+    n = len(objects)
+    arr = (_DynProblem * n)()
+    keep = []
+    for i, o in enumerate(objects):
+        a = (np.ascontiguousarray(o["valid"], np.uint8), np.ascontiguousarray(o["po"], np.float64).reshape(-1, 3),
+             np.ascontiguousarray(o["obs"], np.float32).reshape(-1, 3), np.ascontiguousarray(o["inv_sigma2"], np.float32))
+        keep.append(a)
+        p = arr[i]
+        p.n = len(a[0]); p.valid, p.po, p.obs, p.inv_sigma2 = [x.ctypes.data for x in a]
+        p.last_tco = (ctypes.c_double * 7)(*np.asarray(o["last_tco"], np.float64)); p.last_tcw = (ctypes.c_double * 7)(*np.asarray(o["last_tcw"], np.float64))
+        p.cur_tcw = (ctypes.c_double * 7)(*np.asarray(o["cur_tcw"], np.float64))
+        p.fx, p.fy, p.cx, p.cy = [float(v) for v in o["K"]]
+        p.mbf = float(o["mbf"])
+    check(lib.ps_dynamic_discrimination_batch(self._h, arr, n))
+    return [(arr[i].mono_avg, arr[i].stereo_avg, arr[i].mono_n, arr[i].stereo_n) for i in range(n)]
+
+
+Optimizer.DynamicStaticDiscrimination = _dynamic_static_discrimination

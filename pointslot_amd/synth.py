@@ -370,3 +370,34 @@ def fuse_scene(seed, n=1500, m=800, w=1241, h=376, th=3.0, box=None):
     return {"train": train, "query": query, "R": R, "t": t, "ow": ow, "K5": (np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), np.float32(KITTI_BF)),
             "bounds": bounds, "scale_factors": sig, "inv_level_sigma2": inv_sigma2, "log_scale_factor": np.float32(np.log(np.float32(1.2))),
             "n_levels": 8, "th": th, "src": src}
+
+
+def dynamic_object(seed, n=300, moving=0.0, mono_frac=0.3, outlier_frac=0.05, noise=1.0, valid_frac=0.9):
+    """One tracked detection for the reprojection test of Tracking::DynamicStaticDiscrimination: n object points in a car-sized
+    cuboid, the object pose in the last frame, the camera poses of both frames and the current observations.  `moving` metres of
+    object motion between the frames (0: static object, the chi-squares stay near their noise floor)."""
+    rng = Rng(seed)
+    fx, fy, cx, cy = KITTI_K
+    sig, inv_sigma2 = _level_sigma()
+    po = np.stack([rng.uniform(n, -2.0, 2.0), rng.uniform(n, -0.8, 0.8), rng.uniform(n, -0.75, 0.75)], 1)
+
+    def pose7(R, t):
+        return np.concatenate([t, _quat_from_R(R)])
+    Rco = _Ry(float(rng.uniform(1, -0.6, 0.6)[0])); tco = np.array([float(rng.uniform(1, -4, 4)[0]), 1.0, float(rng.uniform(1, 9, 25)[0])])
+    Rl = _so3_exp(np.radians(rng.uniform(3, -2, 2))); tl = rng.uniform(3, -1, 1)
+    Rc = _so3_exp(np.radians(rng.uniform(3, -2, 2))) @ Rl; tc = tl + np.array([0.05, 0.0, -0.9]) + rng.uniform(3, -0.05, 0.05)
+    # truth: the object moved by `moving` along its own x axis between the frames
+    Plc = po @ Rco.T + tco
+    Pw = (Plc - tl) @ Rl                                  # world points at the last frame
+    Pw_now = Pw + moving * (Rl.T @ Rco)[:, 0]
+    Pc = Pw_now @ Rc.T + tc
+    octave = np.searchsorted(np.cumsum(_QUOTAS) / _QUOTAS.sum(), rng.uniform(n)).clip(0, 7)
+    sd = noise * sig[octave].astype(np.float64)
+    u = fx * Pc[:, 0] / Pc[:, 2] + cx + sd * rng.normal(n); v = fy * Pc[:, 1] / Pc[:, 2] + cy + sd * rng.normal(n)
+    ur = fx * Pc[:, 0] / Pc[:, 2] + cx - KITTI_BF / Pc[:, 2] + sd * rng.normal(n)
+    out = rng.uniform(n) < outlier_frac
+    u[out] += rng.uniform(int(out.sum()), 30, 90)
+    ur = np.where(rng.uniform(n) < mono_frac, -1.0, np.maximum(ur, 0.0))
+    return {"valid": (rng.uniform(n) < valid_frac).astype(np.uint8), "po": po, "obs": np.stack([u, v, ur], 1).astype(np.float32),
+            "inv_sigma2": inv_sigma2[octave], "last_tco": pose7(Rco, tco), "last_tcw": pose7(Rl, tl), "cur_tcw": pose7(Rc, tc),
+            "K": (fx, fy, cx, cy), "mbf": np.float32(KITTI_BF)}

@@ -344,3 +344,16 @@ def fuse_search(pr):
       R.ctypes.data, t.ctypes.data, ow.ctypes.data, K5.ctypes.data, b.ctypes.data, sf.ctypes.data, is2.ctypes.data,
       float(np.float32(pr["log_scale_factor"])), int(pr["n_levels"]), float(np.float32(pr["th"])), bi.ctypes.data, bd.ctypes.data)
     return bi[:m].copy(), bd[:m].copy()
+
+
+def dynamic_discrimination(o):
+    valid = np.ascontiguousarray(o["valid"], np.uint8); po = np.ascontiguousarray(o["po"], np.float64)
+    obs = np.ascontiguousarray(o["obs"], np.float32); is2 = np.ascontiguousarray(o["inv_sigma2"], np.float32)
+    p7 = [np.ascontiguousarray(o[k], np.float64) for k in ("last_tco", "last_tcw", "cur_tcw")]
+    avg = np.zeros(2); cnt = np.zeros(2, np.int32)
+    f = lib().orc_dynamic_discrimination
+    f.restype = None
+    f.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_double] * 4 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    f(len(valid), valid.ctypes.data, po.ctypes.data, obs.ctypes.data, is2.ctypes.data, p7[0].ctypes.data, p7[1].ctypes.data, p7[2].ctypes.data,
+      *[float(k) for k in o["K"]], float(np.float32(o["mbf"])), avg.ctypes.data, cnt.ctypes.data)
+    return avg[0], avg[1], int(cnt[0]), int(cnt[1])

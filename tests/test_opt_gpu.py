@@ -141,3 +141,19 @@ def test_local_ba_shape(opt):
     r, = opt.ObjectLocalBundleAdjustment([g])
     _ba_check(g, r, "local BA")
     assert r["n_erased"] < 0.2 * len(g["e_pose"])
+
+
+def test_dynamic_static_discrimination_bit_exact():
+    """Tracking::DynamicStaticDiscrimination's reprojection test (SURVEY 8f-4): per-kind averages after the 5 x median rejection
+    are bit-identical to the CPU statement (sorted, sequential FP64 sum, no FMA contraction in this kernel)."""
+    from pointslot_amd.optimizer import Optimizer
+    objs = [synth.dynamic_object(100 + k, n=[300, 40, 6, 1200, 2048, 5, 0, 77][k], moving=[0, 0.5, 0, 0.2, 0, 1.0, 0, 0.05][k],
+                                 mono_frac=[0.3, 0.0, 0.5, 0.3, 0.5, 1.0, 0.3, 0.9][k]) for k in range(8)]
+    opt = Optimizer()
+    res = opt.DynamicStaticDiscrimination(objs)
+    for o, r in zip(objs, res):
+        e = oracle_lib.dynamic_discrimination(o)
+        assert r[2] == e[2] and r[3] == e[3], (r, e)
+        assert np.float64(r[0]).tobytes() == np.float64(e[0]).tobytes() and np.float64(r[1]).tobytes() == np.float64(e[1]).tobytes(), (r, e)
+    assert res[1][1] > 10 * res[0][1]                       # the moving object stands out
+    opt.close()

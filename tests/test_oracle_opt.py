@@ -243,3 +243,33 @@ def test_object_ba_erase_list_flags_outliers():
     assert erase[b["e_is_outlier"]].mean() >= 0.85
     assert erase[~b["e_is_outlier"]].mean() < 0.15
     assert len(tr) <= 15 and np.all(np.diff(tr[:5, 0]) <= 1e-9) and np.all(np.diff(tr[5:, 0]) <= 1e-9)
+
+
+def test_dynamic_discrimination_separates_static_from_moving():
+    from pointslot_amd import synth
+    st = oracle_lib.dynamic_discrimination(synth.dynamic_object(7, moving=0.0))
+    mv = oracle_lib.dynamic_discrimination(synth.dynamic_object(7, moving=0.6))
+    assert st[2] >= 5 and st[3] >= 5
+    assert st[0] < 4.0 and st[1] < 6.0                      # noise floor: E[chi2] = 2 (mono), 3 (stereo)
+    assert mv[0] > 10 * st[0] and mv[1] > 10 * st[1]
+    few = synth.dynamic_object(8, n=6, valid_frac=0.5)
+    r = oracle_lib.dynamic_discrimination(few)
+    assert (r[2] < 5 and r[0] == 0.0) or r[2] >= 5            # fewer than 5 points of a kind: average stays 0
+    # independent numpy statement of the same test
+    o = synth.dynamic_object(9, n=200)
+    def T(p7):
+        x, y, z, w = p7[3:]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        M = np.eye(4); M[:3, :3] = R; M[:3, 3] = p7[:3]
+        return M
+    Trel = T(o["cur_tcw"]) @ np.linalg.inv(T(o["last_tcw"])) @ T(o["last_tco"])
+    Pc = o["po"] @ Trel[:3, :3].T + Trel[:3, 3]
+    fx, fy, cx, cy = o["K"]
+    z0 = cx + fx * Pc[:, 0] / Pc[:, 2]; z1 = cy + fy * Pc[:, 1] / Pc[:, 2]; z2 = z0 - float(o["mbf"]) / Pc[:, 2]
+    ob = o["obs"].astype(np.float64); s = o["inv_sigma2"].astype(np.float64); ok = o["valid"].astype(bool)
+    mono = ok & (o["obs"][:, 2] < 0); ster = ok & ~(o["obs"][:, 2] < 0)
+    cm = np.sort((s * ((ob[:, 0] - z0) ** 2 + (ob[:, 1] - z1) ** 2))[mono]); cs = np.sort((s * ((ob[:, 0] - z0) ** 2 + (ob[:, 1] - z1) ** 2 + (ob[:, 2] - z2) ** 2))[ster])
+    exp = [c[c <= 5 * c[len(c) // 2]].mean() for c in (cm, cs)]
+    got = oracle_lib.dynamic_discrimination(o)
+    assert abs(got[0] - exp[0]) < 1e-9 * exp[0] and abs(got[1] - exp[1]) < 1e-9 * exp[1]
