@@ -414,25 +414,32 @@ __global__ __launch_bounds__(256) void orb_border(OrbPlan plan, uint8_t* arena) 
 // ------------------------------------------------------------------------------------------------
 // Exact score of a pixel that is known to be a corner at min_th: s = max over the 16 nine-pixel arcs of
 // min |signed diff| (see above).  c points at the pixel inside the LDS tile.
+typedef unsigned short fsc_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int fast_score_exact(const uint8_t* c, int ts) {
+  // With r_k the ring values:  dark  = v - min over the 16 arcs of (max of the arc's 9 values),
+  //                            bright = max over arcs of (min of 9) - v,   s = max(dark, bright).
+  // Both trees run at once on packed u16: low half r_k, high half 255 - r_k (min r = 255 - max (255 - r)).
   const int v = c[0];
-  int d[16];
-  d[0] = v - c[3 * ts];      d[1] = v - c[3 * ts + 1];  d[2] = v - c[2 * ts + 2];  d[3] = v - c[ts + 3];
-  d[4] = v - c[3];           d[5] = v - c[-ts + 3];     d[6] = v - c[-2 * ts + 2]; d[7] = v - c[-3 * ts + 1];
-  d[8] = v - c[-3 * ts];     d[9] = v - c[-3 * ts - 1]; d[10] = v - c[-2 * ts - 2]; d[11] = v - c[-ts - 3];
-  d[12] = v - c[-3];         d[13] = v - c[ts - 3];     d[14] = v - c[2 * ts - 2]; d[15] = v - c[3 * ts - 1];
-  int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
-#pragma unroll
-  for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
-  int A = -256, Bn = 256;
+  const int off[16] = {3 * ts, 3 * ts + 1, 2 * ts + 2, ts + 3, 3, -ts + 3, -2 * ts + 2, -3 * ts + 1,
+                       -3 * ts, -3 * ts - 1, -2 * ts - 2, -ts - 3, -3, ts - 3, 2 * ts - 2, 3 * ts - 1};
+  fsc_us2 x[16], m2[16], m4[16], m8[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    A = max(A, min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]));
-    Bn = min(Bn, max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]));
+    const uint32_t r = c[off[i]];
+    x[i] = __builtin_bit_cast(fsc_us2, (r | (r << 16)) ^ 0x00FF0000u);
   }
-  return max(A, -Bn);
+#pragma unroll
+  for (int i = 0; i < 16; i++) m2[i] = __builtin_elementwise_max(x[i], x[(i + 1) & 15]);
+#pragma unroll
+  for (int i = 0; i < 16; i++) m4[i] = __builtin_elementwise_max(m2[i], m2[(i + 2) & 15]);
+#pragma unroll
+  for (int i = 0; i < 16; i++) m8[i] = __builtin_elementwise_max(m4[i], m4[(i + 4) & 15]);
+  fsc_us2 best = __builtin_elementwise_max(m8[0], x[8]);
+#pragma unroll
+  for (int i = 1; i < 16; i++) best = __builtin_elementwise_min(best, __builtin_elementwise_max(m8[i], x[(i + 8) & 15]));
+  const uint32_t bb = __builtin_bit_cast(uint32_t, best);
+  const int minmax9 = (int)(bb & 0xFFFFu), maxmin9 = 255 - (int)(bb >> 16);
+  return max(v - minmax9, maxmin9 - v);
 }
 
 // wave-level phase separator: LDS traffic of one wave is processed in order, the fence only keeps the
@@ -451,6 +458,8 @@ __device__ __forceinline__ void wave_sync() {
 //   C  survivors are scored exactly (s > min_th <=> corner) and compacted again
 //   D  strict 3x3 NMS on the LDS score map, threshold fallback, raster-ordered emission into the cell's slots
 #define FAST_T 256
+typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
+typedef short fs_s2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int nimg, int bpi) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform geometry stays on the scalar unit
@@ -534,30 +543,34 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
       w[r][1] = __builtin_amdgcn_alignbyte(a2, a1, shift);
       w[r][2] = __builtin_amdgcn_alignbyte(a3, a2, shift);
     }
+    // Two pixels per operation on packed u16.  "4 consecutive even positions all darker than v - th" is
+    //   min over the 8 windows of (max of the window) < v - th,  and for brighter  max over windows of (min) > v + th,
+    // so the ring values go through pk_max / pk_min trees untouched and the threshold enters in one packed subtraction.
     unsigned long long C[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const bool valid = tv && (4 * g + i) < cw;
-#define PXB(r, b) ((int)((w[r][(b) >> 2] >> (((b) & 3) * 8)) & 0xFFu))
-      const int v = PXB(3, 3 + i);
-      const int vlo = v - th, vhi = v + th;
+    for (int pq = 0; pq < 2; pq++) {
+      const int i = 2 * pq;
+#define PAIR(r, b) __builtin_bit_cast(fs_us2, (b) <= 6 ? __builtin_amdgcn_perm(w[r][1], w[r][0], (uint32_t)(b) | 0x0c000c00u | ((uint32_t)((b) + 1) << 16)) \
+                                                        : __builtin_amdgcn_perm(w[r][2], w[r][1], (uint32_t)((b) - 4) | 0x0c000c00u | ((uint32_t)((b) - 3) << 16)))
       // even ring positions in OpenCV's order: (0,3) (2,2) (3,0) (2,-2) (0,-3) (-2,-2) (-3,0) (-2,2)
-      const int pr[8] = {PXB(6, 3 + i), PXB(5, 5 + i), PXB(3, 6 + i), PXB(1, 5 + i),
-                         PXB(0, 3 + i), PXB(1, 1 + i), PXB(3, 0 + i), PXB(5, 1 + i)};
-#undef PXB
-      uint32_t md = 0, mb = 0;
+      const fs_us2 P[8] = {PAIR(6, 3 + i), PAIR(5, 5 + i), PAIR(3, 6 + i), PAIR(1, 5 + i), PAIR(0, 3 + i), PAIR(1, 1 + i), PAIR(3, 0 + i), PAIR(5, 1 + i)};
+      const fs_s2 cv = __builtin_bit_cast(fs_s2, PAIR(3, 3 + i));
+#undef PAIR
+      fs_us2 x2[8], n2[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        md = __builtin_amdgcn_alignbit(md, (uint32_t)(pr[k] - vlo), 31);
-        mb = __builtin_amdgcn_alignbit(mb, (uint32_t)(vhi - pr[k]), 31);
+      for (int k = 0; k < 8; k++) { x2[k] = __builtin_elementwise_max(P[k], P[(k + 1) & 7]); n2[k] = __builtin_elementwise_min(P[k], P[(k + 1) & 7]); }
+      fs_us2 M = __builtin_elementwise_max(x2[0], x2[2]), m = __builtin_elementwise_min(n2[0], n2[2]);
+#pragma unroll
+      for (int k = 1; k < 8; k++) {
+        M = __builtin_elementwise_min(M, __builtin_elementwise_max(x2[k], x2[(k + 2) & 7]));
+        m = __builtin_elementwise_max(m, __builtin_elementwise_min(n2[k], n2[(k + 2) & 7]));
       }
-      auto run4 = [](uint32_t m8) {   // 4 consecutive set bits in a circular 8-bit mask
-        const uint32_t m = (m8 & 0xFFu) | (m8 << 8);
-        uint32_t r = m & (m >> 1);
-        r &= r >> 2;
-        return r & 0xFFu;
-      };
-      C[i] = __builtin_amdgcn_ballot_w64(valid && ((run4(md) | run4(mb)) != 0));
+      const fs_s2 thv = {(short)th, (short)th};
+      const fs_s2 t1 = __builtin_bit_cast(fs_s2, M) - (cv - thv);     // < 0: four consecutive darker
+      const fs_s2 t2 = (cv + thv) - __builtin_bit_cast(fs_s2, m);     // < 0: four consecutive brighter
+      const uint32_t rr = __builtin_bit_cast(uint32_t, t1 | t2);
+      C[i] = __builtin_amdgcn_ballot_w64(tv && (4 * g + i) < cw && (rr & 0x8000u) != 0);
+      C[i + 1] = __builtin_amdgcn_ballot_w64(tv && (4 * g + i + 1) < cw && (rr & 0x80000000u) != 0);
     }
     // raster-ordered compaction: order (lane, slot)
     const int lower = __popcll(C[0] & ltmask) + __popcll(C[1] & ltmask) + __popcll(C[2] & ltmask) + __popcll(C[3] & ltmask);
