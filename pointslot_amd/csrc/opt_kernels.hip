@@ -25,7 +25,9 @@
 
 namespace {
 
+#ifndef PO_T
 #define PO_T 256
+#endif
 
 struct PoShared {
   double red[PO_T / 64][28];

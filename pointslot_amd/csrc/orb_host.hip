@@ -33,6 +33,9 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum { ST_PYRAMID = 0, ST_FAST, ST_QUADTREE, ST_BLUR, ST_DESCRIBE, ST_COUNT };
 const char* kStageNames[ST_COUNT] = {"orb_pyramid_level", "orb_fast_cells", "orb_quadtree", "orb_blur",
                                      "orb_describe"};
+// with the fused level kernel the first stage is pyramid + border + blur (8 launches of orb_level_fused) and the fourth is empty
+const char* kStageNamesFused[ST_COUNT] = {"orb_level_fused", "orb_fast_cells", "orb_quadtree", "orb_blur",
+                                          "orb_describe"};
 
 }  // namespace
 
@@ -517,7 +520,7 @@ int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n
   const int nb = h->timed_batches < ps_orb::RING ? h->timed_batches : ps_orb::RING;
   *n = ST_COUNT;
   for (int i = 0; i < ST_COUNT && i < cap; i++) {
-    if (names) names[i] = kStageNames[i];
+    if (names) names[i] = h->fused ? kStageNamesFused[i] : kStageNames[i];
     if (ms) {
       double acc = 0;   // per batch: sum over its chunks; then the mean over the recorded batches
       for (int r = 0; r < nb; r++)
