@@ -17,10 +17,16 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
          __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
+// wave-wide unsigned minimum on DPP lanes (xor-1, xor-2, half-row mirror, row mirror) + four readlanes: no LDS round trips.
+// All 64 lanes must be active.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
-  return v;
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, d));
 }
 
 #define TOPK_T 256
@@ -321,46 +327,76 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   __syncthreads();
   const float factor = 30 / 360.0f;
   int nm = 0;
-  for (int qi = 0; qi < P.nq; qi++) {
-    const int q = P.q_off + qi;
-    const int nc = A.ncand[q];
-    if (lane == 0) A.qbest[q] = -1;
-    if (nc == 0) continue;
-    uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
-    for (int c = lane; c < nc; c += 64) {
-      const uint32_t k = A.cand[(size_t)q * PS_PJ_CAP + c];
-      const uint32_t j = k & 0x7FFF;
-      if ((blocked[j >> 5] >> (j & 31)) & 1u) continue;
-      if (k < m1) { m2 = m1; m1 = k; } else if (k < m2) m2 = k;
+  // Queries are taken in order (the assignment is order dependent), 64 at a time: the lane-resident candidate counts give
+  // the non-empty queries of the block as a bit mask, and the first 64 candidate keys of the NEXT non-empty query are
+  // requested before the current one is reduced, so the global-memory latency is paid once per block, not once per query.
+  for (int q0 = 0; q0 < P.nq; q0 += 64) {
+    const int ncv = (q0 + lane < P.nq) ? A.ncand[P.q_off + q0 + lane] : 0;
+    if (q0 + lane < P.nq) A.qbest[P.q_off + q0 + lane] = -1;
+    unsigned long long pend = __builtin_amdgcn_ballot_w64(ncv > 0);
+    uint32_t knext = 0xFFFFFFFFu;
+    if (pend) {
+      const int i0 = __ffsll((long long)pend) - 1;
+      const int n0 = __builtin_amdgcn_readlane(ncv, i0);
+      if (lane < n0) knext = A.cand[(size_t)(P.q_off + q0 + i0) * PS_PJ_CAP + lane];
     }
-    const uint32_t best = wave_min_u32(m1);
-    if (best == 0xFFFFFFFFu) continue;
-    const int bestDist = (int)(best >> 23), bestIdx = (int)(best & 0x7FFF);
-    if (bestDist > P.th_dist) continue;
-    if (P.ratio_test) {
-      const uint32_t second = wave_min_u32(m1 == best ? m2 : m1);
-      if (second != 0xFFFFFFFFu) {
-        const int d2 = (int)(second >> 23);
-        const int l1 = A.toct[P.t_off + bestIdx], l2 = A.toct[P.t_off + (int)(second & 0x7FFF)];
-        if (l1 == l2 && (float)bestDist > __fmul_rn(P.nn_ratio, (float)d2)) continue;
+    while (pend) {
+      const int i = __ffsll((long long)pend) - 1;
+      pend &= pend - 1;
+      const int qi = q0 + i, q = P.q_off + qi;
+      const int nc = __builtin_amdgcn_readlane(ncv, i);
+      const uint32_t kcur = knext;
+      knext = 0xFFFFFFFFu;
+      if (pend) {
+        const int in = __ffsll((long long)pend) - 1;
+        const int nn = __builtin_amdgcn_readlane(ncv, in);
+        if (lane < nn) knext = A.cand[(size_t)(P.q_off + q0 + in) * PS_PJ_CAP + lane];
       }
-      // no second candidate: bestLevel2 = -1 never equals an octave -> accepted
-    }
-    if (lane == 0) {
-      match[bestIdx] = qi;
-      A.qbest[q] = bestIdx;
-      if (A.qobs[q]) blocked[bestIdx >> 5] |= 1u << (bestIdx & 31);
-      if (P.check_ori) {
-        float rot = __fsub_rn(A.qang[q], A.tang[P.t_off + bestIdx]);
-        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-        int bin = (int)roundf(__fmul_rn(rot, factor));
-        if (bin == 30) bin = 0;
-        hist[bin]++;
-        A.qbin[q] = (uint8_t)bin;
+      uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+      {
+        const uint32_t k = kcur;
+        if (lane < nc) {
+          const uint32_t j = k & 0x7FFF;
+          if (!((blocked[j >> 5] >> (j & 31)) & 1u)) m1 = k;
+        }
       }
+      for (int c = 64 + lane; c < nc; c += 64) {
+        const uint32_t k = A.cand[(size_t)q * PS_PJ_CAP + c];
+        const uint32_t j = k & 0x7FFF;
+        if ((blocked[j >> 5] >> (j & 31)) & 1u) continue;
+        if (k < m1) { m2 = m1; m1 = k; } else if (k < m2) m2 = k;
+      }
+      const uint32_t best = wave_min_u32(m1);
+      if (best == 0xFFFFFFFFu) continue;
+      const int bestDist = (int)(best >> 23), bestIdx = (int)(best & 0x7FFF);
+      if (bestDist > P.th_dist) continue;
+      if (P.ratio_test) {
+        const uint32_t second = wave_min_u32(m1 == best ? m2 : m1);
+        if (second != 0xFFFFFFFFu) {
+          const int d2 = (int)(second >> 23);
+          const int l1 = A.toct[P.t_off + bestIdx], l2 = A.toct[P.t_off + (int)(second & 0x7FFF)];
+          if (l1 == l2 && (float)bestDist > __fmul_rn(P.nn_ratio, (float)d2)) continue;
+        }
+        // no second candidate: bestLevel2 = -1 never equals an octave -> accepted
+      }
+      if (lane == 0) {
+        match[bestIdx] = qi;
+        A.qbest[q] = bestIdx;
+        if (A.qobs[q]) blocked[bestIdx >> 5] |= 1u << (bestIdx & 31);
+        if (P.check_ori) {
+          float rot = __fsub_rn(A.qang[q], A.tang[P.t_off + bestIdx]);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, factor));
+          if (bin == 30) bin = 0;
+          hist[bin]++;
+          A.qbin[q] = (uint8_t)bin;
+        }
+      }
+      nm++;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    nm++;
-    __syncthreads();
   }
   __syncthreads();
   if (P.check_ori) {
