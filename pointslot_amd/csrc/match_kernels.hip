@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
 __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   __shared__ uint32_t blocked[1024];   // up to 32768 train features
   __shared__ int hist[32];
+  __shared__ uint8_t loct[32768];      // train octaves (ratio test), staged once: no global load inside the serial loop
   const PjProb P = A.prob[blockIdx.x];
   const int lane = threadIdx.x;
   int32_t* match = A.match + P.t_off;
@@ -324,6 +325,8 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   }
   if (lane < 32) hist[lane] = 0;
   for (int j = lane; j < P.nt; j += 64) match[j] = -1;
+  if (P.ratio_test)
+    for (int j = lane; j < P.nt; j += 64) loct[j] = (uint8_t)A.toct[P.t_off + j];
   __syncthreads();
   const float factor = 30 / 360.0f;
   int nm = 0;
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   // requested before the current one is reduced, so the global-memory latency is paid once per block, not once per query.
   for (int q0 = 0; q0 < P.nq; q0 += 64) {
     const int ncv = (q0 + lane < P.nq) ? A.ncand[P.q_off + q0 + lane] : 0;
+    const int obsv = (q0 + lane < P.nq) ? (int)A.qobs[P.q_off + q0 + lane] : 0;
     if (q0 + lane < P.nq) A.qbest[P.q_off + q0 + lane] = -1;
     unsigned long long pend = __builtin_amdgcn_ballot_w64(ncv > 0);
     uint32_t knext = 0xFFFFFFFFu;
@@ -374,23 +378,16 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
         const uint32_t second = wave_min_u32(m1 == best ? m2 : m1);
         if (second != 0xFFFFFFFFu) {
           const int d2 = (int)(second >> 23);
-          const int l1 = A.toct[P.t_off + bestIdx], l2 = A.toct[P.t_off + (int)(second & 0x7FFF)];
+          const int l1 = loct[bestIdx], l2 = loct[second & 0x7FFF];
           if (l1 == l2 && (float)bestDist > __fmul_rn(P.nn_ratio, (float)d2)) continue;
         }
         // no second candidate: bestLevel2 = -1 never equals an octave -> accepted
       }
+      const int observed = __builtin_amdgcn_readlane(obsv, i);
       if (lane == 0) {
         match[bestIdx] = qi;
         A.qbest[q] = bestIdx;
-        if (A.qobs[q]) blocked[bestIdx >> 5] |= 1u << (bestIdx & 31);
-        if (P.check_ori) {
-          float rot = __fsub_rn(A.qang[q], A.tang[P.t_off + bestIdx]);
-          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-          int bin = (int)roundf(__fmul_rn(rot, factor));
-          if (bin == 30) bin = 0;
-          hist[bin]++;
-          A.qbin[q] = (uint8_t)bin;
-        }
+        if (observed) blocked[bestIdx >> 5] |= 1u << (bestIdx & 31);
       }
       nm++;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -400,6 +397,20 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   }
   __syncthreads();
   if (P.check_ori) {
+    // rotHist[bin].push_back(...) of every assignment (ORBmatcher.cc:1716-1726); order inside a bin is irrelevant
+    for (int qi = lane; qi < P.nq; qi += 64) {
+      const int q = P.q_off + qi;
+      const int bi = A.qbest[q];
+      if (bi >= 0) {
+        float rot = __fsub_rn(A.qang[q], A.tang[P.t_off + bi]);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int bin = (int)roundf(__fmul_rn(rot, factor));
+        if (bin == 30) bin = 0;
+        atomicAdd(&hist[bin], 1);
+        A.qbin[q] = (uint8_t)bin;
+      }
+    }
+    __syncthreads();
     int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
     for (int i = 0; i < 30; i++) {
       const int s = hist[i];
