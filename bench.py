@@ -35,6 +35,7 @@ ALGO_BYTES_PER_IMAGE = {
     "orb_blur": PADDED_PX + LEVEL_PX,                 # blur read + blur write
     "orb_describe": LEVEL_PX + NFEAT * (32 + 28),     # gather (upper bound) + outputs
 }
+RED_DEV = "cuda"            # device of the tensors used for cross-rank reductions
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -95,8 +96,8 @@ def secondary_metrics(rank, world, local_rank, dist, with_cpu):
     res = opt.PoseOptimization(frames)
     wall = time.perf_counter() - t0
     kern_ms = opt.last_kernel_ms()
-    wall = parallel.max_over_ranks(dist, wall, "cuda")
-    kern_ms = parallel.max_over_ranks(dist, kern_ms, "cuda")
+    wall = parallel.max_over_ranks(dist, wall, RED_DEV)
+    kern_ms = parallel.max_over_ranks(dist, kern_ms, RED_DEV)
     out["pose_optimization"] = {"workload": "BASELINE configs[2]: 64 frames x (1 SE3 x 2000 stereo edges), 4 x 10 LM schedule",
                                 "frames": 64, "kernel_ms_per_batch": kern_ms, "wall_ms_per_batch_incl_pcie": wall * 1e3,
                                 "frames_per_s_kernel": 64 / (kern_ms * 1e-3), "inliers_frame0": int(res[0][0]) if res else None}
@@ -111,11 +112,11 @@ def secondary_metrics(rank, world, local_rank, dist, with_cpu):
         trials = max(x["trials"] for x in r)
     else:
         ms, iters, trials = 0.0, 1, 1
-    ms = parallel.max_over_ranks(dist, ms, "cuda")
-    iters = int(parallel.max_over_ranks(dist, iters, "cuda"))
+    ms = parallel.max_over_ranks(dist, ms, RED_DEV)
+    iters = int(parallel.max_over_ranks(dist, iters, RED_DEV))
     out["object_ba"] = {"workload": "BASELINE configs[3]: 8 objects x 50 ObjectKeyFrames x 300 MapObjectPoints (15 000 stereo edges each), "
                                     "Schur LM 5 + 10 iterations", "objects": 8, "gpu_ms_per_batch": ms, "lm_iterations": iters,
-                        "lm_trials": int(parallel.max_over_ranks(dist, trials, "cuda")), "ms_per_iter": ms / max(iters, 1)}
+                        "lm_trials": int(parallel.max_over_ranks(dist, trials, RED_DEV)), "ms_per_iter": ms / max(iters, 1)}
     if with_cpu and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
@@ -159,15 +160,15 @@ def sequence_leg(rank, world, local_rank, dist, with_cpu, n_frames=12):
             traj[k] = np.concatenate([Rwc, twc[:, None]], 1).reshape(12)
             err = max(err, float(np.abs(twc - seq["twc"][k][:, 3]).max()))
     t0 = time.perf_counter()
-    allt = parallel.gather_trajectories(dist, traj, "cuda")
+    allt = parallel.gather_trajectories(dist, traj, RED_DEV)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t0) * 1e3
-    ms = parallel.max_over_ranks(dist, float(np.median(times)) * 1e3, "cuda")
+    ms = parallel.max_over_ranks(dist, float(np.median(times)) * 1e3, RED_DEV)
     out = {"workload": "BASELINE configs[0]/[4]: %d generated 1242x375 stereo sequence(s) x %d frames, one per GPU, host-driven "
                        "tracking loop over the C-ABI (single frame in flight per sequence)" % (world, n_frames),
            "median_ms_per_frame": ms, "frames_per_s_all_sequences": world * 1e3 / ms, "tracked": int(sum(t is not None for t in vo.trajectory)),
-           "max_abs_position_error_m": parallel.max_over_ranks(dist, err, "cuda"), "trajectory_gather_ms": gather_ms,
+           "max_abs_position_error_m": parallel.max_over_ranks(dist, err, RED_DEV), "trajectory_gather_ms": gather_ms,
            "gathered": [list(a.shape) for a in allt]}
     if with_cpu and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -199,12 +200,21 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # PS_BENCH_SHARE_GPU=1 (developer switch): all ranks on GPU 0 over gloo, to exercise the multi-process path on a 1-GPU box
+    share = os.environ.get("PS_BENCH_SHARE_GPU") == "1" and world > 1
+    if share:
+        local_rank = 0
+    global RED_DEV
+    RED_DEV = "cpu" if share else "cuda"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from pointslot_amd import synth
     from pointslot_amd.extractor import ORBextractor
@@ -237,7 +247,7 @@ def main():
     ex.enable_stage_timing(False)
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=RED_DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
