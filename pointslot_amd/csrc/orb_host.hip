@@ -200,8 +200,8 @@ int build_plan(ps_orb* h, int w, int hgt) {
       return ps_set_error(PS_ERR_INVALID, "FAST cell %dx%d exceeds the kernel window", L.w_cell, L.h_cell);
     L.cell_base = cells;
     cells += L.n_cols * L.n_rows;
-    if (L.n_cols * L.n_rows > PS_QT_NCAP)
-      return ps_set_error(PS_ERR_INVALID, "level %d has %d cells (> %d)", l, L.n_cols * L.n_rows, PS_QT_NCAP);
+    if (L.n_cols * L.n_rows > 3 * PS_QT_NCAP)
+      return ps_set_error(PS_ERR_INVALID, "level %d has %d cells (> %d)", l, L.n_cols * L.n_rows, 3 * PS_QT_NCAP);
     L.cell_cap = ((L.w_cell + 1) / 2) * ((L.h_cell + 1) / 2);   // strict 3x3 maxima: <= 1 per 2x2 block
     L.cand_off = cand_elems;
     cand_elems += (uint32_t)(L.n_cols * L.n_rows * L.cell_cap);

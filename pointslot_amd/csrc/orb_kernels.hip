@@ -739,10 +739,13 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
   const int ncell = L.n_cols * L.n_rows;
 
   // ---- gather the cells' candidates in reference emission order (cell-major, raster inside) ----
-  for (int c = t; c < ncell; c += QT_T) s.surv[c] = cellcnt[c];
+  // the cell offsets borrow rank / ord / cpre (contiguous, 3 * NCAP + 1 entries, not yet in use), so the cell count of a level
+  // is not tied to the node capacity
+  int32_t* coff = s.rank;
+  for (int c = t; c < ncell; c += QT_T) coff[c] = cellcnt[c];
   for (int i = t; i < L.n_ini * 4; i += QT_T) s.child[i] = 0;
   __syncthreads();
-  const int n = qt_exscan(s.surv, ncell, s);
+  const int n = qt_exscan(coff, ncell, s);
   if (t == 0) ncand_out[level] = n;
   if (n == 0) {
     if (t == 0) selcnt[level] = 0;
@@ -753,15 +756,15 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
   // keys live in LDS when they fit (generic pointers: the same code serves both cases)
   uint32_t* kxy = n <= QT_KCAP ? s.kxy : gkxy;
   uint32_t* kns = n <= QT_KCAP ? s.kns : gkxy + L.key_cap;   // node | score << 16
-  if (t == 0) s.surv[ncell] = n;
+  if (t == 0) coff[ncell] = n;
   __syncthreads();
   for (int j = t; j < n; j += QT_T) {
     int lo = 0, hi = ncell;          // invariant: off[lo] <= j < off[hi]
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (s.surv[mid] <= j) lo = mid; else hi = mid;
+      if (coff[mid] <= j) lo = mid; else hi = mid;
     }
-    const uint32_t e = slots[(size_t)lo * L.cell_cap + (j - s.surv[lo])];
+    const uint32_t e = slots[(size_t)lo * L.cell_cap + (j - coff[lo])];
     const uint32_t x = e & 0xFFF, y = (e >> 12) & 0xFFF, sc = e >> 24;
     // vpIniNodes[kp.pt.x / hX] (ORBextractor.cc:569): float division, truncation
     const int ni = (int)__fdiv_rn((float)x, L.h_x);
@@ -1252,7 +1255,7 @@ extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int
   bool small = true;
   for (int l = 0; l < plan->nlevels; l++) {
     const OrbLevel& L = plan->lv[l];
-    small = small && L.quota + 4 <= 512 && 4 * L.n_ini <= 512 && L.n_cols * L.n_rows <= 512;
+    small = small && L.quota + 4 <= 512 && 4 * L.n_ini <= 512 && L.n_cols * L.n_rows <= 3 * 512;
   }
   if (small) hipLaunchKernelGGL(orb_quadtree<512>, dim3(plan->nlevels, nimg), dim3(QT_T), 0, st, *plan, arena);
   else hipLaunchKernelGGL(orb_quadtree<PS_QT_NCAP>, dim3(plan->nlevels, nimg), dim3(QT_T), 0, st, *plan, arena);

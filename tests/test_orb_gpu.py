@@ -112,21 +112,26 @@ def test_batch_device_matches_single(images):
         assert np.array_equal(dg, do)
 
 
-@pytest.mark.parametrize("shape,nfeatures,nlevels,ths", [
-    ((480, 640), 1500, 8, (20, 7)),
-    ((300, 800), 500, 8, (20, 5)),
-    ((376, 1241), 3000, 8, (12, 5)),
-    ((375, 1242), 1200, 5, (20, 5)),
-    ((200, 320), 300, 4, (30, 10)),
+@pytest.mark.parametrize("shape,nfeatures,nlevels,ths,scale", [
+    ((480, 640), 1500, 8, (20, 7), 1.2),
+    ((300, 800), 500, 8, (20, 5), 1.2),
+    ((376, 1241), 3000, 8, (12, 5), 1.2),
+    ((375, 1242), 1200, 5, (20, 5), 1.2),
+    ((200, 320), 300, 4, (30, 10), 1.2),
+    ((479, 641), 1000, 8, (20, 7), 1.2),        # odd sizes: partial dword groups and tiles on every edge
+    ((1080, 1920), 2000, 8, (20, 7), 1.2),      # many tiles per level
+    ((600, 800), 800, 4, (20, 7), 1.5),         # other scale factors: different tap spans per lane
+    ((700, 900), 600, 3, (20, 7), 2.5),         # span > 8 source bytes: the generic gather path of the level kernel
+    ((480, 752), 1000, 8, (20, 7), 1.1),
 ])
-def test_other_shapes_and_parameters(shape, nfeatures, nlevels, ths):
-    """parity does not depend on the KITTI geometry: other sizes, level counts, quotas and FAST thresholds"""
+def test_other_shapes_and_parameters(shape, nfeatures, nlevels, ths, scale):
+    """parity does not depend on the KITTI geometry: other sizes, level counts, quotas, FAST thresholds and scale factors"""
     from pointslot_amd import synth
     from pointslot_amd.extractor import ORBextractor
     h, w = shape
     img, _ = synth.stereo_pair(seed=0x77 + h, w=w, h=h)
-    ex = ORBextractor(nfeatures, 1.2, nlevels, ths[0], ths[1])
-    orc = OracleORB(nfeatures, 1.2, nlevels, ths[0], ths[1])
+    ex = ORBextractor(nfeatures, scale, nlevels, ths[0], ths[1])
+    orc = OracleORB(nfeatures, scale, nlevels, ths[0], ths[1])
     kg, dg = ex(img)
     ko, do = orc.run(img)
     assert len(kg) == len(ko) and len(kg) > 50
