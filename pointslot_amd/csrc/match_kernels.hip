@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (qi >= P.nq) return;
   const int q = P.q_off + qi;
-  if (!A.qvalid[q]) { if (lane == 0) A.ncand[q] = 0; return; }
+  if (!A.qvalid[q]) { if (lane == 0) { A.ncand[q] = 0; A.tbest[q] = 0xFFFFFFFFu; A.tsecond[q] = 0xFFFFFFFFu; } return; }
   const float x = A.qu[q], y = A.qv[q], r = A.qrad[q], rer = A.qrer[q], ur = A.qur[q];
   const int minLevel = A.qminl[q], maxLevel = A.qmaxl[q];
   // Frame::GetFeaturesInArea cell range (Frame.cc:1813-1827)
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
   const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, P.min_y), r), P.gh_inv)));
   const int nMaxCellY = min(PS_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, P.min_y), r), P.gh_inv)));
   int count = 0;
+  uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;   // this lane's two smallest keys among the trains that are free at entry
   if (nMinCellX < PS_GRID_COLS && nMaxCellX >= 0 && nMinCellY < PS_GRID_ROWS && nMaxCellY >= 0) {
     const bool check = (minLevel > 0) || (maxLevel >= 0);
     const uint4* qd = reinterpret_cast<const uint4*>(A.qdesc + (size_t)q * 32);
@@ -296,21 +297,30 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
         }
         const unsigned long long m = __ballot(pass);
         const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-        if (pass && pos < PS_PJ_CAP)
-          A.cand[(size_t)q * PS_PJ_CAP + pos] = ((uint32_t)dist << 23) | ((uint32_t)pos << 15) | (uint32_t)j;
+        if (pass && pos < PS_PJ_CAP) {
+          const uint32_t key = ((uint32_t)dist << 23) | ((uint32_t)pos << 15) | (uint32_t)j;
+          A.cand[(size_t)q * PS_PJ_CAP + pos] = key;
+          if (!A.tocc[P.t_off + j]) { if (key < m1) { m2 = m1; m1 = key; } else if (key < m2) m2 = key; }
+        }
         count += __popcll(m);
       }
     }
   }
+  // best and second-best of the query under the occupancy at entry: pj_resolve only falls back to the candidate list when an
+  // earlier query of the same call has taken one of the two
+  const uint32_t tb = wave_min_u32(m1);
+  const uint32_t ts = wave_min_u32(m1 == tb ? m2 : m1);
   if (lane == 0) {
     if (count > PS_PJ_CAP) { atomicAdd(A.overflow, 1); count = PS_PJ_CAP; }
     A.ncand[q] = count;
+    A.tbest[q] = tb; A.tsecond[q] = ts;
   }
 }
 
 __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   __shared__ uint32_t blocked[1024];   // up to 32768 train features
   __shared__ int hist[32];
+  __shared__ uint32_t newly[1024];     // trains blocked by this call
   __shared__ uint8_t loct[32768];      // train octaves (ratio test), staged once: no global load inside the serial loop
   const PjProb P = A.prob[blockIdx.x];
   const int lane = threadIdx.x;
@@ -322,6 +332,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
       if (j < P.nt && A.tocc[P.t_off + j]) bits |= 1u << b;
     }
     blocked[w] = bits;
+    newly[w] = 0;
   }
   if (lane < 32) hist[lane] = 0;
   for (int j = lane; j < P.nt; j += 64) match[j] = -1;
@@ -333,67 +344,76 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   // Queries are taken in order (the assignment is order dependent), 64 at a time: the lane-resident candidate counts give
   // the non-empty queries of the block as a bit mask, and the first 64 candidate keys of the NEXT non-empty query are
   // requested before the current one is reduced, so the global-memory latency is paid once per block, not once per query.
+  // newly: bitmap of the trains blocked by THIS call (the occupancy at entry is already excluded from tbest / tsecond)
   for (int q0 = 0; q0 < P.nq; q0 += 64) {
-    const int ncv = (q0 + lane < P.nq) ? A.ncand[P.q_off + q0 + lane] : 0;
-    const int obsv = (q0 + lane < P.nq) ? (int)A.qobs[P.q_off + q0 + lane] : 0;
-    if (q0 + lane < P.nq) A.qbest[P.q_off + q0 + lane] = -1;
+    const bool qin = q0 + lane < P.nq;
+    const int qq = P.q_off + q0 + lane;
+    const int ncv = qin ? A.ncand[qq] : 0;
+    const int obsv = qin ? (int)A.qobs[qq] : 0;
+    const uint32_t tbv = qin ? A.tbest[qq] : 0xFFFFFFFFu, tsv = qin ? A.tsecond[qq] : 0xFFFFFFFFu;
+    if (qin) A.qbest[qq] = -1;
+    // conflicts with acceptances of earlier blocks: one LDS lookup per lane, in parallel
+    int stale = 0;
+    if (tbv != 0xFFFFFFFFu) { const uint32_t j = tbv & 0x7FFF; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u); }
+    if (P.ratio_test && tsv != 0xFFFFFFFFu) { const uint32_t j = tsv & 0x7FFF; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u); }
     unsigned long long pend = __builtin_amdgcn_ballot_w64(ncv > 0);
-    uint32_t knext = 0xFFFFFFFFu;
-    if (pend) {
-      const int i0 = __ffsll((long long)pend) - 1;
-      const int n0 = __builtin_amdgcn_readlane(ncv, i0);
-      if (lane < n0) knext = A.cand[(size_t)(P.q_off + q0 + i0) * PS_PJ_CAP + lane];
-    }
+    const unsigned long long stale_m = __builtin_amdgcn_ballot_w64(stale != 0);
+    int accidx = -1;        // lane k: the train taken by the k-th observed acceptance of this block
+    int nacc = 0;
     while (pend) {
       const int i = __ffsll((long long)pend) - 1;
       pend &= pend - 1;
       const int qi = q0 + i, q = P.q_off + qi;
-      const int nc = __builtin_amdgcn_readlane(ncv, i);
-      const uint32_t kcur = knext;
-      knext = 0xFFFFFFFFu;
-      if (pend) {
-        const int in = __ffsll((long long)pend) - 1;
-        const int nn = __builtin_amdgcn_readlane(ncv, in);
-        if (lane < nn) knext = A.cand[(size_t)(P.q_off + q0 + in) * PS_PJ_CAP + lane];
+      uint32_t best = (uint32_t)__builtin_amdgcn_readlane((int)tbv, i);
+      uint32_t second = (uint32_t)__builtin_amdgcn_readlane((int)tsv, i);
+      bool redo = (stale_m >> i) & 1ull;
+      if (!redo && best != 0xFFFFFFFFu && nacc > 0) {
+        const int bj = (int)(best & 0x7FFF), sj = (int)(second & 0x7FFF);
+        const bool hit = accidx == bj || (P.ratio_test && second != 0xFFFFFFFFu && accidx == sj);
+        redo = __builtin_amdgcn_ballot_w64(hit) != 0ull;
       }
-      uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
-      {
-        const uint32_t k = kcur;
-        if (lane < nc) {
+      if (redo) {
+        // an earlier query took the best or the second candidate: rescan the list under the current occupancy
+        const int nc = __builtin_amdgcn_readlane(ncv, i);
+        uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+        for (int c = lane; c < nc; c += 64) {
+          const uint32_t k = A.cand[(size_t)q * PS_PJ_CAP + c];
           const uint32_t j = k & 0x7FFF;
-          if (!((blocked[j >> 5] >> (j & 31)) & 1u)) m1 = k;
+          if (((blocked[j >> 5] | newly[j >> 5]) >> (j & 31)) & 1u) continue;
+          if (k < m1) { m2 = m1; m1 = k; } else if (k < m2) m2 = k;
         }
+        best = wave_min_u32(m1);
+        second = wave_min_u32(m1 == best ? m2 : m1);
       }
-      for (int c = 64 + lane; c < nc; c += 64) {
-        const uint32_t k = A.cand[(size_t)q * PS_PJ_CAP + c];
-        const uint32_t j = k & 0x7FFF;
-        if ((blocked[j >> 5] >> (j & 31)) & 1u) continue;
-        if (k < m1) { m2 = m1; m1 = k; } else if (k < m2) m2 = k;
-      }
-      const uint32_t best = wave_min_u32(m1);
       if (best == 0xFFFFFFFFu) continue;
       const int bestDist = (int)(best >> 23), bestIdx = (int)(best & 0x7FFF);
       if (bestDist > P.th_dist) continue;
-      if (P.ratio_test) {
-        const uint32_t second = wave_min_u32(m1 == best ? m2 : m1);
-        if (second != 0xFFFFFFFFu) {
-          const int d2 = (int)(second >> 23);
-          const int l1 = loct[bestIdx], l2 = loct[second & 0x7FFF];
-          if (l1 == l2 && (float)bestDist > __fmul_rn(P.nn_ratio, (float)d2)) continue;
-        }
-        // no second candidate: bestLevel2 = -1 never equals an octave -> accepted
+      if (P.ratio_test && second != 0xFFFFFFFFu) {
+        const int d2 = (int)(second >> 23);
+        const int l1 = loct[bestIdx], l2 = loct[second & 0x7FFF];
+        if (l1 == l2 && (float)bestDist > __fmul_rn(P.nn_ratio, (float)d2)) continue;
+        // (no second candidate: bestLevel2 = -1 never equals an octave -> accepted)
       }
       const int observed = __builtin_amdgcn_readlane(obsv, i);
       if (lane == 0) {
         match[bestIdx] = qi;
         A.qbest[q] = bestIdx;
-        if (observed) blocked[bestIdx >> 5] |= 1u << (bestIdx & 31);
+        if (observed) atomicOr(&newly[bestIdx >> 5], 1u << (bestIdx & 31));
+      }
+      if (observed) {
+        if (lane == nacc) accidx = bestIdx;
+        nacc++;
       }
       nm++;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (observed) {   // the bitmap must be in LDS before a later rescan reads it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   __syncthreads();
   if (P.check_ori) {
