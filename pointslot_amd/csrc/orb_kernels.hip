@@ -221,15 +221,18 @@ __global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, 
     sel[k] = (uint32_t)i0 | (0x0cu << 8) | ((uint32_t)i1 << 16) | (0x0cu << 24);
   }
   const uint32_t sel_copy = (uint32_t)(s0[0] - sb) | ((uint32_t)(s0[1] - sb) << 8) | ((uint32_t)(s0[2] - sb) << 16) | ((uint32_t)(s0[3] - sb) << 24);
-  const uint8_t* src_rows;       // pointer to source pixel (0, 0)
-  int src_stride;
+  // source pixel (x, y) lives at sbase + srel + y * src_stride + x: a wave-uniform 64-bit base plus 32-bit offsets, so the
+  // loads are "scalar base + lane offset" and the per-row address arithmetic stays on the scalar unit
+  const uint8_t* sbase;
+  uint32_t srel, src_stride;
   if (LEVEL0) {
-    src_rows = imgs + (size_t)img * img_pitch; src_stride = img_stride;
+    sbase = imgs + (size_t)img * img_pitch; srel = 0; src_stride = (uint32_t)img_stride;
     fast = fast && sb >= 4 && sb + 12 <= L.w;        // the aligned 12-byte window must stay inside the caller's row
   } else {
     const OrbLevel S = plan.lv[level - 1];
-    src_rows = base + S.plane_off + (size_t)PS_EDGE * S.stride + PS_EDGE; src_stride = S.stride;
+    sbase = base; srel = S.plane_off + (uint32_t)(PS_EDGE * S.stride + PS_EDGE); src_stride = (uint32_t)S.stride;
   }
+  const uint32_t sbase_lo = (uint32_t)reinterpret_cast<uintptr_t>(sbase);
   const bool own_x = lane >= 1 && lane <= 62 && P0 + 4 * lane < PW;
   uint8_t* plane = base + L.plane_off;
   // Consecutive output rows share a source row four times out of five at scale 1.2 (s0 of row r is s1 of row r - 1), so
@@ -253,10 +256,11 @@ __global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, 
 #pragma unroll
       for (int v = 0; v < (LEVEL0 ? 1 : 2); v++) {
         if (v == 0 && !need0[r]) continue;
-        const uint8_t* row = src_rows + (size_t)(v == 0 ? ty[r].x : ty[r].y) * src_stride;
+        const uint32_t roff = srel + (uint32_t)(v == 0 ? ty[r].x : ty[r].y) * src_stride;   // wave-uniform
+        const uint8_t* row = sbase + roff;
         if (fast) {
-          const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(row + sb) & 3);
-          const uint32_t* q = reinterpret_cast<const uint32_t*>(row + sb - sh);
+          const uint32_t sh = (sbase_lo + roff + (uint32_t)sb) & 3u;
+          const uint32_t* q = reinterpret_cast<const uint32_t*>(sbase + (roff + (uint32_t)sb - sh));
           const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
           wl[r][v] = __builtin_amdgcn_alignbyte(d1, d0, sh);
           wh[r][v] = __builtin_amdgcn_alignbyte(d2, d1, sh);
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, 
       tile[rr][lane] = pk;
       const int py = Q0 + rr;
       if (own_x && rr >= 3 && rr < 3 + LV_OWN_R && py < PH)
-        *reinterpret_cast<uint32_t*>(plane + (size_t)py * L.stride + P0 + 4 * lane) = pk;
+        *reinterpret_cast<uint32_t*>(plane + ((uint32_t)py * (uint32_t)L.stride + (uint32_t)(P0 + 4 * lane))) = pk;
     }
     hc_row = ty[LV_RPT / 2 - 1].y;
   }
