@@ -47,6 +47,15 @@ __device__ __forceinline__ double shfl_d(double v, int src) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+// 1 / d to full double precision from the hardware estimate and two Newton steps: a third of the latency of the IEEE
+// division sequence, and the pivots' reciprocals are reused by every row of the panel
+__device__ __forceinline__ double recip_d(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += shfl_xor_d(v, d);
@@ -527,7 +536,8 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   double* rhs = dj + NB;                        // [n]
   double* dall = rhs + 6 * PS_BA_MAX_POSES;     // [n]
   double* lcol = dall + 6 * PS_BA_MAX_POSES;    // [2][64] multipliers of the current elimination step
-  double* panel = lcol + 128;                   // [rows below][NB + 1]
+  double* rdj = lcol + 128;                     // [NB] reciprocals of the block's pivots
+  double* panel = rdj + NB;                     // [rows below][NB + 1]
   __shared__ int fail;
   if (tid == 0) fail = 0;
   for (int i = tid; i < n; i += SOL_T) rhs[i] = A.bs[(size_t)P.pose_base * 6 + i];
@@ -551,7 +561,9 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
         if (j < jb) {
           const double d = shfl_d(a[j], j);
           if (d == 0) bad = true;
-          const double l = lane > j ? a[j] / d : 0.0;
+          const double rd = recip_d(d);
+          if (lane == j) rdj[j] = rd;
+          const double l = lane > j ? a[j] * rd : 0.0;
           double* lc = lcol + (j & 1) * 64;
           lc[lane] = l;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -592,7 +604,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
 #pragma unroll
           for (int q = 0; q < c; q++) v -= xd[q] * Ljj[c * (NB + 1) + q];
           xd[c] = v;
-          prow[c] = v / dj[c];
+          prow[c] = v * rdj[c];
         } else {
           xd[c] = 0.0;
           prow[c] = 0.0;
@@ -875,7 +887,7 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), 0, st, *A);
   {
     const int n_max = 6 * max_free;
-    auto lds = [&](int nb) { return (size_t)(nb * (nb + 1) + nb + 128 + 12 * PS_BA_MAX_POSES + (size_t)(n_max > nb ? n_max - nb + 4 : 4) * (nb + 1) + 8) * sizeof(double); };
+    auto lds = [&](int nb) { return (size_t)(nb * (nb + 1) + 2 * nb + 128 + 12 * PS_BA_MAX_POSES + (size_t)(n_max > nb ? n_max - nb + 4 : 4) * (nb + 1) + 8) * sizeof(double); };
     // > 64 KB of dynamic LDS has to be requested per kernel
     static const int force_nb = getenv("PS_BA_NB") ? atoi(getenv("PS_BA_NB")) : 0;
     if (force_nb == 48 && lds(48) <= 150 * 1024) {   // measured slower than 24 at n = 294 (single-wave diagonal factor)
