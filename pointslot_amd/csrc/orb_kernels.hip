@@ -464,18 +464,18 @@ __device__ __forceinline__ void wave_sync() {
 #define FAST_T 256
 typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
 typedef short fs_s2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int nimg, int bpi) {
+__global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int QS, int nimg, int bpi) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform geometry stays on the scalar unit
   int img, lb;
   if (!xcd_image_block(bpi, nimg, img, lb)) return;
   const int cell = lb * 4 + wave;
   if (cell >= plan.n_cells) return;
-  const int per_wave = TR * TS + SS * (TR - 4) + 3 * LCAP + 16;
+  const int per_wave = TR * TS + SS * (TR - 4) + 2 * LCAP + 16 + 3 + QS * (TR - 6);   // same expression as the launcher
   uint8_t* tile = fast_smem + (size_t)wave * ((per_wave + 15) & ~15);
   uint8_t* smap = tile + TR * TS;
   uint16_t* list = reinterpret_cast<uint16_t*>(smap + ((SS * (TR - 4) + 1) & ~1));
-  uint8_t* lflag = reinterpret_cast<uint8_t*>(list + LCAP);
+  uint8_t* qmap = tile + ((TR * TS + SS * (TR - 4) + 2 * LCAP + 16 + 3) & ~3);   // per pixel: the largest threshold that still passes the necessary test
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
   int level = 0;
 #pragma unroll
@@ -537,6 +537,8 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     const int t = t0 + lane;
     const bool tv = t < ntask;
     const int y = tv ? t / ng : 0, g = tv ? t - y * ng : 0;
+    unsigned long long C[4];
+    if (pass == 0) {
     uint32_t w[7][3];
 #pragma unroll
     for (int r = 0; r < 7; r++) {
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     // Two pixels per operation on packed u16.  "4 consecutive even positions all darker than v - th" is
     //   min over the 8 windows of (max of the window) < v - th,  and for brighter  max over windows of (min) > v + th,
     // so the ring values go through pk_max / pk_min trees untouched and the threshold enters in one packed subtraction.
-    unsigned long long C[4];
+    uint32_t qpair[2];
 #pragma unroll
     for (int pq = 0; pq < 2; pq++) {
       const int i = 2 * pq;
@@ -569,12 +571,21 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
         M = __builtin_elementwise_min(M, __builtin_elementwise_max(x2[k], x2[(k + 2) & 7]));
         m = __builtin_elementwise_max(m, __builtin_elementwise_min(n2[k], n2[(k + 2) & 7]));
       }
+      // four consecutive darker <=> M < v - th <=> th < v - M; brighter <=> th < m - v: the pixel passes at every threshold
+      // below q = max(v - M, m - v), which does not depend on th - kept (one byte per pixel) for the minThFAST pass
+      const fs_s2 zero2 = {0, 0};
+      const fs_s2 qv = __builtin_elementwise_max(__builtin_elementwise_max(cv - __builtin_bit_cast(fs_s2, M), __builtin_bit_cast(fs_s2, m) - cv), zero2);
+      qpair[pq] = __builtin_bit_cast(uint32_t, qv);
       const fs_s2 thv = {(short)th, (short)th};
-      const fs_s2 t1 = __builtin_bit_cast(fs_s2, M) - (cv - thv);     // < 0: four consecutive darker
-      const fs_s2 t2 = (cv + thv) - __builtin_bit_cast(fs_s2, m);     // < 0: four consecutive brighter
-      const uint32_t rr = __builtin_bit_cast(uint32_t, t1 | t2);
+      const uint32_t rr = __builtin_bit_cast(uint32_t, thv - qv);     // < 0: passes
       C[i] = __builtin_amdgcn_ballot_w64(tv && (4 * g + i) < cw && (rr & 0x8000u) != 0);
       C[i + 1] = __builtin_amdgcn_ballot_w64(tv && (4 * g + i + 1) < cw && (rr & 0x80000000u) != 0);
+    }
+    if (tv) *reinterpret_cast<uint32_t*>(qmap + y * QS + 4 * g) = __builtin_amdgcn_perm(qpair[1], qpair[0], 0x06040200u);
+    } else {
+      const uint32_t qq = tv ? *reinterpret_cast<const uint32_t*>(qmap + y * QS + 4 * g) : 0u;
+#pragma unroll
+      for (int i = 0; i < 4; i++) C[i] = __builtin_amdgcn_ballot_w64(tv && (4 * g + i) < cw && (int)((qq >> (8 * i)) & 0xFFu) > th);
     }
     // raster-ordered compaction: order (lane, slot)
     const int lower = __popcll(C[0] & ltmask) + __popcll(C[1] & ltmask) + __popcll(C[2] & ltmask) + __popcll(C[3] & ltmask);
@@ -622,7 +633,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
       const bool lmax = s > m[-1] && s > m[1] && s > m[-SS - 1] && s > m[-SS] && s > m[-SS + 1] &&
                         s > m[SS - 1] && s > m[SS] && s > m[SS + 1];
       f = lmax ? 1 : 0;
-      lflag[idx] = f;
+      if (lmax) list[idx] = (uint16_t)(p | 0x8000);   // bit 15: survives the NMS
     }
     anykp |= __builtin_amdgcn_ballot_w64(f != 0);
   }
@@ -630,11 +641,12 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   if (!anykp && pass == 0) continue;   // no keypoint at iniThFAST: run the cell again at minThFAST
   for (int i0 = 0; i0 < ncand; i0 += 64) {
     const int idx = i0 + lane;
-    const bool keep = idx < ncand && lflag[idx];
+    const int pv = idx < ncand ? list[idx] : 0;
+    const bool keep = (pv & 0x8000) != 0;
     const unsigned long long km = __ballot(keep);
     if (keep) {
       const int pos = total + __popcll(km & ltmask);
-      const int p = list[idx];
+      const int p = pv & 0x7FFF;
       const int y = p / cw, x = p - y * cw;
       const int s = smap[(y + 1) * SS + x + 1];
       // coordinates relative to (minBorderX, minBorderY): local + j*wCell (ORBextractor.cc:822-824)
@@ -1250,10 +1262,11 @@ extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nim
   }
   const int TS = (mw + 16 + 3) & ~3, TR = mh, SS = (mw - 6 + 2 + 3) & ~3;
   const int LCAP = (mw - 6) * (mh - 6);
-  const int per_wave = (TR * TS + SS * (TR - 4) + 3 * LCAP + 16 + 15) & ~15;
+  const int QS = (mw - 6 + 3) & ~3;
+  const int per_wave = (TR * TS + SS * (TR - 4) + 2 * LCAP + 16 + 3 + QS * (TR - 6) + 15) & ~15;
   const int bpi = (plan->n_cells + 3) / 4;
   hipLaunchKernelGGL(orb_fast_cells, dim3(bpi * ((nimg + 7) / 8) * 8), dim3(FAST_T), (size_t)per_wave * 4, st, *plan, arena,
-                     TS, TR, SS, LCAP, nimg, bpi);
+                     TS, TR, SS, LCAP, QS, nimg, bpi);
 }
 extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   bool small = true;
