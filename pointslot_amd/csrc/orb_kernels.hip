@@ -678,7 +678,8 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
 #define QT_T 512
 #define QT_INV 0x80000000u
 
-#define QT_KCAP 4096              // keys kept in LDS (levels with more candidates use the global scratch)
+#define QT_KCAP 2048              // keys kept in LDS (levels with more candidates use the global scratch); sized so that three
+                                  // workgroups share a CU: the kernel is latency-bound and its duration is rounds x workgroup latency
 template <int NCAP>
 struct QtShared {
   uint32_t boxa[2][NCAP];   // x0 | y0 << 16
@@ -739,10 +740,23 @@ __device__ __forceinline__ int qt_quadrant(uint32_t kxy, uint32_t ba, uint32_t b
   return (kx < mx ? 0 : 1) + (ky < my ? 0 : 2);
 }
 
+#ifdef PS_QT_PROFILE   // developer build: 100 MHz ticks per phase of (level 0, image 0), printed by the kernel
+#define QTP_DECL long long qt_t0 = wall_clock64(), qt_tt = qt_t0, qt_ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; int qt_np = 0
+#define QTP_MARK(k) do { const long long _n = wall_clock64(); qt_ph[k] += _n - qt_tt; qt_tt = _n; } while (0)
+#define QTP_PASS() (qt_np++)
+#define QTP_PRINT() do { if (threadIdx.x == 0 && blockIdx.x == 0) printf("qt n=%d passes %d ticks: gather %lld A %lld B %lld C %lld cpre %lld E %lld F %lld init %lld final %lld total %lld\n", n, qt_np, qt_ph[0], qt_ph[1], qt_ph[2], qt_ph[3], qt_ph[4], qt_ph[5], qt_ph[6], qt_ph[7], qt_ph[8], wall_clock64() - qt_t0); } while (0)
+#else
+#define QTP_DECL
+#define QTP_MARK(k)
+#define QTP_PASS()
+#define QTP_PRINT()
+#endif
 template <int NCAP>
-__global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* arena) {
+__global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* arena, int nimg) {
   __shared__ QtShared<NCAP> s;
-  const int level = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
+  QTP_DECL;
+  // level-major block order: the long-running workgroups (level 0, the largest quota) are dispatched first
+  const int level = blockIdx.x / nimg, img = blockIdx.x - level * nimg, t = threadIdx.x;
   const OrbLevel L = plan.lv[level];
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
   const int32_t* cellcnt = reinterpret_cast<const int32_t*>(base + plan.cellcnt_off) + L.cell_base;
@@ -789,6 +803,7 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
     atomicAdd(&s.child[ni], 1u);
   }
   __syncthreads();
+  QTP_MARK(0);
   // ---- initial nodes (ORBextractor.cc:543-586); empty ones stay in the array with count 0 and
   // are dropped at the first rebuild, which is when the reference has already erased them --------
   int cur = 0;
@@ -814,6 +829,7 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
     for (int i = t; i < A * 4; i += QT_T) s.child[i] = 0;
     if (t == 0) { s.cut = 0x7fffffff; s.n_expand = 0; }
     __syncthreads();
+    QTP_MARK(1);
     // B: count keys per child of every candidate node
     for (int k = t; k < n; k += QT_T) {
       const int i = kns[k] & 0xFFFF;
@@ -822,6 +838,7 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
       if (cand) atomicAdd(&s.child[i * 4 + qt_quadrant(kxy[k], boxa[i], boxb[i])], 1u);
     }
     __syncthreads();
+    QTP_MARK(2);
     // C: processing order
     int ncand;
     if (!careful) {
@@ -862,6 +879,7 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
     }
     for (int i = t; i < A; i += QT_T) if (s.rank[i] >= 0) s.ord[s.rank[i]] = i;
     __syncthreads();
+    QTP_MARK(3);
     // non-empty children per candidate, in rank order
     for (int r = t; r < ncand; r += QT_T) {
       const int i = s.ord[r];
@@ -889,6 +907,7 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
     __syncthreads();
     const int nsurv = qt_exscan(s.surv, A, s);
     const int nn_new = TC + nsurv;
+    QTP_MARK(4);
     // E: write the new list into the other buffer
     uint32_t* nboxa = s.boxa[cur ^ 1]; uint32_t* nboxb = s.boxb[cur ^ 1];
     uint32_t* ncnt = s.cnt[cur ^ 1]; uint32_t* nsq = s.seq[cur ^ 1];
@@ -932,6 +951,7 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
         nsq[pos] = sq[i];
       }
     }
+    QTP_MARK(5);
     // F: re-home the keys
     for (int k = t; k < n; k += QT_T) {
       const uint32_t kv = kns[k];
@@ -952,6 +972,8 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
     __syncthreads();
     const int n_expand = s.n_expand;
     __syncthreads();
+    QTP_MARK(6);
+    QTP_PASS();
     seq_base += (uint32_t)TC;
     A = nn_new;
     nn = nn_new;
@@ -961,6 +983,7 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
     if (!careful && nn + 3 * n_expand > N) careful = true;
   }
 
+  QTP_MARK(7);
   // ---- retain the best key of every node (ORBextractor.cc:742-760): max response, first wins ----
   uint32_t* best = s.child;
   for (int i = t; i < nn; i += QT_T) best[i] = 0;
@@ -978,6 +1001,8 @@ __global__ __launch_bounds__(QT_T) void orb_quadtree(OrbPlan plan, uint8_t* aren
     if (i < L.sel_cap) sel[i] = x | (y << 12) | ((bv >> 20) << 24);
   }
   if (t == 0) selcnt[level] = min(nn, L.sel_cap);
+  QTP_MARK(8);
+  QTP_PRINT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1274,8 +1299,9 @@ extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int
     const OrbLevel& L = plan->lv[l];
     small = small && L.quota + 4 <= 512 && 4 * L.n_ini <= 512 && L.n_cols * L.n_rows <= 3 * 512;
   }
-  if (small) hipLaunchKernelGGL(orb_quadtree<512>, dim3(plan->nlevels, nimg), dim3(QT_T), 0, st, *plan, arena);
-  else hipLaunchKernelGGL(orb_quadtree<PS_QT_NCAP>, dim3(plan->nlevels, nimg), dim3(QT_T), 0, st, *plan, arena);
+  // grid: x = level * nimg + image (level-major), y only carries nimg
+  if (small) hipLaunchKernelGGL(orb_quadtree<512>, dim3(plan->nlevels * nimg, 1), dim3(QT_T), 0, st, *plan, arena, nimg);
+  else hipLaunchKernelGGL(orb_quadtree<PS_QT_NCAP>, dim3(plan->nlevels * nimg, 1), dim3(QT_T), 0, st, *plan, arena, nimg);
 }
 extern "C" void psk_orb_launch_blur(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   hipLaunchKernelGGL(orb_blur, dim3(plan->blur_blocks, nimg), dim3(256), 0, st, *plan, arena);
