@@ -55,6 +55,7 @@ struct ps_orb {
   // stereo matcher outputs, indexed like the keypoints of the LEFT image: [max_batch][kp_cap]
   float* d_uright = nullptr; float* d_depth = nullptr; int32_t* d_sad = nullptr; int32_t* d_kept = nullptr;
   StPair* d_pairs = nullptr;
+  uint8_t* d_stscratch = nullptr;   // [max_batch][PS_ST_SCRATCH]
   int last_npairs = 0;
   uint8_t* d_objkeys = nullptr;   // scratch of ps_orb_stereo_match_keys (caller-provided key sets + their outputs)
   uint8_t* h_objkeys = nullptr;
@@ -158,6 +159,8 @@ int free_device(ps_orb* h) {
   if (h->d_sad) hipFree(h->d_sad);
   if (h->d_kept) hipFree(h->d_kept);
   if (h->d_pairs) hipFree(h->d_pairs);
+  if (h->d_stscratch) hipFree(h->d_stscratch);
+  h->d_stscratch = nullptr;
   if (h->d_objkeys) hipFree(h->d_objkeys);
   if (h->h_objkeys) hipHostFree(h->h_objkeys);
   h->d_objkeys = nullptr; h->h_objkeys = nullptr;
@@ -274,6 +277,7 @@ int build_plan(ps_orb* h, int w, int hgt) {
   PS_HIP(hipMalloc(&h->d_sad, (size_t)B * P.kp_cap * 4));
   PS_HIP(hipMalloc(&h->d_kept, (size_t)B * 4));
   PS_HIP(hipMalloc(&h->d_pairs, (size_t)B * sizeof(StPair)));
+  PS_HIP(hipMalloc(&h->d_stscratch, (size_t)B * PS_ST_SCRATCH));
   PS_HIP(hipMemsetAsync(h->d_counts, 0, (size_t)B * 4, h->stream));
   PS_HIP(hipStreamSynchronize(h->stream));
   h->planned = true;
@@ -561,6 +565,7 @@ int ps_orb_stereo_match_batch(ps_orb* h, int npairs, float mb, float mbf) {
     s.kps_r = h->d_kps + r * P.kp_cap; s.desc_r = h->d_desc + r * P.kp_cap * 32; s.cnt_r = h->d_counts + r;
     s.u_right = h->d_uright + (size_t)k * P.kp_cap; s.depth = h->d_depth + (size_t)k * P.kp_cap;
     s.sad = h->d_sad + (size_t)k * P.kp_cap; s.kept = h->d_kept + k;
+    s.scratch = h->d_stscratch + (size_t)k * PS_ST_SCRATCH;
   }
   return stereo_run(h, pairs, mb, mbf);
 }
@@ -609,6 +614,7 @@ int ps_orb_stereo_match_pair(ps_orb* left, ps_orb* right, float mb, float mbf, f
   s.kps_l = left->d_kps; s.desc_l = left->d_desc; s.cnt_l = left->d_counts;
   s.kps_r = right->d_kps; s.desc_r = right->d_desc; s.cnt_r = right->d_counts;
   s.u_right = left->d_uright; s.depth = left->d_depth; s.sad = left->d_sad; s.kept = left->d_kept;
+  s.scratch = left->d_stscratch;
   int rc = stereo_run(left, pairs, mb, mbf);
   if (rc != PS_OK) return rc;
   left->last_nimg = 1;
@@ -658,6 +664,7 @@ int ps_orb_stereo_match_keys(ps_orb* left, ps_orb* right, const ps_keypoint* kps
   s.kps_l = db + o_kl; s.desc_l = db + o_dl; s.cnt_l = (const int32_t*)(db + o_cnt);
   s.kps_r = db + o_kr; s.desc_r = db + o_dr; s.cnt_r = (const int32_t*)(db + o_cnt) + 1;
   s.u_right = (float*)(db + o_ur); s.depth = (float*)(db + o_dp); s.sad = (int32_t*)(db + o_sad); s.kept = (int32_t*)(db + o_cnt) + 2;
+  s.scratch = left->d_stscratch;
   const int keep_npairs = left->last_npairs;
   int rc = stereo_run(left, pairs, mb, mbf, n_left);
   left->last_npairs = keep_npairs;                     // the frame's own ComputeStereoMatches results stay fetchable

@@ -62,4 +62,11 @@ struct StPair {
   const void* kps_l; const uint8_t* desc_l; const int32_t* cnt_l;
   const void* kps_r; const uint8_t* desc_r; const int32_t* cnt_r;
   float* u_right; float* depth; int32_t* sad; int32_t* kept;
+  uint8_t* scratch;         // PS_ST_SCRATCH bytes: row-bucket table of the right keypoints (st_bucket -> st_match)
 };
+// stereo matcher scratch per pair: bucket offsets (8-row buckets of the right keypoints' y), bucketed indices, compact right
+// keypoint records {x, minr | maxr << 12 | octave << 24}
+#define PS_ST_MAXB 512
+#define PS_ST_CAP 4096
+#define PS_ST_OFF_BYTES ((PS_ST_MAXB + 4) * 4)
+#define PS_ST_SCRATCH (PS_ST_OFF_BYTES + PS_ST_CAP * 4 + PS_ST_CAP * 8)
