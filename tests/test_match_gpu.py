@@ -1,4 +1,5 @@
 """GPU parity of the matcher kernels against the CPU oracle: bit-exact distance matrices and match sets."""
+import os
 import numpy as np
 import pytest
 
@@ -154,3 +155,14 @@ def test_fuse_search_batch(matcher):
     for pr, (gi, gd) in zip(prs, res):
         oi, od = oracle_lib.fuse_search(pr)
         assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_randomised_matcher_sweep():
+    """many scene sizes / radii / ratios, including small images where thousands of queries fight for a few keypoints (the
+    order-dependent resolve then runs its rescan path constantly); every variant must stay bit-exact"""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_matchers.py")
+    r = subprocess.run([sys.executable, tool, "11", "16"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
