@@ -1294,14 +1294,17 @@ extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nim
                      TS, TR, SS, LCAP, QS, nimg, bpi);
 }
 extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
-  bool small = true;
+  // smallest node capacity that holds every level (quota + 4 nodes, 4 * n_ini initial children, cells / 3 for the gather table)
+  int need = 0;
   for (int l = 0; l < plan->nlevels; l++) {
     const OrbLevel& L = plan->lv[l];
-    small = small && L.quota + 4 <= 512 && 4 * L.n_ini <= 512 && L.n_cols * L.n_rows <= 3 * 512;
+    need = max(need, max(L.quota + 4, max(4 * L.n_ini, (L.n_cols * L.n_rows + 2) / 3)));
   }
-  // grid: x = level * nimg + image (level-major), y only carries nimg
-  if (small) hipLaunchKernelGGL(orb_quadtree<512>, dim3(plan->nlevels * nimg, 1), dim3(QT_T), 0, st, *plan, arena, nimg);
-  else hipLaunchKernelGGL(orb_quadtree<PS_QT_NCAP>, dim3(plan->nlevels * nimg, 1), dim3(QT_T), 0, st, *plan, arena, nimg);
+  // grid: x = level * nimg + image (level-major)
+  const dim3 grid(plan->nlevels * nimg, 1);
+  if (need <= 512) hipLaunchKernelGGL(orb_quadtree<512>, grid, dim3(QT_T), 0, st, *plan, arena, nimg);
+  else if (need <= 1024) hipLaunchKernelGGL(orb_quadtree<1024>, grid, dim3(QT_T), 0, st, *plan, arena, nimg);
+  else hipLaunchKernelGGL(orb_quadtree<PS_QT_NCAP>, grid, dim3(QT_T), 0, st, *plan, arena, nimg);
 }
 extern "C" void psk_orb_launch_blur(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   hipLaunchKernelGGL(orb_blur, dim3(plan->blur_blocks, nimg), dim3(256), 0, st, *plan, arena);

@@ -276,3 +276,15 @@ def test_object_stereo_matches_bit_exact(images):
     ur2, dp2 = ComputeStereoMatches(exl, exr, mb, mbf)
     assert np.array_equal(ur2.view(np.uint32), ur_frame.view(np.uint32))
     exl.close(); exr.close()
+
+
+def test_randomised_extractor_sweep():
+    """random image sizes (tile and dword-group remainders on every edge), strided views, level counts, scale factors, quotas,
+    thresholds and low-texture images where most cells take the minThFAST pass: keypoints and descriptors stay bit-exact"""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_orb.py")
+    r = subprocess.run([sys.executable, tool, "5", "14"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout

@@ -1,0 +1,42 @@
+"""Randomised parity sweep of the ORB extractor against the CPU checker over image sizes, strides and parameters
+(developer tool, run on the GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from oracle_lib import OracleORB
+from pointslot_amd import synth
+from pointslot_amd.extractor import ORBextractor
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+bad = 0
+for it in range(ncase):
+    nlev = int(rng.choice([1, 3, 5, 8])); scale = float(rng.choice([1.2, 1.2, 1.2, 1.1, 1.4, 2.0]))
+    if scale == 2.0:
+        nlev = min(nlev, 4)
+    top = scale ** (nlev - 1)
+    wmin, hmin = int(np.ceil(70 * top)) + 8, int(np.ceil(70 * top)) + 8
+    w = int(rng.integers(max(wmin, 96), max(wmin, 96) + 1200)); h = int(rng.integers(max(hmin, 96), max(hmin, 96) + 700))
+    if w < h:
+        w, h = h, w                                             # the extractor requires landscape levels
+    nf = int(rng.choice([200, 1000, 2000, 3500])); ini = int(rng.choice([10, 20, 40])); mn = int(rng.choice([3, 5, 7]))
+    img, _ = synth.stereo_pair(seed=int(rng.integers(1, 1 << 30)), w=w, h=h, n_rect=int(w * h / 1200))
+    if rng.random() < 0.3:                                      # low-texture image: most cells take the minThFAST pass
+        img = (img.astype(np.int32) // 6 + 100).astype(np.uint8)
+    if rng.random() < 0.4:                                      # strided view
+        big = np.zeros((h, w + int(rng.integers(1, 37))), np.uint8); big[:, :w] = img; img = big[:, :w]
+    try:
+        ex = ORBextractor(nf, scale, nlev, ini, mn)
+        kg, dg = ex(img)
+    except Exception as e:
+        print("case %d %dx%d L%d s%.1f: %s" % (it, w, h, nlev, scale, str(e)[:90])); continue
+    orc = OracleORB(nf, scale, nlev, ini, mn)
+    ko, do = orc.run(np.ascontiguousarray(img))
+    ok = len(kg) == len(ko) and np.array_equal(kg.view(np.uint8), ko.view(np.uint8)) and (len(kg) == 0 or np.array_equal(dg, do))
+    if not ok:
+        bad += 1
+        print("MISMATCH case %d: %dx%d levels %d scale %.1f nf %d th %d/%d: %d vs %d keypoints" % (it, w, h, nlev, scale, nf, ini, mn, len(kg), len(ko)))
+    ex.close()
+print("orb stress: %d cases, %d mismatches" % (ncase, bad))
+sys.exit(1 if bad else 0)
