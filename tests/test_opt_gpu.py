@@ -157,3 +157,15 @@ def test_dynamic_static_discrimination_bit_exact():
         assert np.float64(r[0]).tobytes() == np.float64(e[0]).tobytes() and np.float64(r[1]).tobytes() == np.float64(e[1]).tobytes(), (r, e)
     assert res[1][1] > 10 * res[0][1]                       # the moving object stands out
     opt.close()
+
+
+def test_randomised_optimiser_sweep():
+    """pose optimisation over random sizes / outlier fractions / mono-stereo mixes / missing points and object BA over random
+    graph sizes and visibilities: inlier counts, outlier masks and erase lists identical, poses within 1e-5"""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_opt.py")
+    r = subprocess.run([sys.executable, tool, "7", "30"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
