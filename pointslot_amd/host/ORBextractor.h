@@ -34,10 +34,11 @@ class ORBextractor {
     const int cap = nfeatures_ + 4 * nlevels_ + 64;
     keypoints.resize(cap);
     std::vector<uint8_t> desc((size_t)cap * 32);
-    // mvImagePyramid: padded parent buffers owned here, ROI views handed out (ORBextractor.cc:1113-1115)
-    std::vector<uint8_t*> planes(nlevels_);
+    // mvImagePyramid: padded parent buffers owned here, ROI views handed out (ORBextractor.cc:1113-1115).  A caller that
+    // matches stereo pairs on the device (ps_orb_stereo_match_pair) clears mbDownloadPyramid and saves the 1.7 MB read-back.
+    std::vector<uint8_t*> planes(nlevels_, nullptr);
     parents_.resize(nlevels_);
-    for (int l = 0; l < nlevels_; l++) {
+    for (int l = 0; mbDownloadPyramid && l < nlevels_; l++) {
       int32_t wl, hl;
       ps_orb_level_size(h_, image.cols, image.rows, l, &wl, &hl);
       parents_[l].create(hl + 38, wl + 38, 0);
@@ -47,7 +48,7 @@ class ORBextractor {
     int n = 0;
     static_assert(sizeof(pscv::KeyPoint) == sizeof(ps_keypoint), "KeyPoint layout");
     if (ps_orb_extract(h_, image.data, image.cols, image.rows, (int)image.step, (ps_keypoint*)keypoints.data(), desc.data(),
-                       cap, &n, planes.data()) != PS_OK)
+                       cap, &n, mbDownloadPyramid ? planes.data() : nullptr) != PS_OK)
       throw std::runtime_error(std::string("ps_orb_extract: ") + ps_last_error());
     keypoints.resize(n);
     if (n == 0) { descriptors.release(); return; }               // :1064-1065
@@ -63,6 +64,8 @@ class ORBextractor {
   std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
   std::vector<pscv::Mat> mvImagePyramid;   // public in the reference: Frame::ComputeStereoMatches reads it
+  bool mbDownloadPyramid = true;           // not in the reference: see operator()
+  ps_orb* handle() { return h_; }          // for the device-resident stereo matcher
 
  protected:
   ps_orb* h_ = nullptr;

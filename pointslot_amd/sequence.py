@@ -87,8 +87,9 @@ def generate(n_frames=20, seed=4, w=1242, h=375, step=0.08, n_boxes=2, K=KITTI_K
     return {"left": left, "right": right, "twc": twc, "boxes": boxes, "seg": seg, "K": (fx, fy, cx, cy), "bf": float(bf)}
 
 
-def write(seq_dir, seq, dt=0.1):
-    """Writes `seq` (from generate()) in the reference's on-disk layout."""
+def write(seq_dir, seq, dt=0.1, pgm=False):
+    """Writes `seq` (from generate()) in the reference's on-disk layout.  pgm=True adds binary PGM copies of the stereo images
+    next to the PNGs (examples/stereo_kitti.cpp reads those: the build image has no PNG decoder for C++)."""
     from PIL import Image
     for d in ("image_02", "image_03", "Segmentation"):
         os.makedirs(os.path.join(seq_dir, d), exist_ok=True)
@@ -97,6 +98,11 @@ def write(seq_dir, seq, dt=0.1):
         Image.fromarray(seq["left"][k]).save(os.path.join(seq_dir, "image_02", "%06d.png" % k))
         Image.fromarray(seq["right"][k]).save(os.path.join(seq_dir, "image_03", "%06d.png" % k))
         Image.fromarray(seq["seg"][k]).save(os.path.join(seq_dir, "Segmentation", "%06d.png" % k))
+        if pgm:
+            for d, im in (("image_02", seq["left"][k]), ("image_03", seq["right"][k])):
+                with open(os.path.join(seq_dir, d, "%06d.pgm" % k), "wb") as f:
+                    f.write(b"P5\n%d %d\n255\n" % (im.shape[1], im.shape[0]))
+                    f.write(np.ascontiguousarray(im).tobytes())
     with open(os.path.join(seq_dir, "timestamp.txt"), "w") as f:
         for k in range(n):
             f.write("%.6f\n" % (k * dt))
