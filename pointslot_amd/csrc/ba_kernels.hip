@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
     double rho = (S.current_chi - temp) / (scale + 1e-3);
     int restore = 0;
     if (rho > 0 && isfinite(temp)) {
-      double alpha = 1. - pow((2 * rho - 1), 3);
+      double alpha = 1. - se3_cube(2 * rho - 1);
       alpha = fmin(alpha, 2. / 3.);
       S.lambda *= fmax(1. / 3., alpha);
       S.ni = 2;

@@ -114,15 +114,35 @@ __device__ __forceinline__ void edge_error(const Se3& T, const PoProb& P, const 
 }
 
 // state byte per edge: bit0 valid, bit1 level 1 (outlier, inactive), bit2 mono
+// one edge's inputs; the edge loops fetch the NEXT edge before they work on the current one, so a pass pays one L2 round trip
+// instead of one per edge (a thread owns n / PO_T edges, PO_T apart)
+struct PoEdge { float x0, x1, x2, o0, o1, o2, is2; uint8_t st; };
+__device__ __forceinline__ PoEdge po_load(const float* xw, const float* obs, const float* inv_sigma2, const uint8_t* state, int i) {
+  PoEdge e;
+  e.x0 = xw[3 * i]; e.x1 = xw[3 * i + 1]; e.x2 = xw[3 * i + 2];
+  e.o0 = obs[3 * i]; e.o1 = obs[3 * i + 1]; e.o2 = obs[3 * i + 2];
+  e.is2 = inv_sigma2[i]; e.st = state[i];
+  return e;
+}
 #define ST_VALID 1
 #define ST_LVL1 2
 #define ST_MONO 4
 
+#ifdef PS_PO_PROFILE   // developer build: 100 MHz ticks per phase of problem 0, printed by the kernel
+#define POP_DECL long long po_t0 = wall_clock64(), po_tt = po_t0, po_ph[5] = {0, 0, 0, 0, 0}; int po_n[5] = {0, 0, 0, 0, 0}
+#define POP_MARK(k) do { const long long _n = wall_clock64(); po_ph[k] += _n - po_tt; po_tt = _n; po_n[k]++; } while (0)
+#define POP_PRINT() do { if (threadIdx.x == 0 && blockIdx.x == 0) printf("pose_lm ticks: setup/other %lld (%d) linearize %lld (%d) solve %lld (%d) trial %lld (%d) classify %lld (%d) total %lld\n", po_ph[0], po_n[0], po_ph[1], po_n[1], po_ph[2], po_n[2], po_ph[3], po_n[3], po_ph[4], po_n[4], wall_clock64() - po_t0); } while (0)
+#else
+#define POP_DECL
+#define POP_MARK(k)
+#define POP_PRINT()
+#endif
 __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVertex* verts, const float* xw,
                                                 const float* obs, const float* inv_sigma2, const uint8_t* valid,
                                                 uint8_t* outlier, double* chi2c, uint8_t* state, double* poses,
                                                 int32_t* results, double* trace) {
   __shared__ PoShared s;
+  POP_DECL;
   const PoProb P = probs[blockIdx.x];
   const int tid = threadIdx.x;
   const int k = P.k;
@@ -193,6 +213,7 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
       int nBad = 0;
       for (int iter = 0; iter < 10; iter++) {
         // ---- computeActiveErrors + buildSystem ----
+        POP_MARK(0);
         double chi_total = 0;
         for (int o = 0; o < k; o++) {
           const PoVertex V = verts[P.v_off + o];
@@ -200,13 +221,18 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
           double acc[28];
 #pragma unroll
           for (int a = 0; a < 28; a++) acc[a] = 0;
+          PoEdge nx = {};
+          if (V.e_begin + tid < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, V.e_begin + tid);
           for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
-            const uint8_t st = state[i];
+            const PoEdge ed = nx;
+            if (i + PO_T < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, i + PO_T);
+            const uint8_t st = ed.st;
             if ((st & (ST_VALID | ST_LVL1)) != ST_VALID) continue;
             const bool mono = st & ST_MONO;
             double p[3], e[3];
-            edge_error(T, P, &xw[3 * i], &obs[3 * i], mono, p, e);
-            const double w = (double)inv_sigma2[i];
+            const float exw[3] = {ed.x0, ed.x1, ed.x2}, eob[3] = {ed.o0, ed.o1, ed.o2};
+            edge_error(T, P, exw, eob, mono, p, e);
+            const double w = (double)ed.is2;
             const double chi2 = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * w;
             chi2c[i] = chi2;
             double rho0 = chi2, rho1 = 1.0;
@@ -270,6 +296,7 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
           chi_total += s.out[27];
         }
         __syncthreads();
+        POP_MARK(1);
         double currentChi = chi_total;
         const double iniChi = currentChi;
         if (iter == 0) {   // computeLambdaInit: tau * max |H_jj| over all vertices (levenberg.cpp:166-180)
@@ -293,29 +320,52 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
           __syncthreads();
           if (tid == 0) {
             double xs[PS_PO_MAX_K][6];
-            for (int o = 0; o < k && ok2; o++) {
-              // unpivoted LDL^T of the 6x6 block (LinearSolverDense uses Eigen::LDLT + isPositive())
+            for (int o = 0; o < k; o++) {
+              // unpivoted LDL^T of the 6x6 block (LinearSolverDense uses Eigen::LDLT + isPositive()).  Every loop has
+              // compile-time bounds and there is no early exit, so A / D / y live in registers (a `break` or a data-dependent
+              // bound sends them to scratch memory, one L2 round trip per access); a failed pivot only clears ok2.
               double A[6][6], D[6];
-              int a = 0;
-              for (int r = 0; r < 6; r++)
-                for (int c = r; c < 6; c++) { A[r][c] = s.H[o][a]; A[c][r] = s.H[o][a]; a++; }
+              {
+                int a = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                  for (int c = r; c < 6; c++) { A[r][c] = s.H[o][a]; A[c][r] = s.H[o][a]; a++; }
+              }
+#pragma unroll
               for (int j = 0; j < 6; j++) A[j][j] += lambda;
-              for (int j = 0; j < 6 && ok2; j++) {
+#pragma unroll
+              for (int j = 0; j < 6; j++) {
                 double d = A[j][j];
+#pragma unroll
                 for (int q = 0; q < j; q++) d -= A[j][q] * A[j][q] * D[q];
-                if (!(d > 0)) { ok2 = false; break; }
+                if (!(d > 0)) ok2 = false;
                 D[j] = d;
+#pragma unroll
                 for (int i = j + 1; i < 6; i++) {
                   double v = A[i][j];
+#pragma unroll
                   for (int q = 0; q < j; q++) v -= A[i][q] * A[j][q] * D[q];
                   A[i][j] = v / d;
                 }
               }
-              if (!ok2) break;
               double y[6];
-              for (int i = 0; i < 6; i++) { double v = s.b[o][i]; for (int q = 0; q < i; q++) v -= A[i][q] * y[q]; y[i] = v; }
+#pragma unroll
+              for (int i = 0; i < 6; i++) {
+                double v = s.b[o][i];
+#pragma unroll
+                for (int q = 0; q < i; q++) v -= A[i][q] * y[q];
+                y[i] = v;
+              }
+#pragma unroll
               for (int i = 0; i < 6; i++) y[i] /= D[i];
-              for (int i = 5; i >= 0; i--) { double v = y[i]; for (int q = i + 1; q < 6; q++) v -= A[q][i] * xs[o][q]; xs[o][i] = v; }
+#pragma unroll
+              for (int i = 5; i >= 0; i--) {
+                double v = y[i];
+#pragma unroll
+                for (int q = i + 1; q < 6; q++) v -= A[q][i] * xs[o][q];
+                xs[o][i] = v;
+              }
             }
             if (ok2)
               for (int o = 0; o < k; o++)
@@ -332,17 +382,23 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
           for (int o = 0; o < k; o++)
             for (int j = 0; j < 6; j++) scale += s.x[o][j] * (lambda * s.x[o][j] + s.b[o][j]);
           // ---- computeActiveErrors at the trial estimate ----
+          POP_MARK(2);
           double c1[1] = {0};
           for (int o = 0; o < k; o++) {
             const PoVertex V = verts[P.v_off + o];
             const Se3 T = load_pose(s.pose[o]);
+            PoEdge nx = {};
+            if (V.e_begin + tid < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, V.e_begin + tid);
             for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
-              const uint8_t st = state[i];
+              const PoEdge ed = nx;
+              if (i + PO_T < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, i + PO_T);
+              const uint8_t st = ed.st;
               if ((st & (ST_VALID | ST_LVL1)) != ST_VALID) continue;
               const bool mono = st & ST_MONO;
               double p[3], e[3];
-              edge_error(T, P, &xw[3 * i], &obs[3 * i], mono, p, e);
-              const double chi2 = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * (double)inv_sigma2[i];
+              const float exw[3] = {ed.x0, ed.x1, ed.x2}, eob[3] = {ed.o0, ed.o1, ed.o2};
+              edge_error(T, P, exw, eob, mono, p, e);
+              const double chi2 = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * (double)ed.is2;
               chi2c[i] = chi2;
               double rho0 = chi2, rho1;
               if (robust) huber(chi2, mono ? deltaMono : deltaStereo, rho0, rho1);
@@ -357,11 +413,12 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
             }
           }
           block_sum<1>(c1, s);
+          POP_MARK(3);
           double tempChi = s.out[0];
           if (!ok2) tempChi = DBL_MAX;
           rho = (currentChi - tempChi) / (scale + 1e-3);
           if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - pow((2 * rho - 1), 3);
+            double alpha = 1. - se3_cube(2 * rho - 1);
             alpha = fmin(alpha, 2. / 3.);
             lambda *= fmax(1. / 3., alpha);
             ni = 2;
@@ -384,6 +441,7 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
     }
     // ---- chi-square classification (Optimizer.cc:404-466 / :652-725) ----
     __syncthreads();
+    POP_MARK(0);
     int bad = 0;
     for (int o = 0; o < k; o++) {
       const PoVertex V = verts[P.v_off + o];
@@ -407,6 +465,7 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
     double c1[1] = {(double)bad};
     block_sum<1>(c1, s);
     nBadTotal = (int)s.out[0];
+    POP_MARK(4);
   }
   __syncthreads();
   for (int i = tid; i < k * 7; i += PO_T) poses[(size_t)P.v_off * 7 + i] = (&s.pose[0][0])[i];
@@ -414,6 +473,7 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
     results[blockIdx.x] = P.mode == 0 ? nInitial - nBadTotal : 1;
     if (tr && ntr < PS_PO_TRACE) tr[3 * ntr + 2] = -1;   // terminator
   }
+  POP_PRINT();
 }
 
 }  // namespace

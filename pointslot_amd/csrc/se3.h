@@ -85,6 +85,29 @@ PS_HD Se3 se3_from_Rt(const double R[9], const double t[3]) {
 }
 // SE3Quat::exp (se3quat.h:248-279).  norollpitch: exptwist_norollpitch (src/g2o_Object.cc:26-56) —
 // R = Rz(omega_z), V from the full Rodrigues series of omega.
+// sin / cos / cube for the exponential map.  On the device the library routines (argument reduction for any magnitude, a generic
+// pow) cost more than the rest of the 6x6 solve they sit in: angles below pi/4 - every LM step in practice - take the classic
+// polynomial kernels directly and x^3 is two multiplications (<= 1 ulp from the library values; the optimisers are a tolerance
+// target).  The host build keeps libm.
+#if defined(__HIP_DEVICE_COMPILE__)
+PS_HD void se3_sincos(double x, double& sn, double& cs) {
+  if (fabs(x) < 0.78539816339744830962) {
+    const double z = x * x;
+    double ps = 1.58962301576546568060e-10;
+    ps = fma(ps, z, -2.50507477628578072866e-8); ps = fma(ps, z, 2.75573136213857245213e-6); ps = fma(ps, z, -1.98412698295895385996e-4);
+    ps = fma(ps, z, 8.33333333332211858878e-3); ps = fma(ps, z, -1.66666666666666307295e-1);
+    sn = fma(x * z, ps, x);
+    double pc = -1.13585365213876817300e-11;
+    pc = fma(pc, z, 2.08757008419747316778e-9); pc = fma(pc, z, -2.75573141792967388112e-7); pc = fma(pc, z, 2.48015872888517045348e-5);
+    pc = fma(pc, z, -1.38888888888730564116e-3); pc = fma(pc, z, 4.16666666666665929218e-2);
+    cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+  } else { sn = sin(x); cs = cos(x); }
+}
+PS_HD double se3_cube(double x) { return x * x * x; }
+#else
+PS_HD void se3_sincos(double x, double& sn, double& cs) { sn = sin(x); cs = cos(x); }
+PS_HD double se3_cube(double x) { return pow(x, 3); }
+#endif
 PS_HD Se3 se3_exp(const double u[6], bool norollpitch) {
   const double wx = u[0], wy = u[1], wz = u[2];
   const double theta = sqrt(wx * wx + wy * wy + wz * wz);
@@ -94,18 +117,23 @@ PS_HD Se3 se3_exp(const double u[6], bool norollpitch) {
     for (int c = 0; c < 3; c++) Om2[r * 3 + c] = Om[r * 3] * Om[c] + Om[r * 3 + 1] * Om[3 + c] + Om[r * 3 + 2] * Om[6 + c];
   double R[9], V[9];
   if (norollpitch) {
-    const double c = cos(wz), s = sin(wz);
+    double c, s;
+    se3_sincos(wz, s, c);
     R[0] = c; R[1] = -s; R[2] = 0; R[3] = s; R[4] = c; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
     if (theta < 0.00001) {
       for (int i = 0; i < 9; i++) V[i] = R[i];
     } else {
-      const double a = (1 - cos(theta)) / (theta * theta), b = (theta - sin(theta)) / pow(theta, 3);
+      double st, ct;
+      se3_sincos(theta, st, ct);
+      const double a = (1 - ct) / (theta * theta), b = (theta - st) / se3_cube(theta);
       for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
     }
   } else if (theta < 0.00001) {
     for (int i = 0; i < 9; i++) { R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
   } else {
-    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
+    double st, ct;
+    se3_sincos(theta, st, ct);
+    const double a = st / theta, b = (1 - ct) / (theta * theta), c = (theta - st) / se3_cube(theta);
     for (int i = 0; i < 9; i++) {
       const double I = (i % 4 == 0) ? 1.0 : 0.0;
       R[i] = I + a * Om[i] + b * Om2[i];
