@@ -44,6 +44,10 @@ typedef struct ps_keypoint {
 const char* ps_last_error(void);
 int ps_device_count(int* count);
 const char* ps_version(void);
+/* Test / diagnostic: fills the LDS of every CU of `device` with the 32-bit `pattern` (e.g. 0xFFFFFFFF: NaN when read as floating
+ * point) and leaves it there.  LDS is not cleared between kernels, so a kernel that reads LDS it never wrote - or multiplies such
+ * a slot by zero - then misbehaves deterministically instead of once in a while; the GPU tests call this before the kernels. */
+int ps_debug_poison_lds(int device, uint32_t pattern);
 
 /* ------------------------------------------------------------------------------------------------
  * ORB extractor — replaces ORB_SLAM2::ORBextractor (/root/reference/include/ORBextractor.h:51-85,

@@ -63,3 +63,9 @@ def device_count():
     n = ctypes.c_int(0)
     rc = lib.ps_device_count(ctypes.byref(n))
     return n.value if rc == PS_OK else 0
+
+
+def poison_lds(pattern=0xFFFFFFFF, device=0):
+    """Test / diagnostic: leave `pattern` in the LDS of every CU (see ps_debug_poison_lds)."""
+    lib.ps_debug_poison_lds.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    check(lib.ps_debug_poison_lds(device, pattern))

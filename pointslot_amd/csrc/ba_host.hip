@@ -140,6 +140,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
     wb += (size_t)P.np * P.nl * 18; sb += (size_t)36 * P.np * P.np;
   }
   PS_HIP(hipMemcpyAsync(D, H, L.host_end, hipMemcpyHostToDevice, st));
+  if (const char* fill = getenv("PS_BA_FILL")) PS_HIP(hipMemsetAsync(D + L.host_end, atoi(fill), L.end - L.host_end, st));   // diagnostic: poison the work arrays
   // W must start as zeros: (pose, point) pairs without an edge are never written (see ba_lin_pose)
   PS_HIP(hipMemsetAsync(D + L.W, 0, NW * 8, st));
   PS_HIP(hipMemsetAsync(D + L.chi2c, 0, NE * 8 + 64, st));

@@ -540,7 +540,10 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   double* panel = rdj + NB;                     // [rows below][NB + 1]
   __shared__ int fail;
   if (tid == 0) fail = 0;
-  for (int i = tid; i < n; i += SOL_T) rhs[i] = A.bs[(size_t)P.pose_base * 6 + i];
+  // LDS keeps whatever the previous kernel on this CU left there, NaN bit patterns included, and 0 * NaN is not 0: every slot
+  // that a partial last block touches with a zero multiplier (rhs beyond n, pivots beyond jb) is given a finite value first
+  for (int i = tid; i < 6 * PS_BA_MAX_POSES; i += SOL_T) { rhs[i] = i < n ? A.bs[(size_t)P.pose_base * 6 + i] : 0.0; dall[i] = 1.0; }
+  if (tid < NB) { dj[tid] = 0.0; rdj[tid] = 0.0; }
   __syncthreads();
   if (n == 0) { if (tid == 0) St.ok2 = 1; return; }
   SOLP_DECL;
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
           if (c < lane) { Ljj[lane * (NB + 1) + c] = a[c]; Sm[(size_t)(J + lane) * lda + J + c] = a[c]; }
           else if (c == lane) { dj[lane] = a[c]; dall[J + lane] = a[c]; }
         }
-      }
+      } else if (lane < NB) { dj[lane] = 0.0; rdj[lane] = 0.0; }   // columns of a partial block that do not exist
       if (bad && lane == 0) fail = 1;
     }
     __syncthreads();
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
 #pragma unroll
       for (int c = 0; c < NB; c++) lc[c] = c < jb ? Sm[(size_t)(J + c) * lda + k] : 0.0;
 #pragma unroll
-      for (int c = 0; c < NB; c++) v -= lc[c] * rhs[J + c];
+      for (int c = 0; c < NB; c++) if (c < jb) v -= lc[c] * rhs[J + c];
       rhs[k] = v;
     }
     __syncthreads();

@@ -38,6 +38,7 @@ struct PoShared {
   double H[PS_PO_MAX_K][21];
   double b[PS_PO_MAX_K][6];
   double x[PS_PO_MAX_K][6];
+  double xnew[PS_PO_MAX_K][6];      // candidate step of the current solve (committed to x only when every block factorises)
   double prior_obs[PS_PO_MAX_K][3];
   double prior_err[PS_PO_MAX_K][3];
   uint8_t prior_robust[PS_PO_MAX_K];
@@ -275,12 +276,14 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
             acc[27] += rho0;
             double J[3][6];
             const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+#pragma unroll
             for (int d = 0; d < 6; d++) {
               double add[6] = {0, 0, 0, 0, 0, 0};
               add[d] = delta;
               const Se3 Tp = se3_mul(se3_exp(add, false), T);
               add[d] = -delta;
               const Se3 Tm = se3_mul(se3_exp(add, false), T);
+#pragma unroll
               for (int r = 0; r < 3; r++)
                 J[r][d] = scalar * ((s.prior_obs[o][r] - Tp.t[r]) - (s.prior_obs[o][r] - Tm.t[r]));
             }
@@ -319,7 +322,6 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
           for (int i = tid; i < k * 7; i += PO_T) (&s.backup[0][0])[i] = (&s.pose[0][0])[i];
           __syncthreads();
           if (tid == 0) {
-            double xs[PS_PO_MAX_K][6];
             for (int o = 0; o < k; o++) {
               // unpivoted LDL^T of the 6x6 block (LinearSolverDense uses Eigen::LDLT + isPositive()).  Every loop has
               // compile-time bounds and there is no early exit, so A / D / y live in registers (a `break` or a data-dependent
@@ -359,17 +361,20 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
               }
 #pragma unroll
               for (int i = 0; i < 6; i++) y[i] /= D[i];
+              double xv[6];
 #pragma unroll
               for (int i = 5; i >= 0; i--) {
                 double v = y[i];
 #pragma unroll
-                for (int q = i + 1; q < 6; q++) v -= A[q][i] * xs[o][q];
-                xs[o][i] = v;
+                for (int q = i + 1; q < 6; q++) v -= A[q][i] * xv[q];
+                xv[i] = v;
               }
+#pragma unroll
+              for (int i = 0; i < 6; i++) s.xnew[o][i] = xv[i];
             }
             if (ok2)
               for (int o = 0; o < k; o++)
-                for (int j = 0; j < 6; j++) s.x[o][j] = xs[o][j];
+                for (int j = 0; j < 6; j++) s.x[o][j] = s.xnew[o][j];
             s.icount = ok2 ? 1 : 0;
             // update: estimate <- exp(x) * estimate (VertexSE3Expmap::oplusImpl), with whatever x holds
             for (int o = 0; o < k; o++) {

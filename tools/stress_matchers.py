@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
+from pointslot_amd._lib import poison_lds
 import oracle_lib
 from pointslot_amd import synth
 from pointslot_amd.matcher import ORBmatcher, build_grid
@@ -12,6 +13,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 nscenes = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
 for it in range(nscenes):
+    poison_lds(0xFFFFFFFF if it % 2 == 0 else 0x7FF00000)      # uninitialised-LDS reads become deterministic failures
     n = int(rng.choice([60, 300, 1000, 2000, 3000])); m = int(rng.choice([40, 500, 1500, 4000]))
     th = float(rng.choice([3.0, 7.0, 15.0, 30.0]))
     w, h = (1241, 376) if rng.random() < 0.7 else (400, 200)       # the small image makes many queries fight for few keypoints

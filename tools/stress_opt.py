@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
+from pointslot_amd._lib import poison_lds
 import oracle_lib
 from pointslot_amd import synth
 from pointslot_amd.optimizer import Optimizer
@@ -10,6 +11,7 @@ from pointslot_amd.optimizer import Optimizer
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 opt = Optimizer()
+poison_lds(0xFFFFFFFF)      # uninitialised-LDS reads become deterministic failures
 bad = 0
 frames = []
 for it in range(ncase):

@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
+from pointslot_amd._lib import poison_lds
 from oracle_lib import OracleORB
 from pointslot_amd import synth
 from pointslot_amd.extractor import ORBextractor
@@ -12,6 +13,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 bad = 0
 for it in range(ncase):
+    poison_lds(0xFFFFFFFF if it % 2 == 0 else 0x7FF00000)      # uninitialised-LDS reads become deterministic failures
     nlev = int(rng.choice([1, 3, 5, 8])); scale = float(rng.choice([1.2, 1.2, 1.2, 1.1, 1.4, 2.0]))
     if scale == 2.0:
         nlev = min(nlev, 4)
