@@ -4,6 +4,7 @@
 // host<->device traffic inside the loop is one 4-byte counter per global step.
 // Replaces Optimizer::ObjectLocalBundleAdjustment (/root/reference/src/Optimizer.cc:820-1075; the graph
 // collection of :755-818 stays on the host, in the caller).
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <vector>
@@ -32,6 +33,7 @@ int ensure(BaCtx* c, size_t dbytes, size_t hbytes) {
     if (c->d_buf) hipFree(c->d_buf);
     c->d_buf = nullptr;
     PS_HIP(hipMalloc(&c->d_buf, dbytes));
+    if (const char* fill = getenv("PS_DEBUG_FILL")) PS_HIP(hipMemset(c->d_buf, atoi(fill), dbytes));   // diagnostic: poison fresh device memory
     c->d_bytes = dbytes;
   }
   if (hbytes > c->h_bytes) {

@@ -1,6 +1,7 @@
 // Host side of the matcher C-ABI (include/pointslot_hip.h): packs the caller's per-object problems into
 // one upload, launches the kernels of match_kernels.hip on the handle's stream, copies the results back.
 // Replaces ORBmatcher::SearchByBruceMatching / DescriptorDistance — /root/reference/src/ORBmatcher.cc.
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <vector>
@@ -33,6 +34,7 @@ int ensure(ps_matcher* m, size_t bytes) {
     if (m->d_buf) hipFree(m->d_buf);
     m->d_buf = nullptr;
     PS_HIP(hipMalloc(&m->d_buf, bytes));
+    if (const char* fill = getenv("PS_DEBUG_FILL")) PS_HIP(hipMemset(m->d_buf, atoi(fill), bytes));   // diagnostic: poison fresh device memory
     m->d_bytes = bytes;
   }
   if (bytes > m->h_bytes) {

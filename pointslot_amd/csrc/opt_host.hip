@@ -2,6 +2,7 @@
 // problems into one device arena, launches the persistent LM kernels, copies the results back.
 // Replaces Optimizer::PoseOptimization / CFSE3ObjStateOptimization / ObjectLocalBundleAdjustment
 // (/root/reference/src/Optimizer.cc:249-1075) and the g2o machinery underneath.
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <vector>
@@ -34,6 +35,7 @@ int ensure(ps_optimizer* m, size_t bytes) {
     if (m->d_buf) hipFree(m->d_buf);
     m->d_buf = nullptr;
     PS_HIP(hipMalloc(&m->d_buf, bytes));
+    if (const char* fill = getenv("PS_DEBUG_FILL")) PS_HIP(hipMemset(m->d_buf, atoi(fill), bytes));   // diagnostic: poison fresh device memory
     m->d_bytes = bytes;
   }
   if (bytes > m->h_bytes) {

@@ -265,7 +265,10 @@ int build_plan(ps_orb* h, int w, int hgt) {
   free_device(h);
   const int B = h->cfg.max_batch;
   PS_HIP(hipMalloc(&h->d_arena, P.arena_bytes * B));
-  PS_HIP(hipMemsetAsync(h->d_arena, 0, P.arena_bytes * B, h->stream));
+  {   // PS_DEBUG_FILL (diagnostic): a byte pattern instead of zeros, to prove that nothing depends on the initial content
+    const char* fill = getenv("PS_DEBUG_FILL");
+    PS_HIP(hipMemsetAsync(h->d_arena, fill ? atoi(fill) : 0, P.arena_bytes * B, h->stream));
+  }
   PS_HIP(hipMalloc(&h->d_tabs, (h->tabs_host.size() + 1) * sizeof(int4)));
   if (!h->tabs_host.empty())
     PS_HIP(hipMemcpyAsync(h->d_tabs, h->tabs_host.data(), h->tabs_host.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
