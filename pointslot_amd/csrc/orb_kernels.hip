@@ -1,13 +1,14 @@
 // CDNA4 (gfx950) kernels of the ORB front-end.  Wave = 64 lanes everywhere.
 //
-// Pipeline per batch of images (all images of a batch in one launch, image = blockIdx.z / .y):
-//   orb_pyramid_level   x nlevels  cascaded bilinear pyramid, writes the 19-px REFLECT_101 border too
-//   orb_fast_cells      x 1        one workgroup per 30-px FAST cell: score map in LDS, per-cell NMS,
-//                                  threshold fallback, raster-ordered compaction into the cell's slots
-//   orb_quadtree        x 1        one workgroup per (image, level): DistributeOctTree as parallel
-//                                  key passes + node-level list bookkeeping in LDS
-//   orb_blur            x 1        7x7 sigma-2 fixed-point Gaussian, register sliding window
-//   orb_describe        x 1        one wave per keypoint: intensity-centroid angle + 256-bit rBRIEF
+// Pipeline per batch of images (all images of a batch in one launch):
+//   orb_level_fused     x nlevels  one launch per level: bilinear level (OpenCV fixed point), its 19-px REFLECT_101 border and
+//                                  its 7x7 sigma-2 blurred plane, the blur taken from LDS
+//   orb_fast_cells      x 1        one wave per 30-px FAST cell: necessary test on packed u16 trees, exact score of the
+//                                  survivors, per-cell NMS, iniThFAST / minThFAST fallback, raster-ordered compaction
+//   orb_quadtree        x 1        one workgroup per (level, image): DistributeOctTree as parallel key passes + node-level
+//                                  list bookkeeping in LDS
+//   orb_describe        x 1        one wave per keypoint: intensity-centroid angle + 256-bit rBRIEF from an LDS-staged patch
+// (orb_pyramid_level / orb_border / orb_blur are the unfused forms of the first stage, kept behind PS_ORB_FUSED=0.)
 //
 // Reference semantics each kernel reproduces are cited at the kernel.  Integer stages are exact;
 // float expressions use __f*_rn intrinsics so that hipcc cannot contract them into FMAs.
