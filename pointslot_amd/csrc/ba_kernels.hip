@@ -558,26 +558,38 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       double a[NB];
 #pragma unroll
       for (int c = 0; c < NB; c++) a[c] = (lane < jb && c <= lane) ? Sm[(size_t)(J + lane) * lda + J + c] : 0.0;
+#ifdef PS_BA_PROFILE
+      { double chk = 0; for (int c = 0; c < NB; c++) chk += a[c]; if (chk == 1.2345e300) fail = 2; }
+      SOLP_MARK(3);
+#endif
       bool bad = false;
+      // The critical path of a step is pivot -> reciprocal -> multiplier -> update of the NEXT pivot column; the other 22 updates
+      // are off it.  The next pivot is therefore updated first and its reciprocal started before the rest of the row is touched.
+      double d = shfl_d(a[0], 0), rd = recip_d(d);
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         if (j < jb) {
-          const double d = shfl_d(a[j], j);
           if (d == 0) bad = true;
-          const double rd = recip_d(d);
           if (lane == j) rdj[j] = rd;
           const double l = lane > j ? a[j] * rd : 0.0;
-          double* lc = lcol + (j & 1) * 64;
-          lc[lane] = l;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // the other rows' multipliers come straight out of their lanes' registers (v_readlane into a scalar pair that feeds
+          // the FMA): no LDS round trip
           const double ld = l * d;
+          double dn = 1.0, rdn = 1.0;
+          if (j + 1 < NB) {
+            a[j + 1] -= ld * shfl_d(l, j + 1);
+            dn = shfl_d(a[j + 1], j + 1);
+            rdn = recip_d(dn);
+          }
 #pragma unroll
-          for (int k = j + 1; k < NB; k++) a[k] -= ld * lc[k];
+          for (int k = j + 2; k < NB; k++) a[k] -= ld * shfl_d(l, k);
           if (lane > j) a[j] = l;
+          d = dn; rd = rdn;
         }
       }
+#ifdef PS_BA_PROFILE
+      SOLP_MARK(4);
+#endif
       if (lane < jb) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
