@@ -523,6 +523,7 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
 #define SOLP_MARK(k)
 #define SOLP_PRINT()
 #endif
+typedef double sol_d4 __attribute__((ext_vector_type(4)));
 template <int NB>
 __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   const BaProb P = A.prob[blockIdx.x];
@@ -653,51 +654,38 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       rhs[m0 + i] = v;
     }
     SOLP_MARK(1);
-    // ---- (3) trailing update, lower triangle, 1 x 4 register blocking ----
-    // 4 x 4 register blocking with lanes along the COLUMN index (row-major S: consecutive lanes write consecutive
-    // doubles): a thread owns 4 consecutive rows and columns k, k+64, k+128, k+192 of a 256-column slab.  The
-    // column-side panel reads have stride (NB + 1) doubles (conflict-free), the row-side reads are LDS broadcasts.
-    const int iq = (m + 3) >> 2, ncs = (m + 255) >> 8;
-    for (int q = tid; q < ncs * iq * 64; q += SOL_T) {
-      const int kl = q & 63, i4 = ((q >> 6) % iq) * 4, cs = (q >> 6) / iq;
-      const int c0 = cs * 256 + kl;
-      if (c0 > min(i4 + 3, m - 1)) continue;
-      // the 16 old values of S are fetched first: their L2 latency hides behind the NB-deep accumulation
-      double acc[4][4];
+    // ---- (3) trailing update S_22 -= L_21 D L_21^T on the FP64 matrix cores: 16 x 16 tiles of the lower triangle, one tile per wave
+    // at a time, K = NB in steps of 4 (v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+    // C/D rows (lane >> 4) + 4 r, column lane & 15).  Both operands come from the panel in LDS (row stride NB + 1 doubles keeps
+    // the 16 rows of a tile on different banks); the accumulator starts from the tile of S, so one pass reads and writes it once.
+    {
+      const int wave = tid >> 6, nwave = SOL_T / 64;
+      const int ntile = (m + 15) >> 4, ntri = ntile * (ntile + 1) / 2;
+      const int li = lane & 15, lk = lane >> 4;
+      for (int t = wave; t < ntri; t += nwave) {
+        int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (ti * (ti + 1) / 2 > t) ti--;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+        const int tj = t - ti * (ti + 1) / 2;
+        const int I0 = ti * 16, J0 = tj * 16;
+        const int col = J0 + li;
+        sol_d4 acc;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int i = min(i4 + r, m - 1);
-        const double* srow = Sm + (size_t)(m0 + i) * lda + m0;
-#pragma unroll
-        for (int c4 = 0; c4 < 4; c4++) {
-          const int k = c0 + 64 * c4;
-          acc[r][c4] = k <= i ? srow[k] : 0.0;
+        for (int r = 0; r < 4; r++) {
+          const int row = I0 + lk + 4 * r;
+          acc[r] = (row < m && col <= row) ? Sm[(size_t)(m0 + row) * lda + m0 + col] : 0.0;
         }
-      }
-      const double* pr = panel + (size_t)i4 * (NB + 1);
-      const double* q0 = panel + (size_t)min(c0, m - 1) * (NB + 1);
-      const double* q1 = panel + (size_t)min(c0 + 64, m - 1) * (NB + 1);
-      const double* q2 = panel + (size_t)min(c0 + 128, m - 1) * (NB + 1);
-      const double* q3 = panel + (size_t)min(c0 + 192, m - 1) * (NB + 1);
-#pragma unroll 4
-      for (int c = 0; c < NB; c++) {
-        const double dc = -dj[c];
-        const double a0 = pr[c] * dc, a1 = pr[(NB + 1) + c] * dc, a2 = pr[2 * (NB + 1) + c] * dc, a3 = pr[3 * (NB + 1) + c] * dc;
-        const double k0 = q0[c], k1 = q1[c], k2 = q2[c], k3 = q3[c];
-        acc[0][0] += a0 * k0; acc[0][1] += a0 * k1; acc[0][2] += a0 * k2; acc[0][3] += a0 * k3;
-        acc[1][0] += a1 * k0; acc[1][1] += a1 * k1; acc[1][2] += a1 * k2; acc[1][3] += a1 * k3;
-        acc[2][0] += a2 * k0; acc[2][1] += a2 * k1; acc[2][2] += a2 * k2; acc[2][3] += a2 * k3;
-        acc[3][0] += a3 * k0; acc[3][1] += a3 * k1; acc[3][2] += a3 * k2; acc[3][3] += a3 * k3;
-      }
+        const double* pa = panel + (size_t)min(I0 + li, m - 1) * (NB + 1);
+        const double* pb = panel + (size_t)min(J0 + li, m - 1) * (NB + 1);
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int i = i4 + r;
-        if (i >= m) continue;
-        double* dst = Sm + (size_t)(m0 + i) * lda + m0;
+        for (int kc = 0; kc < NB / 4; kc++) {
+          const int k = 4 * kc + lk;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k], -dj[k] * pb[k], acc, 0, 0, 0);
+        }
 #pragma unroll
-        for (int c4 = 0; c4 < 4; c4++) {
-          const int k = c0 + 64 * c4;
-          if (k <= i) dst[k] = acc[r][c4];
+        for (int r = 0; r < 4; r++) {
+          const int row = I0 + lk + 4 * r;
+          if (row < m && col <= row) Sm[(size_t)(m0 + row) * lda + m0 + col] = acc[r];
         }
       }
     }
