@@ -189,7 +189,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   const size_t in_bytes = off;
   const size_t o_match = take(NT * 4), o_nm = take((size_t)nprob * 4), o_ovf = take(4);
   const size_t out_end = off;
-  const size_t o_cand = take(NQ * PS_PJ_CAP * 4), o_ncand = take(NQ * 4), o_qbest = take(NQ * 4), o_qbin = take(NQ), o_tb = take(NQ * 4), o_ts = take(NQ * 4);
+  const size_t o_cand = take(NQ * PS_PJ_CAP * 4), o_ncand = take(NQ * 4), o_qbest = take(NQ * 4), o_qbin = take(NQ), o_tt = take(NQ * 16);
   int rc = ensure(m, off);
   if (rc != PS_OK) return rc;
   uint8_t* H = m->h_buf;
@@ -246,7 +246,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   A.qxw = (const float*)(D + o_qxw); A.qoct = (const int32_t*)(D + o_qoct);
   A.cand = (uint32_t*)(D + o_cand); A.ncand = (int32_t*)(D + o_ncand); A.match = (int32_t*)(D + o_match);
   A.nmatch = (int32_t*)(D + o_nm); A.overflow = (int32_t*)(D + o_ovf); A.qbest = (int32_t*)(D + o_qbest); A.qbin = D + o_qbin;
-  A.tbest = (uint32_t*)(D + o_tb); A.tsecond = (uint32_t*)(D + o_ts);
+  A.ttop = (uint4*)(D + o_tt);
   psk_pj_launch(&A, nprob, max_nq > 0 ? max_nq : 1, any_frame, m->stream);
   PS_HIP(hipGetLastError());
   PS_HIP(hipMemcpyAsync(H + o_match, D + o_match, out_end - o_match, hipMemcpyDeviceToHost, m->stream));

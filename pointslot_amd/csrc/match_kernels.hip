@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (qi >= P.nq) return;
   const int q = P.q_off + qi;
-  if (!A.qvalid[q]) { if (lane == 0) { A.ncand[q] = 0; A.tbest[q] = 0xFFFFFFFFu; A.tsecond[q] = 0xFFFFFFFFu; } return; }
+  if (!A.qvalid[q]) { if (lane == 0) { A.ncand[q] = 0; A.ttop[q] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); } return; }
   const float x = A.qu[q], y = A.qv[q], r = A.qrad[q], rer = A.qrer[q], ur = A.qur[q];
   const int minLevel = A.qminl[q], maxLevel = A.qmaxl[q];
   // Frame::GetFeaturesInArea cell range (Frame.cc:1813-1827)
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
   const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, P.min_y), r), P.gh_inv)));
   const int nMaxCellY = min(PS_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, P.min_y), r), P.gh_inv)));
   int count = 0;
-  uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;   // this lane's two smallest keys among the trains that are free at entry
+  uint32_t mk[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // this lane's four smallest keys among the trains free at entry
   if (nMinCellX < PS_GRID_COLS && nMaxCellX >= 0 && nMinCellY < PS_GRID_ROWS && nMaxCellY >= 0) {
     const bool check = (minLevel > 0) || (maxLevel >= 0);
     const uint4* qd = reinterpret_cast<const uint4*>(A.qdesc + (size_t)q * 32);
@@ -300,20 +300,33 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
         if (pass && pos < PS_PJ_CAP) {
           const uint32_t key = ((uint32_t)dist << 23) | ((uint32_t)pos << 15) | (uint32_t)j;
           A.cand[(size_t)q * PS_PJ_CAP + pos] = key;
-          if (!A.tocc[P.t_off + j]) { if (key < m1) { m2 = m1; m1 = key; } else if (key < m2) m2 = key; }
+          if (!A.tocc[P.t_off + j]) {   // sorted insertion
+            uint32_t kk = key;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const uint32_t lo = min(mk[r], kk); kk = max(mk[r], kk); mk[r] = lo; }
+          }
         }
         count += __popcll(m);
       }
     }
   }
-  // best and second-best of the query under the occupancy at entry: pj_resolve only falls back to the candidate list when an
-  // earlier query of the same call has taken one of the two
-  const uint32_t tb = wave_min_u32(m1);
-  const uint32_t ts = wave_min_u32(m1 == tb ? m2 : m1);
+  // the four smallest keys of the query under the occupancy at entry (keys are unique: they carry the traversal position):
+  // pj_resolve takes the first ones that no earlier query of the same call has claimed and only goes back to the candidate
+  // list when all four are gone
+  uint32_t top[4];
+  uint32_t prev = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    uint32_t c = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 3; u >= 0; u--) if (r == 0 || mk[u] > prev) c = min(c, mk[u]);
+    top[r] = wave_min_u32(c);
+    prev = top[r];
+  }
   if (lane == 0) {
     if (count > PS_PJ_CAP) { atomicAdd(A.overflow, 1); count = PS_PJ_CAP; }
     A.ncand[q] = count;
-    A.tbest[q] = tb; A.tsecond[q] = ts;
+    A.ttop[q] = make_uint4(top[0], top[1], top[2], top[3]);
   }
 }
 
@@ -341,6 +354,10 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   __syncthreads();
   const float factor = 30 / 360.0f;
   int nm = 0;
+#ifdef PS_PJ_PROFILE
+  const long long pj_t0 = wall_clock64();
+  long long pj_t1 = 0;
+#endif
   // Queries are taken in order (the assignment is order dependent), 64 at a time: the lane-resident candidate counts give
   // the non-empty queries of the block as a bit mask, and the first 64 candidate keys of the NEXT non-empty query are
   // requested before the current one is reduced, so the global-memory latency is paid once per block, not once per query.
@@ -350,31 +367,44 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
     const int qq = P.q_off + q0 + lane;
     const int ncv = qin ? A.ncand[qq] : 0;
     const int obsv = qin ? (int)A.qobs[qq] : 0;
-    const uint32_t tbv = qin ? A.tbest[qq] : 0xFFFFFFFFu, tsv = qin ? A.tsecond[qq] : 0xFFFFFFFFu;
+    const uint4 tt = qin ? A.ttop[qq] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    const uint32_t tk[4] = {tt.x, tt.y, tt.z, tt.w};
     if (qin) A.qbest[qq] = -1;
-    // conflicts with acceptances of earlier blocks: one LDS lookup per lane, in parallel
+    // claims of earlier blocks against the four keys: one LDS lookup per key and lane, in parallel
     int stale = 0;
-    if (tbv != 0xFFFFFFFFu) { const uint32_t j = tbv & 0x7FFF; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u); }
-    if (P.ratio_test && tsv != 0xFFFFFFFFu) { const uint32_t j = tsv & 0x7FFF; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u); }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (tk[r] != 0xFFFFFFFFu) { const uint32_t j = tk[r] & 0x7FFF; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u) << r; }
     unsigned long long pend = __builtin_amdgcn_ballot_w64(ncv > 0);
-    const unsigned long long stale_m = __builtin_amdgcn_ballot_w64(stale != 0);
     int accidx = -1;        // lane k: the train taken by the k-th observed acceptance of this block
     int nacc = 0;
+    int allq = -1, allt = 0, nall = 0;   // lane k: query and train of the k-th acceptance of this block (at most 64)
     while (pend) {
       const int i = __ffsll((long long)pend) - 1;
       pend &= pend - 1;
       const int qi = q0 + i, q = P.q_off + qi;
-      uint32_t best = (uint32_t)__builtin_amdgcn_readlane((int)tbv, i);
-      uint32_t second = (uint32_t)__builtin_amdgcn_readlane((int)tsv, i);
-      bool redo = (stale_m >> i) & 1ull;
-      if (!redo && best != 0xFFFFFFFFu && nacc > 0) {
-        const int bj = (int)(best & 0x7FFF), sj = (int)(second & 0x7FFF);
-        const bool hit = accidx == bj || (P.ratio_test && second != 0xFFFFFFFFu && accidx == sj);
-        redo = __builtin_amdgcn_ballot_w64(hit) != 0ull;
+      const int nc = __builtin_amdgcn_readlane(ncv, i);
+      const int sb = __builtin_amdgcn_readlane(stale, i);
+      // first (and, for the ratio test, second) of the four keys that nobody has claimed
+      uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+      bool need_scan = false;
+      {
+        int found = 0;
+        const int want = P.ratio_test ? 2 : 1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (found < want) {
+            const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)tk[r], i);
+            if (key != 0xFFFFFFFFu) {
+              bool taken = (sb >> r) & 1;
+              if (!taken && nacc > 0) taken = __builtin_amdgcn_ballot_w64(accidx == (int)(key & 0x7FFF)) != 0ull;
+              if (!taken) { if (found == 0) best = key; else second = key; found++; }
+            }
+          }
+        }
+        need_scan = found < want && nc > 4;   // the list may hold unclaimed candidates beyond the four
       }
-      if (redo) {
-        // an earlier query took the best or the second candidate: rescan the list under the current occupancy
-        const int nc = __builtin_amdgcn_readlane(ncv, i);
+      if (need_scan) {
         uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
         for (int c = lane; c < nc; c += 64) {
           const uint32_t k = A.cand[(size_t)q * PS_PJ_CAP + c];
@@ -395,27 +425,32 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
         // (no second candidate: bestLevel2 = -1 never equals an octave -> accepted)
       }
       const int observed = __builtin_amdgcn_readlane(obsv, i);
-      if (lane == 0) {
-        match[bestIdx] = qi;
-        A.qbest[q] = bestIdx;
-        if (observed) atomicOr(&newly[bestIdx >> 5], 1u << (bestIdx & 31));
-      }
+      // nothing leaves the wave inside the serial loop (a release fence after a global store waits for the store: ~0.4 us per
+      // accepted query): the claim goes to the LDS bitmap and to the lane-resident lists, the outputs are written per block
+      if (observed && lane == 0) atomicOr(&newly[bestIdx >> 5], 1u << (bestIdx & 31));
+      if (lane == nall) { allq = qi; allt = bestIdx; }
+      nall++;
       if (observed) {
         if (lane == nacc) accidx = bestIdx;
         nacc++;
       }
       nm++;
-      if (observed) {   // the bitmap must be in LDS before a later rescan reads it
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // outputs of the block: the reference's "last assignment wins" for a keypoint claimed twice (possible when the claimant
+    // is not observed) is the larger query index, i.e. an atomic max
+    if (lane < nall) {
+      atomicMax(&match[allt], allq);
+      A.qbest[P.q_off + allq] = allt;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   __syncthreads();
+#ifdef PS_PJ_PROFILE
+  pj_t1 = wall_clock64();
+#endif
   if (P.check_ori) {
     // rotHist[bin].push_back(...) of every assignment (ORBmatcher.cc:1716-1726); order inside a bin is irrelevant
     for (int qi = lane; qi < P.nq; qi += 64) {
@@ -454,6 +489,9 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
     nm -= removed;
   }
   if (lane == 0) A.nmatch[blockIdx.x] = nm;
+#ifdef PS_PJ_PROFILE
+  if (lane == 0 && blockIdx.x == 0) printf("pj_resolve nq %d nt %d: loop %lld ticks, tail %lld ticks, matches %d\n", P.nq, P.nt, pj_t1 - pj_t0, wall_clock64() - pj_t1, nm);
+#endif
 }
 
 }  // namespace

@@ -44,7 +44,7 @@ struct PjArrays {
   // work / outputs
   uint32_t* cand; int32_t* ncand; int32_t* match; int32_t* nmatch; int32_t* overflow;
   int32_t* qbest;                            // per query: matched train (or -1), for the rotation pass
-  uint32_t* tbest; uint32_t* tsecond;        // per query: best / second candidate key among the trains free at entry (pj_gather)
+  uint4* ttop;                               // per query: the four smallest candidate keys among the trains free at entry (pj_gather)
   uint8_t* qbin;
 };
 
