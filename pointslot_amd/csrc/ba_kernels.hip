@@ -429,6 +429,7 @@ __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
 // ONE (pose, point) pair of one side — its 6x3 W block is 18 contiguous doubles — the A side multiplies by D_l^-1 on
 // the fly; then every thread accumulates a 3 x 3 register block from the two LDS tiles.
 #define SCH_LC 16
+typedef double sch_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
   const BaProb P = A.prob[blockIdx.y];
   const BaState& St = A.state[blockIdx.y];
@@ -440,14 +441,19 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
   const int tb = rem;
   __shared__ double As[48][SCH_LC * 3 + 1];
   __shared__ double Bs[48][SCH_LC * 3 + 1];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int tid = threadIdx.x;
   // staging role of this thread
   const int side = tid >> 7, pl = (tid & 127) >> 4, lc = tid & 15;
   const int pc = (side == 0 ? ta : tb) * PS_BA_TILE + pl;               // compact pose index
   const bool pose_ok = pc < npa;
   const double* Wrow = pose_ok ? A.W + P.W_base + (size_t)A.pact[P.pose_base + pc] * P.nl * 18 : nullptr;
   double (*dstT)[SCH_LC * 3 + 1] = side == 0 ? As : Bs;
-  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  // 48 x 48 tile = 3 x 3 tiles of the FP64 matrix cores (v_mfma_f64_16x16x4_f64); wave w (< 3) owns tile row w.  The vector
+  // form of this contraction (3 x 3 register blocks, six LDS reads per nine FMAs) was bound by LDS instruction issue.
+  const int wv = tid >> 6, ln = tid & 63, li = ln & 15, lk = ln >> 4;
+  sch_d4 acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) acc[c] = sch_d4{0.0, 0.0, 0.0, 0.0};
   for (int l0 = 0; l0 < P.nl; l0 += SCH_LC) {
     const int l = l0 + lc;
     double w[18];
@@ -479,30 +485,32 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
 #pragma unroll
       for (int k = 0; k < 3; k++) dstT[pl * 6 + r][lc * 3 + k] = w[r * 3 + k];
     __syncthreads();
-#pragma unroll 4
-    for (int kk = 0; kk < SCH_LC * 3; kk++) {
-      const double a0 = As[ty * 3][kk], a1 = As[ty * 3 + 1][kk], a2 = As[ty * 3 + 2][kk];
-      const double b0 = Bs[tx * 3][kk], b1 = Bs[tx * 3 + 1][kk], b2 = Bs[tx * 3 + 2][kk];
-      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2;
-      acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2;
-      acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2;
+    if (wv < 3) {
+#pragma unroll
+      for (int kc = 0; kc < SCH_LC * 3 / 4; kc++) {
+        const double a = As[wv * 16 + li][4 * kc + lk];
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[c * 16 + li][4 * kc + lk], acc[c], 0, 0, 0);
+      }
     }
   }
   const int lda = 6 * P.np, n = 6 * npa;
   double* Sm = A.S + P.S_base;
+  if (wv < 3) {
 #pragma unroll
-  for (int i = 0; i < 3; i++)
+    for (int c = 0; c < 3; c++)
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int gr = ta * 48 + ty * 3 + i, gc = tb * 48 + tx * 3 + j;
-      if (gr >= n || gc >= n) continue;
-      double h = 0;
-      if (gr / 6 == gc / 6) {
-        h = A.Hpp[(size_t)(P.pose_base + A.pact[P.pose_base + gr / 6]) * 36 + (gr % 6) * 6 + (gc % 6)];
-        if (gr == gc) h += St.lambda;
+      for (int r = 0; r < 4; r++) {   // C/D layout of the f64 MFMA: row (lane >> 4) + 4 r, column lane & 15
+        const int gr = ta * 48 + wv * 16 + lk + 4 * r, gc = tb * 48 + c * 16 + li;
+        if (gr >= n || gc >= n) continue;
+        double h = 0;
+        if (gr / 6 == gc / 6) {
+          h = A.Hpp[(size_t)(P.pose_base + A.pact[P.pose_base + gr / 6]) * 36 + (gr % 6) * 6 + (gc % 6)];
+          if (gr == gc) h += St.lambda;
+        }
+        Sm[(size_t)gr * lda + gc] = h - acc[c][r];
       }
-      Sm[(size_t)gr * lda + gc] = h - acc[i][j];
-    }
+  }
 }
 
 // Blocked unpivoted LDL^T of the reduced system S (n = 6 * active poses) and the two triangular solves, one
