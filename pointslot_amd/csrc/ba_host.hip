@@ -74,8 +74,8 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
     NW += (size_t)P.np * P.nl * 18;
     NS += (size_t)36 * P.np * P.np;
   }
-  const int nbl = (max_nl + 255) / 256, nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
-  const int part_cap = max_np + nbl + nbp + nbe + 8;
+  const int nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
+  const int part_cap = max_np + (max_nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB + nbp + nbe + 8;
   NPART = (size_t)part_cap * nprob;
   const int nt = (max_free + PS_BA_TILE - 1) / PS_BA_TILE, max_tilepairs = nt * (nt + 1) / 2 > 0 ? nt * (nt + 1) / 2 : 1;
 

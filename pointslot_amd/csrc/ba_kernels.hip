@@ -746,26 +746,37 @@ __global__ __launch_bounds__(256) void ba_update(BaArrays A) {
   if (S.phase != BA_PH_TRIAL) return;
   __shared__ double red[4];
   const int tid = threadIdx.x;
-  const int nbl = (P.nl + 255) / 256;
+  const int nbl = (P.nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB;
   const double lambda = S.lambda;
   double sc = 0;
   if ((int)blockIdx.x < nbl) {
-    const int l = blockIdx.x * 256 + tid;
-    if (l < P.nl) {
+    // 16 lanes per point: each takes every 16th free pose of c = b_l - sum_a W_a^T x_a, then the group adds up (the thread-per-
+    // point form walked all the poses with one dependent L2 round trip each)
+    const int l = blockIdx.x * PS_BA_UPD_PPB + (tid >> 4), sub = tid & 15;
+    const bool lv = l < P.nl;
+    const bool act = lv && A.lact[P.point_base + l];
+    double c[3] = {0, 0, 0};
+    if (act && S.ok2) {
+      for (int a = sub; a < S.npa; a += 16) {
+        const double* Wb = A.W + P.W_base + ((size_t)A.pact[P.pose_base + a] * P.nl + l) * 18;
+        const double* xp = A.xp + (size_t)P.pose_base * 6 + a * 6;
+#pragma unroll
+        for (int r = 0; r < 6; r++) { c[0] -= Wb[r * 3] * xp[r]; c[1] -= Wb[r * 3 + 1] * xp[r]; c[2] -= Wb[r * 3 + 2] * xp[r]; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) c[q] += shfl_xor_d(c[q], d);
+    if (lv && sub == 0) {
       double* X = A.points + (size_t)(P.point_base + l) * 3;
       double* Xb = A.points_bak + (size_t)(P.point_base + l) * 3;
       Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
-      if (A.lact[P.point_base + l]) {
+      if (act) {
         double* xl = A.xl + (size_t)(P.point_base + l) * 3;
         const double* b = A.bl + (size_t)(P.point_base + l) * 3;
         if (S.ok2) {
-          double c[3] = {b[0], b[1], b[2]};
-          for (int a = 0; a < S.npa; a++) {
-            const double* Wb = A.W + P.W_base + ((size_t)A.pact[P.pose_base + a] * P.nl + l) * 18;
-            const double* xp = A.xp + (size_t)P.pose_base * 6 + a * 6;
-#pragma unroll
-            for (int r = 0; r < 6; r++) { c[0] -= Wb[r * 3] * xp[r]; c[1] -= Wb[r * 3 + 1] * xp[r]; c[2] -= Wb[r * 3 + 2] * xp[r]; }
-          }
+          c[0] += b[0]; c[1] += b[1]; c[2] += b[2];
           const double* Di = A.Dinv + (size_t)(P.point_base + l) * 9;
           xl[0] = Di[0] * c[0] + Di[1] * c[1] + Di[2] * c[2];
           xl[1] = Di[3] * c[0] + Di[4] * c[1] + Di[5] * c[2];
@@ -836,7 +847,7 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
   __shared__ int s_restore;
   const int tid = threadIdx.x;
   if (tid == 0) {
-    const int nbl = (P.nl + 255) / 256, nbp = (P.np + 255) / 256, nbe = (P.ne + 255) / 256;
+    const int nbl = (P.nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB, nbp = (P.np + 255) / 256, nbe = (P.ne + 255) / 256;
     double scale = 0, temp = 0;
     for (int b = 0; b < nbl + nbp; b++) scale += A.part[P.part_base + P.np + b];
     for (int b = 0; b < nbe; b++) temp += A.part[P.part_base + err_part_off + b];
@@ -889,7 +900,8 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
 extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int max_nl, int max_ne, int max_tilepairs,
                                    int max_free, hipStream_t st) {
   const int nbl = (max_nl + 255) / 256, nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
-  const int err_off = max_np + nbl + nbp;   // layout of `part`: [np chi partials][update partials][error partials]
+  const int nblu = (max_nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB;   // ba_update's point blocks
+  const int err_off = max_np + nblu + nbp;   // layout of `part`: [np chi partials][update partials][error partials]
   hipLaunchKernelGGL(ba_begin, dim3(nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_lin_pose, dim3((max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_lin_point, dim3((max_nl + 15) / 16, nprob), dim3(256), 0, st, *A);
@@ -912,7 +924,7 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
       hipLaunchKernelGGL(ba_solve<12>, dim3(nprob), dim3(SOL_T), lds(12), st, *A);
     }
   }
-  hipLaunchKernelGGL(ba_update, dim3(nbl + nbp, nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_update, dim3(nblu + nbp, nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_error_k, dim3(nbe, nprob), dim3(256), 0, st, *A, err_off);
   hipLaunchKernelGGL(ba_decide, dim3(nprob), dim3(256), 0, st, *A, err_off);
 }

@@ -50,3 +50,5 @@ struct BaArrays {
   double* W; double* S; double* part; double* trace;
   int32_t* ndone;
 };
+// ba_update: points per 256-thread block (16 lanes per point share the sum over the free poses)
+#define PS_BA_UPD_PPB 16
