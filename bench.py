@@ -149,7 +149,52 @@ def secondary_metrics(rank, world, local_rank, dist, with_cpu):
         out["object_ba"]["cpu_port_ms_per_iter_1core_1object"] = dt * 1e3 / max(len(tr), 1)
     opt.close()
     out["sequence_tracking"] = sequence_leg(rank, world, local_rank, dist, with_cpu)
+    out["lockstep_tracking"] = lockstep_leg(rank, world, local_rank, dist)
     return out
+
+
+def lockstep_leg(rank, world, local_rank, dist, n_sequences=64, n_frames=12, n_distinct=4):
+    """BASELINE config 4 at batch scale: every rank tracks `n_sequences` independent stereo sequences in lockstep with the
+    C++ host driver (examples/stereo_kitti_batch.cpp -> StereoOdometryBatch: one batched extraction + stereo matching per
+    step, one C-ABI call per round of SearchByProjection / PoseOptimization problems, next step's upload and extraction
+    overlapped).  The driver runs as a child process on this rank's GPU; images are in page-locked host memory when the
+    clock starts, so the figure includes every PCIe transfer of the tracking loop but no disk I/O."""
+    import shutil
+    import subprocess
+    import tempfile
+    from pointslot_amd import parallel, sequence
+    exe = os.path.join(ROOT, "build", "stereo_kitti_batch")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build_examples()
+    tmp = tempfile.mkdtemp(prefix="ps_lockstep_%d_" % rank)
+    try:
+        dirs, truth = [], []
+        for k in range(n_distinct):
+            seq = sequence.generate(n_frames=n_frames, seed=40 + 16 * rank + k, step=0.05 + 0.01 * k)
+            d = os.path.join(tmp, "%04d" % k)
+            sequence.write_pgm(d, seq)
+            dirs.append(d); truth.append(seq["twc"][:, :, 3])
+        run = subprocess.run([exe, "--device", str(local_rank)] + [dirs[i % n_distinct] for i in range(n_sequences)], capture_output=True, text=True, timeout=600)
+        if run.returncode != 0:
+            raise RuntimeError("stereo_kitti_batch failed: " + run.stdout[-800:] + run.stderr[-800:])
+        st = json.loads(run.stdout.strip().splitlines()[-1])
+        err = 0.0
+        for d, tw in zip(dirs, truth):
+            traj = np.loadtxt(os.path.join(d, "CameraTrajectoryBatch.txt")).reshape(-1, 12)
+            if len(traj) == n_frames:
+                err = max(err, float(np.abs(traj[:, [3, 7, 11]] - tw).max()))
+            else:
+                err = float("inf")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    ms = parallel.max_over_ranks(dist, st["median_ms_per_step"], RED_DEV)
+    return {"workload": "BASELINE config 4: %d independent 1242x375 stereo sequences per GPU x %d frames tracked in lockstep (C++ host over the "
+                        "C-ABI, images in pinned host memory, all PCIe transfers included)" % (n_sequences, n_frames),
+            "sequences_per_gpu": n_sequences, "median_ms_per_step": ms, "tracked_frames_per_s": world * n_sequences * 1e3 / ms,
+            "untracked_frames": int(parallel.max_over_ranks(dist, st["untracked_frames"], RED_DEV)),
+            "max_abs_position_error_m": parallel.max_over_ranks(dist, err, RED_DEV),
+            "ms_per_step_parts_rank0": {k[12:]: st[k] for k in st if k.startswith("ms_per_step_")}, "device_rounds_per_step": st["device_rounds_per_step"]}
 
 
 def sequence_leg(rank, world, local_rank, dist, with_cpu, n_frames=12):

@@ -48,6 +48,10 @@ const char* ps_version(void);
  * point) and leaves it there.  LDS is not cleared between kernels, so a kernel that reads LDS it never wrote - or multiplies such
  * a slot by zero - then misbehaves deterministically instead of once in a while; the GPU tests call this before the kernels. */
 int ps_debug_poison_lds(int device, uint32_t pattern);
+/* Page-locked host memory for image and result buffers: copies from/to it are asynchronous and run at full PCIe rate
+ * (ps_orb_extract_batch reads the caller's image buffers directly).  NULL on failure (ps_last_error has the text). */
+void* ps_pinned_alloc(size_t bytes);
+void ps_pinned_free(void* p);
 
 /* ------------------------------------------------------------------------------------------------
  * ORB extractor — replaces ORB_SLAM2::ORBextractor (/root/reference/include/ORBextractor.h:51-85,
@@ -102,6 +106,13 @@ int ps_orb_batch_fetch(ps_orb* h, int image, ps_keypoint* kps, uint8_t* desc, in
 /* Waits for all work queued on the handle. */
 int ps_orb_sync(ps_orb* h);
 
+/* The same batched extraction for images in HOST memory (nimg pointers, identical size, rows `stride` bytes apart): one
+ * upload per image on the handle's stream, then the batch pipeline.  Asynchronous when the buffers come from
+ * ps_pinned_alloc; results are read with ps_orb_batch_fetch / ps_orb_stereo_fetch_frames.  This is Frame::Frame's
+ * ExtractORB(0, imLeft) + ExtractORB(1, imRight) (src/Frame.cc:709-712) for many frames at once: image 2k = left,
+ * 2k+1 = right of frame k when ps_orb_stereo_match_batch follows. */
+int ps_orb_extract_batch(ps_orb* h, const uint8_t* const* imgs, int nimg, int w, int hgt, int stride);
+
 /* Frame::ComputeStereoMatches (/root/reference/src/Frame.cc:2142-2316) on extraction results that
  * are still in HBM: both padded pyramids (mvImagePyramid of the left and the right extractor), keypoints and descriptors.
  * mb = Frame::mb (baseline in metres), mbf = Frame::mbf.  Outputs are indexed like the LEFT image's keypoints:
@@ -112,6 +123,16 @@ int ps_orb_stereo_match_batch(ps_orb* h, int npairs, float mb, float mbf);
 int ps_orb_stereo_device_outputs(const ps_orb* h, const float** d_uright, const float** d_depth, const int32_t** d_kept);
 int ps_orb_stereo_fetch(ps_orb* h, int pair, float* u_right, float* depth, int cap, int* n_left, int* kept);
 int ps_orb_stereo_match_pair(ps_orb* left, ps_orb* right, float mb, float mbf, float* u_right, float* depth, int cap, int* n_left);
+/* Everything a stereo Frame keeps from its two extractors and ComputeStereoMatches (mvKeys, mDescriptors, mvuRight,
+ * mvDepth; src/Frame.cc:709-722), for the first `npairs` pairs of the last ps_orb_stereo_match_batch, in one
+ * synchronisation and one pipelined transfer.  In: kps/desc/u_right/depth buffers with room for `cap` keypoints.
+ * Out: n (left keypoints), n_right, kept (matches that survive the median cut). */
+typedef struct ps_stereo_frame {
+  ps_keypoint* kps; uint8_t* desc; float* u_right; float* depth;
+  int32_t cap;
+  int32_t n, n_right, kept;
+} ps_stereo_frame;
+int ps_orb_stereo_fetch_frames(ps_orb* h, ps_stereo_frame* frames, int npairs);
 /* Frame::ComputeObjStereoMatches (src/Frame.cc:2318-2503): the same matcher on caller-provided key sets (the frame's object
  * features, mvTempObjKeys / mvTempObjKeysRight + descriptors, <= 4096 each) against the two extractors' device-resident
  * pyramids.  u_right / depth: n_left floats (-1 where unmatched); *kept (nullable) = matches that survive the median cut.

@@ -69,3 +69,33 @@ def poison_lds(pattern=0xFFFFFFFF, device=0):
     """Test / diagnostic: leave `pattern` in the LDS of every CU (see ps_debug_poison_lds)."""
     lib.ps_debug_poison_lds.argtypes = [ctypes.c_int, ctypes.c_uint32]
     check(lib.ps_debug_poison_lds(device, pattern))
+
+
+lib.ps_pinned_alloc.restype = ctypes.c_void_p
+lib.ps_pinned_alloc.argtypes = [ctypes.c_size_t]
+lib.ps_pinned_free.restype = None
+lib.ps_pinned_free.argtypes = [ctypes.c_void_p]
+
+
+class PinnedBuffer:
+    """Page-locked host memory (ps_pinned_alloc) as a numpy uint8 array: image buffers uploaded from it do not stall the
+    caller (ps_orb_extract_batch).  Free with close() or let it go out of scope."""
+
+    def __init__(self, nbytes):
+        import numpy as np
+        self._p = lib.ps_pinned_alloc(nbytes)
+        if not self._p:
+            raise PointslotError(-2, lib.ps_last_error().decode("utf-8", "replace"))
+        self.array = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(self._p))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib.ps_pinned_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -29,7 +29,9 @@ struct ps_matcher {
 namespace {
 inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
-int ensure(ps_matcher* m, size_t bytes) {
+int ensure(ps_matcher* m, size_t need) {
+  // 25 % headroom: batch sizes drift from call to call (keypoint counts), and re-allocating pinned memory costs milliseconds
+  const size_t bytes = (need > m->d_bytes || need > m->h_bytes) ? al(need + need / 4) : need;
   if (bytes > m->d_bytes) {
     if (m->d_buf) hipFree(m->d_buf);
     m->d_buf = nullptr;
@@ -193,13 +195,19 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   int rc = ensure(m, off);
   if (rc != PS_OK) return rc;
   uint8_t* H = m->h_buf;
-  memset(H, 0, in_bytes);
   PjProb* hp = (PjProb*)(H + o_prob);
-  size_t t0 = 0, q0 = 0;
-  for (int p = 0; p < nprob; p++) {
+  std::vector<size_t> toff(nprob), qoff(nprob);
+  {
+    size_t t0 = 0, q0 = 0;
+    for (int p = 0; p < nprob; p++) { toff[p] = t0; qoff[p] = q0; t0 += probs[p].train.n; q0 += probs[p].nq; }
+  }
+  // every problem fills (or zeroes) exactly its own slices of the staging buffer: independent, memcpy-bound
+  ps_parallel_for(nprob, in_bytes, [&](int p) {
     const ps_proj_problem& P = probs[p];
     const ps_proj_train& T = P.train;
+    const size_t t0 = toff[p], q0 = qoff[p];
     PjProb& d = hp[p];
+    memset(&d, 0, sizeof(d));
     d.t_off = (int32_t)t0; d.nt = T.n; d.q_off = (int32_t)q0; d.nq = P.nq; d.grid_off = p * (NCELL + 1);
     d.min_x = T.min_x; d.min_y = T.min_y; d.gw_inv = T.grid_w_inv; d.gh_inv = T.grid_h_inv;
     d.th_dist = P.th_dist; d.ratio_test = P.ratio_test; d.nn_ratio = P.nn_ratio; d.check_ori = P.check_orientation;
@@ -209,29 +217,34 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
     memcpy(d.bounds, P.bounds, 16); memcpy(d.scale, P.scale_factors, 32);
     d.th = P.th; d.mono = P.mono;
     if (T.n > 0) {
-      memcpy(H + o_tx + t0 * 4, T.x, (size_t)T.n * 4); memcpy(H + o_ty + t0 * 4, T.y, (size_t)T.n * 4);
-      memcpy(H + o_toct + t0 * 4, T.octave, (size_t)T.n * 4); memcpy(H + o_tang + t0 * 4, T.angle, (size_t)T.n * 4);
-      memcpy(H + o_tur + t0 * 4, T.u_right, (size_t)T.n * 4); memcpy(H + o_tdesc + t0 * 32, T.desc, (size_t)T.n * 32);
-      memcpy(H + o_tocc + t0, T.occupied, T.n);
-      if (T.in_bbox) memcpy(H + o_tbb + t0, T.in_bbox, T.n);
+      const size_t n = (size_t)T.n, filled = (size_t)T.cell_off[NCELL];
+      memcpy(H + o_tx + t0 * 4, T.x, n * 4); memcpy(H + o_ty + t0 * 4, T.y, n * 4);
+      memcpy(H + o_toct + t0 * 4, T.octave, n * 4); memcpy(H + o_tang + t0 * 4, T.angle, n * 4);
+      memcpy(H + o_tur + t0 * 4, T.u_right, n * 4); memcpy(H + o_tdesc + t0 * 32, T.desc, n * 32);
+      memcpy(H + o_tocc + t0, T.occupied, n);
+      if (T.in_bbox) memcpy(H + o_tbb + t0, T.in_bbox, n); else memset(H + o_tbb + t0, 0, n);
       memcpy(H + o_coff + (size_t)d.grid_off * 4, T.cell_off, (size_t)(NCELL + 1) * 4);
-      memcpy(H + o_cidx + t0 * 4, T.cell_idx, (size_t)T.cell_off[NCELL] * 4);
+      memcpy(H + o_cidx + t0 * 4, T.cell_idx, std::min(filled, n) * 4);
+      if (filled < n) memset(H + o_cidx + (t0 + filled) * 4, 0, (n - filled) * 4);
+    } else {
+      memset(H + o_coff + (size_t)d.grid_off * 4, 0, (size_t)(NCELL + 1) * 4);
     }
     if (P.nq > 0) {
-      memcpy(H + o_qvalid + q0, P.q_valid, P.nq); memcpy(H + o_qdesc + q0 * 32, P.q_desc, (size_t)P.nq * 32);
-      memcpy(H + o_qobs + q0, P.q_observed, P.nq);
-      if (P.q_angle) memcpy(H + o_qang + q0 * 4, P.q_angle, (size_t)P.nq * 4);
+      const size_t n = (size_t)P.nq;
+      memcpy(H + o_qvalid + q0, P.q_valid, n); memcpy(H + o_qdesc + q0 * 32, P.q_desc, n * 32);
+      memcpy(H + o_qobs + q0, P.q_observed, n);
+      if (P.q_angle) memcpy(H + o_qang + q0 * 4, P.q_angle, n * 4); else memset(H + o_qang + q0 * 4, 0, n * 4);
+      const size_t pre[7] = {o_qu, o_qv, o_qur, o_qrad, o_qrer, o_qminl, o_qmaxl};
       if (P.frame_mode) {
-        memcpy(H + o_qxw + q0 * 12, P.q_xw, (size_t)P.nq * 12); memcpy(H + o_qoct + q0 * 4, P.q_octave, (size_t)P.nq * 4);
+        memcpy(H + o_qxw + q0 * 12, P.q_xw, n * 12); memcpy(H + o_qoct + q0 * 4, P.q_octave, n * 4);
+        for (size_t o : pre) memset(H + o + q0 * 4, 0, n * 4);
       } else {
-        memcpy(H + o_qu + q0 * 4, P.q_u, (size_t)P.nq * 4); memcpy(H + o_qv + q0 * 4, P.q_v, (size_t)P.nq * 4);
-        memcpy(H + o_qur + q0 * 4, P.q_ur, (size_t)P.nq * 4); memcpy(H + o_qrad + q0 * 4, P.q_radius, (size_t)P.nq * 4);
-        memcpy(H + o_qrer + q0 * 4, P.q_radius_er, (size_t)P.nq * 4); memcpy(H + o_qminl + q0 * 4, P.q_min_level, (size_t)P.nq * 4);
-        memcpy(H + o_qmaxl + q0 * 4, P.q_max_level, (size_t)P.nq * 4);
+        const void* src[7] = {P.q_u, P.q_v, P.q_ur, P.q_radius, P.q_radius_er, P.q_min_level, P.q_max_level};
+        for (int k = 0; k < 7; k++) memcpy(H + pre[k] + q0 * 4, src[k], n * 4);
+        memset(H + o_qxw + q0 * 12, 0, n * 12); memset(H + o_qoct + q0 * 4, 0, n * 4);
       }
     }
-    t0 += T.n; q0 += P.nq;
-  }
+  });
   uint8_t* D = m->d_buf;
   PS_HIP(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, m->stream));
   PS_HIP(hipMemsetAsync(D + o_ovf, 0, 4, m->stream));
@@ -253,12 +266,10 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   PS_HIP(hipStreamSynchronize(m->stream));
   if (*(const int32_t*)(H + o_ovf) > 0)
     return ps_set_error(PS_ERR_CAPACITY, "a search window held more than %d candidates", PS_PJ_CAP);
-  t0 = 0;
   for (int p = 0; p < nprob; p++) {
     ps_proj_problem& P = probs[p];
-    if (P.train.n > 0) memcpy(P.match_of_train, H + o_match + t0 * 4, (size_t)P.train.n * 4);
+    if (P.train.n > 0) memcpy(P.match_of_train, H + o_match + toff[p] * 4, (size_t)P.train.n * 4);
     P.nmatches = ((const int32_t*)(H + o_nm))[p];
-    t0 += P.train.n;
   }
   return PS_OK;
 }

@@ -30,7 +30,9 @@ struct ps_optimizer {
 
 namespace {
 inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
-int ensure(ps_optimizer* m, size_t bytes) {
+int ensure(ps_optimizer* m, size_t need) {
+  // 25 % headroom: batch sizes drift from call to call, and re-allocating pinned memory costs milliseconds
+  const size_t bytes = (need > m->d_bytes || need > m->h_bytes) ? al(need + need / 4) : need;
   if (bytes > m->d_bytes) {
     if (m->d_buf) hipFree(m->d_buf);
     m->d_buf = nullptr;

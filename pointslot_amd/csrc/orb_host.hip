@@ -59,8 +59,10 @@ struct ps_orb {
   int last_npairs = 0;
   uint8_t* d_objkeys = nullptr;   // scratch of ps_orb_stereo_match_keys (caller-provided key sets + their outputs)
   uint8_t* h_objkeys = nullptr;
-  uint8_t* d_img = nullptr;       // staging for ps_orb_extract (one host image)
+  uint8_t* d_img = nullptr;       // staging for ps_orb_extract / ps_orb_extract_batch (host images)
   size_t d_img_bytes = 0;
+  uint8_t* h_frames = nullptr;    // pinned staging of ps_orb_stereo_fetch_frames
+  size_t h_frames_bytes = 0;
   hipStream_t stream = nullptr;
   // stage timing: a ring of event sets so that consecutive batches can be timed without a host
   // synchronisation in between; ps_orb_stage_times() averages over the recorded batches.
@@ -73,6 +75,7 @@ struct ps_orb {
   bool timing = false;
   int timed_batches = 0;
   int last_nimg = 0;
+  hipStream_t last_stream = nullptr;   // stream of the last batch (the handle's own unless the caller passed one)
 };
 
 namespace {
@@ -163,7 +166,8 @@ int free_device(ps_orb* h) {
   h->d_stscratch = nullptr;
   if (h->d_objkeys) hipFree(h->d_objkeys);
   if (h->h_objkeys) hipHostFree(h->h_objkeys);
-  h->d_objkeys = nullptr; h->h_objkeys = nullptr;
+  if (h->h_frames) hipHostFree(h->h_frames);
+  h->d_objkeys = nullptr; h->h_objkeys = nullptr; h->h_frames = nullptr; h->h_frames_bytes = 0;
   h->d_uright = nullptr; h->d_depth = nullptr; h->d_sad = nullptr; h->d_kept = nullptr; h->d_pairs = nullptr;
   h->d_arena = nullptr; h->d_tabs = nullptr; h->d_kps = nullptr; h->d_desc = nullptr; h->d_counts = nullptr;
   return 0;
@@ -322,6 +326,7 @@ int run_batch(ps_orb* h, const uint8_t* d_imgs, int nimg, int stride, size_t pit
   PS_HIP(hipGetLastError());
   if (tm) { h->timed_chunks[slot] = nchunks; h->timed_batches++; }
   h->last_nimg = nimg;
+  h->last_npairs = 0;   // stereo results of the previous batch are gone
   return PS_OK;
 }
 
@@ -394,7 +399,8 @@ int ps_orb_extract_batch_device(ps_orb* h, const uint8_t* d_imgs, int nimg, int 
     int rc = build_plan(h, w, hgt);
     if (rc != PS_OK) return rc;
   }
-  return run_batch(h, d_imgs, nimg, stride, image_pitch, stream ? (hipStream_t)stream : h->stream);
+  h->last_stream = stream ? (hipStream_t)stream : h->stream;
+  return run_batch(h, d_imgs, nimg, stride, image_pitch, h->last_stream);
 }
 
 int ps_orb_batch_device_outputs(const ps_orb* h, const ps_keypoint** d_kps, const uint8_t** d_desc,
@@ -458,6 +464,72 @@ int ps_orb_extract(ps_orb* h, const uint8_t* img, int w, int hgt, int stride, ps
                          L.h + 2 * PS_EDGE, hipMemcpyDeviceToHost));
     }
   }
+  return PS_OK;
+}
+
+int ps_orb_extract_batch(ps_orb* h, const uint8_t* const* imgs, int nimg, int w, int hgt, int stride) {
+  if (!h || !imgs || nimg < 1 || w < 1 || hgt < 1 || stride < w) return ps_set_error(PS_ERR_INVALID, "ps_orb_extract_batch: bad argument");
+  if (nimg > h->cfg.max_batch) return ps_set_error(PS_ERR_CAPACITY, "nimg %d > max_batch %d", nimg, h->cfg.max_batch);
+  for (int i = 0; i < nimg; i++)
+    if (!imgs[i]) return ps_set_error(PS_ERR_INVALID, "ps_orb_extract_batch: image %d is null", i);
+  PS_HIP(hipSetDevice(h->cfg.device));
+  const size_t pitch = (size_t)stride * hgt, bytes = pitch * nimg;
+  if (bytes > h->d_img_bytes) {
+    PS_HIP(hipDeviceSynchronize());
+    if (h->d_img) hipFree(h->d_img);
+    h->d_img = nullptr;
+    PS_HIP(hipMalloc(&h->d_img, bytes));
+    h->d_img_bytes = bytes;
+  }
+  // one copy per image on the handle's stream: asynchronous when the caller's buffers are pinned (ps_pinned_alloc)
+  for (int i = 0; i < nimg; i++) PS_HIP(hipMemcpyAsync(h->d_img + pitch * i, imgs[i], pitch, hipMemcpyHostToDevice, h->stream));
+  return ps_orb_extract_batch_device(h, h->d_img, nimg, w, hgt, stride, pitch, nullptr);
+}
+
+int ps_orb_stereo_fetch_frames(ps_orb* h, ps_stereo_frame* frames, int npairs) {
+  if (!h || !h->planned || !frames || npairs < 1 || npairs > h->last_npairs || 2 * npairs > h->last_nimg)
+    return ps_set_error(PS_ERR_INVALID, "ps_orb_stereo_fetch_frames: needs ps_orb_stereo_match_batch over >= npairs pairs");
+  PS_HIP(hipSetDevice(h->cfg.device));
+  const OrbPlan& P = h->plan;
+  const size_t cap = P.kp_cap;
+  // pinned staging: counts + kept, then per pair keypoints | descriptors | uRight | depth at full capacity
+  const size_t o_cnt = 0, o_kept = (size_t)h->last_nimg * 4, o_data = (o_kept + (size_t)npairs * 4 + 255) & ~(size_t)255;
+  const size_t per = cap * (sizeof(ps_keypoint) + 32 + 4 + 4), need = o_data + per * npairs;
+  if (need > h->h_frames_bytes) {
+    if (h->h_frames) hipHostFree(h->h_frames);
+    h->h_frames = nullptr;
+    PS_HIP(hipHostMalloc(&h->h_frames, need, hipHostMallocDefault));
+    h->h_frames_bytes = need;
+  }
+  uint8_t* H = h->h_frames;
+  PS_HIP(hipMemcpyAsync(H + o_cnt, h->d_counts, (size_t)h->last_nimg * 4, hipMemcpyDeviceToHost, h->stream));
+  PS_HIP(hipMemcpyAsync(H + o_kept, h->d_kept, (size_t)npairs * 4, hipMemcpyDeviceToHost, h->stream));
+  // four transfers for the whole batch: the left images are every second row of the [image][kp_cap] result arrays
+  uint8_t* B0 = H + o_data;
+  PS_HIP(hipMemcpy2DAsync(B0, per, h->d_kps, 2 * cap * sizeof(ps_keypoint), cap * sizeof(ps_keypoint), npairs, hipMemcpyDeviceToHost, h->stream));
+  PS_HIP(hipMemcpy2DAsync(B0 + cap * sizeof(ps_keypoint), per, h->d_desc, 2 * cap * 32, cap * 32, npairs, hipMemcpyDeviceToHost, h->stream));
+  PS_HIP(hipMemcpy2DAsync(B0 + cap * (sizeof(ps_keypoint) + 32), per, h->d_uright, cap * 4, cap * 4, npairs, hipMemcpyDeviceToHost, h->stream));
+  PS_HIP(hipMemcpy2DAsync(B0 + cap * (sizeof(ps_keypoint) + 36), per, h->d_depth, cap * 4, cap * 4, npairs, hipMemcpyDeviceToHost, h->stream));
+  PS_HIP(hipStreamSynchronize(h->stream));
+  const int32_t* cnt = reinterpret_cast<const int32_t*>(H + o_cnt);
+  const int32_t* kept = reinterpret_cast<const int32_t*>(H + o_kept);
+  for (int k = 0; k < npairs; k++) {
+    ps_stereo_frame& F = frames[k];
+    const int n = cnt[2 * k];
+    F.n = n; F.n_right = cnt[2 * k + 1]; F.kept = kept[k];
+    if (n > F.cap) return ps_set_error(PS_ERR_CAPACITY, "pair %d: %d keypoints, caller capacity %d", k, n, F.cap);
+    if (n > 0 && (!F.kps || !F.desc || !F.u_right || !F.depth)) return ps_set_error(PS_ERR_INVALID, "pair %d: null output buffer", k);
+  }
+  ps_parallel_for(npairs, per * npairs / 2, [&](int k) {
+    ps_stereo_frame& F = frames[k];
+    const size_t n = (size_t)F.n;
+    if (n == 0) return;
+    const uint8_t* B = H + o_data + per * k;
+    memcpy(F.kps, B, n * sizeof(ps_keypoint));
+    memcpy(F.desc, B + cap * sizeof(ps_keypoint), n * 32);
+    memcpy(F.u_right, B + cap * (sizeof(ps_keypoint) + 32), n * 4);
+    memcpy(F.depth, B + cap * (sizeof(ps_keypoint) + 36), n * 4);
+  });
   return PS_OK;
 }
 
@@ -557,7 +629,8 @@ int ps_orb_stereo_match_batch(ps_orb* h, int npairs, float mb, float mbf) {
     return ps_set_error(PS_ERR_INVALID, "ps_orb_stereo_match_batch: needs a batch with 2 * npairs images (left, right interleaved)");
   if (h->plan.kp_cap > 4096) return ps_set_error(PS_ERR_CAPACITY, "stereo matcher supports at most 4096 keypoints per image");
   PS_HIP(hipSetDevice(h->cfg.device));
-  PS_HIP(hipDeviceSynchronize());   // the extraction may have run on a caller stream
+  // the matcher runs on the handle's stream: ordered behind the extraction unless that ran on a caller stream
+  if (h->last_stream && h->last_stream != h->stream) PS_HIP(hipStreamSynchronize(h->last_stream));
   const OrbPlan& P = h->plan;
   std::vector<StPair> pairs(npairs);
   for (int k = 0; k < npairs; k++) {

@@ -463,6 +463,32 @@ __device__ __forceinline__ void wave_sync() {
 //   C  survivors are scored exactly (s > min_th <=> corner) and compacted again
 //   D  strict 3x3 NMS on the LDS score map, threshold fallback, raster-ordered emission into the cell's slots
 #define FAST_T 256
+#ifdef PS_FAST_PROFILE   // developer build: core-clock cycles per phase summed over all cell-waves, printed after the launch
+#define FP_MAXW 262144
+__device__ unsigned long long g_fast_prof[FP_MAXW * 10];
+#define FP_DECL long long fp_t = clock64(); unsigned long long fp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define FP_MARK(k) do { const long long _n = clock64(); fp_acc[k] += (unsigned long long)(_n - fp_t); fp_t = _n; } while (0)
+#define FP_COUNT(k, v) (fp_acc[k] += (unsigned long long)(v))
+#define FP_FLUSH() do { const int _w = blockIdx.x * 4 + wave; if (lane == 0 && _w < FP_MAXW) for (int _k = 0; _k < 10; _k++) g_fast_prof[_w * 10 + _k] = fp_acc[_k]; } while (0)
+__global__ void fast_prof_dump() {
+  __shared__ unsigned long long acc[10];
+  if (threadIdx.x < 10) acc[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int w = threadIdx.x; w < FP_MAXW; w += blockDim.x)
+    for (int k = 0; k < 10; k++) { a[k] += g_fast_prof[w * 10 + k]; g_fast_prof[w * 10 + k] = 0; }
+  for (int k = 0; k < 10; k++) atomicAdd(&acc[k], a[k]);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    printf("fast cycles: A %llu B %llu C %llu D %llu emit %llu | waves %llu nsurv %llu ncand %llu pass2 %llu kp %llu\n", acc[0], acc[1], acc[2], acc[3], acc[4],
+           acc[5], acc[6], acc[7], acc[8], acc[9]);
+}
+#else
+#define FP_DECL
+#define FP_MARK(k)
+#define FP_COUNT(k, v)
+#define FP_FLUSH()
+#endif
 typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
 typedef short fs_s2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int QS, int nimg, int bpi) {
@@ -495,6 +521,8 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     return;
   }
   // ---- A: window -> LDS (aligned dwords), score map cleared ----
+  FP_DECL;
+  FP_COUNT(5, 1);
   const int shift = (PS_EDGE + iniX) & 3;   // plane origins are 256-B aligned, strides multiples of 64
   const uint8_t* ga = base + L.plane_off + (size_t)(PS_EDGE + iniY) * L.stride + (PS_EDGE + iniX - shift);
   const int nd = (shift + ww + 3) >> 2;
@@ -521,6 +549,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   }
   for (int t = lane; t < (SS * (ch + 2) + 3) / 4; t += 64) reinterpret_cast<uint32_t*>(smap)[t] = 0;
   wave_sync();
+  FP_MARK(0);
   // ---- B: cheap NECESSARY test on the 8 even ring positions, 4 pixels per lane and step.  Nine contiguous ring
   // pixels always contain four consecutive even positions, so a pixel without 4 consecutive dark (or bright) even
   // positions cannot be a corner at min_th; this rejects most pixels for ~1/3 of the full test's work. ----
@@ -603,6 +632,9 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   }
   nsurv = min(nsurv, LCAP);
   wave_sync();
+  FP_MARK(1);
+  FP_COUNT(6, nsurv);
+  if (pass == 1) FP_COUNT(8, 1);
   // ---- C: exact score of the survivors; s > min_th <=> corner.  The list is compacted in place (a chunk is read
   // before anything is written, and writes never run ahead of the reads). ----
   int ncand = 0;
@@ -621,6 +653,8 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     ncand += __popcll(cm);
   }
   wave_sync();
+  FP_MARK(2);
+  FP_COUNT(7, ncand);
   // ---- D: per-cell NMS and emission (every listed pixel is a corner at th) ----
   unsigned long long anykp = 0;
   for (int i0 = 0; i0 < ncand; i0 += 64) {
@@ -639,6 +673,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     anykp |= __builtin_amdgcn_ballot_w64(f != 0);
   }
   wave_sync();
+  FP_MARK(3);
   if (!anykp && pass == 0) continue;   // no keypoint at iniThFAST: run the cell again at minThFAST
   for (int i0 = 0; i0 < ncand; i0 += 64) {
     const int idx = i0 + lane;
@@ -656,9 +691,12 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     }
     total += __popcll(km);
   }
+  FP_MARK(4);
+  FP_COUNT(9, total);
   break;
   }   // pass
   if (lane == 0) cellcnt[cell] = min(total, L.cell_cap);
+  FP_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1324,6 +1362,9 @@ extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nim
   const int bpi = (plan->n_cells + 3) / 4;
   hipLaunchKernelGGL(orb_fast_cells, dim3(bpi * ((nimg + 7) / 8) * 8), dim3(FAST_T), (size_t)per_wave * 4, st, *plan, arena,
                      TS, TR, SS, LCAP, QS, nimg, bpi);
+#ifdef PS_FAST_PROFILE
+  hipLaunchKernelGGL(fast_prof_dump, dim3(1), dim3(1024), 0, st);
+#endif
 }
 extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   // smallest node capacity that holds every level (quota + 4 nodes, 4 * n_ini initial children, cells / 3 for the gather table)

@@ -35,6 +35,17 @@ int ps_debug_poison_lds(int device, uint32_t pattern) {
   PS_HIP(hipDeviceSynchronize());
   return PS_OK;
 }
+void* ps_pinned_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    ps_set_error(PS_ERR_HIP, "ps_pinned_alloc(%zu) failed", bytes);
+    return nullptr;
+  }
+  return p;
+}
+void ps_pinned_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
 const char* ps_last_error(void) { return g_err; }
 const char* ps_version(void) { return "pointslot_hip 0.1 (gfx950)"; }
 int ps_device_count(int* count) {

@@ -44,6 +44,15 @@ lib.ps_orb_stereo_match_keys.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, c
                                          ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 lib.ps_orb_stereo_match_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+lib.ps_orb_extract_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+
+
+class _StereoFrame(ctypes.Structure):
+    _fields_ = [("kps", ctypes.c_void_p), ("desc", ctypes.c_void_p), ("u_right", ctypes.c_void_p), ("depth", ctypes.c_void_p),
+                ("cap", ctypes.c_int32), ("n", ctypes.c_int32), ("n_right", ctypes.c_int32), ("kept", ctypes.c_int32)]
+
+
+lib.ps_orb_stereo_fetch_frames.argtypes = [ctypes.c_void_p, ctypes.POINTER(_StereoFrame), ctypes.c_int]
 lib.ps_orb_enable_stage_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.ps_orb_stage_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.POINTER(ctypes.c_int)]
@@ -124,6 +133,16 @@ class ORBextractor:
     def extract_batch_device(self, d_ptr, nimg, w, h, stride, pitch, stream=None):
         check(lib.ps_orb_extract_batch_device(self._h, d_ptr, nimg, w, h, stride, pitch, stream))
 
+    def extract_batch(self, images):
+        """ps_orb_extract_batch: images of identical shape in host memory (a list of 2-D uint8 arrays); results stay on the
+        device until fetch() / stereo_fetch_frames()."""
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        h, w = imgs[0].shape
+        if any(im.shape != (h, w) for im in imgs):
+            raise ValueError("all images of a batch must have the same size")
+        ptrs = (ctypes.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
+        check(lib.ps_orb_extract_batch(self._h, ptrs, len(imgs), w, h, w))
+
     def sync(self):
         check(lib.ps_orb_sync(self._h))
 
@@ -171,6 +190,17 @@ class ORBextractor:
         n = ctypes.c_int(0); kept = ctypes.c_int(0)
         check(lib.ps_orb_stereo_fetch(self._h, pair, ur.ctypes.data, dp.ctypes.data, self.capacity, ctypes.byref(n), ctypes.byref(kept)))
         return ur[:n.value].copy(), dp[:n.value].copy(), kept.value
+
+    def stereo_fetch_frames(self, npairs):
+        """ps_orb_stereo_fetch_frames: (keypoints, descriptors, mvuRight, mvDepth, kept) of every left image, one transfer."""
+        bufs, frames = [], (_StereoFrame * npairs)()
+        for k in range(npairs):
+            b = (np.zeros(self.capacity, KEYPOINT_DTYPE), np.zeros((self.capacity, 32), np.uint8), np.zeros(self.capacity, np.float32),
+                 np.zeros(self.capacity, np.float32))
+            bufs.append(b)
+            frames[k] = _StereoFrame(b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data, b[3].ctypes.data, self.capacity, 0, 0, 0)
+        check(lib.ps_orb_stereo_fetch_frames(self._h, frames, npairs))
+        return [(b[0][:f.n].copy(), b[1][:f.n].copy(), b[2][:f.n].copy(), b[3][:f.n].copy(), f.kept) for b, f in zip(bufs, frames)]
 
 
 def ComputeStereoMatches(left, right, mb, mbf):

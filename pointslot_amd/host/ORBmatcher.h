@@ -53,18 +53,25 @@ class ORBmatcher {
 
   // The three SearchByProjection overloads; the caller fills ps_proj_problem from its Frame.
   // th_dist / ratio_test / check_orientation are set here from the overload being emulated.
-  int SearchByProjectionFrame(ps_proj_problem& p) {      // (Frame& cur, const Frame& last, th, bMono)
-    p.frame_mode = 1; p.th_dist = TH_HIGH; p.ratio_test = 0; p.nn_ratio = mfNNratio;
-    p.check_orientation = mbCheckOrientation ? 1 : 0; p.use_bbox = 0;
-    return run(p);
+  static void ConfigureProjectionFrame(ps_proj_problem& p, float nnratio, bool checkOri) {   // (Frame& cur, const Frame& last, th, bMono)
+    p.frame_mode = 1; p.th_dist = TH_HIGH; p.ratio_test = 0; p.nn_ratio = nnratio; p.check_orientation = checkOri ? 1 : 0; p.use_bbox = 0;
   }
-  int SearchByProjectionPoints(ps_proj_problem& p) {     // (Frame& F, const vector<MapPoint*>&, th)
-    p.frame_mode = 0; p.th_dist = TH_HIGH; p.ratio_test = 1; p.nn_ratio = mfNNratio; p.check_orientation = 0; p.use_bbox = 0;
-    return run(p);
+  static void ConfigureProjectionPoints(ps_proj_problem& p, float nnratio) {                 // (Frame& F, const vector<MapPoint*>&, th)
+    p.frame_mode = 0; p.th_dist = TH_HIGH; p.ratio_test = 1; p.nn_ratio = nnratio; p.check_orientation = 0; p.use_bbox = 0;
   }
-  int SearchByProjectionObject(ps_proj_problem& p) {     // (Frame& F, nOrder, const vector<MapObjectPoint*>&, th)
-    p.frame_mode = 0; p.th_dist = TH_HIGH_FORDYNAMIC; p.ratio_test = 1; p.nn_ratio = mfNNratio; p.check_orientation = 0; p.use_bbox = 1;
-    return run(p);
+  static void ConfigureProjectionObject(ps_proj_problem& p, float nnratio) {                 // (Frame& F, nOrder, const vector<MapObjectPoint*>&, th)
+    p.frame_mode = 0; p.th_dist = TH_HIGH_FORDYNAMIC; p.ratio_test = 1; p.nn_ratio = nnratio; p.check_orientation = 0; p.use_bbox = 1;
+  }
+  int SearchByProjectionFrame(ps_proj_problem& p) { ConfigureProjectionFrame(p, mfNNratio, mbCheckOrientation); return run(p); }
+  int SearchByProjectionPoints(ps_proj_problem& p) { ConfigureProjectionPoints(p, mfNNratio); return run(p); }
+  int SearchByProjectionObject(ps_proj_problem& p) { ConfigureProjectionObject(p, mfNNratio); return run(p); }
+  // already-configured problems (possibly of different overloads / matcher settings) in one call; returns the summed match count
+  int SearchByProjectionBatch(ps_proj_problem* p, int n) {
+    if (n <= 0) return 0;
+    if (ps_search_by_projection(h_, p, n) != PS_OK) throw std::runtime_error(ps_last_error());
+    int total = 0;
+    for (int i = 0; i < n; i++) total += p[i].nmatches;
+    return total;
   }
   static float RadiusByViewingCos(const float& viewCos) { return viewCos > 0.998 ? 2.5f : 4.0f; }   // ORBmatcher.cc:252-258
 

@@ -122,6 +122,24 @@ def write(seq_dir, seq, dt=0.1, pgm=False):
         f.write("Camera.fx: %.9g\nCamera.fy: %.9g\nCamera.cx: %.9g\nCamera.cy: %.9g\nCamera.bf: %.9g\nThDepth: 35\n" % (fx, fy, cx, cy, seq["bf"]))
 
 
+def write_pgm(seq_dir, seq, dt=0.1):
+    """Only what examples/stereo_kitti*.cpp read: binary PGM stereo images, timestamp.txt, calib.txt (no PNG encoding)."""
+    for d in ("image_02", "image_03"):
+        os.makedirs(os.path.join(seq_dir, d), exist_ok=True)
+    n = len(seq["left"])
+    for k in range(n):
+        for d, im in (("image_02", seq["left"][k]), ("image_03", seq["right"][k])):
+            with open(os.path.join(seq_dir, d, "%06d.pgm" % k), "wb") as f:
+                f.write(b"P5\n%d %d\n255\n" % (im.shape[1], im.shape[0]))
+                f.write(np.ascontiguousarray(im).tobytes())
+    with open(os.path.join(seq_dir, "timestamp.txt"), "w") as f:
+        for k in range(n):
+            f.write("%.6f\n" % (k * dt))
+    fx, fy, cx, cy = seq["K"]
+    with open(os.path.join(seq_dir, "calib.txt"), "w") as f:
+        f.write("Camera.fx: %.9g\nCamera.fy: %.9g\nCamera.cx: %.9g\nCamera.cy: %.9g\nCamera.bf: %.9g\nThDepth: 35\n" % (fx, fy, cx, cy, seq["bf"]))
+
+
 def _to_gray(a, rgb_order=True):
     """cv::cvtColor RGB2GRAY / BGR2GRAY of OpenCV 3.4 on 8-bit data: (R*4899 + G*9617 + B*1868 + 8192) >> 14
     (Tracking.cc:1016-1037; `Camera.RGB` picks which channel gets the R weight)."""

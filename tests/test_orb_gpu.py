@@ -248,6 +248,49 @@ def test_stereo_matches_bit_exact(images):
     exl.close(); exr.close(); exb.close()
 
 
+def test_host_image_batch_and_bulk_frame_fetch(images):
+    """ps_orb_extract_batch (host images, pinned or pageable) + ps_orb_stereo_match_batch + ps_orb_stereo_fetch_frames: what a
+    batch of stereo Frames keeps (mvKeys, mDescriptors, mvuRight, mvDepth) equals the oracle's and the per-image entry points',
+    including a pair of blank images (no keypoints) in the middle of the batch and a second batch on the same handle."""
+    from oracle_lib import stereo_match
+    from pointslot_amd import synth
+    from pointslot_amd._lib import PinnedBuffer
+    from pointslot_amd.extractor import ORBextractor
+    bf, fx = 384.38148, 721.5377
+    mb, mbf = np.float32(bf / fx), np.float32(bf)
+    batch = synth.stereo_batch(2)
+    h, w = batch.shape[1:]
+    blank = np.full((h, w), 90, np.uint8)
+    imgs = [batch[0], batch[1], blank, blank, batch[2], batch[3]]
+    pin = PinnedBuffer(len(imgs) * h * w)
+    pinned = pin.array.reshape(len(imgs), h, w)
+    pinned[:] = np.stack(imgs)
+    ex = ORBextractor(2000, 1.2, 8, 20, 5, max_batch=6)
+    ol, orr = OracleORB(2000), OracleORB(2000)
+    for source in ([pinned[i] for i in range(6)], imgs):          # page-locked, then pageable host memory
+        ex.extract_batch(source)
+        ex.stereo_match_batch(3, mb, mbf)
+        frames = ex.stereo_fetch_frames(3)
+        for k, (kps, desc, ur, dp, kept) in enumerate(frames):
+            ko, do = ol.run(imgs[2 * k]); orr.run(imgs[2 * k + 1])
+            if k == 1:
+                assert len(kps) == 0 and len(ko) == 0 and kept == 0
+                continue
+            kept_o, uro, dpo = stereo_match(ol, orr, mb, mbf)
+            assert len(kps) == len(ko) > 1000 and kept == kept_o
+            assert np.array_equal(kps.view(np.uint8), ko.view(np.uint8)) and np.array_equal(desc, do)
+            assert np.array_equal(ur.view(np.uint32), uro.view(np.uint32)) and np.array_equal(dp.view(np.uint32), dpo.view(np.uint32))
+            k1, d1 = ex.fetch(2 * k)
+            u1, p1, kept1 = ex.stereo_fetch(k)
+            assert np.array_equal(k1.view(np.uint8), kps.view(np.uint8)) and np.array_equal(d1, desc)
+            assert np.array_equal(u1.view(np.uint32), ur.view(np.uint32)) and np.array_equal(p1.view(np.uint32), dp.view(np.uint32)) and kept1 == kept
+    # a new extraction invalidates the previous stereo results until the matcher has run again
+    ex.extract_batch(imgs[:2])
+    with pytest.raises(Exception):
+        ex.stereo_fetch_frames(1)
+    ex.close(); pin.close()
+
+
 def test_object_stereo_matches_bit_exact(images):
     """Frame::ComputeObjStereoMatches (Frame.cc:2318-2503): caller-provided object key sets (here: the frame's keypoints inside
     a detection box, in shuffled order) matched against the device-resident pyramids; bit-exact against the checker."""

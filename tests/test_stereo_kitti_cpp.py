@@ -9,19 +9,21 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "stereo_kitti")
+EXE_BATCH = os.path.join(ROOT, "tests", "cpp", "stereo_kitti_batch")
 
 
-def _build():
+def _build(exe=EXE):
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "pointslot_amd", "host"), "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "stereo_kitti.cpp"), "-o", EXE, "-L", os.path.join(ROOT, "pointslot_amd"),
+           os.path.join(ROOT, "examples", os.path.basename(exe) + ".cpp"), "-o", exe, "-L", os.path.join(ROOT, "pointslot_amd"),
            "-lpointslot_hip", "-pthread", "-Wl,-rpath," + os.path.join(ROOT, "pointslot_amd"), "-Wl,-rpath-link,/opt/rocm/lib"]
     subprocess.check_call(cmd)
 
 
-def test_stereo_kitti_cpp_compiles_and_links():
-    _build()
-    assert os.path.exists(EXE)
-    out = subprocess.run([EXE], capture_output=True, text=True)
+@pytest.mark.parametrize("exe", [EXE, EXE_BATCH])
+def test_stereo_kitti_cpp_compiles_and_links(exe):
+    _build(exe)
+    assert os.path.exists(exe)
+    out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 1 and "Usage" in out.stderr
 
 
@@ -50,3 +52,38 @@ def test_stereo_kitti_cpp_tracks_like_the_python_driver(tmp_path):
     be.close()
     py = np.array([np.concatenate([t[:3, :3].T, (-(t[:3, :3].T @ t[:3, 3]))[:, None]], 1).reshape(12) for t in vo.trajectory])
     assert np.abs(py - traj).max() < 2e-3, np.abs(py - traj).max()
+
+
+@pytest.mark.gpu
+def test_lockstep_batch_tracks_every_sequence_like_the_single_sequence_driver(tmp_path):
+    """StereoOdometryBatch (one batched extraction per step, one C-ABI call per round of search / pose problems) against
+    StereoOdometry (the reference's per-frame call structure) on the same sequences: identical trajectory files.  One of the
+    sequences is blank (no keypoints: it never initialises) and must not disturb the others."""
+    import json
+    from pointslot_amd import sequence
+    _build(EXE)
+    _build(EXE_BATCH)
+    dirs = []
+    for k, seed in enumerate((4, 9, 21)):
+        seq = sequence.generate(n_frames=6, seed=seed, step=0.06 + 0.02 * k)
+        d = str(tmp_path / ("%04d" % k))
+        sequence.write(d, seq, pgm=True)
+        dirs.append(d)
+    blank = dict(seq)
+    blank["left"] = np.full_like(seq["left"], 128); blank["right"] = np.full_like(seq["right"], 128)
+    dblank = str(tmp_path / "blank")
+    sequence.write(dblank, blank, pgm=True)
+    for d in dirs:
+        out = subprocess.run([EXE, d], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    order = [dirs[0], dblank, dirs[1], dirs[2]]
+    out = subprocess.run([EXE_BATCH] + order, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    stats = json.loads(out.stdout.strip().splitlines()[-1])
+    assert stats["sequences"] == 4 and stats["frames_per_sequence"] == 6 and stats["untracked_frames"] == 6   # the blank one
+    for d in dirs:
+        single = open(os.path.join(d, "CameraTrajectory.txt")).read()
+        batch = open(os.path.join(d, "CameraTrajectoryBatch.txt")).read()
+        assert len(single.splitlines()) == 6
+        assert single == batch, d
+    assert open(os.path.join(dblank, "CameraTrajectoryBatch.txt")).read() == ""
