@@ -1,8 +1,9 @@
-// Usage: stereo_kitti_batch [--max-frames N] [--device D] path_to_sequence_1 path_to_sequence_2 ...
+// Usage: stereo_kitti_batch [--max-frames N] [--device D] [--groups G] path_to_sequence_1 path_to_sequence_2 ...
 //
 // BASELINE config 4 on one GPU: several independent stereo sequences (the reference's on-disk layout, see kitti_io.h) tracked
 // in lockstep by ORB_SLAM2::StereoOdometryBatch — every step extracts all sequences' stereo pairs as one batch and serves
-// each round of SearchByProjection / PoseOptimization problems with one C-ABI call.  All images are loaded into page-locked
+// each round of SearchByProjection / PoseOptimization problems with one C-ABI call.  --groups G splits the sequences over G
+// such batches on G threads (own handles), which overlap one group's transfers with another's kernels.  All images are loaded into page-locked
 // memory before the clock starts (the figure is tracking throughput, not disk or PGM decoding).  Writes
 // CameraTrajectoryBatch.txt next to each sequence (System::SaveTrajectoryKITTI format) and prints one JSON line.
 //   g++ -std=c++17 -O2 -pthread -I pointslot_amd/host -I include examples/stereo_kitti_batch.cpp -L pointslot_amd -lpointslot_hip
@@ -13,13 +14,14 @@
 
 int main(int argc, char** argv) {
   std::vector<std::string> seqs;
-  int maxFrames = 1 << 30, device = 0;
+  int maxFrames = 1 << 30, device = 0, groups = 1;
   for (int a = 1; a < argc; a++) {
     if (std::string(argv[a]) == "--max-frames" && a + 1 < argc) maxFrames = std::atoi(argv[++a]);
     else if (std::string(argv[a]) == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
+    else if (std::string(argv[a]) == "--groups" && a + 1 < argc) groups = std::atoi(argv[++a]);
     else seqs.push_back(argv[a]);
   }
-  if (seqs.empty()) { std::cerr << "Usage: ./stereo_kitti_batch [--max-frames N] [--device D] path_to_sequence ..." << std::endl; return 1; }
+  if (seqs.empty()) { std::cerr << "Usage: ./stereo_kitti_batch [--max-frames N] [--device D] [--groups G] path_to_sequence ..." << std::endl; return 1; }
   const int S = (int)seqs.size();
   std::vector<std::vector<std::string>> vstrLeft(S), vstrRight(S);
   int nImages = maxFrames;
@@ -46,54 +48,94 @@ int main(int argc, char** argv) {
         if (!LoadPGM(path, px, wi, hi) || wi != w || hi != h) { std::cerr << "Failed to load image at: " << path << std::endl; return 1; }
         std::memcpy(image(k, ni, right), px.data(), pitch);
       }
-  try {
-    ORB_SLAM2::StereoOdometryBatch SLAM(S, (float)calib["Camera.fx"], (float)calib["Camera.fy"], (float)calib["Camera.cx"], (float)calib["Camera.cy"],
-                                        (float)calib["Camera.bf"], w, h, (float)calib["ThDepth"], 2000, 1.2f, 8, 20, 5, device);
-    const bool prefetch = std::getenv("PS_ODO_NO_PREFETCH") == nullptr;   // queue step n+1's extraction during step n's search / pose rounds
-    std::vector<double> vTimesTrack(nImages);
-    std::vector<std::vector<double>> vParts(4, std::vector<double>(nImages));   // frames / host / search / pose seconds per step
-    std::vector<const uint8_t*> left(S), right(S), nextLeft(S), nextRight(S);
-    int lost = 0;
-    std::cout << "Start processing " << S << " sequences in lockstep ... Images per sequence: " << nImages << std::endl;
-    for (int ni = 0; ni < nImages; ni++) {
-      const bool more = prefetch && ni + 1 < nImages;
-      for (int k = 0; k < S; k++) {
-        left[k] = image(k, ni, 0); right[k] = image(k, ni, 1);
-        if (more) { nextLeft[k] = image(k, ni + 1, 0); nextRight[k] = image(k, ni + 1, 1); }
+  // `groups` StereoOdometryBatch instances, each with its own handles and its own thread, share the sequences round-robin:
+  // while one group waits for a transfer or a kernel the others keep the GPU and the PCIe link busy
+  const int G = std::max(1, std::min(groups, S));
+  const bool prefetch = std::getenv("PS_ODO_NO_PREFETCH") == nullptr;   // queue step n+1's extraction during step n's search / pose rounds
+  const int warm = nImages > 2 ? 2 : (nImages > 1 ? 1 : 0);             // step 0 initialises, step 1 sizes the staging buffers
+  struct Group {
+    std::vector<int> members;
+    std::vector<double> times, parts[4];
+    int lost = 0, rounds = 0;
+    std::chrono::steady_clock::time_point tStart, tEnd;
+    std::string error;
+  };
+  std::vector<Group> grp(G);
+  for (int k = 0; k < S; k++) grp[k % G].members.push_back(k);
+  std::vector<std::vector<std::vector<float>>> trajectories(S);
+  std::mutex mtx;
+  std::condition_variable cv;
+  int arrived = 0;
+  std::cout << "Start processing " << S << " sequences in " << G << " lockstep group(s) ... Images per sequence: " << nImages << std::endl;
+  auto runGroup = [&](int g) {
+    Group& R = grp[g];
+    const int n = (int)R.members.size();
+    try {
+      ORB_SLAM2::StereoOdometryBatch SLAM(n, (float)calib["Camera.fx"], (float)calib["Camera.fy"], (float)calib["Camera.cx"], (float)calib["Camera.cy"],
+                                          (float)calib["Camera.bf"], w, h, (float)calib["ThDepth"], 2000, 1.2f, 8, 20, 5, device);
+      R.times.assign(nImages, 0.0);
+      for (auto& v : R.parts) v.assign(nImages, 0.0);
+      std::vector<const uint8_t*> left(n), right(n), nextLeft(n), nextRight(n);
+      for (int ni = 0; ni < nImages; ni++) {
+        if (ni == warm) {   // all groups start the timed steps together
+          std::unique_lock<std::mutex> lk(mtx);
+          if (++arrived == G) cv.notify_all(); else cv.wait(lk, [&]() { return arrived >= G; });
+          R.tStart = std::chrono::steady_clock::now();
+        }
+        const bool more = prefetch && ni + 1 < nImages;
+        for (int i = 0; i < n; i++) {
+          const int k = R.members[i];
+          left[i] = image(k, ni, 0); right[i] = image(k, ni, 1);
+          if (more) { nextLeft[i] = image(k, ni + 1, 0); nextRight[i] = image(k, ni + 1, 1); }
+        }
+        const double e0 = SLAM.tExtract, h0 = SLAM.tHost, s0 = SLAM.tSearch, p0 = SLAM.tPose;
+        const auto t1 = std::chrono::steady_clock::now();
+        const int tracked = SLAM.TrackAll(left, right, w, more ? &nextLeft : nullptr, more ? &nextRight : nullptr);
+        const auto t2 = std::chrono::steady_clock::now();
+        R.times[ni] = std::chrono::duration<double>(t2 - t1).count();
+        R.lost += n - tracked;
+        R.parts[0][ni] = SLAM.tExtract - e0; R.parts[1][ni] = SLAM.tHost - h0; R.parts[2][ni] = SLAM.tSearch - s0; R.parts[3][ni] = SLAM.tPose - p0;
+        if (G == 1)
+          std::printf("step %d: %d of %d sequences tracked, %.3f ms (frames %.3f, host %.3f, search %.3f, pose %.3f)\n", ni, tracked, n, 1e3 * R.times[ni],
+                      1e3 * R.parts[0][ni], 1e3 * R.parts[1][ni], 1e3 * R.parts[2][ni], 1e3 * R.parts[3][ni]);
       }
-      const double e0 = SLAM.tExtract, h0 = SLAM.tHost, s0 = SLAM.tSearch, p0 = SLAM.tPose;
-      const auto t1 = std::chrono::steady_clock::now();
-      const int tracked = SLAM.TrackAll(left, right, w, more ? &nextLeft : nullptr, more ? &nextRight : nullptr);
-      const auto t2 = std::chrono::steady_clock::now();
-      vTimesTrack[ni] = std::chrono::duration<double>(t2 - t1).count();
-      lost += S - tracked;
-      vParts[0][ni] = SLAM.tExtract - e0; vParts[1][ni] = SLAM.tHost - h0; vParts[2][ni] = SLAM.tSearch - s0; vParts[3][ni] = SLAM.tPose - p0;
-      std::printf("step %d: %d of %d sequences tracked, %.3f ms (frames %.3f, host %.3f, search %.3f, pose %.3f)\n", ni, tracked, S, 1e3 * vTimesTrack[ni],
-                  1e3 * vParts[0][ni], 1e3 * vParts[1][ni], 1e3 * vParts[2][ni], 1e3 * vParts[3][ni]);
+      R.tEnd = std::chrono::steady_clock::now();
+      R.rounds = SLAM.rounds;
+      for (int i = 0; i < n; i++) trajectories[R.members[i]] = SLAM.sequence(i).trajectory;
+    } catch (const std::exception& e) {
+      R.error = e.what();
+      std::unique_lock<std::mutex> lk(mtx);   // do not leave the other groups waiting at the start line
+      if (arrived < G) { arrived = G; cv.notify_all(); }
     }
-    for (int k = 0; k < S; k++) SaveTrajectoryKITTI(seqs[k] + "/CameraTrajectoryBatch.txt", SLAM.sequence(k).trajectory);
-    // the first step initialises every sequence (and builds the plans): statistics over the tracked steps
-    std::vector<double> sorted(vTimesTrack.begin() + (nImages > 1 ? 1 : 0), vTimesTrack.end());
-    std::sort(sorted.begin(), sorted.end());
-    double total = 0;
-    for (double t : sorted) total += t;
-    const double median = sorted[sorted.size() / 2], mean = total / sorted.size();
-    double part[4];
-    for (int q = 0; q < 4; q++) {
-      std::vector<double> v(vParts[q].begin() + (nImages > 1 ? 1 : 0), vParts[q].end());
-      std::sort(v.begin(), v.end());
-      part[q] = v[v.size() / 2];
-    }
-    std::printf("{\"sequences\": %d, \"frames_per_sequence\": %d, \"untracked_frames\": %d, \"median_ms_per_step\": %.4f, \"mean_ms_per_step\": %.4f, "
-                "\"frames_per_s\": %.1f, \"ms_per_step_frames\": %.4f, \"ms_per_step_host\": %.4f, \"ms_per_step_search\": %.4f, "
-                "\"ms_per_step_pose\": %.4f, \"device_rounds_per_step\": %.2f}\n",
-                S, nImages, lost, 1e3 * median, 1e3 * mean, S / median, 1e3 * part[0], 1e3 * part[1], 1e3 * part[2], 1e3 * part[3],
-                SLAM.rounds / (double)nImages);
-  } catch (const std::exception& e) {
-    std::cerr << "error: " << e.what() << std::endl;
-    ps_pinned_free(pinned);
-    return 2;
+  };
+  {
+    std::vector<std::thread> threads;
+    for (int g = 1; g < G; g++) threads.emplace_back(runGroup, g);
+    runGroup(0);
+    for (std::thread& t : threads) t.join();
   }
+  for (const Group& R : grp)
+    if (!R.error.empty()) { std::cerr << "error: " << R.error << std::endl; ps_pinned_free(pinned); return 2; }
+  for (int k = 0; k < S; k++) SaveTrajectoryKITTI(seqs[k] + "/CameraTrajectoryBatch.txt", trajectories[k]);
+  // statistics over the timed steps: wall clock from the common start to the last group's end
+  auto medianOf = [&](const std::vector<double>& v) {
+    std::vector<double> t(v.begin() + warm, v.end());
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+  };
+  double median = 0, wall = 0;
+  int lost = 0;
+  for (const Group& R : grp) {
+    median = std::max(median, medianOf(R.times));
+    wall = std::max(wall, std::chrono::duration<double>(R.tEnd - grp[0].tStart).count());
+    lost += R.lost;
+  }
+  const int timedSteps = nImages - warm;
+  std::printf("{\"sequences\": %d, \"groups\": %d, \"frames_per_sequence\": %d, \"timed_steps\": %d, \"untracked_frames\": %d, \"median_ms_per_step\": %.4f, "
+              "\"wall_ms_timed_steps\": %.4f, \"frames_per_s\": %.1f, \"ms_per_step_frames\": %.4f, \"ms_per_step_host\": %.4f, \"ms_per_step_search\": %.4f, "
+              "\"ms_per_step_pose\": %.4f, \"device_rounds_per_step\": %.2f}\n",
+              S, G, nImages, timedSteps, lost, 1e3 * median, 1e3 * wall, timedSteps > 0 ? S * timedSteps / wall : 0.0, 1e3 * medianOf(grp[0].parts[0]),
+              1e3 * medianOf(grp[0].parts[1]), 1e3 * medianOf(grp[0].parts[2]), 1e3 * medianOf(grp[0].parts[3]), grp[0].rounds / (double)nImages);
   ps_pinned_free(pinned);
   return 0;
 }

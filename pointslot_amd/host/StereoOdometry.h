@@ -432,6 +432,9 @@ class StereoOdometryBatch {
       : nseq(nSequences), w(width), h(height), device_(device), matcher(0.9f, true, device) {
     ps_orb_config cfg{nFeatures, scale, nLevels, iniTh, minTh, 2 * nSequences, device};
     if (ps_orb_create(&cfg, &orb) != PS_OK) throw std::runtime_error(std::string("ps_orb_create: ") + ps_last_error());
+    // an optimiser handle of its own (not the process-wide one of the static Optimizer functions): several batches may run
+    // on different threads
+    if (ps_optimizer_create(device, &opt) != PS_OK) { ps_orb_destroy(orb); throw std::runtime_error(std::string("ps_optimizer_create: ") + ps_last_error()); }
     std::vector<float> sfv(nLevels), isf(nLevels), s2(nLevels), is2(nLevels);
     ps_orb_get_tables(orb, sfv.data(), isf.data(), s2.data(), is2.data(), nullptr);
     cam.reset(new OdoCamera(fx, fy, cx, cy, bf, width, height, thDepth, sfv, is2));
@@ -447,6 +450,7 @@ class StereoOdometryBatch {
     }
     cvStart.notify_all();
     for (std::thread& th : workers) th.join();
+    ps_optimizer_destroy(opt);
     ps_orb_destroy(orb);
   }
   StereoOdometryBatch(const StereoOdometryBatch&) = delete;
@@ -516,7 +520,7 @@ class StereoOdometryBatch {
       poses.clear(); owner.clear();
       for (int k = 0; k < nseq; k++) if (rq[k] == OdoSequence::POSE) { poses.push_back(seqs[k]->posep); owner.push_back(k); }
       if (!poses.empty()) {
-        Optimizer::PoseOptimizationBatch(poses, device_);
+        check(ps_pose_optimize_batch(opt, poses.data(), (int)poses.size()));
         for (size_t i = 0; i < owner.size(); i++) seqs[owner[i]]->posep = poses[i];
       }
       auto t4 = clk::now();
@@ -535,6 +539,7 @@ class StereoOdometryBatch {
  private:
   int nseq, w, h, device_, cap = 0, nthreads = 1;
   ps_orb* orb = nullptr;
+  ps_optimizer* opt = nullptr;
   ORBmatcher matcher;
   std::unique_ptr<OdoCamera> cam;
   std::vector<std::unique_ptr<OdoSequence>> seqs;
