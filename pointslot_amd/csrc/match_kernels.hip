@@ -330,11 +330,13 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
   }
 }
 
+#define PJ_TBL 8192
 __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   __shared__ uint32_t blocked[1024];   // up to 32768 train features
   __shared__ int hist[32];
   __shared__ uint32_t newly[1024];     // trains blocked by this call
   __shared__ uint8_t loct[32768];      // train octaves (ratio test), staged once: no global load inside the serial loop
+  __shared__ uint32_t first_lane[PJ_TBL];   // hashed train -> earliest lane of the current block that lists it among its four keys
   const PjProb P = A.prob[blockIdx.x];
   const int lane = threadIdx.x;
   int32_t* match = A.match + P.t_off;
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
     newly[w] = 0;
   }
   if (lane < 32) hist[lane] = 0;
+  for (int w = lane; w < PJ_TBL; w += 64) first_lane[w] = 0xFFFFFFFFu;
   for (int j = lane; j < P.nt; j += 64) match[j] = -1;
   if (P.ratio_test)
     for (int j = lane; j < P.nt; j += 64) loct[j] = (uint8_t)A.toct[P.t_off + j];
@@ -357,17 +360,27 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
 #ifdef PS_PJ_PROFILE
   const long long pj_t0 = wall_clock64();
   long long pj_t1 = 0;
+  int pj_clean = 0, pj_dirty = 0, pj_serial_blocks = 0;
 #endif
   // Queries are taken in order (the assignment is order dependent), 64 at a time: the lane-resident candidate counts give
   // the non-empty queries of the block as a bit mask, and the first 64 candidate keys of the NEXT non-empty query are
   // requested before the current one is reduced, so the global-memory latency is paid once per block, not once per query.
   // newly: bitmap of the trains blocked by THIS call (the occupancy at entry is already excluded from tbest / tsecond)
+  const uint4 no_keys = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  int ncv_next = lane < P.nq ? A.ncand[P.q_off + lane] : 0;
+  int obsv_next = lane < P.nq ? (int)A.qobs[P.q_off + lane] : 0;
+  uint4 tt_next = lane < P.nq ? A.ttop[P.q_off + lane] : no_keys;
   for (int q0 = 0; q0 < P.nq; q0 += 64) {
     const bool qin = q0 + lane < P.nq;
     const int qq = P.q_off + q0 + lane;
-    const int ncv = qin ? A.ncand[qq] : 0;
-    const int obsv = qin ? (int)A.qobs[qq] : 0;
-    const uint4 tt = qin ? A.ttop[qq] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    const int ncv = ncv_next, obsv = obsv_next;
+    const uint4 tt = tt_next;
+    {   // the next block's per-query data is requested now and arrives while this block is decided
+      const bool nin = q0 + 64 + lane < P.nq;
+      ncv_next = nin ? A.ncand[qq + 64] : 0;
+      obsv_next = nin ? (int)A.qobs[qq + 64] : 0;
+      tt_next = nin ? A.ttop[qq + 64] : no_keys;
+    }
     const uint32_t tk[4] = {tt.x, tt.y, tt.z, tt.w};
     if (qin) A.qbest[qq] = -1;
     // claims of earlier blocks against the four keys: one LDS lookup per key and lane, in parallel
@@ -376,6 +389,75 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
     for (int r = 0; r < 4; r++)
       if (tk[r] != 0xFFFFFFFFu) { const uint32_t j = tk[r] & 0x7FFF; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u) << r; }
     unsigned long long pend = __builtin_amdgcn_ballot_w64(ncv > 0);
+    // ---- queries whose outcome cannot depend on the other queries of the block are decided by all lanes at once ----
+    // A query's choice among its four keys only changes when an EARLIER query of the block claims one of those trains.  Every
+    // lane enters its (up to four) trains into a hashed table with an atomic min of the lane number; a lane that is the
+    // earliest in all of its buckets shares no train with any earlier lane (hash collisions only make the test stricter), so
+    // its decision is the one the sequential loop would take, whatever the others do.  The rest goes through the loop below.
+    // A query that could run out of unclaimed keys (fewer exclusive ones than the decision reads, and a candidate list longer
+    // than the four) might fall back to scanning its whole list, which can pick any train: it stays in the sequential loop ...
+    {
+      const int want = P.ratio_test ? 2 : 1;
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (ncv > 0 && tk[r] != 0xFFFFFFFFu) atomicMin(&first_lane[(tk[r] & 0x7FFF) & (PJ_TBL - 1)], (uint32_t)lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+      int found = 0, exclusive = 0;
+      bool clean = ncv > 0;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (ncv > 0 && tk[r] != 0xFFFFFFFFu) {
+          const bool mine = first_lane[(tk[r] & 0x7FFF) & (PJ_TBL - 1)] == (uint32_t)lane;
+          clean = clean && mine;
+          if (!((stale >> r) & 1)) {
+            if (found == 0) best = tk[r]; else if (found == 1) second = tk[r];
+            found++;
+            exclusive += mine ? 1 : 0;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (ncv > 0 && tk[r] != 0xFFFFFFFFu) first_lane[(tk[r] & 0x7FFF) & (PJ_TBL - 1)] = 0xFFFFFFFFu;
+      // (fewer than four keys: they are ALL the candidates that were free at entry, a scan cannot find another one)
+      const bool may_scan = ncv > 4 && tk[3] != 0xFFFFFFFFu && exclusive < want;
+      // ... and so does everything after it: only the lanes before the first such query take the parallel path
+      const unsigned long long scanners = __builtin_amdgcn_ballot_w64(may_scan);
+      const unsigned long long before = scanners ? ((1ull << (__ffsll((long long)scanners) - 1)) - 1ull) : ~0ull;
+      clean = clean && ((before >> lane) & 1ull);
+      {
+        bool accept = clean && best != 0xFFFFFFFFu && (int)(best >> 23) <= P.th_dist;
+        const int bestIdx = (int)(best & 0x7FFF);
+        if (accept && P.ratio_test && second != 0xFFFFFFFFu) {
+          const int l1 = loct[bestIdx], l2 = loct[second & 0x7FFF];
+          if (l1 == l2 && (float)(int)(best >> 23) > __fmul_rn(P.nn_ratio, (float)(int)(second >> 23))) accept = false;
+        }
+        if (accept) {
+          if (obsv) atomicOr(&newly[bestIdx >> 5], 1u << (bestIdx & 31));
+          atomicMax(&match[bestIdx], q0 + lane);
+          A.qbest[qq] = bestIdx;
+        }
+        nm += __popcll(__builtin_amdgcn_ballot_w64(accept));
+        pend &= ~__builtin_amdgcn_ballot_w64(clean);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the remaining queries see the claims just made by earlier lanes of the block (later lanes share no train with them)
+        stale = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (tk[r] != 0xFFFFFFFFu) { const uint32_t j = tk[r] & 0x7FFF; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u) << r; }
+#ifdef PS_PJ_PROFILE
+        pj_clean += __popcll(__builtin_amdgcn_ballot_w64(clean)); pj_dirty += __popcll(pend); pj_serial_blocks += scanners ? 1 : 0;
+#endif
+      }
+    }
     int accidx = -1;        // lane k: the train taken by the k-th observed acceptance of this block
     int nacc = 0;
     int allq = -1, allt = 0, nall = 0;   // lane k: query and train of the k-th acceptance of this block (at most 64)
@@ -490,7 +572,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   }
   if (lane == 0) A.nmatch[blockIdx.x] = nm;
 #ifdef PS_PJ_PROFILE
-  if (lane == 0 && blockIdx.x == 0) printf("pj_resolve nq %d nt %d: loop %lld ticks, tail %lld ticks, matches %d\n", P.nq, P.nt, pj_t1 - pj_t0, wall_clock64() - pj_t1, nm);
+  if (lane == 0 && blockIdx.x == 0) printf("pj_resolve nq %d nt %d: loop %lld ticks, tail %lld ticks, matches %d, decided in parallel %d, sequentially %d, blocks with a scanning query %d\n", P.nq, P.nt, pj_t1 - pj_t0, wall_clock64() - pj_t1, nm, pj_clean, pj_dirty, pj_serial_blocks);
 #endif
 }
 
