@@ -392,22 +392,31 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
           for (int o = 0; o < k; o++) {
             const PoVertex V = verts[P.v_off + o];
             const Se3 T = load_pose(s.pose[o]);
-            PoEdge nx = {};
-            if (V.e_begin + tid < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, V.e_begin + tid);
-            for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
-              const PoEdge ed = nx;
-              if (i + PO_T < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, i + PO_T);
-              const uint8_t st = ed.st;
-              if ((st & (ST_VALID | ST_LVL1)) != ST_VALID) continue;
-              const bool mono = st & ST_MONO;
-              double p[3], e[3];
-              const float exw[3] = {ed.x0, ed.x1, ed.x2}, eob[3] = {ed.o0, ed.o1, ed.o2};
-              edge_error(T, P, exw, eob, mono, p, e);
-              const double chi2 = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * (double)ed.is2;
-              chi2c[i] = chi2;
-              double rho0 = chi2, rho1;
-              if (robust) huber(chi2, mono ? deltaMono : deltaStereo, rho0, rho1);
-              c1[0] += rho0;
+            // four edges per step, all loads issued before the first use: the pass is short (an error and a Huber weight per
+            // edge), so the memory round trip would otherwise be paid once per edge
+            for (int i0 = V.e_begin + tid; i0 < V.e_end; i0 += 4 * PO_T) {
+              PoEdge eds[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * PO_T;
+                eds[u] = po_load(xw, obs, inv_sigma2, state, i < V.e_end ? i : i0);
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * PO_T;
+                const PoEdge ed = eds[u];
+                const uint8_t st = ed.st;
+                if (i >= V.e_end || (st & (ST_VALID | ST_LVL1)) != ST_VALID) continue;
+                const bool mono = st & ST_MONO;
+                double p[3], e[3];
+                const float exw[3] = {ed.x0, ed.x1, ed.x2}, eob[3] = {ed.o0, ed.o1, ed.o2};
+                edge_error(T, P, exw, eob, mono, p, e);
+                const double chi2 = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * (double)ed.is2;
+                chi2c[i] = chi2;
+                double rho0 = chi2, rho1;
+                if (robust) huber(chi2, mono ? deltaMono : deltaStereo, rho0, rho1);
+                c1[0] += rho0;
+              }
             }
             if (P.mode == 1 && tid == 0) {
               const double e0 = s.prior_obs[o][0] - T.t[0], e1 = s.prior_obs[o][1] - T.t[1], e2 = s.prior_obs[o][2] - T.t[2];
