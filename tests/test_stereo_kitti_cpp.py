@@ -27,6 +27,38 @@ def test_stereo_kitti_cpp_compiles_and_links(exe):
     assert out.returncode == 1 and "Usage" in out.stderr
 
 
+def test_cpp_host_state_machine_with_the_cpu_checker_behind_it(tmp_path):
+    """OdoSequence (the C++ host side of the tracking loop: request preparation, match application, outlier handling, motion
+    model) with oracle/liboracle.so serving its SearchByProjection / PoseOptimization requests, against the Python twin of the
+    loop over the same checker: same match counts, same trajectory.  No GPU involved."""
+    import oracle_lib  # noqa: F401  (builds oracle/liboracle.so when missing)
+    from pointslot_amd import sequence
+    from pointslot_amd.tracker import StereoOdometry
+    from oracle_backend import OracleBackend
+    exe = os.path.join(ROOT, "tests", "cpp", "odo_oracle_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "pointslot_amd", "host"), "-I", os.path.join(ROOT, "include"),
+                           exe + ".cpp", "-o", exe, "-L", os.path.join(ROOT, "oracle"), "-loracle", "-L", os.path.join(ROOT, "pointslot_amd"), "-lpointslot_hip",
+                           "-pthread", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,-rpath," + os.path.join(ROOT, "pointslot_amd"),
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    seq = sequence.generate(n_frames=5, seed=4, w=800, h=300)
+    d = str(tmp_path / "0000")
+    sequence.write_pgm(d, seq)
+    out = subprocess.run([exe, d], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-1000:]
+    traj = np.loadtxt(os.path.join(d, "CameraTrajectoryOracle.txt"))
+    assert traj.shape == (5, 12)
+    vo = StereoOdometry(OracleBackend(), seq["K"], seq["bf"], 800, 300)
+    for l, r in zip(seq["left"], seq["right"]):
+        vo.track(l, r)
+    py = np.array([np.concatenate([t[:3, :3].T, (-(t[:3, :3].T @ t[:3, 3]))[:, None]], 1).reshape(12) for t in vo.trajectory])
+    assert np.abs(py - traj).max() < 1e-6, np.abs(py - traj).max()      # host float arithmetic may differ in the last ulp
+    assert np.abs(traj[:, 3] - seq["twc"][:, 0, 3]).max() < 0.03
+    lines = [l for l in out.stdout.splitlines() if l.startswith("frame")]
+    for k in range(1, 5):
+        st = vo.stats[k]
+        assert "matches %d map %d local inliers %d" % (st["matches"], st["map_matches"], st["local_inliers"]) in lines[k], (lines[k], st)
+
+
 @pytest.mark.gpu
 def test_stereo_kitti_cpp_tracks_like_the_python_driver(tmp_path):
     from pointslot_amd import sequence
