@@ -183,13 +183,27 @@ __global__ __launch_bounds__(256) void orb_pyramid_level(OrbPlan plan, int level
 #define LV_R (4 * LV_RPT)         // region rows per workgroup
 #define LV_OWN_R (LV_R - 6)       // owned rows
 #define LV_OWN_C 248              // owned columns (62 dword groups; lanes 0 and 63 are halo)
+#ifndef LV_HALVES
+#define LV_HALVES 2            // the region rows of a thread are loaded and resized in this many groups
+#endif
+#define LV_HROWS (LV_RPT / LV_HALVES)
 #define LV_BLUR_ROWS 9            // 4 row chunks of <= 9 cover the 34 owned rows
 typedef unsigned short lv_us2 __attribute__((ext_vector_type(2)));
 
+#ifdef PS_LV_PROFILE   // developer build: 100 MHz ticks of one workgroup in the middle of the launch
+#define LVP_DECL long long lv_t[8]; int lv_n = 0; lv_t[lv_n++] = wall_clock64()
+#define LVP_MARK() (lv_t[lv_n++] = wall_clock64())
+#define LVP_PRINT() do { if (threadIdx.x == 0 && blockIdx.x == 2 && blockIdx.y == 5 && blockIdx.z == 64) printf("level %d ticks: setup %lld half0 %lld half1 %lld barrier %lld blur %lld\n", level, lv_t[1] - lv_t[0], lv_t[2] - lv_t[1], lv_t[3] - lv_t[2], lv_t[4] - lv_t[3], wall_clock64() - lv_t[4]); } while (0)
+#else
+#define LVP_DECL
+#define LVP_MARK()
+#define LVP_PRINT()
+#endif
 template <bool LEVEL0>
 __global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, uint8_t* arena, const uint8_t* imgs,
                                                       int img_stride, size_t img_pitch, const int4* tabs) {
   __shared__ uint32_t tile[LV_R][64];
+  LVP_DECL;
   const OrbLevel L = plan.lv[level];
   const int img = blockIdx.z;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
@@ -240,14 +254,18 @@ __global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, 
   // the horizontally interpolated row is carried over instead of being recomputed; the row indices are wave-uniform.
   uint32_t hc[4] = {0, 0, 0, 0};
   int hc_row = -1;
+#ifdef PS_LV_PROFILE
+  if (coef[0] == 0x7fffffffu) tile[0][0] = 1;   // keeps the table loads before the first stamp
+  LVP_MARK();
+#endif
 #pragma unroll
-  for (int half = 0; half < 2; half++) {
-    uint32_t wl[LV_RPT / 2][2], wh[LV_RPT / 2][2];
-    int4 ty[LV_RPT / 2];
-    bool need0[LV_RPT / 2];
+  for (int half = 0; half < LV_HALVES; half++) {
+    uint32_t wl[LV_HROWS][2], wh[LV_HROWS][2];
+    int4 ty[LV_HROWS];
+    bool need0[LV_HROWS];
 #pragma unroll
-    for (int r = 0; r < LV_RPT / 2; r++) {
-      const int rr = tyq * LV_RPT + half * (LV_RPT / 2) + r;
+    for (int r = 0; r < LV_HROWS; r++) {
+      const int rr = tyq * LV_RPT + half * (LV_HROWS) + r;
       const int py = min(max(Q0 + rr, 0), PH - 1);
       const int ly = reflect101(py - PS_EDGE, L.h);
       if (LEVEL0) ty[r] = make_int4(ly, ly, 0, 0);
@@ -273,8 +291,8 @@ __global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, 
       }
     }
 #pragma unroll
-    for (int r = 0; r < LV_RPT / 2; r++) {
-      const int rr = tyq * LV_RPT + half * (LV_RPT / 2) + r;
+    for (int r = 0; r < LV_HROWS; r++) {
+      const int rr = tyq * LV_RPT + half * (LV_HROWS) + r;
       uint32_t pk;
       if (LEVEL0) {
         pk = fast ? __builtin_amdgcn_perm(wh[r][0], wl[r][0], sel_copy) : wl[r][0];
@@ -302,9 +320,11 @@ __global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, 
       if (own_x && rr >= 3 && rr < 3 + LV_OWN_R && py < PH)
         *reinterpret_cast<uint32_t*>(plane + ((uint32_t)py * (uint32_t)L.stride + (uint32_t)(P0 + 4 * lane))) = pk;
     }
-    hc_row = ty[LV_RPT / 2 - 1].y;
+    hc_row = ty[LV_HROWS - 1].y;
+    LVP_MARK();
   }
   __syncthreads();
+  LVP_MARK();
 
   // ---- phase 2: GaussianBlur 7x7 of the owned in-image pixels from LDS (fixed point, see orb_blur) ----
   const int tid = threadIdx.x;
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, 
     }
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.bstride) = pk;
   }
+  LVP_PRINT();
 }
 
 // copyMakeBorder(REFLECT_101) of all levels in one launch: every border dword is recomputed from the interior.
