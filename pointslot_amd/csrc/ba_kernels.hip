@@ -514,10 +514,11 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
 }
 
 // Blocked unpivoted LDL^T of the reduced system S (n = 6 * active poses) and the two triangular solves, one
-// workgroup per problem.  Block width NB (48 for n <= 312): per block column
-//   (1) ONE wave factors the NB x NB diagonal block with its rows in registers (lane = row, broadcasts by shuffle,
+// workgroup per problem.  Block width NB (24 in practice): per block column
+//   (1) ONE wave factors the NB x NB diagonal block with its rows in registers (lane = row, broadcasts by v_readlane,
 //       no workgroup barrier), (2) every other row solves its NB-wide panel against it (thread per row, panel kept
-//       in LDS), (3) the trailing matrix gets the rank-NB update from the LDS panel, 1 x 4 register blocking.
+//       in LDS), (3) the trailing matrix gets the rank-NB update from the LDS panel on the FP64 matrix cores — first the
+//       tiles of the next block column, then, while wave 0 already factors the next diagonal block (1), the rest.
 // Global traffic is n^3 / (3 NB) instead of n^3 / 18 with 6-wide blocks.  x_p only changes when the factorisation
 // succeeds (linear_solver_eigen.h:94-120 returns false without touching x); a zero pivot = failure, like
 // SimplicialLDLT.
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
 #ifdef PS_BA_PROFILE   // developer build: per-phase wall-clock ticks (100 MHz) of problem 0, printed by the kernel
 #define SOLP_DECL long long T0 = wall_clock64(), tph[6] = {0, 0, 0, 0, 0, 0}, tt = T0
 #define SOLP_MARK(k) do { const long long _n = wall_clock64(); tph[k] += _n - tt; tt = _n; } while (0)
-#define SOLP_PRINT() do { if (tid == 0 && blockIdx.x == 0) printf("solve n=%d NB=%d ticks: diag %lld panel %lld trail %lld fwd %lld bwd %lld total %lld\n", n, NB, tph[0], tph[1], tph[2], tph[3], tph[4], wall_clock64() - T0); } while (0)
+#define SOLP_PRINT() do { if (tid == 0 && blockIdx.x == 0) printf("solve n=%d NB=%d ticks: diag + rest of trailing %lld panel %lld trailing, next block column %lld fwd %lld bwd %lld total %lld\n", n, NB, tph[0], tph[1], tph[2], tph[3], tph[4], wall_clock64() - T0); } while (0)
 #else
 #define SOLP_DECL
 #define SOLP_MARK(k)
@@ -540,76 +541,70 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   const int n = 6 * St.npa, lda = 6 * P.np, tid = threadIdx.x, lane = tid & 63;
   double* Sm = A.S + P.S_base;
   extern __shared__ __attribute__((aligned(16))) double sol_smem[];
-  double* Ljj = sol_smem;                       // [NB][NB + 1]
-  double* dj = Ljj + NB * (NB + 1);             // [NB]
-  double* rhs = dj + NB;                        // [n]
+  // the diagonal block's factor, pivots and pivot reciprocals exist twice: while the trailing update still reads block J's,
+  // wave 0 already produces block J + NB's (look-ahead, see (3b))
+  double* Ljj2 = sol_smem;                      // [2][NB][NB + 1]
+  double* dj2 = Ljj2 + 2 * NB * (NB + 1);       // [2][NB]
+  double* rdj2 = dj2 + 2 * NB;                  // [2][NB] reciprocals of the block's pivots
+  double* rhs = rdj2 + 2 * NB;                  // [n]
   double* dall = rhs + 6 * PS_BA_MAX_POSES;     // [n]
-  double* lcol = dall + 6 * PS_BA_MAX_POSES;    // [2][64] multipliers of the current elimination step
-  double* rdj = lcol + 128;                     // [NB] reciprocals of the block's pivots
-  double* panel = rdj + NB;                     // [rows below][NB + 1]
+  double* panel = dall + 6 * PS_BA_MAX_POSES;   // [rows below][NB + 1]
   __shared__ int fail;
   if (tid == 0) fail = 0;
   // LDS keeps whatever the previous kernel on this CU left there, NaN bit patterns included, and 0 * NaN is not 0: every slot
   // that a partial last block touches with a zero multiplier (rhs beyond n, pivots beyond jb) is given a finite value first
   for (int i = tid; i < 6 * PS_BA_MAX_POSES; i += SOL_T) { rhs[i] = i < n ? A.bs[(size_t)P.pose_base * 6 + i] : 0.0; dall[i] = 1.0; }
-  if (tid < NB) { dj[tid] = 0.0; rdj[tid] = 0.0; }
+  if (tid < 2 * NB) { dj2[tid] = 0.0; rdj2[tid] = 0.0; }
   __syncthreads();
   if (n == 0) { if (tid == 0) St.ok2 = 1; return; }
   SOLP_DECL;
-  for (int J = 0; J < n; J += NB) {
-    const int jb = min(NB, n - J);
-    SOLP_MARK(5);
-    // ---- (1) diagonal block, wave 0: lane = row, rows in registers.  Step j: every lane forms its multiplier
-    // l = a[j] / d_j and publishes it in LDS; the rank-1 update reads the other rows' multipliers back as LDS
-    // BROADCASTS (all lanes read the same address).  Entries above the diagonal are never consumed, so the update
-    // needs no masking.
-    if (tid < 64) {
-      double a[NB];
+  // ---- (1) diagonal block, ONE wave: lane = row, rows in registers.  Step j: every lane forms its multiplier l = a[j] / d_j;
+  // the rank-1 update reads the other rows' multipliers straight out of their lanes' registers (v_readlane into a scalar pair
+  // that feeds the FMA).  Entries above the diagonal are never consumed, so the update needs no masking.
+  auto diag_block = [&](int J, int jb, double* Ljj, double* dj, double* rdj) {
+    double a[NB];
 #pragma unroll
-      for (int c = 0; c < NB; c++) a[c] = (lane < jb && c <= lane) ? Sm[(size_t)(J + lane) * lda + J + c] : 0.0;
-#ifdef PS_BA_PROFILE
-      { double chk = 0; for (int c = 0; c < NB; c++) chk += a[c]; if (chk == 1.2345e300) fail = 2; }
-      SOLP_MARK(3);
-#endif
-      bool bad = false;
-      // The critical path of a step is pivot -> reciprocal -> multiplier -> update of the NEXT pivot column; the other 22 updates
-      // are off it.  The next pivot is therefore updated first and its reciprocal started before the rest of the row is touched.
-      double d = shfl_d(a[0], 0), rd = recip_d(d);
+    for (int c = 0; c < NB; c++) a[c] = (lane < jb && c <= lane) ? Sm[(size_t)(J + lane) * lda + J + c] : 0.0;
+    bool bad = false;
+    // The critical path of a step is pivot -> reciprocal -> multiplier -> update of the NEXT pivot column; the other 22 updates
+    // are off it.  The next pivot is therefore updated first and its reciprocal started before the rest of the row is touched.
+    double d = shfl_d(a[0], 0), rd = recip_d(d);
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        if (j < jb) {
-          if (d == 0) bad = true;
-          if (lane == j) rdj[j] = rd;
-          const double l = lane > j ? a[j] * rd : 0.0;
-          // the other rows' multipliers come straight out of their lanes' registers (v_readlane into a scalar pair that feeds
-          // the FMA): no LDS round trip
-          const double ld = l * d;
-          double dn = 1.0, rdn = 1.0;
-          if (j + 1 < NB) {
-            a[j + 1] -= ld * shfl_d(l, j + 1);
-            dn = shfl_d(a[j + 1], j + 1);
-            rdn = recip_d(dn);
-          }
-#pragma unroll
-          for (int k = j + 2; k < NB; k++) a[k] -= ld * shfl_d(l, k);
-          if (lane > j) a[j] = l;
-          d = dn; rd = rdn;
+    for (int j = 0; j < NB; j++) {
+      if (j < jb) {
+        if (d == 0) bad = true;
+        if (lane == j) rdj[j] = rd;
+        const double l = lane > j ? a[j] * rd : 0.0;
+        const double ld = l * d;
+        double dn = 1.0, rdn = 1.0;
+        if (j + 1 < NB) {
+          a[j + 1] -= ld * shfl_d(l, j + 1);
+          dn = shfl_d(a[j + 1], j + 1);
+          rdn = recip_d(dn);
         }
+#pragma unroll
+        for (int k = j + 2; k < NB; k++) a[k] -= ld * shfl_d(l, k);
+        if (lane > j) a[j] = l;
+        d = dn; rd = rdn;
       }
-#ifdef PS_BA_PROFILE
-      SOLP_MARK(4);
-#endif
-      if (lane < jb) {
-#pragma unroll
-        for (int c = 0; c < NB; c++) {
-          if (c < lane) { Ljj[lane * (NB + 1) + c] = a[c]; Sm[(size_t)(J + lane) * lda + J + c] = a[c]; }
-          else if (c == lane) { dj[lane] = a[c]; dall[J + lane] = a[c]; }
-        }
-      } else if (lane < NB) { dj[lane] = 0.0; rdj[lane] = 0.0; }   // columns of a partial block that do not exist
-      if (bad && lane == 0) fail = 1;
     }
-    __syncthreads();
-    SOLP_MARK(0);
+    if (lane < jb) {
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        if (c < lane) { Ljj[lane * (NB + 1) + c] = a[c]; Sm[(size_t)(J + lane) * lda + J + c] = a[c]; }
+        else if (c == lane) { dj[lane] = a[c]; dall[J + lane] = a[c]; }
+      }
+    } else if (lane < NB) { dj[lane] = 0.0; rdj[lane] = 0.0; }   // columns of a partial block that do not exist
+    if (bad && lane == 0) fail = 1;
+  };
+  if (tid < 64) diag_block(0, min(NB, n), Ljj2, dj2, rdj2);
+  __syncthreads();
+  SOLP_MARK(0);
+  for (int J = 0, cur = 0; J < n; J += NB, cur ^= 1) {
+    const int jb = min(NB, n - J);
+    double* Ljj = Ljj2 + cur * NB * (NB + 1);
+    double* dj = dj2 + cur * NB;
+    double* rdj = rdj2 + cur * NB;
     if (fail) break;
     // ---- (2) panel rows below the block: coalesced load into LDS, thread-per-row solve in LDS, coalesced store ----
     const int m0 = J + jb, m = n - m0;
@@ -666,15 +661,14 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     // at a time, K = NB in steps of 4 (v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
     // C/D rows (lane >> 4) + 4 r, column lane & 15).  Both operands come from the panel in LDS (row stride NB + 1 doubles keeps
     // the 16 rows of a tile on different banks); the accumulator starts from the tile of S, so one pass reads and writes it once.
+    // (3a) every wave: the tile columns that hold the NEXT block column (diagonal block + panel).  (3b) wave 0 factors the next
+    // diagonal block into the other Ljj / dj / rdj buffers while the remaining waves finish the rest of the trailing matrix:
+    // the serial factorisation no longer has the other fifteen waves waiting for it.
     {
       const int wave = tid >> 6, nwave = SOL_T / 64;
-      const int ntile = (m + 15) >> 4, ntri = ntile * (ntile + 1) / 2;
+      const int ntile = (m + 15) >> 4;
       const int li = lane & 15, lk = lane >> 4;
-      for (int t = wave; t < ntri; t += nwave) {
-        int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (ti * (ti + 1) / 2 > t) ti--;
-        while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-        const int tj = t - ti * (ti + 1) / 2;
+      auto trail_tile = [&](int ti, int tj) {
         const int I0 = ti * 16, J0 = tj * 16;
         const int col = J0 + li;
         sol_d4 acc;
@@ -695,10 +689,33 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
           const int row = I0 + lk + 4 * r;
           if (row < m && col <= row) Sm[(size_t)(m0 + row) * lda + m0 + col] = acc[r];
         }
+      };
+      constexpr int TA = (NB + 15) / 16;          // tile columns of the next block column
+      const int ta = min(TA, ntile);
+      int nA = 0;
+      for (int c = 0; c < ta; c++) nA += ntile - c;
+      for (int t = wave; t < nA; t += nwave) {
+        int tj = 0, u = t;
+        while (u >= ntile - tj) { u -= ntile - tj; tj++; }
+        trail_tile(tj + u, tj);
+      }
+      __syncthreads();
+      SOLP_MARK(2);
+      const int nt2 = ntile - ta, nB = nt2 > 0 ? nt2 * (nt2 + 1) / 2 : 0;
+      if (wave == 0) {
+        if (m > 0) diag_block(m0, min(NB, m), Ljj2 + (cur ^ 1) * NB * (NB + 1), dj2 + (cur ^ 1) * NB, rdj2 + (cur ^ 1) * NB);
+      } else {
+        for (int t = wave - 1; t < nB; t += nwave - 1) {
+          int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+          while (ti * (ti + 1) / 2 > t) ti--;
+          while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+          const int tj = t - ti * (ti + 1) / 2;
+          trail_tile(ti + ta, tj + ta);
+        }
       }
     }
     __syncthreads();
-    SOLP_MARK(2);
+    SOLP_MARK(0);
   }
   if (fail) { if (tid == 0) St.ok2 = 0; return; }
   for (int i = tid; i < n; i += SOL_T) rhs[i] /= dall[i];
@@ -910,7 +927,7 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), 0, st, *A);
   {
     const int n_max = 6 * max_free;
-    auto lds = [&](int nb) { return (size_t)(nb * (nb + 1) + 2 * nb + 128 + 12 * PS_BA_MAX_POSES + (size_t)(n_max > nb ? n_max - nb + 4 : 4) * (nb + 1) + 8) * sizeof(double); };
+    auto lds = [&](int nb) { return (size_t)(2 * nb * (nb + 1) + 4 * nb + 12 * PS_BA_MAX_POSES + (size_t)(n_max > nb ? n_max - nb + 4 : 4) * (nb + 1) + 8) * sizeof(double); };
     // > 64 KB of dynamic LDS has to be requested per kernel
     static const int force_nb = getenv("PS_BA_NB") ? atoi(getenv("PS_BA_NB")) : 0;
     if (force_nb == 48 && lds(48) <= 150 * 1024) {   // measured slower than 24 at n = 294 (single-wave diagonal factor)
