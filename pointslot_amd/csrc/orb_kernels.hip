@@ -547,6 +547,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   const int shift = (PS_EDGE + iniX) & 3;   // plane origins are 256-B aligned, strides multiples of 64
   const uint8_t* ga = base + L.plane_off + (size_t)(PS_EDGE + iniY) * L.stride + (PS_EDGE + iniX - shift);
   const int nd = (shift + ww + 3) >> 2;
+  int lshift = shift;                       // byte offset of the window inside the LDS rows
   if (TR <= 40 && nd <= 16) {
     // 16 lanes per row, 4 rows per step; every load is issued before the first LDS store so that the window costs one
     // memory round trip instead of one per step (windows of the usual 30-px cells: <= 40 rows, <= 16 dwords)
@@ -559,9 +560,14 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
       const int y = min(4 * i + wr, wh - 1) - wr;
       tmp[i] = *reinterpret_cast<const uint32_t*>(gp + (ptrdiff_t)y * L.stride);
     }
+    // the window goes into LDS already shifted to its own origin (next dword of the row from the neighbouring lane of the
+    // 16-lane DPP row): the later stages read aligned dwords and skip the per-row v_alignbyte
 #pragma unroll
-    for (int i = 0; i < 10; i++)
-      if (wact && 4 * i + wr < wh) *reinterpret_cast<uint32_t*>(tile + (4 * i + wr) * TS + 4 * wd) = tmp[i];
+    for (int i = 0; i < 10; i++) {
+      const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tmp[i], 0x101 /* row_shl:1 */, 0xF, 0xF, true);
+      if (wact && 4 * i + wr < wh) *reinterpret_cast<uint32_t*>(tile + (4 * i + wr) * TS + 4 * wd) = __builtin_amdgcn_alignbyte(nxt, tmp[i], (uint32_t)shift);
+    }
+    lshift = 0;
   } else {
     for (int t = lane; t < wh * nd; t += 64) {
       const int y = t / nd, dd = t - y * nd;
@@ -575,6 +581,8 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   // pixels always contain four consecutive even positions, so a pixel without 4 consecutive dark (or bright) even
   // positions cannot be a corner at min_th; this rejects most pixels for ~1/3 of the full test's work. ----
   const int ng = (cw + 3) >> 2, ntask = ch * ng;
+  // exact for t < 65536 / ng: the error of the rounded-up reciprocal stays below 1 / ng (ntask is a few hundred)
+  const uint32_t ng_recip = (65536u + (uint32_t)ng - 1u) / (uint32_t)ng;
   const unsigned long long ltmask = (1ull << lane) - 1ull;
   uint32_t* slots = reinterpret_cast<uint32_t*>(base + plan.cand_base) + L.cand_off + (size_t)ci * L.cell_cap;
   int total = 0;
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   for (int t0 = 0; t0 < ntask; t0 += 64) {
     const int t = t0 + lane;
     const bool tv = t < ntask;
-    const int y = tv ? t / ng : 0, g = tv ? t - y * ng : 0;
+    const int y = tv ? (int)(((uint32_t)t * ng_recip) >> 16) : 0, g = tv ? t - y * ng : 0;   // t / ng without the division sequence
     unsigned long long C[4];
     if (pass == 0) {
     uint32_t w[7][3];
@@ -595,10 +603,14 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     for (int r = 0; r < 7; r++) {
       if (r == 2 || r == 4) continue;   // rows +-1 hold odd ring positions only
       const uint32_t* p = reinterpret_cast<const uint32_t*>(tile + (y + r) * TS + 4 * g);
-      const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
-      w[r][0] = __builtin_amdgcn_alignbyte(a1, a0, shift);
-      w[r][1] = __builtin_amdgcn_alignbyte(a2, a1, shift);
-      w[r][2] = __builtin_amdgcn_alignbyte(a3, a2, shift);
+      if (lshift == 0) {   // wave-uniform
+        w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
+      } else {
+        const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+        w[r][0] = __builtin_amdgcn_alignbyte(a1, a0, lshift);
+        w[r][1] = __builtin_amdgcn_alignbyte(a2, a1, lshift);
+        w[r][2] = __builtin_amdgcn_alignbyte(a3, a2, lshift);
+      }
     }
     // Two pixels per operation on packed u16.  "4 consecutive even positions all darker than v - th" is
     //   min over the 8 windows of (max of the window) < v - th,  and for brighter  max over windows of (min) > v + th,
@@ -639,13 +651,18 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
       for (int i = 0; i < 4; i++) C[i] = __builtin_amdgcn_ballot_w64(tv && (4 * g + i) < cw && (int)((qq >> (8 * i)) & 0xFFu) > th);
     }
     // raster-ordered compaction: order (lane, slot)
-    const int lower = __popcll(C[0] & ltmask) + __popcll(C[1] & ltmask) + __popcll(C[2] & ltmask) + __popcll(C[3] & ltmask);
+    // survivors in lower lanes: v_mbcnt counts the mask bits below the lane and adds an accumulator, two instructions per mask
+    uint32_t lower_u = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      lower_u = __builtin_amdgcn_mbcnt_hi((uint32_t)(C[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)C[i], lower_u));
+    const int lower = (int)lower_u;
     int own = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if ((C[i] >> lane) & 1ull) {
         const int pos = nsurv + lower + own;
-        if (pos < LCAP) list[pos] = (uint16_t)(y * cw + 4 * g + i);
+        if (pos < LCAP) list[pos] = (uint16_t)((y << 7) | (4 * g + i));   // y and x in seven bits each (PS_FAST_WIN <= 72), bit 15 stays free: no division later
         own++;
       }
     }
@@ -664,8 +681,8 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     int p = 0, sc = 0;
     if (idx < nsurv) {
       p = list[idx];
-      const int y = p / cw, x = p - y * cw;
-      sc = fast_score_exact(tile + (y + 3) * TS + shift + x + 3, TS);
+      const int y = (p >> 7) & 127, x = p & 127;
+      sc = fast_score_exact(tile + (y + 3) * TS + lshift + x + 3, TS);
       if (sc > th) smap[(y + 1) * SS + x + 1] = (uint8_t)sc;
     }
     const unsigned long long cm = __builtin_amdgcn_ballot_w64(sc > th);
@@ -683,7 +700,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     uint8_t f = 0;
     if (idx < ncand) {
       const int p = list[idx];
-      const int y = p / cw, x = p - y * cw;
+      const int y = (p >> 7) & 127, x = p & 127;
       const uint8_t* m = smap + (y + 1) * SS + x + 1;
       const int s = m[0];
       const bool lmax = s > m[-1] && s > m[1] && s > m[-SS - 1] && s > m[-SS] && s > m[-SS + 1] &&
@@ -704,7 +721,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     if (keep) {
       const int pos = total + __popcll(km & ltmask);
       const int p = pv & 0x7FFF;
-      const int y = p / cw, x = p - y * cw;
+      const int y = (p >> 7) & 127, x = p & 127;
       const int s = smap[(y + 1) * SS + x + 1];
       // coordinates relative to (minBorderX, minBorderY): local + j*wCell (ORBextractor.cc:822-824)
       const uint32_t xr = (uint32_t)(x + 3 + ci_x * L.w_cell), yr = (uint32_t)(y + 3 + ci_y * L.h_cell);
