@@ -19,15 +19,16 @@
 namespace {
 
 // XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MB L2; workgroup b is observed to run on XCD b % 8).
-// Kernels whose workgroups re-read one image's planes (FAST windows, keypoint patches) keep every image on ONE XCD:
-// linear block b -> xcd = b % 8, image = (b / 8 / blocks_per_image) * 8 + xcd, local block = (b / 8) % blocks_per_image.
-// Placement only affects speed (L2 hit rate), never results.
-__device__ __forceinline__ bool xcd_image_block(int blocks_per_image, int nimg, int& img, int& local_block) {
-  const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-  img = (j / blocks_per_image) * 8 + xcd;
-  local_block = j % blocks_per_image;
+// Kernels whose workgroups re-read one image's planes (FAST windows, keypoint patches) keep every image on ONE XCD.
+// Workgroups are dealt to the 8 XCDs round-robin in linear order; with a grid of (8 * blocks_per_image, ceil(nimg / 8)) the
+// linear index is y * gridDim.x + x and gridDim.x is a multiple of 8, so xcd = x % 8: image = 8 y + x % 8, local block = x / 8
+// (no integer division in the kernel).  Placement only affects speed (L2 hit rate), never results.
+__device__ __forceinline__ bool xcd_image_block(int nimg, int& img, int& local_block) {
+  img = (int)blockIdx.y * 8 + ((int)blockIdx.x & 7);
+  local_block = (int)blockIdx.x >> 3;
   return img < nimg;
 }
+#define PS_XCD_GRID(blocks_per_image, nimg) dim3((unsigned)(blocks_per_image) * 8u, (unsigned)(((nimg) + 7) / 8))
 
 __device__ __forceinline__ int reflect101(int p, int len) {
   // cv::borderInterpolate(BORDER_REFLECT_101); the border (19) is smaller than any level here, but
@@ -490,7 +491,7 @@ __device__ unsigned long long g_fast_prof[FP_MAXW * 10];
 #define FP_DECL long long fp_t = clock64(); unsigned long long fp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define FP_MARK(k) do { const long long _n = clock64(); fp_acc[k] += (unsigned long long)(_n - fp_t); fp_t = _n; } while (0)
 #define FP_COUNT(k, v) (fp_acc[k] += (unsigned long long)(v))
-#define FP_FLUSH() do { const int _w = blockIdx.x * 4 + wave; if (lane == 0 && _w < FP_MAXW) for (int _k = 0; _k < 10; _k++) g_fast_prof[_w * 10 + _k] = fp_acc[_k]; } while (0)
+#define FP_FLUSH() do { const int _w = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave; if (lane == 0 && _w < FP_MAXW) for (int _k = 0; _k < 10; _k++) g_fast_prof[_w * 10 + _k] = fp_acc[_k]; } while (0)
 __global__ void fast_prof_dump() {
   __shared__ unsigned long long acc[10];
   if (threadIdx.x < 10) acc[threadIdx.x] = 0;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform geometry stays on the scalar unit
   int img, lb;
-  if (!xcd_image_block(bpi, nimg, img, lb)) return;
+  if (!xcd_image_block(nimg, img, lb)) return;
   const int cell = lb * 4 + wave;
   if (cell >= plan.n_cells) return;
   const int per_wave = TR * TS + SS * (TR - 4) + 2 * LCAP + 16 + 3 + QS * (TR - 6);   // same expression as the launcher
@@ -1238,7 +1239,7 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena, PsKeyPoint* out_kps,
                                                    uint8_t* out_desc, int32_t* out_counts, int nimg, int bpi) {
   int img, lb;
-  if (!xcd_image_block(bpi, nimg, img, lb)) return;
+  if (!xcd_image_block(nimg, img, lb)) return;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the level lookup on the scalar unit
   const int slot = lb * 4 + wv;
   const int lane = threadIdx.x & 63;
@@ -1398,7 +1399,7 @@ extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nim
   const int QS = (mw - 6 + 3) & ~3;
   const int per_wave = (TR * TS + SS * (TR - 4) + 2 * LCAP + 16 + 3 + QS * (TR - 6) + 15) & ~15;
   const int bpi = (plan->n_cells + 3) / 4;
-  hipLaunchKernelGGL(orb_fast_cells, dim3(bpi * ((nimg + 7) / 8) * 8), dim3(FAST_T), (size_t)per_wave * 4, st, *plan, arena,
+  hipLaunchKernelGGL(orb_fast_cells, PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)per_wave * 4, st, *plan, arena,
                      TS, TR, SS, LCAP, QS, nimg, bpi);
 #ifdef PS_FAST_PROFILE
   hipLaunchKernelGGL(fast_prof_dump, dim3(1), dim3(1024), 0, st);
@@ -1424,6 +1425,6 @@ extern "C" int psk_orb_blur_rows() { return BLUR_ROWS; }
 extern "C" void psk_orb_launch_describe(const OrbPlan* plan, uint8_t* arena, void* kps, uint8_t* desc,
                                         int32_t* counts, int nimg, hipStream_t st) {
   const int bpi = (plan->sel_total + 3) / 4;
-  hipLaunchKernelGGL(orb_describe, dim3(bpi * ((nimg + 7) / 8) * 8), dim3(256), 0, st, *plan, arena,
+  hipLaunchKernelGGL(orb_describe, PS_XCD_GRID(bpi, nimg), dim3(256), 0, st, *plan, arena,
                      (PsKeyPoint*)kps, desc, counts, nimg, bpi);
 }
