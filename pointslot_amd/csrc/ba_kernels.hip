@@ -524,15 +524,16 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
 // SimplicialLDLT.
 #define SOL_T 1024
 #ifdef PS_BA_PROFILE   // developer build: per-phase wall-clock ticks (100 MHz) of problem 0, printed by the kernel
-#define SOLP_DECL long long T0 = wall_clock64(), tph[6] = {0, 0, 0, 0, 0, 0}, tt = T0
+#define SOLP_DECL long long T0 = wall_clock64(), tph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tt = T0
 #define SOLP_MARK(k) do { const long long _n = wall_clock64(); tph[k] += _n - tt; tt = _n; } while (0)
-#define SOLP_PRINT() do { if (tid == 0 && blockIdx.x == 0) printf("solve n=%d NB=%d ticks: diag + rest of trailing %lld panel %lld trailing, next block column %lld fwd %lld bwd %lld total %lld\n", n, NB, tph[0], tph[1], tph[2], tph[3], tph[4], wall_clock64() - T0); } while (0)
+#define SOLP_PRINT() do { if (tid == 0 && blockIdx.x == 0) printf("solve n=%d NB=%d ticks: diag + rest of trailing %lld panel (load %lld solve %lld store + forward %lld rhs %lld) trailing, next block column %lld fwd %lld bwd %lld total %lld\n", n, NB, tph[0], tph[5], tph[6], tph[7], tph[1], tph[2], tph[3], tph[4], wall_clock64() - T0); } while (0)
 #else
 #define SOLP_DECL
 #define SOLP_MARK(k)
 #define SOLP_PRINT()
 #endif
 typedef double sol_d4 __attribute__((ext_vector_type(4)));
+typedef double sol_d2 __attribute__((ext_vector_type(2)));
 template <int NB>
 __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   const BaProb P = A.prob[blockIdx.x];
@@ -546,7 +547,8 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   double* Ljj2 = sol_smem;                      // [2][NB][NB + 1]
   double* dj2 = Ljj2 + 2 * NB * (NB + 1);       // [2][NB]
   double* rdj2 = dj2 + 2 * NB;                  // [2][NB] reciprocals of the block's pivots
-  double* rhs = rdj2 + 2 * NB;                  // [n]
+  double* Lt2 = rdj2 + 2 * NB;                  // [2][NB][NB] the block's multipliers again, column-major: Lt[q][c] = L[c][q]
+  double* rhs = Lt2 + 2 * NB * NB;              // [n]
   double* dall = rhs + 6 * PS_BA_MAX_POSES;     // [n]
   double* panel = dall + 6 * PS_BA_MAX_POSES;   // [rows below][NB + 1]
   __shared__ int fail;
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   // ---- (1) diagonal block, ONE wave: lane = row, rows in registers.  Step j: every lane forms its multiplier l = a[j] / d_j;
   // the rank-1 update reads the other rows' multipliers straight out of their lanes' registers (v_readlane into a scalar pair
   // that feeds the FMA).  Entries above the diagonal are never consumed, so the update needs no masking.
-  auto diag_block = [&](int J, int jb, double* Ljj, double* dj, double* rdj) {
+  auto diag_block = [&](int J, int jb, double* Ljj, double* dj, double* rdj, double* Lt) {
     double a[NB];
 #pragma unroll
     for (int c = 0; c < NB; c++) a[c] = (lane < jb && c <= lane) ? Sm[(size_t)(J + lane) * lda + J + c] : 0.0;
@@ -591,13 +593,13 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     if (lane < jb) {
 #pragma unroll
       for (int c = 0; c < NB; c++) {
-        if (c < lane) { Ljj[lane * (NB + 1) + c] = a[c]; Sm[(size_t)(J + lane) * lda + J + c] = a[c]; }
+        if (c < lane) { Ljj[lane * (NB + 1) + c] = a[c]; Lt[c * NB + lane] = a[c]; Sm[(size_t)(J + lane) * lda + J + c] = a[c]; }
         else if (c == lane) { dj[lane] = a[c]; dall[J + lane] = a[c]; }
       }
     } else if (lane < NB) { dj[lane] = 0.0; rdj[lane] = 0.0; }   // columns of a partial block that do not exist
     if (bad && lane == 0) fail = 1;
   };
-  if (tid < 64) diag_block(0, min(NB, n), Ljj2, dj2, rdj2);
+  if (tid < 64) diag_block(0, min(NB, n), Ljj2, dj2, rdj2, Lt2);
   __syncthreads();
   SOLP_MARK(0);
   for (int J = 0, cur = 0; J < n; J += NB, cur ^= 1) {
@@ -605,6 +607,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     double* Ljj = Ljj2 + cur * NB * (NB + 1);
     double* dj = dj2 + cur * NB;
     double* rdj = rdj2 + cur * NB;
+    const double* Lt = Lt2 + cur * NB * NB;
     if (fail) break;
     // ---- (2) panel rows below the block: coalesced load into LDS, thread-per-row solve in LDS, coalesced store ----
     const int m0 = J + jb, m = n - m0;
@@ -613,24 +616,33 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       panel[(size_t)i * (NB + 1) + c] = Sm[(size_t)(m0 + i) * lda + J + c];
     }
     __syncthreads();
+    SOLP_MARK(5);
     for (int i = tid; i < m; i += SOL_T) {
+      // x L_JJ^T D = row of S: column q of the row is final once columns < q have been eliminated from it.  Right-looking order:
+      // as soon as column q is final it is subtracted from every later column, so the 23 .. 1 updates of a step are independent
+      // of each other (the dot-product order makes each column one serial FMA chain); every column still receives its
+      // subtractions in the order q = 0, 1, 2, ..., i.e. the result is bit-identical.  Only full blocks have rows below them.
+      // (Broadcasting the multipliers with v_readlane from registers instead of reading them from LDS was measured slower.)
       double* prow = panel + (size_t)i * (NB + 1);
-      double xd[NB];   // x[q] * d_q = the un-divided value of column q
+      double v[NB];
 #pragma unroll
-      for (int c = 0; c < NB; c++) {
-        if (c < jb) {
-          double v = prow[c];
+      for (int c = 0; c < NB; c++) v[c] = c < jb ? prow[c] : 0.0;
 #pragma unroll
-          for (int q = 0; q < c; q++) v -= xd[q] * Ljj[c * (NB + 1) + q];
-          xd[c] = v;
-          prow[c] = v * rdj[c];
-        } else {
-          xd[c] = 0.0;
-          prow[c] = 0.0;
+      for (int q = 0; q < NB; q++) {
+        const double xq = v[q];          // x[q] * d_q, the un-divided value of column q
+        // column q of L is contiguous in Lt: two multipliers per LDS read (16-byte aligned pairs start at even c)
+        if (((q + 1) & 1) && q + 1 < NB) v[q + 1] -= xq * Lt[q * NB + q + 1];
+#pragma unroll
+        for (int c = (q + 2) & ~1; c + 1 < NB; c += 2) {
+          const sol_d2 l2 = *reinterpret_cast<const sol_d2*>(&Lt[q * NB + c]);
+          v[c] -= xq * l2.x;
+          v[c + 1] -= xq * l2.y;
         }
+        prow[q] = xq * rdj[q];
       }
     }
     __syncthreads();
+    SOLP_MARK(6);
     for (int q = tid; q < m * jb; q += SOL_T) {
       const int i = q / jb, c = q - i * jb;
       Sm[(size_t)(m0 + i) * lda + J + c] = panel[(size_t)i * (NB + 1) + c];
@@ -649,11 +661,15 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       if (lane < jb) rhs[J + lane] = y;
     }
     __syncthreads();
+    SOLP_MARK(7);
     for (int i = tid; i < m; i += SOL_T) {
       double v = rhs[m0 + i];
       const double* prow = panel + (size_t)i * (NB + 1);
+      double pr[NB], yj[NB];   // all operands first (only full blocks have rows below them), then the chain
 #pragma unroll
-      for (int c = 0; c < NB; c++) if (c < jb) v -= prow[c] * rhs[J + c];
+      for (int c = 0; c < NB; c++) { pr[c] = prow[c]; yj[c] = rhs[J + c]; }
+#pragma unroll
+      for (int c = 0; c < NB; c++) v -= pr[c] * yj[c];
       rhs[m0 + i] = v;
     }
     SOLP_MARK(1);
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       SOLP_MARK(2);
       const int nt2 = ntile - ta, nB = nt2 > 0 ? nt2 * (nt2 + 1) / 2 : 0;
       if (wave == 0) {
-        if (m > 0) diag_block(m0, min(NB, m), Ljj2 + (cur ^ 1) * NB * (NB + 1), dj2 + (cur ^ 1) * NB, rdj2 + (cur ^ 1) * NB);
+        if (m > 0) diag_block(m0, min(NB, m), Ljj2 + (cur ^ 1) * NB * (NB + 1), dj2 + (cur ^ 1) * NB, rdj2 + (cur ^ 1) * NB, Lt2 + (cur ^ 1) * NB * NB);
       } else {
         for (int t = wave - 1; t < nB; t += nwave - 1) {
           int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -927,7 +943,7 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), 0, st, *A);
   {
     const int n_max = 6 * max_free;
-    auto lds = [&](int nb) { return (size_t)(2 * nb * (nb + 1) + 4 * nb + 12 * PS_BA_MAX_POSES + (size_t)(n_max > nb ? n_max - nb + 4 : 4) * (nb + 1) + 8) * sizeof(double); };
+    auto lds = [&](int nb) { return (size_t)(2 * nb * (nb + 1) + 4 * nb + 2 * nb * nb + 12 * PS_BA_MAX_POSES + (size_t)(n_max > nb ? n_max - nb + 4 : 4) * (nb + 1) + 8) * sizeof(double); };
     // > 64 KB of dynamic LDS has to be requested per kernel
     static const int force_nb = getenv("PS_BA_NB") ? atoi(getenv("PS_BA_NB")) : 0;
     if (force_nb == 48 && lds(48) <= 150 * 1024) {   // measured slower than 24 at n = 294 (single-wave diagonal factor)
