@@ -523,6 +523,7 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
 // succeeds (linear_solver_eigen.h:94-120 returns false without touching x); a zero pivot = failure, like
 // SimplicialLDLT.
 #define SOL_T 1024
+static_assert(6 * PS_BA_MAX_POSES <= SOL_T - 64, "ba_solve: one thread per row of the reduced system behind wave 0");
 #ifdef PS_BA_PROFILE   // developer build: per-phase wall-clock ticks (100 MHz) of problem 0, printed by the kernel
 #define SOLP_DECL long long T0 = wall_clock64(), tph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tt = T0
 #define SOLP_MARK(k) do { const long long _n = wall_clock64(); tph[k] += _n - tt; tt = _n; } while (0)
@@ -651,11 +652,14 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     // which the rows below subtract L_panel y_J) — no extra pass over L in global memory
     if (tid < 64) {
       double y = lane < jb ? rhs[J + lane] : 0.0;
+      double lrow[NB];   // the lane's row of the block factor, fetched before the chain of broadcasts starts
+#pragma unroll
+      for (int j = 0; j < NB; j++) lrow[j] = (lane > j && lane < jb) ? Ljj[lane * (NB + 1) + j] : 0.0;
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         if (j < jb) {
           const double yj = shfl_d(y, j);
-          if (lane > j && lane < jb) y -= Ljj[lane * (NB + 1) + j] * yj;
+          if (lane > j && lane < jb) y -= lrow[j] * yj;
         }
       }
       if (lane < jb) rhs[J + lane] = y;
@@ -738,33 +742,49 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   __syncthreads();
   SOLP_MARK(3);
   // ---- backward substitution L^T x = z ----
-  for (int J = ((n - 1) / NB) * NB; J >= 0; J -= NB) {
-    const int jb = min(NB, n - J);
-    if (tid < 64) {   // lane = column r of the block: x_r -= sum_{c > r} L[J+c][J+r] x_c (column fetched up front)
-      double Lc[NB];
+  // Per block column, from the last one: wave 0 solves the block's unit upper triangle (lane = column r: x_r -= sum_{c > r}
+  // L[J+c][J+r] x_c), then the rows above subtract L_panel^T x_J.  The factor lives in global memory (L2); both parties request
+  // their part of it BEFORE they have to wait for the other one - waves 1.. fetch their panel column while wave 0 solves, wave 0
+  // fetches the next block while they update - so a step costs one round trip instead of two.
+  {
+    const int Jlast = ((n - 1) / NB) * NB;
+    double Lc[NB];
+    if (tid < 64) {
+      const int jb = min(NB, n - Jlast);
 #pragma unroll
-      for (int c = 0; c < NB; c++) Lc[c] = (c < jb && lane < c) ? Sm[(size_t)(J + c) * lda + J + lane] : 0.0;
-      double x = lane < jb ? rhs[J + lane] : 0.0;
-#pragma unroll
-      for (int c = NB - 1; c >= 1; c--) {
-        if (c < jb) {
-          const double xc = shfl_d(x, c);
-          if (lane < c) x -= Lc[c] * xc;
-        }
-      }
-      if (lane < jb) rhs[J + lane] = x;
+      for (int c = 0; c < NB; c++) Lc[c] = (c < jb && lane < c) ? Sm[(size_t)(Jlast + c) * lda + Jlast + lane] : 0.0;
     }
-    __syncthreads();
-    for (int k = tid; k < J; k += SOL_T) {
-      double v = rhs[k];
+    for (int J = Jlast; J >= 0; J -= NB) {
+      const int jb = min(NB, n - J);
       double lc[NB];
+      const int k = tid - 64;   // row of the update: J <= 6 * PS_BA_MAX_POSES - NB rows fit the 960 threads behind wave 0
+      if (tid < 64) {
+        double x = lane < jb ? rhs[J + lane] : 0.0;
 #pragma unroll
-      for (int c = 0; c < NB; c++) lc[c] = c < jb ? Sm[(size_t)(J + c) * lda + k] : 0.0;
+        for (int c = NB - 1; c >= 1; c--) {
+          if (c < jb) {
+            const double xc = shfl_d(x, c);
+            if (lane < c) x -= Lc[c] * xc;
+          }
+        }
+        if (lane < jb) rhs[J + lane] = x;
+        if (J >= NB) {   // the block above is a full one
 #pragma unroll
-      for (int c = 0; c < NB; c++) if (c < jb) v -= lc[c] * rhs[J + c];
-      rhs[k] = v;
+          for (int c = 0; c < NB; c++) Lc[c] = lane < c ? Sm[(size_t)(J - NB + c) * lda + J - NB + lane] : 0.0;
+        }
+      } else if (k < J) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) lc[c] = c < jb ? Sm[(size_t)(J + c) * lda + k] : 0.0;
+      }
+      __syncthreads();
+      if (tid >= 64 && k < J) {
+        double v = rhs[k];
+#pragma unroll
+        for (int c = 0; c < NB; c++) if (c < jb) v -= lc[c] * rhs[J + c];
+        rhs[k] = v;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   SOLP_MARK(4);
   for (int i = tid; i < n; i += SOL_T) A.xp[(size_t)P.pose_base * 6 + i] = rhs[i];
