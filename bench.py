@@ -150,6 +150,60 @@ def secondary_metrics(rank, world, local_rank, dist, with_cpu):
     opt.close()
     out["sequence_tracking"] = sequence_leg(rank, world, local_rank, dist, with_cpu)
     out["lockstep_tracking"] = lockstep_leg(rank, world, local_rank, dist)
+    if rank == 0:
+        try:
+            out["next_rows"] = next_rows_leg(local_rank)
+        except Exception as e:   # noqa: BLE001  (a failure of this leg must not take the bench line down)
+            out["next_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def next_rows_leg(local_rank):
+    """SURVEY.md 8f rows 3 and 4, one wall-clock figure each on rank 0 (host buffers, PCIe included; the parity of every
+    row is in tests/): LocalBundleAdjustment, ComputeDistinctiveDescriptors, the search half of Fuse, and the
+    DynamicStaticDiscrimination reprojection test."""
+    from pointslot_amd import synth
+    from pointslot_amd.matcher import ORBmatcher, build_grid
+    from pointslot_amd.optimizer import Optimizer
+    out = {}
+    opt = Optimizer(device=local_rank)
+    # f-3: a local-BA shaped graph - 10 free + 6 fixed keyframes (VertexSE3Expmap), 1200 world points, 35 % visibility
+    g = synth.object_ba_problem(0x51070060, n_kf=10, n_pts=1200, p_vis=0.35, perturb=(0.05, 1.0, 0.03), perturb_axis="y", n_fixed_extra=6, mono_frac=0.15)
+    g["pose_flags"] = (g["pose_flags"] & 1).astype(np.uint8)
+    opt.ObjectLocalBundleAdjustment([g])
+    r, = opt.ObjectLocalBundleAdjustment([g])
+    out["local_ba"] = {"workload": "f-3: 16 keyframes (6 fixed) x 1200 points, %d edges" % len(g["e_pose"]), "gpu_ms": opt.last_kernel_ms(),
+                       "lm_iterations": int(r["iterations"]), "ms_per_iter": opt.last_kernel_ms() / max(int(r["iterations"]), 1)}
+    # f-4: DynamicStaticDiscrimination on 8 detections x 300 object points
+    objs = [synth.dynamic_object(100 + k, n=300, moving=0.1 * k) for k in range(8)]
+    opt.DynamicStaticDiscrimination(objs)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        opt.DynamicStaticDiscrimination(objs)
+    out["dynamic_static_discrimination"] = {"workload": "f-4: 8 detections x 300 object points per call", "wall_ms_per_call": (time.perf_counter() - t0) * 100}
+    opt.close()
+    m = ORBmatcher(0.6, True, device=local_rank)
+    # f-4: ComputeDistinctiveDescriptors of 2400 map points with 2..50 observations each
+    rng = np.random.default_rng(7)
+    lists = [rng.integers(0, 256, (int(n), 32), dtype=np.uint8) for n in rng.integers(2, 51, 2400)]
+    m.ComputeDistinctiveDescriptors(lists)
+    t0 = time.perf_counter()
+    m.ComputeDistinctiveDescriptors(lists)
+    dt = time.perf_counter() - t0
+    out["distinctive_descriptors"] = {"workload": "f-4: 2400 map points, 2..50 observations each (%d descriptors)" % sum(len(x) for x in lists),
+                                      "wall_ms_per_call": dt * 1e3, "points_per_s": len(lists) / dt}
+    # f-4: the search half of Fuse, 6 keyframes x (1500 features, 800 candidate points)
+    prs = []
+    for k in range(6):
+        pr = synth.fuse_scene(60 + k, n=1500, m=800)
+        T = pr["train"]
+        T["cell_off"], T["cell_idx"] = build_grid(T["x"], T["y"], *T["grid"])
+        prs.append(pr)
+    m.FuseSearch(prs)
+    t0 = time.perf_counter()
+    m.FuseSearch(prs)
+    out["fuse_search"] = {"workload": "f-4: 6 keyframes x (1500 features, 800 candidate points) per call", "wall_ms_per_call": (time.perf_counter() - t0) * 1e3}
+    m.close()
     return out
 
 
