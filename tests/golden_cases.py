@@ -1,4 +1,7 @@
-"""The seeded problems behind tests/golden/match_golden.json and opt_golden.json (shared by the generator and the tests)."""
+"""The seeded problems behind tests/golden/match_golden.json, opt_golden.json and aux_golden.json (shared by the generator and
+the tests)."""
+import numpy as np
+
 from pointslot_amd import synth
 from pointslot_amd.matcher import build_grid
 
@@ -38,3 +41,51 @@ def pose_cases():
 def ba_cases():
     return [("object_ba_small", synth.object_ba_problem(0x51070050, n_kf=8, n_pts=40, perturb=(0.05, 1.0, 0.02), perturb_axis="z")),
             ("object_ba_sparse", synth.object_ba_problem(0x51070051, n_kf=12, n_pts=60, p_vis=0.6, perturb=(0.05, 1.0, 0.02), perturb_axis="z"))]
+
+
+def cfse3_cases(se3_from_mat4f):
+    """frames of CFSE3ObjStateOptimization: object-frame points seen through a perturbed object pose (se3_from_mat4f: the
+    float matrix -> 7-double pose conversion of whichever side builds the case; both sides' are bit-identical)"""
+    out = []
+    for seed, k in ((11, 1), (12, 3)):
+        rng = np.random.default_rng(seed)
+        objs = []
+        for o in range(k):
+            p = synth.pose_problem(seed * 100 + o, n=120 + 30 * o, outlier_frac=0.15, mono_frac=0.2, valid_frac=0.8)
+            Tp = p["tcw_true"].copy(); Tp[:3, 3] += rng.uniform(-0.2, 0.2, 3)
+            objs.append({"xo": p["xw"], "obs": p["obs"], "inv_sigma2": p["inv_sigma2"], "valid": p["valid"], "pose7": se3_from_mat4f(Tp.astype(np.float32))})
+        out.append(("cfse3_%d_objects" % k, {"objs": objs, "K": p["K"]}))
+    return out
+
+
+def fuse_cases():
+    out = []
+    for seed, kw in ((71, {}), (72, {"box": (300, 600, 100, 300)})):
+        pr = synth.fuse_scene(seed, **kw)
+        T = pr["train"]
+        T["cell_off"], T["cell_idx"] = build_grid(T["x"], T["y"], *T["grid"])
+        out.append(("fuse_%d" % seed, pr))
+    return out
+
+
+def distinctive_case():
+    rng = np.random.default_rng(12)
+    lists = []
+    for n in [1, 2, 3, 7, 50, 64, 65, 128, 31]:
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        obs = []
+        for _ in range(n):
+            d = base.copy()
+            for b in rng.integers(0, 256, rng.integers(0, 40)):
+                d[b >> 3] ^= np.uint8(1 << (b & 7))
+            obs.append(d)
+        lists.append(np.array(obs, np.uint8).reshape(n, 32))
+    return lists
+
+
+def dynamic_cases():
+    return [synth.dynamic_object(200 + k, n=[300, 40, 1200][k], moving=[0.0, 0.5, 0.2][k], mono_frac=[0.3, 0.0, 0.5][k]) for k in range(3)]
+
+
+def stereo_case():
+    return synth.stereo_pair()

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 import oracle_lib
-from golden_cases import matcher_cases, pose_cases, ba_cases
+from golden_cases import matcher_cases, pose_cases, ba_cases, cfse3_cases, fuse_cases, distinctive_case, dynamic_cases, stereo_case
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -75,3 +75,35 @@ def test_optimiser_fixtures():
         check_pose(gold[name], *oracle_lib.pose_optimize(p, want_trace=True))
     for name, p in ba_cases():
         check_ba(gold[name], *oracle_lib.object_ba(p))
+
+
+def check_aux(gold, cfse3, fuse, distinctive, dynamic, stereo, strict=True):
+    """cfse3: {name: (ok, poses, outliers)}, fuse: {name: (best_idx, best_dist)}, distinctive: indices, dynamic: list of
+    (mono_avg, stereo_avg, n_mono, n_stereo), stereo: (kept, u_right, depth)"""
+    for name, (ok, poses, outl) in cfse3.items():
+        g = gold[name]
+        assert int(ok) == g["ok"] and [int(o.sum()) for o in outl] == g["n_outliers"]
+        assert [sha(np.asarray(o, np.uint8)) for o in outl] == g["outlier_sha256"]
+        assert np.allclose(poses, g["poses"], rtol=0, atol=1e-9 if strict else 1e-6)
+    for name, (bi, bd) in fuse.items():
+        g = gold[name]
+        assert sha(np.asarray(bi, np.int32)) == g["best_idx_sha256"] and sha(np.asarray(bd, np.int32)) == g["best_dist_sha256"]
+        assert int((np.asarray(bi) >= 0).sum()) == g["n_found"] > 10
+    assert [int(v) for v in distinctive] == gold["distinctive"]["best"]
+    for r, g in zip(dynamic, gold["dynamic"]):      # bit-identical on both sides (sorted, sequential FP64 sums)
+        assert [float(r[0]).hex(), float(r[1]).hex(), int(r[2]), int(r[3])] == g
+    kept, ur, dp = stereo
+    g = gold["stereo"]
+    assert int(kept) == g["kept"] > 500 and len(ur) == g["n"]
+    assert sha(np.asarray(ur, np.float32)) == g["u_right_sha256"] and sha(np.asarray(dp, np.float32)) == g["depth_sha256"]
+
+
+def test_further_fixtures():
+    gold = json.load(open(os.path.join(GOLD, "aux_golden.json")))
+    cf = {name: oracle_lib.cfse3_optimize(f["objs"], f["K"]) for name, f in cfse3_cases(oracle_lib.se3_from_mat4f)}
+    fu = {name: oracle_lib.fuse_search(pr) for name, pr in fuse_cases()}
+    L, R = stereo_case()
+    ol, orr = oracle_lib.OracleORB(2000), oracle_lib.OracleORB(2000)
+    ol.run(L); orr.run(R)
+    st = oracle_lib.stereo_match(ol, orr, np.float32(384.38148 / 721.5377), np.float32(384.38148))
+    check_aux(gold, cf, fu, oracle_lib.distinctive_descriptors(distinctive_case()), [oracle_lib.dynamic_discrimination(o) for o in dynamic_cases()], st)
