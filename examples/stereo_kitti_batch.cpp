@@ -39,7 +39,12 @@ int main(int argc, char** argv) {
   const size_t pitch = (size_t)w * h;
   unsigned char* pinned = (unsigned char*)ps_pinned_alloc(pitch * 2 * (size_t)S * nImages);
   if (!pinned) { std::cerr << ps_last_error() << std::endl; return 1; }
-  auto image = [&](int k, int ni, int right) { return pinned + pitch * ((((size_t)ni * S) + k) * 2 + right); };
+  // layout: step-major, inside a step group by group (sequence k belongs to group k % G), left / right interleaved - so the
+  // images of one group's step are one contiguous block in the order the batch wants them and go up in a single transfer
+  const int G = std::max(1, std::min(groups, S));
+  std::vector<int> groupBase(G + 1, 0);
+  for (int g = 0; g < G; g++) groupBase[g + 1] = groupBase[g] + (S - g + G - 1) / G;
+  auto image = [&](int k, int ni, int right) { return pinned + pitch * ((((size_t)ni * S) + groupBase[k % G] + k / G) * 2 + right); };
   for (int k = 0; k < S; k++)
     for (int ni = 0; ni < nImages; ni++)
       for (int right = 0; right < 2; right++) {
@@ -50,7 +55,6 @@ int main(int argc, char** argv) {
       }
   // `groups` StereoOdometryBatch instances, each with its own handles and its own thread, share the sequences round-robin:
   // while one group waits for a transfer or a kernel the others keep the GPU and the PCIe link busy
-  const int G = std::max(1, std::min(groups, S));
   const bool prefetch = std::getenv("PS_ODO_NO_PREFETCH") == nullptr;   // queue step n+1's extraction during step n's search / pose rounds
   const int warm = nImages > 2 ? 2 : (nImages > 1 ? 1 : 0);             // step 0 initialises, step 1 sizes the staging buffers
   struct Group {

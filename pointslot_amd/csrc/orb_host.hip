@@ -481,8 +481,14 @@ int ps_orb_extract_batch(ps_orb* h, const uint8_t* const* imgs, int nimg, int w,
     PS_HIP(hipMalloc(&h->d_img, bytes));
     h->d_img_bytes = bytes;
   }
-  // one copy per image on the handle's stream: asynchronous when the caller's buffers are pinned (ps_pinned_alloc)
-  for (int i = 0; i < nimg; i++) PS_HIP(hipMemcpyAsync(h->d_img + pitch * i, imgs[i], pitch, hipMemcpyHostToDevice, h->stream));
+  // uploads on the handle's stream, asynchronous when the caller's buffers are pinned (ps_pinned_alloc).  Images that follow each
+  // other in host memory go in ONE transfer: a 0.47 MB copy reaches half the PCIe rate of a multi-megabyte one.
+  for (int i = 0; i < nimg;) {
+    int j = i + 1;
+    while (j < nimg && imgs[j] == imgs[j - 1] + pitch) j++;
+    PS_HIP(hipMemcpyAsync(h->d_img + pitch * i, imgs[i], pitch * (size_t)(j - i), hipMemcpyHostToDevice, h->stream));
+    i = j;
+  }
   return ps_orb_extract_batch_device(h, h->d_img, nimg, w, hgt, stride, pitch, nullptr);
 }
 
