@@ -6,7 +6,10 @@ TAG=$1; SRC=$2; shift 2
 cd "$(dirname "$0")/../pointslot_amd/csrc"
 mkdir -p ../../build_exp
 OBJ=../../build_exp/${SRC%.hip}_$TAG.o
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off "$@" -c $SRC -o $OBJ
+# same floating-point contraction as the Makefile: off everywhere except the FP64 optimiser kernels
+CONTRACT=off
+case $SRC in ba_kernels.hip|opt_kernels.hip) CONTRACT=fast;; esac
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=$CONTRACT "$@" -c $SRC -o $OBJ
 OTHERS=$(ls *.o | grep -v "^${SRC%.hip}.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build_exp/libps_$TAG.so $OBJ $OTHERS
 echo build_exp/libps_$TAG.so
