@@ -33,6 +33,20 @@ __global__ void k(double* out, long long* cyc, int iters) {
     for (int i = 0; i < 24; i++) a[i] = __fma_rn(-x, b[i], a[i]);
   }
   long long t3b = clock64();
+  __shared__ __attribute__((aligned(16))) double lbuf[64];
+  lbuf[lane & 63] = x;
+  __syncthreads();
+  long long t3c = clock64();
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  for (int it = 0; it < iters; it++) {   // FMAs whose operand is an LDS broadcast, two values per 128-bit read
+#pragma unroll
+    for (int i = 0; i < 24; i += 2) {
+      const d2 v = *reinterpret_cast<volatile d2*>(&lbuf[i]);
+      a[i] = __fma_rn(-x, v.x, a[i]);
+      a[i + 1] = __fma_rn(-x, v.y, a[i + 1]);
+    }
+  }
+  long long t3d = clock64();
   double r = x;
   for (int it = 0; it < iters; it++)
 #pragma unroll
@@ -41,7 +55,7 @@ __global__ void k(double* out, long long* cyc, int iters) {
   double s = c + r;
   for (int i = 0; i < 24; i++) s += a[i];
   out[blockIdx.x * blockDim.x + lane] = s;
-  if (lane == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = t2 - t1; cyc[2] = t3 - t2; cyc[3] = t4 - t3b; cyc[4] = t3b - t3; }
+  if (lane == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = t2 - t1; cyc[2] = t3 - t2; cyc[3] = t4 - t3d; cyc[4] = t3b - t3; cyc[5] = t3d - t3c; }
 }
 int main() {
   double* out; long long* cyc;
@@ -50,9 +64,9 @@ int main() {
   for (int waves = 1; waves <= 4; waves *= 2) {
     hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves * 4), 0, 0, out, cyc, iters);   // `waves` wavefronts per SIMD on one CU
     hipDeviceSynchronize();
-    long long h[5]; hipMemcpy(h, cyc, 40, hipMemcpyDeviceToHost);
-    printf("%d wave(s) per SIMD: independent FMA %.1f, dependent FMA %.1f, FMA + 2 readlane %.1f (per FMA), rcp + 2 Newton + add %.1f, broadcasts first then FMAs %.1f clock64 ticks\n", waves,
-           h[0] / (24.0 * iters), h[1] / (24.0 * iters), h[2] / (24.0 * iters), h[3] / (8.0 * iters), h[4] / (24.0 * iters));
+    long long h[6]; hipMemcpy(h, cyc, 48, hipMemcpyDeviceToHost);
+    printf("%d wave(s) per SIMD: independent FMA %.1f, dependent FMA %.1f, FMA + 2 readlane %.1f (per FMA), rcp + 2 Newton + add %.1f, broadcasts first then FMAs %.1f, FMA with LDS broadcast operand (b128 per two) %.1f clock64 ticks\n", waves,
+           h[0] / (24.0 * iters), h[1] / (24.0 * iters), h[2] / (24.0 * iters), h[3] / (8.0 * iters), h[4] / (24.0 * iters), h[5] / (24.0 * iters));
   }
   return 0;
 }
