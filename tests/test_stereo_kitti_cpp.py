@@ -59,6 +59,28 @@ def test_cpp_host_state_machine_with_the_cpu_checker_behind_it(tmp_path):
         assert "matches %d map %d local inliers %d" % (st["matches"], st["map_matches"], st["local_inliers"]) in lines[k], (lines[k], st)
 
 
+def test_cpp_host_state_machine_under_address_and_ub_sanitizers(tmp_path):
+    """The same CPU-only driver built with -fsanitize=address,undefined (sanitizers run on the CPU build only): the host side of
+    the tracking loop indexes a dozen parallel arrays per frame; no report, same exit code."""
+    import oracle_lib  # noqa: F401
+    from pointslot_amd import sequence
+    exe = str(tmp_path / "odo_oracle_driver_asan")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "pointslot_amd", "host"),
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "odo_oracle_driver.cpp"), "-o", exe, "-L", os.path.join(ROOT, "oracle"),
+                        "-loracle", "-L", os.path.join(ROOT, "pointslot_amd"), "-lpointslot_hip", "-pthread", "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                        "-Wl,-rpath," + os.path.join(ROOT, "pointslot_amd"), "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[-200:])
+    seq = sequence.generate(n_frames=4, seed=5, w=800, h=300)
+    d = str(tmp_path / "0000")
+    sequence.write_pgm(d, seq)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([exe, d], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-2000:]
+    assert out.stdout.count(": ok ") == 4
+
+
 @pytest.mark.gpu
 def test_stereo_kitti_cpp_tracks_like_the_python_driver(tmp_path):
     from pointslot_amd import sequence
