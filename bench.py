@@ -57,6 +57,22 @@ def pmc_traffic(kernel, nimg):
     return None
 
 
+def pmc_valu_issue(kernel, nimg):
+    """Share of the launch that VALU issue alone accounts for (waves x VALU instructions x 4 cycles / 1024 SIMDs / clock), from the
+    committed PMC pass (tools/pmc_issue.sh: SQ_INSTS_VALU, SQ_WAVES, own run).  Explains a low HBM fraction: the kernel is bound by
+    instruction issue, not by memory.  None when no measurement for this launch shape is on file."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_valu_issue.json")))
+    except (OSError, ValueError):
+        return None
+    if t.get("images_per_launch") != nimg:
+        return None
+    for name, v in t.get("kernels", {}).items():
+        if name.split("<")[0] == kernel:
+            return {"valu_issue_share": v.get("valu_issue_share"), "valu_instructions_per_wave": v.get("valu_per_wave"), "waves_per_launch": v.get("waves_per_launch")}
+    return None
+
+
 def cpu_baseline(batch, pairs_sample):
     """Times the CPU restatement (oracle/, kind "port") on a bounded sample of the same workload, using the
     reference's thread model: left and right image on two threads (/root/reference/src/Frame.cc:709-710)."""
@@ -427,7 +443,7 @@ def main():
                        "parallelism": "images sharded over %d GPU(s), no collective in the data path" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, nimg),
-                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms},
+                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms, "issue": pmc_valu_issue(dom, nimg)},
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         }
         if secondary is not None:
