@@ -316,6 +316,23 @@ def sequence_leg(rank, world, local_rank, dist, with_cpu, n_frames=12):
            "median_ms_per_frame": ms, "frames_per_s_all_sequences": world * 1e3 / ms, "tracked": int(sum(t is not None for t in vo.trajectory)),
            "max_abs_position_error_m": parallel.max_over_ranks(dist, err, RED_DEV), "trajectory_gather_ms": gather_ms,
            "gathered": [list(a.shape) for a in allt]}
+    if rank == 0:
+        # the same sequence through the C++ driver (examples/stereo_kitti.cpp, the reference's per-frame call structure), GPU 0
+        try:
+            import shutil
+            import subprocess
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="ps_single_")
+            try:
+                sequence.write_pgm(tmp, seq)
+                run = subprocess.run([os.path.join(ROOT, "build", "stereo_kitti"), tmp], capture_output=True, text=True, timeout=300)
+                med = [l for l in run.stdout.splitlines() if l.startswith("median tracking time")]
+                if run.returncode == 0 and med:
+                    out["cpp_driver_median_ms_per_frame"] = float(med[0].split(":")[1].split()[0])
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        except Exception as e:   # noqa: BLE001
+            out["cpp_driver_error"] = "%s: %s" % (type(e).__name__, e)
     if with_cpu and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_backend import OracleBackend
