@@ -3,6 +3,7 @@
 // Replaces ORBmatcher::SearchByBruceMatching / DescriptorDistance — /root/reference/src/ORBmatcher.cc.
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <string.h>
 #include <vector>
 #include "match_plan.h"
@@ -195,6 +196,8 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   int rc = ensure(m, off);
   if (rc != PS_OK) return rc;
   uint8_t* H = m->h_buf;
+  static const bool prof = getenv("PS_MATCH_PROFILE") != nullptr;   // developer switch: host-side breakdown of the call on stderr
+  const auto tp0 = std::chrono::steady_clock::now();
   PjProb* hp = (PjProb*)(H + o_prob);
   std::vector<size_t> toff(nprob), qoff(nprob);
   {
@@ -246,7 +249,10 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
     }
   });
   uint8_t* D = m->d_buf;
+  const auto tp1 = std::chrono::steady_clock::now();
   PS_HIP(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, m->stream));
+  if (prof) PS_HIP(hipStreamSynchronize(m->stream));
+  const auto tp2 = std::chrono::steady_clock::now();
   PS_HIP(hipMemsetAsync(D + o_ovf, 0, 4, m->stream));
   PjArrays A;
   A.prob = (const PjProb*)(D + o_prob);
@@ -262,8 +268,16 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   A.ttop = (uint4*)(D + o_tt);
   psk_pj_launch(&A, nprob, max_nq > 0 ? max_nq : 1, any_frame, m->stream);
   PS_HIP(hipGetLastError());
+  if (prof) PS_HIP(hipStreamSynchronize(m->stream));
+  const auto tp3 = std::chrono::steady_clock::now();
   PS_HIP(hipMemcpyAsync(H + o_match, D + o_match, out_end - o_match, hipMemcpyDeviceToHost, m->stream));
   PS_HIP(hipStreamSynchronize(m->stream));
+  const auto tp4 = std::chrono::steady_clock::now();
+  if (prof) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "ps_search_by_projection %d problems, %.1f MB in: pack %.3f ms, upload %.3f, kernels %.3f, read-back %.3f\n", nprob, in_bytes / 1e6, ms(tp0, tp1),
+            ms(tp1, tp2), ms(tp2, tp3), ms(tp3, tp4));
+  }
   if (*(const int32_t*)(H + o_ovf) > 0)
     return ps_set_error(PS_ERR_CAPACITY, "a search window held more than %d candidates", PS_PJ_CAP);
   for (int p = 0; p < nprob; p++) {

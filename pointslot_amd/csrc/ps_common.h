@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 #include "../../include/pointslot_hip.h"
@@ -21,7 +22,8 @@ int ps_set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2
 template <typename Fn>
 inline void ps_parallel_for(int n, size_t total_bytes, Fn fn) {
   const unsigned hw = std::thread::hardware_concurrency();
-  const size_t want = std::min<size_t>(std::min<size_t>((size_t)n, hw ? hw : 1), std::min<size_t>(16, total_bytes / ((size_t)1 << 20) + 1));
+  static const size_t cap = getenv("PS_PACK_THREADS") ? (size_t)atoi(getenv("PS_PACK_THREADS")) : 16;   // developer switch
+  const size_t want = std::min<size_t>(std::min<size_t>((size_t)n, hw ? hw : 1), std::min<size_t>(cap, total_bytes / ((size_t)1 << 20) + 1));
   const int nt = (int)want;
   if (nt <= 1) {
     for (int i = 0; i < n; i++) fn(i);

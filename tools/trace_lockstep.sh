@@ -10,7 +10,7 @@ for k in range(4):
     sequence.write_pgm("/tmp/ps_ls/%04d" % k, sequence.generate(n_frames=12, seed=30 + k, step=0.05 + 0.01 * k))
 PY
 ARGS=""
-for i in $(seq 0 63); do ARGS="$ARGS /tmp/ps_ls/000$((i % 4))"; done
+for i in $(seq 0 $((${PS_SEQS:-64} - 1))); do ARGS="$ARGS /tmp/ps_ls/000$((i % 4))"; done
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_lockstep -o ls -- $R/build/stereo_kitti_batch --groups ${PS_GROUPS:-1} $ARGS > $R/gpurun_out/lockstep.log 2>&1
 cd $R
