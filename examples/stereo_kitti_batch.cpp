@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
     std::vector<double> times, parts[4];
     int lost = 0, rounds = 0;
     std::chrono::steady_clock::time_point tStart, tEnd;
+    double unixStart = 0, unixEnd = 0;   // the same instants on the system clock: several driver processes can be laid side by side
     std::string error;
   };
   std::vector<Group> grp(G);
@@ -85,6 +86,7 @@ int main(int argc, char** argv) {
           std::unique_lock<std::mutex> lk(mtx);
           if (++arrived == G) cv.notify_all(); else cv.wait(lk, [&]() { return arrived >= G; });
           R.tStart = std::chrono::steady_clock::now();
+          R.unixStart = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
         }
         const bool more = prefetch && ni + 1 < nImages;
         for (int i = 0; i < n; i++) {
@@ -104,6 +106,7 @@ int main(int argc, char** argv) {
                       1e3 * R.parts[0][ni], 1e3 * R.parts[1][ni], 1e3 * R.parts[2][ni], 1e3 * R.parts[3][ni]);
       }
       R.tEnd = std::chrono::steady_clock::now();
+      R.unixEnd = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
       R.rounds = SLAM.rounds;
       for (int i = 0; i < n; i++) trajectories[R.members[i]] = SLAM.sequence(i).trajectory;
     } catch (const std::exception& e) {
@@ -127,9 +130,10 @@ int main(int argc, char** argv) {
     std::sort(t.begin(), t.end());
     return t[t.size() / 2];
   };
-  double median = 0, wall = 0;
+  double median = 0, wall = 0, unixStart = 1e300, unixEnd = 0;
   int lost = 0;
   for (const Group& R : grp) {
+    unixStart = std::min(unixStart, R.unixStart); unixEnd = std::max(unixEnd, R.unixEnd);
     median = std::max(median, medianOf(R.times));
     wall = std::max(wall, std::chrono::duration<double>(R.tEnd - grp[0].tStart).count());
     lost += R.lost;
@@ -137,9 +141,9 @@ int main(int argc, char** argv) {
   const int timedSteps = nImages - warm;
   std::printf("{\"sequences\": %d, \"groups\": %d, \"frames_per_sequence\": %d, \"timed_steps\": %d, \"untracked_frames\": %d, \"median_ms_per_step\": %.4f, "
               "\"wall_ms_timed_steps\": %.4f, \"frames_per_s\": %.1f, \"ms_per_step_frames\": %.4f, \"ms_per_step_host\": %.4f, \"ms_per_step_search\": %.4f, "
-              "\"ms_per_step_pose\": %.4f, \"device_rounds_per_step\": %.2f}\n",
+              "\"ms_per_step_pose\": %.4f, \"device_rounds_per_step\": %.2f, \"unix_start\": %.6f, \"unix_end\": %.6f}\n",
               S, G, nImages, timedSteps, lost, 1e3 * median, 1e3 * wall, timedSteps > 0 ? S * timedSteps / wall : 0.0, 1e3 * medianOf(grp[0].parts[0]),
-              1e3 * medianOf(grp[0].parts[1]), 1e3 * medianOf(grp[0].parts[2]), 1e3 * medianOf(grp[0].parts[3]), grp[0].rounds / (double)nImages);
+              1e3 * medianOf(grp[0].parts[1]), 1e3 * medianOf(grp[0].parts[2]), 1e3 * medianOf(grp[0].parts[3]), grp[0].rounds / (double)nImages, unixStart, unixEnd);
   ps_pinned_free(pinned);
   return 0;
 }
