@@ -336,6 +336,9 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
               }
 #pragma unroll
               for (int j = 0; j < 6; j++) A[j][j] += lambda;
+              // (the 21 divisions by a pivot go through one reciprocal per pivot - hardware estimate + two Newton steps, full
+              // double precision - like the LDL^T of the BA solver: a division sequence is a dozen dependent instructions)
+              double rD[6];
 #pragma unroll
               for (int j = 0; j < 6; j++) {
                 double d = A[j][j];
@@ -343,12 +346,17 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
                 for (int q = 0; q < j; q++) d -= A[j][q] * A[j][q] * D[q];
                 if (!(d > 0)) ok2 = false;
                 D[j] = d;
+                double r = __builtin_amdgcn_rcp(d);
+                double e = __builtin_fma(-d, r, 1.0);
+                r = __builtin_fma(r, e, r);
+                e = __builtin_fma(-d, r, 1.0);
+                rD[j] = __builtin_fma(r, e, r);
 #pragma unroll
                 for (int i = j + 1; i < 6; i++) {
                   double v = A[i][j];
 #pragma unroll
                   for (int q = 0; q < j; q++) v -= A[i][q] * A[j][q] * D[q];
-                  A[i][j] = v / d;
+                  A[i][j] = v * rD[j];
                 }
               }
               double y[6];
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
                 y[i] = v;
               }
 #pragma unroll
-              for (int i = 0; i < 6; i++) y[i] /= D[i];
+              for (int i = 0; i < 6; i++) y[i] *= rD[i];
               double xv[6];
 #pragma unroll
               for (int i = 5; i >= 0; i--) {
