@@ -55,18 +55,43 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
 // sums acc[0..N) over the workgroup in a fixed order; the result lands in s.out[0..N) for every thread
 template <int N>
 __device__ void block_sum(double* acc, PoShared& s) {
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    double v = acc[i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += shfl_xor_d(v, d);
-    acc[i] = v;
-  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();   // protect s.out / s.red from the previous use
-  if (lane == 0)
+  if (N > 4) {
+    // Many values: instead of one 6-step butterfly per value (6 N exchanges), every step halves the number of values a lane
+    // carries - the lane keeps one half, sends the other to its partner and adds what it receives - so the wave makes
+    // 16 + 8 + 4 + 2 + 1 + 1 exchanges for up to 32 values.  After the five halving steps lane l holds value (l >> 1) & 31
+    // summed over its 32-lane class; the last step adds the two classes.
+    static_assert(N <= 32, "block_sum: at most 32 values");
+    double v[32];
 #pragma unroll
-    for (int i = 0; i < N; i++) s.red[wave][i] = acc[i];
+    for (int i = 0; i < 32; i++) v[i] = i < N ? acc[i] : 0.0;
+#pragma unroll
+    for (int step = 0; step < 5; step++) {
+      const int d = 32 >> step, half = 16 >> step;
+      const bool upper = (lane & d) != 0;
+#pragma unroll
+      for (int i = 0; i < half; i++) {
+        const double keep = upper ? v[i + half] : v[i];
+        const double send = upper ? v[i] : v[i + half];
+        v[i] = keep + shfl_xor_d(send, d);
+      }
+    }
+    const double total = v[0] + shfl_xor_d(v[0], 1);
+    __syncthreads();   // protect s.out / s.red from the previous use
+    if ((lane & 1) == 0 && (lane >> 1) < N) s.red[wave][lane >> 1] = total;
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      double v = acc[i];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += shfl_xor_d(v, d);
+      acc[i] = v;
+    }
+    __syncthreads();   // protect s.out / s.red from the previous use
+    if (lane == 0)
+#pragma unroll
+      for (int i = 0; i < N; i++) s.red[wave][i] = acc[i];
+  }
   __syncthreads();
   if (threadIdx.x < N) {
     double v = 0;
