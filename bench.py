@@ -366,12 +366,27 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the pose-optimisation / object-BA legs")
     args = ap.parse_args()
 
-    import torch
+    # `python bench.py --gpus N` with no launcher around it: this process only starts N ranks (fresh children, one per GPU)
+    # and forwards rank 0's JSON line; it never touches the GPU itself.  PS_BENCH_LAUNCH_ONLY=1 (CPU test of this path):
+    # every rank prints what it was started with and exits before anything imports torch.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        from pointslot_amd import parallel
+        sys.exit(parallel.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py: %d rank(s) were started (WORLD_SIZE) but --gpus is %d" % (world, args.gpus))
+    if os.environ.get("PS_BENCH_LAUNCH_ONLY") == "1":
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": world, "rank": rank, "local_rank": local_rank,
+                              "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}))
+        if os.environ.get("PS_BENCH_LAUNCH_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        return
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # PS_BENCH_SHARE_GPU=1 (developer switch): all ranks on GPU 0 over gloo, to exercise the multi-process path on a 1-GPU box

@@ -73,3 +73,49 @@ def gather_trajectories(dist, local, device="cpu"):
     outs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf)
     return [o[:int(c.item())].cpu().numpy() for o, c in zip(outs, counts)]
+
+
+def launch_ranks(script, argv, n_ranks, timeout=None, extra_env=None):
+    """`python bench.py --gpus N` without a launcher: starts N fresh child processes of `script` (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, the layout `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N` would give them), forwards rank 0's stdout and returns the largest exit code.  The calling process
+    must not have initialised the GPU (it only waits); every child is killed if one of them fails or the timeout expires."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    if n_ranks < 1:
+        raise ValueError("n_ranks must be >= 1")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.update(extra_env or {})
+    procs = []
+    for r in range(n_ranks):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        out = None if r == 0 else subprocess.DEVNULL       # rank 0 prints the JSON line; stderr of every rank is inherited
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=out))
+    deadline = None if timeout is None else time.time() + timeout
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is not None:
+                    pending.remove(p)
+                    if code != 0:
+                        rc = max(rc, code if code > 0 else 1)
+            if rc != 0 or (deadline is not None and time.time() > deadline):
+                if pending and rc == 0:
+                    rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    return rc

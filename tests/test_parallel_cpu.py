@@ -57,3 +57,30 @@ def test_gloo_world2_gather_and_timing(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+def _bench(args, **env):
+    e = dict(os.environ, PS_BENCH_LAUNCH_ONLY="1", **env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=120)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (it silently ran one)."""
+    import json
+    r = _bench(["--gpus", "3", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                     # only rank 0's line is forwarded
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["rank"] == 0 and out["master"].startswith("127.0.0.1:")
+    # a failing rank fails the launcher
+    r = _bench(["--gpus", "2"], PS_BENCH_LAUNCH_FAIL_RANK="1")
+    assert r.returncode != 0
+    # started by an external launcher with a different world size: loud failure, not a silent single-rank run
+    r = _bench(["--gpus", "4"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert r.returncode != 0 and "--gpus is 4" in (r.stderr + r.stdout)
+    r = _bench(["--gpus", "1"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert r.returncode != 0
