@@ -384,6 +384,62 @@ int ps_dynamic_discrimination_batch(ps_optimizer* h, ps_dyn_problem* problems, i
  * mnId == 0 and the fixed cameras) and world-frame map points.  The abort flag of the reference is not modelled. */
 int ps_local_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int nprob);
 
+/* ------------------------------------------------------------------------------------------------
+ * Lockstep tracker — the tracking thread's per-frame chain for many independent stereo sequences, resident on the device:
+ *   Frame::Frame (ExtractORB x 2, ComputeStereoMatches, AssignFeaturesToGrid)      /root/reference/src/Frame.cc:709-722,1636-1656
+ *   StereoInitialization / UpdateLastFrame / TrackWithMotionModel / TrackLocalMap   src/Tracking.cc:2840-3160
+ *   (SearchByProjection(cur, last, th) with its 2 th retry, PoseOptimization, isInFrustum, SearchByProjection(F, points),
+ *   PoseOptimization) and the constant-velocity model, src/Tracking.cc:1260-1286
+ * in localisation mode (mbOnlyTracking), exactly the slice pointslot_amd/host/StereoOdometry.h drives through the calls
+ * above — but queued on ONE stream per step with nothing returning to the host: no packing, no PCIe traffic besides the
+ * images.  Independent sequences are the unit of parallelism (BASELINE config 4 / SURVEY.md 8e).  Results are identical to
+ * the per-call driver's.  A handle is not re-entrant; several handles may run on several threads / streams side by side.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ps_tracker ps_tracker;
+typedef struct ps_tracker_config {
+  int32_t n_sequences;               /* sequences advanced by one call                                         */
+  int32_t width, height;             /* image size (all sequences share the rig)                               */
+  float fx, fy, cx, cy, bf;          /* Camera.fx .. Camera.bf of the settings file                            */
+  float th_depth;                    /* ThDepth (35 in the KITTI settings)                                     */
+  int32_t nfeatures; float scale_factor; int32_t nlevels, ini_th_fast, min_th_fast;   /* ORBextractor.*      */
+  int32_t max_steps;                 /* frames per sequence the handle keeps results for                       */
+  int32_t device;
+} ps_tracker_config;
+/* what Tracking::Track leaves per frame and sequence */
+typedef struct ps_track_stat {
+  int32_t state;          /* 0 NOT_INITIALIZED, 1 OK, 2 LOST after the frame                                   */
+  int32_t tracked;        /* the frame has a pose                                                              */
+  int32_t n;              /* keypoints of the left image                                                       */
+  int32_t mm_matches;     /* SearchByProjection(cur, last): matches of the attempt that was used               */
+  int32_t retried;        /* the 2 * th retry ran (Tracking.cc:3042-3048)                                      */
+  int32_t matches;        /* after the first PoseOptimization and the outlier discard (Tracking.cc:3062-3082)  */
+  int32_t map_matches;    /* ... of which on map points with observations                                      */
+  int32_t lm_candidates;  /* local-map points that passed Frame::isInFrustum                                   */
+  int32_t lm_inliers;     /* mnMatchesInliers of TrackLocalMap                                                 */
+  int32_t reserved[3];
+} ps_track_stat;
+int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out);
+void ps_tracker_destroy(ps_tracker* t);
+/* One stereo frame of every sequence.  _device: images already in HBM, sequence k's left image at d_imgs + 2k * image_pitch,
+ * its right image one pitch further, rows `stride` bytes apart.  The host form takes one pointer per image (asynchronous when
+ * they come from ps_pinned_alloc).  Both return as soon as the step is queued. */
+int ps_tracker_step_device(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_pitch);
+int ps_tracker_step(ps_tracker* t, const uint8_t* const* left, const uint8_t* const* right, int stride);
+int ps_tracker_sync(ps_tracker* t);
+int ps_tracker_steps(const ps_tracker* t, int* steps);
+/* Blocks, then copies the results of steps [first_step, first_step + nsteps): tcw [nsteps][n_sequences][16] (mTcw row-major,
+ * all zero for a frame without a pose) and stats [nsteps][n_sequences]; either pointer may be NULL.  PS_ERR_CAPACITY if a
+ * search window overflowed the candidate store since the last reset (the results are then not the reference's). */
+int ps_tracker_fetch(ps_tracker* t, int first_step, int nsteps, float* tcw, ps_track_stat* stats);
+/* All sequences back to NOT_INITIALIZED, step counter 0. */
+int ps_tracker_reset(ps_tracker* t);
+/* GPU time per stage of a step (HIP events on the tracker's stream, mean over the recorded steps, at most 64):
+ * orb_extract, stereo_match, track_glue, search_by_projection, pose_optimization. */
+int ps_tracker_enable_stage_timing(ps_tracker* t, int enable);
+int ps_tracker_stage_times(ps_tracker* t, const char** names, float* ms, int cap, int* n);
+/* The extractor the tracker owns (its per-kernel stage times, debug reads). */
+int ps_tracker_orb(ps_tracker* t, ps_orb** orb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,7 @@ struct ps_orb {
   // stereo matcher outputs, indexed like the keypoints of the LEFT image: [max_batch][kp_cap]
   float* d_uright = nullptr; float* d_depth = nullptr; int32_t* d_sad = nullptr; int32_t* d_kept = nullptr;
   StPair* d_pairs = nullptr;
+  std::vector<StPair> pairs_host;   // what d_pairs holds
   uint8_t* d_stscratch = nullptr;   // [max_batch][PS_ST_SCRATCH]
   int last_npairs = 0;
   uint8_t* d_objkeys = nullptr;   // scratch of ps_orb_stereo_match_keys (caller-provided key sets + their outputs)
@@ -162,6 +163,7 @@ int free_device(ps_orb* h) {
   if (h->d_sad) hipFree(h->d_sad);
   if (h->d_kept) hipFree(h->d_kept);
   if (h->d_pairs) hipFree(h->d_pairs);
+  h->pairs_host.clear();
   if (h->d_stscratch) hipFree(h->d_stscratch);
   h->d_stscratch = nullptr;
   if (h->d_objkeys) hipFree(h->d_objkeys);
@@ -369,6 +371,15 @@ void ps_orb_destroy(ps_orb* h) {
       for (int i = 0; i <= ST_COUNT; i++) if (h->ev[r][c][i]) hipEventDestroy(h->ev[r][c][i]);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
+}
+
+// accessors for track_host.hip (the lockstep tracker owns an extractor and queues its own kernels behind it)
+hipStream_t psi_orb_stream(ps_orb* h) { return h->stream; }
+const OrbPlan* psi_orb_plan(ps_orb* h) { return &h->plan; }
+int psi_orb_prepare(ps_orb* h, int w, int hgt) {
+  PS_HIP(hipSetDevice(h->cfg.device));
+  if (!h->planned || h->plan.img_w != w || h->plan.img_h != hgt) return build_plan(h, w, hgt);
+  return PS_OK;
 }
 
 int ps_orb_get_tables(const ps_orb* h, float* s, float* is, float* s2, float* is2, int32_t* q) {
@@ -623,7 +634,13 @@ int ps_orb_stage_times(ps_orb* h, const char** names, float* ms, int cap, int* n
 
 // ---- Frame::ComputeStereoMatches (Frame.cc:2142-2316) on device-resident extraction results ----
 static int stereo_run(ps_orb* out_h, const std::vector<StPair>& pairs, float mb, float mbf, int max_left = 0) {
-  PS_HIP(hipMemcpyAsync(out_h->d_pairs, pairs.data(), pairs.size() * sizeof(StPair), hipMemcpyHostToDevice, out_h->stream));
+  // the pair table is the same from call to call in a tracking loop: uploaded only when it changes (a copy from pageable memory
+  // would make the caller wait for everything queued on the stream)
+  if (out_h->pairs_host.size() != pairs.size() || memcmp(out_h->pairs_host.data(), pairs.data(), pairs.size() * sizeof(StPair)) != 0) {
+    PS_HIP(hipStreamSynchronize(out_h->stream));   // an earlier launch may still read the old table
+    out_h->pairs_host = pairs;
+    PS_HIP(hipMemcpy(out_h->d_pairs, pairs.data(), pairs.size() * sizeof(StPair), hipMemcpyHostToDevice));
+  }
   psk_stereo_launch(&out_h->plan, out_h->d_pairs, (int)pairs.size(), max_left > 0 ? max_left : out_h->plan.kp_cap, mb, mbf, out_h->stream);
   PS_HIP(hipGetLastError());
   out_h->last_npairs = (int)pairs.size();

@@ -209,6 +209,7 @@ class OdoSequence {
     last = std::move(F);
     trajectory.push_back(pose(*last));
     lastFrameTracked = true;
+    state = OK;                                        // `if (bOK) mState = OK;` - also after a frame that was lost
     return NONE;
   }
 
@@ -590,6 +591,53 @@ class StereoOdometryBatch {
     std::unique_lock<std::mutex> lk(mtx);
     cvDone.wait(lk, [&]() { return pending == 0; });
   }
+};
+
+// ---- many independent sequences in lockstep, the whole chain resident on the device ----
+// Same frames, same results as StereoOdometryBatch, but a step is one ps_tracker_step call that only queues work: the host
+// side of Tracking::Track (grid, UpdateLastFrame, match application, isInFrustum, motion model) runs in the glue kernels of
+// the library between the hot-path kernels, nothing is packed or copied per call, and results are read when asked for.
+class StereoOdometryDevice {
+ public:
+  StereoOdometryDevice(int nSequences, float fx, float fy, float cx, float cy, float bf, int width, int height, int maxFrames, float thDepth = 35.f,
+                       int nFeatures = 2000, float scale = 1.2f, int nLevels = 8, int iniTh = 20, int minTh = 5, int device = 0)
+      : nseq(nSequences) {
+    ps_tracker_config cfg{nSequences, width, height, fx, fy, cx, cy, bf, thDepth, nFeatures, scale, nLevels, iniTh, minTh, maxFrames, device};
+    if (ps_tracker_create(&cfg, &trk) != PS_OK) throw std::runtime_error(std::string("ps_tracker_create: ") + ps_last_error());
+  }
+  ~StereoOdometryDevice() { ps_tracker_destroy(trk); }
+  StereoOdometryDevice(const StereoOdometryDevice&) = delete;
+
+  int size() const { return nseq; }
+  ps_tracker* handle() { return trk; }
+  // queues one stereo frame of every sequence (host images; buffers from ps_pinned_alloc make the upload asynchronous)
+  void TrackAll(const std::vector<const uint8_t*>& left, const std::vector<const uint8_t*>& right, int stride) {
+    if ((int)left.size() != nseq || (int)right.size() != nseq) throw std::runtime_error("TrackAll: one image pair per sequence");
+    check(ps_tracker_step(trk, left.data(), right.data(), stride));
+  }
+  // ... or images that already are in device memory: sequence k's left image at d_imgs + 2k * pitch, right one pitch further
+  void TrackAllDevice(const uint8_t* d_imgs, int stride, size_t pitch) { check(ps_tracker_step_device(trk, d_imgs, stride, pitch)); }
+  void Sync() { check(ps_tracker_sync(trk)); }
+  int Steps() const { int n = 0; ps_tracker_steps(trk, &n); return n; }
+  // blocks; trajectories[k][step] = Tcw (16 floats), empty for a frame without a pose; stats[step * size() + k]
+  void Fetch(std::vector<std::vector<std::vector<float>>>& trajectories, std::vector<ps_track_stat>* stats = nullptr) {
+    const int n = Steps();
+    std::vector<float> tcw((size_t)n * nseq * 16);
+    std::vector<ps_track_stat> st((size_t)n * nseq);
+    check(ps_tracker_fetch(trk, 0, n, tcw.data(), st.data()));
+    trajectories.assign(nseq, {});
+    for (int k = 0; k < nseq; k++)
+      for (int i = 0; i < n; i++) {
+        const size_t o = (size_t)i * nseq + k;
+        trajectories[k].push_back(st[o].tracked ? std::vector<float>(tcw.begin() + o * 16, tcw.begin() + o * 16 + 16) : std::vector<float>());
+      }
+    if (stats) *stats = st;
+  }
+
+ private:
+  int nseq;
+  ps_tracker* trk = nullptr;
+  static void check(int rc) { if (rc != PS_OK) throw std::runtime_error(ps_last_error()); }
 };
 
 }  // namespace ORB_SLAM2

@@ -286,6 +286,7 @@ class StereoOdometry:
         F.mp_valid[tmp] = False
         F.outlier[tmp] = 0
         self.last = F
+        self.state = "OK"                # `if (bOK) mState = OK;` - also after a frame that was lost
         self.trajectory.append(F.tcw.copy())
         self.stats.append(st)
         return F.tcw

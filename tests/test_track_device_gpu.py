@@ -1,0 +1,78 @@
+"""The device-resident lockstep tracker (ps_tracker_*) against the host-driven chain over the per-call C-ABI
+(StereoOdometryBatch, itself held to the CPU checker by test_tracker_gpu.py / test_stereo_kitti_cpp.py): every frame of
+every sequence must come out with the same tracked flag, the same Tcw bit for bit and the same match / inlier counts."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "track_device_check")
+
+
+def _build():
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "pointslot_amd", "host"), "-I", os.path.join(ROOT, "include"),
+                           EXE + ".cpp", "-o", EXE, "-L", os.path.join(ROOT, "pointslot_amd"), "-lpointslot_hip", "-pthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "pointslot_amd"), "-Wl,-rpath-link,/opt/rocm/lib"])
+
+
+def test_track_device_check_compiles():
+    _build()
+    out = subprocess.run([EXE], capture_output=True, text=True)
+    assert out.returncode == 1 and "Usage" in out.stderr
+
+
+@pytest.mark.gpu
+def test_device_tracker_equals_host_driven_chain(tmp_path):
+    from pointslot_amd import sequence
+    if not os.path.exists(EXE):
+        _build()
+    dirs = []
+    # five sequences with different speeds; the last one is nearly textureless for two frames in the middle (loses track)
+    for k in range(5):
+        seq = sequence.generate(n_frames=7, seed=70 + k, step=0.04 + 0.03 * k)
+        if k == 4:
+            seq["left"][3:5] = 128; seq["right"][3:5] = 128
+        d = str(tmp_path / ("%04d" % k))
+        sequence.write_pgm(d, seq)
+        dirs.append(d)
+    out = subprocess.run([EXE] + dirs, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["sequences"] == 5 and r["frames"] == 7
+    assert r["tracked"] >= 5 * 7 - 6, r
+    assert r["tracked_flag_differs"] == 0 and r["state_differs"] == 0 and r["counts_differ"] == 0, (r, out.stderr[-1000:])
+    assert r["pose_bits_differ"] == 0 and r["max_abs_pose_diff"] == 0.0, r
+
+
+@pytest.mark.gpu
+def test_device_tracker_images_in_hbm_and_reset():
+    """ps_tracker_step_device (images already in HBM, as bench.py feeds it) gives what ps_tracker_step (host images) gives, the
+    trajectory is the generated one, and a reset handle repeats itself."""
+    import torch
+    from pointslot_amd import sequence
+    from pointslot_amd.tracker_device import LockstepTracker
+    S, n = 3, 6
+    seqs = [sequence.generate(n_frames=n, seed=80 + k, step=0.05 + 0.02 * k) for k in range(S)]
+    h, w = seqs[0]["left"][0].shape
+    trk = LockstepTracker(S, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n)
+    for i in range(n):
+        trk.step([np.ascontiguousarray(q["left"][i]) for q in seqs], [np.ascontiguousarray(q["right"][i]) for q in seqs])
+    tcw_a, st_a = trk.fetch()
+    assert st_a["tracked"].all() and (st_a["state"] == 1).all()
+    assert (st_a["mm_matches"][1:] >= 20).all() and (st_a["lm_inliers"][1:] >= 30).all()
+    # ground truth: pure translation along +x
+    for k in range(S):
+        twc = np.array([-(tcw_a[i, k, :3, :3].T @ tcw_a[i, k, :3, 3]) for i in range(n)])
+        assert np.abs(twc - seqs[k]["twc"][:, :, 3]).max() < 0.03
+    trk.reset()
+    imgs = np.stack([np.stack([q["left"][i], q["right"][i]]) for i in range(n) for q in seqs]).reshape(n, S, 2, h, w)
+    d = torch.from_numpy(imgs).cuda()
+    for i in range(n):
+        trk.step_device(d[i].data_ptr())
+    tcw_b, st_b = trk.fetch()
+    assert np.array_equal(tcw_a.view(np.uint32), tcw_b.view(np.uint32))
+    assert np.array_equal(st_a.view(np.int32), st_b.view(np.int32))
+    trk.close()
