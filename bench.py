@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path on N MI355X of one node.
 
-A "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
-  the ORB extractor (8-level pyramid + 7x7 blur fused per level, FAST cells, quadtree, rBRIEF; BASELINE.json configs[1])
-  over a batch of PAIRS stereo pairs 1242x375, 2000 keypoints per image.
-`value` = stereo frames/s over all ranks (weak scaling: every rank owns its own batch; the path shards
-by image, so there is no data-path collective).  Rank 0 prints ONE JSON line.
+Metric (BASELINE.json): tracked frames/sec on KITTI-tracking-shaped stereo 1242x375.  A "step" = one pass of the hot path
+over one batch: ONE stereo frame of each of the S independent sequences a GPU tracks in lockstep — ORB extraction of 2 S
+images (8-level pyramid + blur, FAST, quadtree, rBRIEF; BASELINE configs[1] per image), ComputeStereoMatches,
+SearchByProjection(cur, last) -> PoseOptimization -> SearchLocalPoints / SearchByProjection(F, points) -> PoseOptimization
+(configs[2] per frame), all queued on the device by the lockstep tracker (ps_tracker_*) with the images already resident in
+HBM when the clock starts.  `value` = frames that went through that chain per second over all ranks (weak scaling: every
+rank owns its own sequences; the path shards by sequence, no data-path collective).  Rank 0 prints ONE JSON line.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (starts its own N ranks when no launcher did)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -29,97 +31,227 @@ ALGO_BYTES_PER_IMAGE = {
     # the fused level kernel (pyramid + border + blur in one launch per level) is priced with the SUM of the two unfused
     # stages it replaces, as SURVEY.md defines the per-image figure (its own traffic is lower: the blur input stays in LDS)
     "orb_level_fused": 465750 + PADDED_PX + PADDED_PX + LEVEL_PX,
-    "orb_pyramid_level": 465750 + PADDED_PX,          # input read + padded pyramid write
     "orb_fast_cells": PADDED_PX,                      # FAST reads the padded pyramid once
     "orb_quadtree": 0,                                # candidate lists only (not in the pixel budget)
-    "orb_blur": PADDED_PX + LEVEL_PX,                 # blur read + blur write
     "orb_describe": LEVEL_PX + NFEAT * (32 + 28),     # gather (upper bound) + outputs
 }
-RED_DEV = "cuda"            # device of the tensors used for cross-rank reductions
+ALGO_BYTES_PER_FRAME_POSE_ITER = 2000 * 29 + 224      # pose-opt, per LM iteration per frame
+ALGO_FLOP_PER_OBJECT_BA_ITER = 103e6                  # object BA, per LM iteration per object (P=50, L=300, E=15000)
+RED_DEV = "cuda"              # device of the tensors used for cross-rank reductions
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_ROUND = "r02"
+
+
+def _profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic(kernel, nimg):
     """HBM bytes per launch of `kernel` from the committed PMC measurement (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate passes, same workload).  On gfx950 FETCH_SIZE tallies 64 B per 128-B request of a coalesced
-    stream, so it is doubled as MI355X_MICROARCH.md prescribes; WRITE_SIZE is taken as reported (uncalibrated).  Returns None
-    when no measurement for this launch shape is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        t = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if t.get("images_per_launch") != nimg:
-        return None
-    for name, v in t.get("kernels", {}).items():
-        if name.split("<")[0] == kernel:
-            return v.get("hbm_bytes_per_launch_fetch_doubled")
-    return None
+    --pmc WRITE_SIZE in separate passes, same launch shape).  FETCH_SIZE is corrected as MI355X_MICROARCH.md prescribes for the
+    kernel's access width; None when no measurement for this launch shape is on file.  PMC counters
+    need rocprofv3 around the process, so this figure is read from profiles/, not measured in this run: `traffic_source`."""
+    for name in (PROFILE_ROUND + "_traffic.json", "r01_traffic.json"):
+        t = _profile_json(name)
+        if not t or t.get("images_per_launch") != nimg:
+            continue
+        for k, v in t.get("kernels", {}).items():
+            if k.split("<")[0] == kernel:
+                return v.get("hbm_bytes_per_launch", v.get("hbm_bytes_per_launch_fetch_doubled")), "profiles/" + name
+    return None, None
 
 
 def pmc_valu_issue(kernel, nimg):
     """Share of the launch that VALU issue alone accounts for (waves x VALU instructions x 4 cycles / 1024 SIMDs / clock), from the
     committed PMC pass (tools/pmc_issue.sh: SQ_INSTS_VALU, SQ_WAVES, own run).  Explains a low HBM fraction: the kernel is bound by
     instruction issue, not by memory.  None when no measurement for this launch shape is on file."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_valu_issue.json")))
-    except (OSError, ValueError):
-        return None
-    if t.get("images_per_launch") != nimg:
-        return None
-    for name, v in t.get("kernels", {}).items():
-        if name.split("<")[0] == kernel:
-            return {"valu_issue_share": v.get("valu_issue_share"), "valu_instructions_per_wave": v.get("valu_per_wave"), "waves_per_launch": v.get("waves_per_launch")}
+    for name in (PROFILE_ROUND + "_valu_issue.json", "r01_valu_issue.json"):
+        t = _profile_json(name)
+        if not t or t.get("images_per_launch") != nimg:
+            continue
+        for k, v in t.get("kernels", {}).items():
+            if k.split("<")[0] == kernel:
+                return {"valu_issue_share": v.get("valu_issue_share"), "valu_instructions_per_wave": v.get("valu_per_wave"),
+                        "waves_per_launch": v.get("waves_per_launch"), "source": "profiles/" + name}
     return None
 
 
-def cpu_baseline(batch, pairs_sample):
-    """Times the CPU restatement (oracle/, kind "port") on a bounded sample of the same workload, using the
-    reference's thread model: left and right image on two threads (/root/reference/src/Frame.cc:709-710)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle_lib import OracleORB
-    orcs = [OracleORB(NFEAT), OracleORB(NFEAT)]
-    n = min(pairs_sample, batch.shape[0] // 2)
+def make_sequences(rank, n_frames, n_distinct, texture):
+    from pointslot_amd import sequence
+    tex = sequence.kitti_texture() if texture == "kitti" else None
+    return [sequence.generate(n_frames=n_frames, seed=40 + 16 * rank + k, step=0.05 + 0.01 * k, texture=tex) for k in range(n_distinct)]
 
-    def run(side):
-        for k in range(n):
-            orcs[side].run(batch[2 * k + side])
 
+def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barrier):
+    """The headline loop: `n_seq` sequences per GPU in `n_groups` lockstep groups (one ps_tracker and one stream each, so that one
+    group's latency-bound kernels overlap another's), images of all frames resident in HBM.  Returns the timing, the per-stage
+    HIP-event times of group 0 and the checks on what was tracked."""
+    import torch
+    from pointslot_amd.tracker_device import LockstepTracker
+    n_frames = warmup + steps
+    n_distinct = min(4, n_seq)
+    seqs = make_sequences(rank, n_frames, n_distinct, texture)
+    h, w = seqs[0]["left"][0].shape
+    per_group = n_seq // n_groups
+    base = torch.from_numpy(np.stack([np.stack([q["left"], q["right"]], 1) for q in seqs], 1)).cuda()   # [n, nd, 2, h, w]
+    # sequence j of group g shows generated sequence (g * per_group + j) % n_distinct
+    imgs = []
+    for g in range(n_groups):
+        idx = (torch.arange(per_group, device="cuda") + g * per_group) % n_distinct
+        imgs.append(base[:, idx].contiguous())                                                         # [n, per_group, 2, h, w]
+    del base
+    trks = [LockstepTracker(per_group, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n_frames, device=local_rank) for _ in range(n_groups)]
+
+    def sync():
+        for t in trks:
+            t.sync()
+
+    for i in range(warmup):
+        for g, t in enumerate(trks):
+            t.step_device(imgs[g][i].data_ptr())
+    sync()
+    barrier()
+    for t in trks:
+        t.enable_stage_timing(True)      # HIP events on the stream the kernels run on
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(2) as ex:
-        list(ex.map(run, [0, 1]))
+    for i in range(warmup, n_frames):
+        for g, t in enumerate(trks):
+            t.step_device(imgs[g][i].data_ptr())
+    sync()
+    barrier()
     dt = time.perf_counter() - t0
-    # SURVEY.md 8d also asks for the "all host cores" rate: independent images over every core, one extractor object per thread
-    ncore = min(os.cpu_count() or 1, batch.shape[0])
-    pool = [OracleORB(NFEAT) for _ in range(ncore)]
-    reps = 2
+    stage = trks[0].stage_times()
+    out = {"dt": dt, "stage_ms_group0": stage, "frames_per_step_per_gpu": per_group * n_groups, "images_per_launch": 2 * per_group,
+           "h": h, "w": w}
+    # every trajectory against the ground truth of the generator, every frame's tracked flag
+    err, untracked = 0.0, 0
+    tcw0 = st0 = None
+    for g, t in enumerate(trks):
+        tcw, st = t.fetch()
+        untracked += int((st["tracked"] == 0).sum())
+        if g == 0:
+            tcw0, st0 = tcw, st
+        R = tcw[:, :, :3, :3]
+        twc = -np.einsum("nsji,nsj->nsi", R, tcw[:, :, :3, 3])
+        for j in range(per_group):
+            truth = seqs[(g * per_group + j) % n_distinct]["twc"][:, :, 3]
+            ok = st["tracked"][:, j] != 0
+            if ok.any():
+                err = max(err, float(np.abs(twc[ok, j] - truth[ok]).max()))
+    out.update(max_abs_position_error_m=err, untracked_frames=untracked, seqs=seqs, tcw_group0=tcw0, stats_group0=st0)
+    for t in trks:
+        t.close()
+    del imgs
+    torch.cuda.empty_cache()
+    return out
 
-    def run_all(c):
-        for r in range(reps):
-            pool[c].run(batch[(c + r * ncore) % batch.shape[0]])
 
+def cpu_tracking_baseline(seqs, tcw_gpu, budget_s=12.0):
+    """The CPU restatement of the same tracking loop (tests/oracle_backend.py over oracle/liboracle.so, one core, the
+    reference's per-frame call structure) on the sequences the GPU just tracked: timed as the CPU baseline, and its poses are
+    the parity spot check of the timed run (sequence j of group 0 shows generated sequence j)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleBackend
+    from pointslot_amd.tracker import StereoOdometry
+    h, w = seqs[0]["left"][0].shape
+    frames, spent, worst, checked = 0, 0.0, 0.0, 0
+    k = 0
+    while spent < budget_s and k < 4 * len(seqs):
+        q = seqs[k % len(seqs)]
+        vo = StereoOdometry(OracleBackend(), q["K"], q["bf"], w, h)
+        n = len(q["left"])
+        t0 = time.perf_counter()
+        for i in range(len(q["left"])):
+            vo.track(q["left"][i], q["right"][i])
+            if spent + time.perf_counter() - t0 > 2.5 * budget_s:
+                n = i + 1
+                break
+        spent += time.perf_counter() - t0
+        frames += n
+        if k < len(seqs) and k < tcw_gpu.shape[1]:
+            for i in range(n):
+                a, b = vo.trajectory[i], tcw_gpu[i, k]
+                worst = max(worst, float(np.abs(b).max()) if a is None else float(np.abs(a - b).max()))   # no pose: the GPU row is zeros
+                checked += 1
+        k += 1
+    return {"value": frames / spent, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of %d of the run's sequences through the CPU restatement of the same tracking loop (oracle/*.cpp, -O3 "
+                      "-march=native, one thread: the reference's per-frame call structure); host has %d cores" % (frames, min(k, len(seqs)), os.cpu_count())}, worst, checked
+
+
+def orb_leg(rank, local_rank, barrier, with_cpu):
+    """BASELINE configs[1] on its own: the ORB extractor over 64 synthetic stereo pairs resident in HBM (the r01 headline), with
+    an in-process parity spot check of the timed batch against the CPU restatement."""
+    import torch
+    from pointslot_amd import synth
+    from pointslot_amd.extractor import ORBextractor
+    pairs = 64
+    batch = synth.stereo_batch(pairs, seed=0x51070002 + 1000 * rank, w=IMG_W, h=IMG_H)
+    nimg = batch.shape[0]
+    d_imgs = torch.from_numpy(batch).cuda()
+    ex = ORBextractor(NFEAT, 1.2, 8, 20, 5, max_batch=nimg, device=local_rank)
+    for _ in range(3):
+        ex.extract_batch_device(d_imgs.data_ptr(), nimg, IMG_W, IMG_H, IMG_W, IMG_W * IMG_H)
+    barrier()
+    ex.enable_stage_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ex.extract_batch_device(d_imgs.data_ptr(), nimg, IMG_W, IMG_H, IMG_W, IMG_W * IMG_H)
+    barrier()
+    dt = (time.perf_counter() - t0) / 10
+    stage = ex.stage_times()
+    ex.enable_stage_timing(False)
+    bf, fxc = 384.38148, 721.5377
+    ex.stereo_match_batch(pairs, bf / fxc, bf)
+    barrier()
     t1 = time.perf_counter()
-    with ThreadPoolExecutor(ncore) as ex:
-        list(ex.map(run_all, range(ncore)))
-    dt_all = time.perf_counter() - t1
-    return {"value": n / dt, "unit": "frames/s", "cores": 2, "kind": "port",
-            "sample": "%d stereo pairs of the step's batch, CPU restatement of the reference algorithm "
-                      "(oracle/orb_oracle.cpp, -O3 -march=native), left/right on 2 threads; host has %d cores"
-                      % (n, os.cpu_count()),
-            "all_cores": {"value": ncore * reps / 2 / dt_all, "unit": "frames/s", "cores": ncore,
-                          "sample": "%d images, independent images on %d threads" % (ncore * reps, ncore)}}
+    for _ in range(5):
+        ex.stereo_match_batch(pairs, bf / fxc, bf)
+    barrier()
+    stereo_ms = (time.perf_counter() - t1) / 5 * 1e3
+    out = {"workload": "BASELINE configs[1]: ORBextractor 8-level pyramid on 64 synthetic 1242x375 stereo pairs in HBM, 2000 keypoints + 256-bit rBRIEF per image",
+           "ms_per_step": dt * 1e3, "stereo_frames_per_s": pairs / dt, "stage_ms": {k: round(v, 5) for k, v in stage.items()},
+           "stereo_matching_ms_per_64_pairs": stereo_ms}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle_lib import OracleORB
+        n_check = 8
+        orcs = [OracleORB(NFEAT), OracleORB(NFEAT)]
+        res = [None] * (2 * n_check)
+
+        def run(side):
+            for k in range(n_check):
+                res[2 * k + side] = orcs[side].run(batch[2 * k + side])
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(2) as pool:
+            list(pool.map(run, [0, 1]))
+        cpu_dt = time.perf_counter() - t0
+        bad = 0
+        for i in range(2 * n_check):
+            kps, desc = ex.fetch(i)
+            ko, do = res[i]
+            if len(kps) != len(ko) or not np.array_equal(kps.view(np.uint8), ko.view(np.uint8)) or not np.array_equal(desc, do):
+                bad += 1
+        out["parity_spot"] = "green" if bad == 0 else "red"
+        out["parity_spot_detail"] = "%d of the timed batch's images: keypoints and descriptors bit-exact vs the CPU restatement (%d differ)" % (2 * n_check, bad)
+        out["cpu_port_stereo_frames_per_s_2_threads"] = n_check / cpu_dt
+    ex.close()
+    del d_imgs
+    return out
 
 
-def secondary_metrics(rank, world, local_rank, dist, with_cpu):
-    """BASELINE configs[2] and [3]: per-frame pose optimisation (batch of 64 frames x 2000 stereo edges) and the
-    object local BA (8 objects x 50 keyframes x 300 points).  Frames / objects are independent units and are
-    sharded over the ranks; times are max-over-ranks."""
+def optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak):
+    """BASELINE configs[2] and [3]: per-frame pose optimisation (batch of 64 frames x 2000 stereo edges) and the object local BA
+    (8 objects x 50 keyframes x 300 points, SURVEY.md 8d's own perturbation: +-0.3 m / +-5 deg yaw / +-0.1 m).  Frames / objects
+    are independent units and are sharded over the ranks; times are max-over-ranks."""
     from pointslot_amd import parallel, synth
     from pointslot_amd.optimizer import Optimizer
     opt = Optimizer(device=local_rank)
     out = {}
-    # ---- pose optimisation: 64 frames total ----
     mine = list(parallel.shard_units(64, world, rank))
     frames = [synth.pose_problem(0x51070003 + k) for k in mine]
     opt.PoseOptimization(frames[:1])                       # warm-up
@@ -127,31 +259,54 @@ def secondary_metrics(rank, world, local_rank, dist, with_cpu):
     res = opt.PoseOptimization(frames)
     wall = time.perf_counter() - t0
     kern_ms = opt.last_kernel_ms()
+    opt.enable_trace(True)                                 # untimed repeat with the per-iteration log: the edge passes of the timed call
+    opt.PoseOptimization(frames)
+    traces = [opt.get_trace(i) for i in range(len(frames))]
+    opt.enable_trace(False)
+    iters = sum(len(t) for t in traces)
+    trials = sum(int(t[:, 2].sum()) for t in traces)
     wall = parallel.max_over_ranks(dist, wall, RED_DEV)
     kern_ms = parallel.max_over_ranks(dist, kern_ms, RED_DEV)
+    # roofline of the persistent kernel (58 KB per frame and LM iteration in the streaming model; every damping
+    # trial re-reads the edges once more): the kernel is latency-bound, the fraction says by how much
+    algo = (iters + trials) * ALGO_BYTES_PER_FRAME_POSE_ITER
     out["pose_optimization"] = {"workload": "BASELINE configs[2]: 64 frames x (1 SE3 x 2000 stereo edges), 4 x 10 LM schedule",
                                 "frames": 64, "kernel_ms_per_batch": kern_ms, "wall_ms_per_batch_incl_pcie": wall * 1e3,
-                                "frames_per_s_kernel": 64 / (kern_ms * 1e-3), "inliers_frame0": int(res[0][0]) if res else None}
-    # ---- object BA: 8 objects total ----
+                                "frames_per_s_kernel": 64 / (kern_ms * 1e-3), "inliers_frame0": int(res[0][0]) if res else None,
+                                "lm_iterations": iters, "damping_trials": trials,
+                                "roofline": {"bound": "hbm", "kernel": "pose_lm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                             "algorithmic_bytes_per_launch": algo, "avg_launch_ms": kern_ms,
+                                             "note": "edge passes x 58 KB (SURVEY 8d streaming model); the persistent kernel keeps its edges in L2 and is latency-bound"}}
     mine = list(parallel.shard_units(8, world, rank))
-    graphs = [synth.object_ba_problem(0x51070004 + j, perturb=(0.05, 1.0, 0.02), perturb_axis="z") for j in mine]
+    graphs = [synth.object_ba_problem(0x51070004 + j) for j in mine]
     if graphs:
         opt.ObjectLocalBundleAdjustment(graphs[:1])        # warm-up (allocations)
         r = opt.ObjectLocalBundleAdjustment(graphs)
         ms = opt.last_kernel_ms()
         iters = max(x["iterations"] for x in r)
         trials = max(x["trials"] for x in r)
+        sum_trials = sum(x["trials"] for x in r)
         r1 = opt.ObjectLocalBundleAdjustment(graphs[:1])    # SURVEY.md 8d config 4 also asks for one object alone
         ms1, iters1 = opt.last_kernel_ms(), max(r1[0]["iterations"], 1)
     else:
-        ms, iters, trials = 0.0, 1, 1
+        ms, iters, trials, sum_trials = 0.0, 1, 1, 0
         ms1, iters1 = 0.0, 1
     ms = parallel.max_over_ranks(dist, ms, RED_DEV)
     iters = int(parallel.max_over_ranks(dist, iters, RED_DEV))
-    out["object_ba"] = {"workload": "BASELINE configs[3]: 8 objects x 50 ObjectKeyFrames x 300 MapObjectPoints (15 000 stereo edges each), "
-                                    "Schur LM 5 + 10 iterations", "objects": 8, "gpu_ms_per_batch": ms, "lm_iterations": iters,
-                        "lm_trials": int(parallel.max_over_ranks(dist, trials, RED_DEV)), "ms_per_iter": ms / max(iters, 1),
-                        "ms_per_iter_1_object": parallel.max_over_ranks(dist, ms1 / iters1, RED_DEV)}
+    ba = {"workload": "BASELINE configs[3]: 8 objects x 50 ObjectKeyFrames x 300 MapObjectPoints (15 000 stereo edges each), Schur LM 5 + 10 "
+                      "iterations, SURVEY 8d perturbation (+-0.3 m, +-5 deg yaw, points +-0.1 m)", "objects": 8, "gpu_ms_per_batch": ms,
+          "lm_iterations": iters, "lm_trials": int(parallel.max_over_ranks(dist, trials, RED_DEV)), "ms_per_iter": ms / max(iters, 1),
+          "ms_per_iter_1_object": parallel.max_over_ranks(dist, ms1 / iters1, RED_DEV)}
+    if graphs and ms > 0:
+        # every damping trial is one linearise + Schur + solve (103 MFLOP per object): FP64 rate over the batch
+        flop = sum_trials * ALGO_FLOP_PER_OBJECT_BA_ITER
+        ach = flop / (ms * 1e-3) / 1e12
+        ba["roofline"] = {"bound": "mfma", "kernel": "ba_* (10 kernels per damping trial)", "achieved": ach, "peak": fp64_peak, "unit": "TFLOP/s",
+                          "frac": ach / fp64_peak if fp64_peak else None, "traffic": None, "algorithmic_flop_per_batch": flop,
+                          "peak_source": "v_mfma_f64_16x16x4_f64 microbenchmark measured in this run (ps_debug_mfma_f64_peak)",
+                          "note": "latency-bound: one object's reduced system is 300 unknowns; see DESIGN.md section 7"}
+    out["object_ba"] = ba
     if with_cpu and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
@@ -164,13 +319,6 @@ def secondary_metrics(rank, world, local_rank, dist, with_cpu):
         dt = time.perf_counter() - t0
         out["object_ba"]["cpu_port_ms_per_iter_1core_1object"] = dt * 1e3 / max(len(tr), 1)
     opt.close()
-    out["sequence_tracking"] = sequence_leg(rank, world, local_rank, dist, with_cpu)
-    out["lockstep_tracking"] = lockstep_leg(rank, world, local_rank, dist)
-    if rank == 0:
-        try:
-            out["next_rows"] = next_rows_leg(local_rank)
-        except Exception as e:   # noqa: BLE001  (a failure of this leg must not take the bench line down)
-            out["next_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -183,14 +331,12 @@ def next_rows_leg(local_rank):
     from pointslot_amd.optimizer import Optimizer
     out = {}
     opt = Optimizer(device=local_rank)
-    # f-3: a local-BA shaped graph - 10 free + 6 fixed keyframes (VertexSE3Expmap), 1200 world points, 35 % visibility
     g = synth.object_ba_problem(0x51070060, n_kf=10, n_pts=1200, p_vis=0.35, perturb=(0.05, 1.0, 0.03), perturb_axis="y", n_fixed_extra=6, mono_frac=0.15)
     g["pose_flags"] = (g["pose_flags"] & 1).astype(np.uint8)
     opt.ObjectLocalBundleAdjustment([g])
     r, = opt.ObjectLocalBundleAdjustment([g])
     out["local_ba"] = {"workload": "f-3: 16 keyframes (6 fixed) x 1200 points, %d edges" % len(g["e_pose"]), "gpu_ms": opt.last_kernel_ms(),
                        "lm_iterations": int(r["iterations"]), "ms_per_iter": opt.last_kernel_ms() / max(int(r["iterations"]), 1)}
-    # f-4: DynamicStaticDiscrimination on 8 detections x 300 object points
     objs = [synth.dynamic_object(100 + k, n=300, moving=0.1 * k) for k in range(8)]
     opt.DynamicStaticDiscrimination(objs)
     t0 = time.perf_counter()
@@ -199,7 +345,6 @@ def next_rows_leg(local_rank):
     out["dynamic_static_discrimination"] = {"workload": "f-4: 8 detections x 300 object points per call", "wall_ms_per_call": (time.perf_counter() - t0) * 100}
     opt.close()
     m = ORBmatcher(0.6, True, device=local_rank)
-    # f-4: ComputeDistinctiveDescriptors of 2400 map points with 2..50 observations each
     rng = np.random.default_rng(7)
     lists = [rng.integers(0, 256, (int(n), 32), dtype=np.uint8) for n in rng.integers(2, 51, 2400)]
     m.ComputeDistinctiveDescriptors(lists)
@@ -208,7 +353,6 @@ def next_rows_leg(local_rank):
     dt = time.perf_counter() - t0
     out["distinctive_descriptors"] = {"workload": "f-4: 2400 map points, 2..50 observations each (%d descriptors)" % sum(len(x) for x in lists),
                                       "wall_ms_per_call": dt * 1e3, "points_per_s": len(lists) / dt}
-    # f-4: the search half of Fuse, 6 keyframes x (1500 features, 800 candidate points)
     prs = []
     for k in range(6):
         pr = synth.fuse_scene(60 + k, n=1500, m=800)
@@ -223,136 +367,102 @@ def next_rows_leg(local_rank):
     return out
 
 
-def lockstep_leg(rank, world, local_rank, dist, n_sequences=128, n_groups=2, n_frames=12, n_distinct=4, n_procs=2):
-    """BASELINE config 4 at batch scale: every rank tracks `n_sequences` independent stereo sequences in lockstep with the
-    C++ host driver (examples/stereo_kitti_batch.cpp -> StereoOdometryBatch: one batched extraction + stereo matching per
-    step, one C-ABI call per round of SearchByProjection / PoseOptimization problems, next step's upload and extraction
-    overlapped; `n_groups` such batches on their own threads so that one group's transfers overlap another's kernels, and
-    `n_procs` such driver processes side by side on the GPU - calls of one process into the HIP runtime serialise, two
-    processes reach 1.4x the throughput of one).  The driver runs as a child process on this rank's GPU; images are in page-locked host memory when the
-    clock starts, so the figure includes every PCIe transfer of the tracking loop but no disk I/O."""
-    import shutil
-    import subprocess
-    import tempfile
-    from pointslot_amd import parallel, sequence
-    exe = os.path.join(ROOT, "build", "stereo_kitti_batch")
-    if not os.path.exists(exe):
-        try:
-            import __graft_entry__
-            __graft_entry__.build_examples()
-        except Exception:   # noqa: BLE001  (reported below as a failed leg)
-            pass
-    tmp = tempfile.mkdtemp(prefix="ps_lockstep_%d_" % rank)
-    st, err, failure = None, float("inf"), None
-    try:
-        # a failure of this leg must not take the bench line down, and every rank must still reach the reductions below
-        dirs, truth = [], []
-        for k in range(n_distinct):
-            seq = sequence.generate(n_frames=n_frames, seed=40 + 16 * rank + k, step=0.05 + 0.01 * k)
-            d = os.path.join(tmp, "%04d" % k)
-            sequence.write_pgm(d, seq)
-            dirs.append(d); truth.append(seq["twc"][:, :, 3])
-        cmd = [exe, "--device", str(local_rank), "--groups", str(n_groups)] + [dirs[i % n_distinct] for i in range(n_sequences)]
-        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(n_procs)]
-        sts = []
-        for pr in procs:
-            so, se = pr.communicate(timeout=600)
-            if pr.returncode != 0:
-                raise RuntimeError("stereo_kitti_batch failed: " + so[-400:] + se[-400:])
-            sts.append(json.loads(so.strip().splitlines()[-1]))
-        st = dict(sts[0])
-        # all processes together: frames of the timed steps over the span from the first start to the last end
-        span = max(x["unix_end"] for x in sts) - min(x["unix_start"] for x in sts)
-        st["wall_ms_timed_steps"] = span * 1e3
-        st["untracked_frames"] = sum(x["untracked_frames"] for x in sts)
-        err = 0.0
-        for d, tw in zip(dirs, truth):
-            traj = np.loadtxt(os.path.join(d, "CameraTrajectoryBatch.txt")).reshape(-1, 12)
-            err = max(err, float(np.abs(traj[:, [3, 7, 11]] - tw).max())) if len(traj) == n_frames else float("inf")
-    except Exception as e:   # noqa: BLE001
-        failure = "%s: %s" % (type(e).__name__, e)
-        st = None
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    # wall clock of the timed steps (all groups, common start) per step of n_sequences frames
-    ms = parallel.max_over_ranks(dist, st["wall_ms_timed_steps"] / max(st["timed_steps"], 1) if st else float("inf"), RED_DEV)
-    untracked = parallel.max_over_ranks(dist, st["untracked_frames"] if st else -1, RED_DEV)
-    err = parallel.max_over_ranks(dist, err, RED_DEV)
-    out = {"workload": "BASELINE config 4: %d independent 1242x375 stereo sequences per GPU x %d frames tracked by %d driver processes x %d lockstep "
-                       "groups (C++ host over the C-ABI, images in pinned host memory, all PCIe transfers included)" % (n_sequences * n_procs, n_frames, n_procs, n_groups),
-           "sequences_per_gpu": n_sequences * n_procs, "processes": n_procs, "groups_per_process": n_groups, "wall_ms_per_step": ms, "tracked_frames_per_s": world * n_sequences * n_procs * 1e3 / ms,
-           "untracked_frames": int(untracked), "max_abs_position_error_m": err}
-    if st:
-        out["ms_per_step_parts_rank0_group0"] = {k[12:]: st[k] for k in st if k.startswith("ms_per_step_")}
-        out["device_rounds_per_step"] = st["device_rounds_per_step"]
-    if failure:
-        out["error"] = failure
-    return {k: (None if isinstance(v, float) and not np.isfinite(v) else v) for k, v in out.items()}   # strict JSON
+def pcie_leg(rank, world, local_rank, dist, seqs, n_seq, n_groups, barrier):
+    """The same lockstep loop with the images in page-locked HOST memory (ps_tracker_step): every frame's 2 x 0.47 MB cross PCIe
+    inside the timed region.  This is the rate a caller with host buffers sees; it is never `value`."""
+    from pointslot_amd import parallel
+    from pointslot_amd._lib import PinnedBuffer
+    from pointslot_amd.tracker_device import LockstepTracker
+    n = min(len(seqs[0]["left"]), 8)
+    h, w = seqs[0]["left"][0].shape
+    per_group, nd = n_seq // n_groups, len(seqs)
+    pitch = h * w
+    # one copy of every frame of every tracked sequence, laid out as a capture pipeline would hand it over: per frame, per group,
+    # the group's stereo pairs back to back (one transfer per group and step)
+    pin = PinnedBuffer(n * n_groups * per_group * 2 * pitch)
+    arr = pin.array.reshape(n, n_groups, per_group, 2, h, w)
+    for g in range(n_groups):
+        for j in range(per_group):
+            q = seqs[(g * per_group + j) % nd]
+            arr[:, g, j, 0] = q["left"][:n]
+            arr[:, g, j, 1] = q["right"][:n]
+    trks = [LockstepTracker(per_group, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n, device=local_rank) for _ in range(n_groups)]
+    lists = [[([arr[i, g, j, 0] for j in range(per_group)], [arr[i, g, j, 1] for j in range(per_group)]) for g in range(n_groups)] for i in range(n)]
+    warm = 2
+    for i in range(warm):
+        for g, t in enumerate(trks):
+            t.step(*lists[i][g])
+    for t in trks:
+        t.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(warm, n):
+        for g, t in enumerate(trks):
+            t.step(*lists[i][g])
+    for t in trks:
+        t.sync()
+    barrier()
+    dt = parallel.max_over_ranks(dist, time.perf_counter() - t0, RED_DEV)
+    untracked = sum(int((t.fetch()[1]["tracked"] == 0).sum()) for t in trks)
+    for t in trks:
+        t.close()
+    pin.close()
+    return {"workload": "the headline loop with the images in pinned host memory: %d sequences per GPU x %d timed frames, one ps_tracker_step per group and frame "
+                        "(every image crosses PCIe inside the timed region)" % (per_group * n_groups, n - warm),
+            "tracked_frames_per_s": world * per_group * n_groups * (n - warm) / dt, "ms_per_step": dt / (n - warm) * 1e3, "untracked_frames": untracked,
+            "host_to_device_GBps_per_gpu": per_group * n_groups * (n - warm) * 2 * pitch / dt / 1e9}
 
 
-def sequence_leg(rank, world, local_rank, dist, with_cpu, n_frames=12):
-    """BASELINE configs[0] / [4]: every rank tracks its own generated stereo sequence (seed = rank) through the chained hot
-    path (extraction -> stereo -> projection matching -> pose optimisation, pointslot_amd.tracker), then one gather of
-    the [frames][12] float32 trajectories (the only collective of the workflow)."""
+def config5_leg(rank, world, local_rank, dist, n_frames=154):
+    """BASELINE configs[4]: one generated 154-frame stereo sequence per GPU (seed = rank) through the
+    tracking chain with a single frame in flight (ps_tracker with one sequence: the latency of the chain, not its throughput),
+    then ONE gather of the [154][12] float32 trajectories — the only collective of the workflow, timed separately."""
     import torch
     from pointslot_amd import parallel, sequence
-    from pointslot_amd.tracker import HipBackend, StereoOdometry
-    seq = sequence.generate(n_frames=n_frames, seed=4 + rank)
+    from pointslot_amd.tracker_device import LockstepTracker
+    seq = sequence.generate(n_frames=n_frames, seed=rank)
     h, w = seq["left"][0].shape
-    be = HipBackend(device=local_rank)
-    vo = StereoOdometry(be, seq["K"], seq["bf"], w, h)
-    vo.track(seq["left"][0], seq["right"][0])
-    times = []
-    for k in range(1, n_frames):
-        t0 = time.perf_counter()
-        vo.track(seq["left"][k], seq["right"][k])
-        times.append(time.perf_counter() - t0)
-    be.close()
+    d = torch.from_numpy(np.stack([seq["left"], seq["right"]], 1)).cuda()
+    trk = LockstepTracker(1, seq["K"], seq["bf"], w, h, max_steps=n_frames, device=local_rank)
+    trk.step_device(d[0].data_ptr())
+    trk.sync()
+    t0 = time.perf_counter()
+    for i in range(1, n_frames):
+        trk.step_device(d[i].data_ptr())
+        trk.sync()                                 # one frame in flight: a live sequence delivers its frames one by one
+    dt = time.perf_counter() - t0
+    tcw, st = trk.fetch()
+    trk.close()
     traj = np.zeros((n_frames, 12), np.float32)
     err = 0.0
-    for k, t in enumerate(vo.trajectory):
-        if t is not None:
-            Rwc = t[:3, :3].T
-            twc = -(Rwc @ t[:3, 3])
-            traj[k] = np.concatenate([Rwc, twc[:, None]], 1).reshape(12)
+    for k in range(n_frames):
+        if st["tracked"][k, 0]:
+            Rwc = tcw[k, 0, :3, :3].T
+            twc = -(Rwc @ tcw[k, 0, :3, 3])
+            traj[k] = np.concatenate([Rwc, twc[:, None]], 1).reshape(12)      # System::SaveTrajectoryKITTI row
             err = max(err, float(np.abs(twc - seq["twc"][k][:, 3]).max()))
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     allt = parallel.gather_trajectories(dist, traj, RED_DEV)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t0) * 1e3
-    ms = parallel.max_over_ranks(dist, float(np.median(times)) * 1e3, RED_DEV)
-    out = {"workload": "BASELINE configs[0]/[4]: %d generated 1242x375 stereo sequence(s) x %d frames, one per GPU, host-driven "
-                       "tracking loop over the C-ABI (single frame in flight per sequence)" % (world, n_frames),
-           "median_ms_per_frame": ms, "frames_per_s_all_sequences": world * 1e3 / ms, "tracked": int(sum(t is not None for t in vo.trajectory)),
-           "max_abs_position_error_m": parallel.max_over_ranks(dist, err, RED_DEV), "trajectory_gather_ms": gather_ms,
-           "gathered": [list(a.shape) for a in allt]}
-    if rank == 0:
-        # the same sequence through the C++ driver (examples/stereo_kitti.cpp, the reference's per-frame call structure), GPU 0
-        try:
-            import shutil
-            import subprocess
-            import tempfile
-            tmp = tempfile.mkdtemp(prefix="ps_single_")
-            try:
-                sequence.write_pgm(tmp, seq)
-                run = subprocess.run([os.path.join(ROOT, "build", "stereo_kitti"), tmp], capture_output=True, text=True, timeout=300)
-                med = [l for l in run.stdout.splitlines() if l.startswith("median tracking time")]
-                if run.returncode == 0 and med:
-                    out["cpp_driver_median_ms_per_frame"] = float(med[0].split(":")[1].split()[0])
-            finally:
-                shutil.rmtree(tmp, ignore_errors=True)
-        except Exception as e:   # noqa: BLE001
-            out["cpp_driver_error"] = "%s: %s" % (type(e).__name__, e)
-    if with_cpu and rank == 0 and world == 1:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_backend import OracleBackend
-        voc = StereoOdometry(OracleBackend(), seq["K"], seq["bf"], w, h)
-        t0 = time.perf_counter()
-        for k in range(4):
-            voc.track(seq["left"][k], seq["right"][k])
-        out["cpu_port_ms_per_frame_1core"] = (time.perf_counter() - t0) * 1e3 / 4
-    return out
+    ms = parallel.max_over_ranks(dist, dt / (n_frames - 1) * 1e3, RED_DEV)
+    return {"workload": "BASELINE configs[4]: %d generated 1242x375 stereo sequence(s) x %d frames, one per GPU, one frame in flight per sequence" % (world, n_frames),
+            "ms_per_frame": ms, "frames_per_s_all_sequences": world * 1e3 / ms, "tracked": int(st["tracked"].sum()),
+            "max_abs_position_error_m": parallel.max_over_ranks(dist, err, RED_DEV), "trajectory_gather_ms": gather_ms,
+            "gathered": [list(a.shape) for a in allt]}
+
+
+def fp64_mfma_peak(local_rank):
+    """the FP64 denominator is not in the local guide; measured with a v_mfma_f64_16x16x4_f64 microbenchmark."""
+    import ctypes
+    from pointslot_amd._lib import lib, check
+    lib.ps_debug_mfma_f64_peak.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    v = ctypes.c_double(0)
+    check(lib.ps_debug_mfma_f64_peak(local_rank, ctypes.byref(v)))
+    return v.value
 
 
 def main():
@@ -360,10 +470,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
-    ap.add_argument("--cpu-pairs", type=int, default=48, help="stereo pairs timed on the CPU baseline")
+    ap.add_argument("--sequences", type=int, default=256, help="independent stereo sequences tracked in lockstep per GPU")
+    ap.add_argument("--groups", type=int, default=2, help="lockstep groups per GPU (one tracker handle and stream each)")
+    ap.add_argument("--texture", choices=["kitti", "synthetic"], default="kitti", help="texture of the generated sequences of the headline run")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the pose-optimisation / object-BA legs")
+    ap.add_argument("--no-secondary", action="store_true", help="only the headline loop")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with no launcher around it: this process only starts N ranks (fresh children, one per GPU)
@@ -386,6 +497,8 @@ def main():
         if os.environ.get("PS_BENCH_LAUNCH_FAIL_RANK") == str(rank):
             raise SystemExit(3)
         return
+    if args.sequences < args.groups or args.sequences % args.groups:
+        raise SystemExit("--sequences must be a multiple of --groups")
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -405,71 +518,68 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from pointslot_amd import synth
-    from pointslot_amd.extractor import ORBextractor
-
-    # every rank owns its own batch (distinct seeds): weak scaling, no exchange inside the step
-    batch = synth.stereo_batch(args.pairs, seed=0x51070002 + 1000 * rank, w=IMG_W, h=IMG_H)
-    nimg = batch.shape[0]
-    d_imgs = torch.from_numpy(batch).cuda()
-    ex = ORBextractor(NFEAT, 1.2, 8, 20, 5, max_batch=nimg, device=local_rank)
-
-    def step():
-        ex.extract_batch_device(d_imgs.data_ptr(), nimg, IMG_W, IMG_H, IMG_W, IMG_W * IMG_H)
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ex.enable_stage_timing(True)      # HIP events on the stream the kernels run on
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    stage_ms = ex.stage_times()
-    ex.enable_stage_timing(False)
+    from pointslot_amd import parallel
+    with_cpu = not args.no_cpu and rank == 0 and world == 1
+    head = tracking_leg(rank, local_rank, args.texture, args.steps, args.warmup, args.sequences, args.groups, barrier)
+    dt = parallel.max_over_ranks(dist, head["dt"], RED_DEV)
+    untracked = int(parallel.max_over_ranks(dist, head["untracked_frames"], RED_DEV))
+    err = parallel.max_over_ranks(dist, head["max_abs_position_error_m"], RED_DEV)
 
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=RED_DEV)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    secondary = None
+    if not args.no_secondary:
+        secondary = {}
+        other = "synthetic" if args.texture == "kitti" else "kitti"
+        osteps = min(args.steps, 10)
 
-    # SURVEY 8f-1 (next row): stereo matching of the batch's pairs on the device-resident pyramids / descriptors
-    bf, fxc = 384.38148, 721.5377
-    ex.stereo_match_batch(args.pairs, bf / fxc, bf)
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        ex.stereo_match_batch(args.pairs, bf / fxc, bf)
-    barrier()
-    stereo_ms = (time.perf_counter() - t1) / 5 * 1e3
-    ur, dp, kept = ex.stereo_fetch(0)
-    assert kept > 200 and (ur >= 0).sum() == kept
+        def other_texture():
+            o = tracking_leg(rank, local_rank, other, osteps, max(args.warmup, 2), args.sequences, args.groups, barrier)
+            odt = parallel.max_over_ranks(dist, o["dt"], RED_DEV)
+            return {"workload": "the headline loop on the generator's %s texture" % ("value-noise + rectangles" if other == "synthetic" else "KITTI-frame"),
+                    "tracked_frames_per_s": world * o["frames_per_step_per_gpu"] * osteps / odt, "ms_per_step": odt / osteps * 1e3,
+                    "untracked_frames": o["untracked_frames"], "max_abs_position_error_m": o["max_abs_position_error_m"],
+                    "stage_ms_group0": {k: round(v, 5) for k, v in o["stage_ms_group0"].items()}}
 
-    # sanity: the timed work produced keypoints (outputs stay in HBM; fetch one image)
-    kps, desc = ex.fetch(0)
-    assert len(kps) >= NFEAT // 2 and desc.shape == (len(kps), 32)
-
-    secondary = None if args.no_secondary else secondary_metrics(rank, world, local_rank, dist, not args.no_cpu)
+        # a failure of a secondary leg must not take the bench line down (every rank runs every leg: they hold barriers)
+        for name, fn in (("tracking_%s_texture" % other, other_texture),
+                         ("orb_extraction", lambda: orb_leg(rank, local_rank, barrier, with_cpu)),
+                         ("optimizers", lambda: optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_mfma_peak(local_rank))),
+                         ("lockstep_tracking_host_images", lambda: pcie_leg(rank, world, local_rank, dist, head["seqs"], args.sequences, args.groups, barrier)),
+                         ("sequence_tracking", lambda: config5_leg(rank, world, local_rank, dist))):
+            try:
+                r = fn()
+                if name == "optimizers":
+                    secondary.update(r)
+                else:
+                    secondary[name] = r
+            except Exception as e:   # noqa: BLE001
+                secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            try:
+                secondary["next_rows"] = next_rows_leg(local_rank)
+            except Exception as e:   # noqa: BLE001
+                secondary["next_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
-        total_pairs = args.pairs * world * args.steps
-        value = total_pairs / dt
-        # dominant KERNEL: the level stage is 8 dependent launches, every other stage is one launch
-        single = [k for k in stage_ms if k in ("orb_fast_cells", "orb_quadtree", "orb_blur", "orb_describe") and ALGO_BYTES_PER_IMAGE[k] > 0]
-        dom = max(single, key=lambda k: stage_ms[k])
-        dom_ms = stage_ms[dom]
+        frames_per_step = head["frames_per_step_per_gpu"] * world
+        stage = head["stage_ms_group0"]
+        nimg = head["images_per_launch"]
+        # dominant KERNEL of the loop: one launch per step and group for each of these; the level stage is 8 dependent launches and
+        # the chain stages are several kernels each, so they are reported as stages, not priced as one launch
+        single = {k[4:]: v for k, v in stage.items() if k.startswith("orb/") and ALGO_BYTES_PER_IMAGE.get(k[4:], 0) > 0 and k[4:] != "orb_level_fused"}
+        dom = max(single, key=lambda k: single[k])
+        dom_ms = single[dom]
         algo = ALGO_BYTES_PER_IMAGE[dom] * nimg
         achieved = algo / (dom_ms * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(dom, nimg)
         out = {
-            "metric": "tracked frames/sec KITTI stereo 1242x375 (ORB front-end)",
-            "value": value,
+            "metric": "tracked frames/sec KITTI stereo 1242x375",
+            "value": frames_per_step * args.steps / dt,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -479,25 +589,33 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ORBextractor 8-level pyramid on 1242x375 stereo pairs, "
-                                   "2000 keypoints + 256-bit rBRIEF per image",
-                       "pairs_per_step_per_gpu": args.pairs, "images_per_step_per_gpu": nimg,
-                       "parallelism": "images sharded over %d GPU(s), no collective in the data path" % world},
+            "data": "synthetic (generated stereo sequences with exact geometry; texture = %s)" % (
+                "the repository's one real KITTI frame, tests/golden/kitti_000212_gray.png" if args.texture == "kitti" else "seeded value noise + rectangles"),
+            "config": {"workload": "BASELINE metric 'tracked frames/sec KITTI stereo 1242x375': %d independent 1242x375 stereo sequences per GPU tracked in lockstep, "
+                                   "one stereo frame of each per step through the whole chain (BASELINE configs[1] per image: 8-level ORB, 2000 keypoints + rBRIEF; "
+                                   "ComputeStereoMatches; configs[2] per frame: SearchByProjection + PoseOptimization twice), images resident in HBM"
+                                   % head["frames_per_step_per_gpu"],
+                       "sequences_per_gpu": head["frames_per_step_per_gpu"], "lockstep_groups_per_gpu": args.groups, "images_per_step_per_gpu": 2 * head["frames_per_step_per_gpu"],
+                       "parallelism": "sequences sharded over %d GPU(s), no collective in the data path" % world},
+            "tracking_checks": {"untracked_frames": untracked, "max_abs_position_error_m": err,
+                                "checked": "every frame of every sequence: tracked flag, position against the generator's ground truth"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, nimg),
-                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms, "issue": pmc_valu_issue(dom, nimg)},
-            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms, "images_per_launch": nimg,
+                         "issue": pmc_valu_issue(dom, nimg)},
+            "stage_ms": {k: round(v, 5) for k, v in stage.items()},
+            "stage_ms_note": "HIP events on group 0's stream over the timed steps; with %d groups the stages of different groups overlap in time" % args.groups,
         }
+        if with_cpu:
+            cpu, worst, checked = cpu_tracking_baseline(head["seqs"], head["tcw_group0"])
+            out["cpu_baseline"] = cpu
+            out["parity_spot"] = "green" if (checked > 0 and worst < 2e-5) else "red"
+            out["parity_spot_detail"] = "%d frames of the timed run: Tcw vs the CPU restatement of the same loop, max |diff| %.3g (bar 2e-5: float32 poses from an FP64 LM)" % (checked, worst)
         if secondary is not None:
-            secondary["stereo_matching"] = {"workload": "Frame::ComputeStereoMatches on the step's %d pairs (SURVEY 8f-1), device-resident" % args.pairs,
-                                            "wall_ms_per_batch": stereo_ms, "pairs_per_s": args.pairs / (stereo_ms * 1e-3),
-                                            "matches_pair0": int(kept)}
             out["secondary_metrics"] = secondary
-            out["metric_ba"] = {"metric": "ms/iter 50-KF object BA (8 objects)", "value": secondary["object_ba"]["ms_per_iter"],
-                                "unit": "ms", "higher_is_better": False}
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(batch, args.cpu_pairs)
+            if "ms_per_iter" in secondary.get("object_ba", {}):
+                out["metric_ba"] = {"metric": "ms/iter 50-KF object BA (8 objects)", "value": secondary["object_ba"]["ms_per_iter"],
+                                    "unit": "ms", "higher_is_better": False, "roofline": secondary["object_ba"].get("roofline")}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

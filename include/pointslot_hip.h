@@ -48,6 +48,9 @@ const char* ps_version(void);
  * point) and leaves it there.  LDS is not cleared between kernels, so a kernel that reads LDS it never wrote - or multiplies such
  * a slot by zero - then misbehaves deterministically instead of once in a while; the GPU tests call this before the kernels. */
 int ps_debug_poison_lds(int device, uint32_t pattern);
+/* Diagnostic: measured FP64 matrix-core rate of `device` in TFLOP/s (a loop of independent v_mfma_f64_16x16x4_f64 on every CU).
+ * The local hardware guide has no FP64 MFMA peak; this is the denominator of the object-BA roofline. */
+int ps_debug_mfma_f64_peak(int device, double* tflops);
 /* Page-locked host memory for image and result buffers: copies from/to it are asynchronous and run at full PCIe rate
  * (ps_orb_extract_batch reads the caller's image buffers directly).  NULL on failure (ps_last_error has the text). */
 void* ps_pinned_alloc(size_t bytes);

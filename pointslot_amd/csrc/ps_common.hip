@@ -23,9 +23,54 @@ __global__ void poison_lds(uint32_t pattern, int words, uint32_t* sink) {
   __syncthreads();
   if (sink && lds_words[(threadIdx.x * 97) % words] != pattern) sink[0] = 1;   // keeps the stores alive
 }
+// FP64 matrix-core rate: every wave keeps 8 independent accumulator tiles in flight (v_mfma_f64_16x16x4_f64: 2 * 16 * 16 * 4 flop per
+// instruction and wave), no memory traffic inside the loop
+typedef double ps_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_f64_loop(double* sink, int iters) {
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  ps_d4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = ps_d4{(double)i, 0.0, 0.0, 0.0};
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+  if (s == 12345.678) sink[0] = s;   // keeps the loop alive
+}
 }  // namespace
 
 extern "C" {
+int ps_debug_mfma_f64_peak(int device, double* tflops) {
+  if (!tflops) return ps_set_error(PS_ERR_INVALID, "null argument");
+  PS_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PS_HIP(hipGetDeviceProperties(&prop, device));
+  double* sink = nullptr;
+  PS_HIP(hipMalloc(&sink, 8));
+  hipEvent_t e0, e1;
+  PS_HIP(hipEventCreate(&e0)); PS_HIP(hipEventCreate(&e1));
+  const int blocks = prop.multiProcessorCount * 8, iters = 4096;   // 8 workgroups of 4 waves per CU: 8 waves per SIMD
+  hipLaunchKernelGGL(mfma_f64_loop, dim3(blocks), dim3(256), 0, 0, sink, 64);   // warm-up (code load, clocks)
+  double best = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    PS_HIP(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(mfma_f64_loop, dim3(blocks), dim3(256), 0, 0, sink, iters);
+    PS_HIP(hipEventRecord(e1, 0));
+    PS_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    PS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const double flop = (double)blocks * 4 /*waves*/ * iters * 8 * 2048.0;
+    if (ms > 0 && flop / (ms * 1e-3) / 1e12 > best) best = flop / (ms * 1e-3) / 1e12;
+  }
+  PS_HIP(hipGetLastError());
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipFree(sink);
+  *tflops = best;
+  return PS_OK;
+}
 int ps_debug_poison_lds(int device, uint32_t pattern) {
   PS_HIP(hipSetDevice(device));
   const int bytes = 64 * 1024, words = bytes / 4;

@@ -40,9 +40,31 @@ def _resample_rows(base, shift, w):
     return base[rows, x0] * (1 - fx) + base[rows, x0 + 1] * fx
 
 
-def generate(n_frames=20, seed=4, w=1242, h=375, step=0.08, n_boxes=2, K=KITTI_K, bf=KITTI_BF):
+def kitti_texture():
+    """The one real KITTI frame in the repository (tests/golden/kitti_000212_gray.png, the grey-converted data file that ships
+    in the reference's root) as a float array, for generate(texture=...)."""
+    from PIL import Image
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "kitti_000212_gray.png")
+    return np.asarray(Image.open(p)).astype(np.float64)
+
+
+def _texture_from_image(img, w, h, shift):
+    """A base texture of w x h from a real image: rows cropped / mirror-padded to h, columns continued by mirroring (a
+    reflection keeps the local statistics - corners per pixel, contrast - of the photograph); `shift` moves the start column so
+    that sequences with different seeds see different parts first."""
+    img = np.asarray(img, np.float64)
+    if img.shape[0] < h:
+        img = np.pad(img, ((0, h - img.shape[0]), (0, 0)), mode="reflect")
+    img = img[:h]
+    period = np.concatenate([img, img[:, ::-1]], 1)
+    reps = (w + shift) // period.shape[1] + 2
+    return np.tile(period, (1, reps))[:, shift:shift + w].copy()
+
+
+def generate(n_frames=20, seed=4, w=1242, h=375, step=0.08, n_boxes=2, K=KITTI_K, bf=KITTI_BF, texture=None):
     """Returns a dict: left/right uint8 [n, h, w], twc float64 [n, 3, 4] (ground truth), boxes (per frame, per box:
-    x1 y1 x2 y2 in the left image, depth), seg uint16 [n, h, w], K, bf."""
+    x1 y1 x2 y2 in the left image, depth), seg uint16 [n, h, w], K, bf.  texture: None = the seeded value-noise + rectangles
+    texture; an image array = that photograph as the static surface's texture (same exact geometry)."""
     rng = Rng(0x51070000 + seed)
     fx, fy, cx, cy = [float(v) for v in K]
     z = 60.0 + (6.0 - 60.0) * (np.arange(h) / (h - 1))
@@ -51,7 +73,10 @@ def generate(n_frames=20, seed=4, w=1242, h=375, step=0.08, n_boxes=2, K=KITTI_K
     steps[0] = 0.0
     tx = np.cumsum(steps)
     margin = int(np.ceil(fx * tx[-1] / z.min() + bf / z.min())) + 8
-    base = _texture(rng, w + margin, h, int(400 * (w + margin) / 1242))
+    if texture is None:
+        base = _texture(rng, w + margin, h, int(400 * (w + margin) / 1242))
+    else:
+        base = _texture_from_image(texture, w + margin, h, int(rng.integers(1, 0, 997)[0]))
     box_tex, box_geo = [], []
     for b in range(n_boxes):
         bw, bh = int(rng.integers(1, 90, 140)[0]), int(rng.integers(1, 50, 80)[0])
