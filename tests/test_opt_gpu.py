@@ -40,13 +40,13 @@ def test_se3_converters(opt):
 
 
 def test_pose_optimization_batch(opt):
-    frames = [synth.pose_problem(0x51070003 + k) for k in range(8)]
+    frames = [synth.pose_problem(0x51070003 + k) for k in range(64)]   # all 64 frames of BASELINE config 3
     frames.append(synth.pose_problem(77, n=400, mono_frac=0.5, valid_frac=0.7))
     frames.append(synth.pose_problem(78, n=14))                       # < 15 correspondences -> 0, pose untouched
     frames.append(synth.pose_problem(79, n=200, outlier_frac=0.6))
     frames.append(synth.pose_problem(80, n=3000, noise=3.0))
     frames[-1]["outlier0"] = (np.arange(3000) % 7 == 0).astype(np.uint8)
-    frames[9]["tcw0"] = frames[0]["tcw_true"].astype(np.float32)
+    frames[65]["tcw0"] = frames[0]["tcw_true"].astype(np.float32)
     opt.enable_trace(True)
     res = opt.PoseOptimization(frames)
     for i, (f, (r, tcw, outl)) in enumerate(zip(frames, res)):
@@ -65,7 +65,7 @@ def test_pose_optimization_batch(opt):
             sig = (np.abs(prev - tro[:, 0]) > 1e-4 * tro[:, 0]) & (tro[:, 2] == 1)
             bad = ~np.isclose(trg[:, 1], tro[:, 1], rtol=1e-5) & sig
             assert not bad.any(), (i, trg[bad], tro[bad])
-    assert np.array_equal(res[9][1], frames[9]["tcw0"])                # early return leaves the pose alone
+    assert np.array_equal(res[65][1], frames[65]["tcw0"])              # early return leaves the pose alone
     opt.enable_trace(False)
 
 
@@ -123,13 +123,22 @@ def test_object_ba_small_and_realistic(opt):
 
 
 def test_object_ba_config4_shape(opt):
-    """BASELINE config 4: 50 object keyframes x 300 points, p = 1.0 (15 000 edges) and p = 0.6."""
-    graphs = [synth.object_ba_problem(0x51070004, perturb=(0.05, 1.0, 0.02), perturb_axis="z"),
-              synth.object_ba_problem(0x51070005, p_vis=0.6, perturb=(0.05, 1.0, 0.02), perturb_axis="z")]
+    """BASELINE config 4 as SURVEY.md 8d defines it: 8 objects (seeds 0x51070004 + j) x 50 object keyframes x 300 points, p = 1.0
+    (15 000 edges) and p = 0.6, initial poses perturbed +-0.3 m / +-5 deg yaw, points +-0.1 m - all 16 graphs in one batch, as
+    bench.py runs them.  The survey's yaw perturbation turns about the camera's y axis, which VertexSE3Fix (roll / pitch locked,
+    only Rz is free: src/g2o_Object.cc:190-213) cannot undo: the 5-iteration first round ends far from the optimum and the
+    chi-square pass erases most observations (11 811 of 15 000 for object 0) - the reference's schedule does exactly that, and
+    parity has to hold there too.  Two more graphs perturb about z (correctable) at the same magnitudes, two at a fifth of it
+    (the converging regime)."""
+    graphs = [synth.object_ba_problem(0x51070004 + j) for j in range(8)]
+    graphs += [synth.object_ba_problem(0x51070004 + j, p_vis=0.6) for j in range(8)]
+    graphs += [synth.object_ba_problem(0x51070004, perturb_axis="z"), synth.object_ba_problem(0x51070005, p_vis=0.6, perturb_axis="z")]
+    graphs += [synth.object_ba_problem(0x51070004, perturb=(0.05, 1.0, 0.02), perturb_axis="z"),
+               synth.object_ba_problem(0x51070005, p_vis=0.6, perturb=(0.05, 1.0, 0.02), perturb_axis="z")]
     res = opt.ObjectLocalBundleAdjustment(graphs)
     for i, (g, r) in enumerate(zip(graphs, res)):
         _ba_check(g, r, "config4 %d" % i)
-    print("config-4 BA: %d + %d LM iterations, %.3f ms GPU" % (res[0]["iterations"], res[1]["iterations"], opt.last_kernel_ms()))
+    print("config-4 BA: %d graphs, %.3f ms GPU" % (len(graphs), opt.last_kernel_ms()))
 
 
 def test_local_ba_shape(opt):
