@@ -121,6 +121,7 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
   __shared__ int cursor[PS_TRK_NCELL];
   __shared__ float sdepth[4352];
   __shared__ int red[4];
+  __shared__ unsigned long long far_red[TRK_T / 64];
   __shared__ float pose_pred[16];
   const int s = blockIdx.x, tid = threadIdx.x;
   const TrkCam& C = A.cam;
@@ -238,21 +239,50 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
   for (int i = tid; i < NL; i += TRK_T) sdepth[i] = A.last.depth[b + i];
   __syncthreads();
   {
+    // The reference sorts (depth, index) and walks the list until it has passed 100 points AND the first one beyond
+    // 2 * mThDepth: the visited set is every point up to sorted position J = max(c, 100), c = number of near points.  With
+    // c >= 100 (any ordinary frame) that is "all near points and the nearest far one" - no ranks needed, one min-reduction;
+    // only a frame with fewer than 100 near points needs the positions of its 101 nearest points (rank counting).
     const float thr = 2 * C.th_depth;
     int near = 0;
-    for (int i = tid; i < NL; i += TRK_T) near += (sdepth[i] > 0 && !(sdepth[i] > thr)) ? 1 : 0;
+    unsigned long long far_min = ~0ull;   // (depth bits, index) of the nearest far point: positive floats order like their bit patterns
+    for (int i = tid; i < NL; i += TRK_T) {
+      const float d = sdepth[i];
+      if (!(d > 0)) continue;
+      if (!(d > thr)) near++;
+      else { const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i; far_min = k < far_min ? k : far_min; }
+    }
     const int c = block_sum_i(near, red);
-    const int J = c > 100 ? c : 100;   // sorted positions 0..J are visited (the loop breaks after the first far point beyond 100)
+    const int J = c > 100 ? c : 100;
+    if (c >= 100) {
+#pragma unroll
+      for (int dd = 32; dd >= 1; dd >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)far_min, dd), hi = __shfl_xor((unsigned)(far_min >> 32), dd);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        far_min = o < far_min ? o : far_min;
+      }
+      if ((tid & 63) == 0) far_red[tid >> 6] = far_min;
+      __syncthreads();
+      far_min = far_red[0];
+      for (int w = 1; w < TRK_T / 64; w++) far_min = far_red[w] < far_min ? far_red[w] : far_min;
+    }
+    const int far_first = (c >= 100 && far_min != ~0ull) ? (int)(unsigned)far_min : -1;
     for (int i0 = 0; i0 < NL; i0 += TRK_T) {
       const int i = i0 + tid;
       const float d = i < NL ? sdepth[i] : -1.f;
       if (!(d > 0)) continue;
-      int rank = 0;   // position in the sort by (depth, index)
-      for (int j = 0; j < NL; j++) {
-        const float dj = sdepth[j];
-        rank += (dj > 0 && (dj < d || (dj == d && j < i))) ? 1 : 0;
+      bool visited;
+      if (c >= 100) {
+        visited = !(d > thr) || i == far_first;
+      } else {
+        int rank = 0;   // position in the sort by (depth, index)
+        for (int j = 0; j < NL; j++) {
+          const float dj = sdepth[j];
+          rank += (dj > 0 && (dj < d || (dj == d && j < i))) ? 1 : 0;
+        }
+        visited = rank <= J;
       }
-      if (rank <= J && (!A.last.mp_valid[b + i] || !A.last.mp_observed[b + i])) {
+      if (visited && (!A.last.mp_valid[b + i] || !A.last.mp_observed[b + i])) {
         float P[3];
         unproject(C, Tl, A.last.x[b + i], A.last.y[b + i], d, P);
         for (int k = 0; k < 3; k++) A.last.xw[3 * (b + i) + k] = P[k];

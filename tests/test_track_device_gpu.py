@@ -27,8 +27,7 @@ def test_track_device_check_compiles():
 @pytest.mark.gpu
 def test_device_tracker_equals_host_driven_chain(tmp_path):
     from pointslot_amd import sequence
-    if not os.path.exists(EXE):
-        _build()
+    _build()          # always: a binary that travelled with the snapshot may predate the headers
     dirs = []
     # five sequences with different speeds; the last one is nearly textureless for two frames in the middle (loses track)
     for k in range(5):
@@ -45,6 +44,14 @@ def test_device_tracker_equals_host_driven_chain(tmp_path):
     assert r["tracked"] >= 5 * 7 - 6, r
     assert r["tracked_flag_differs"] == 0 and r["state_differs"] == 0 and r["counts_differ"] == 0, (r, out.stderr[-1000:])
     assert r["pose_bits_differ"] == 0 and r["max_abs_pose_diff"] == 0.0, r
+    # ThDepth 3: fewer than 100 keypoints are "close", UpdateLastFrame then takes the 101 nearest (the rank-counting branch)
+    for d in dirs[:2]:
+        txt = open(os.path.join(d, "calib.txt")).read().replace("ThDepth: 35", "ThDepth: 3")
+        open(os.path.join(d, "calib.txt"), "w").write(txt)
+    out = subprocess.run([EXE, "--max-frames", "4"] + dirs[:2], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["tracked"] == 8 and r["tracked_flag_differs"] == 0 and r["counts_differ"] == 0 and r["pose_bits_differ"] == 0, (r, out.stderr[-1000:])
 
 
 @pytest.mark.gpu
