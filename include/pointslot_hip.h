@@ -216,7 +216,9 @@ int ps_match_bruteforce(ps_matcher* m, ps_bf_problem* probs, int nprob, float nn
  *                q_min_level / q_max_level = level-1 / level (level+1 for objects)
  * th_dist = TH_HIGH (100) or TH_HIGH_FORDYNAMIC (130); ratio_test/nn_ratio = the same-level mfNNratio test;
  * check_orientation = mbCheckOrientation (frame mode).
- *   match_of_train[j] : out, index of the query assigned to slot j, -1 where the call leaves the slot alone / NULL
+ *   match_of_train[j] : out, index of the query assigned to slot j; -1 where the call leaves the slot alone (the caller keeps
+ *                       its pointer); -2 where the call assigned the slot and the rotation check then reset it to NULL
+ *                       (ORBmatcher.cc:1742-1750: the caller writes NULL)
  *   nmatches          : out, the return value */
 typedef struct ps_proj_train {
   int32_t n;

@@ -211,7 +211,7 @@ int orc_search_projection_frame(const OrcTrain* F, int m, const float* xw, const
     three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
     for (int i = 0; i < HISTO_LENGTH; i++)
       if (i != ind1 && i != ind2 && i != ind3)
-        for (int idx : rotHist[i]) { match_of_train[idx] = -1; nmatches--; }
+        for (int idx : rotHist[i]) { match_of_train[idx] = -2; nmatches--; }   // -2: assigned in this call, then set to NULL (:1742-1750)
   }
   return nmatches;
 }

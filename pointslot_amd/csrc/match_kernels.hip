@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
       const int bi = A.qbest[q];
       if (bi >= 0) {
         const int b = A.qbin[q];
-        if (b != i1 && b != i2 && b != i3) { match[bi] = -1; removed++; }
+        if (b != i1 && b != i2 && b != i3) { match[bi] = -2; removed++; }   // -2: assigned in this call, then set to NULL by the rotation check
       }
     }
 #pragma unroll

@@ -40,6 +40,15 @@ class Mat {
   template <typename T> const T* ptr(int r = 0) const { return (const T*)(data + (size_t)r * step); }
   template <typename T> T& at(int r, int c) { return ptr<T>(r)[c]; }
   template <typename T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
+  // element i of a row or column vector (cv::Mat::at<T>(int))
+  template <typename T> T& at(int i) { return cols == 1 ? ptr<T>(i)[0] : ptr<T>(0)[i]; }
+  template <typename T> const T& at(int i) const { return cols == 1 ? ptr<T>(i)[0] : ptr<T>(0)[i]; }
+  Mat clone() const {
+    Mat m(rows, cols, flags);
+    for (int r = 0; r < rows; r++) std::memcpy(m.data + (size_t)r * m.step, data + (size_t)r * step, (size_t)cols * elemSize(flags));
+    return m;
+  }
+  bool isContinuous() const { return step == (size_t)cols * elemSize(flags); }
   Mat row(int r) const { Mat m(1, cols, flags, data + (size_t)r * step, step); m.own_ = own_; return m; }
   static size_t elemSize(int type) { return type == CV_32F ? 4 : 1; }
  private:
