@@ -88,7 +88,9 @@ int main(int argc, char** argv) {
           R.tStart = std::chrono::steady_clock::now();
           R.unixStart = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
         }
-        const bool more = prefetch && ni + 1 < nImages;
+        // every timed step pays for its own extraction: the last warm-up step queues nothing ahead (the extraction of step
+        // `warm` then starts inside the timed window), and the last step has nothing to queue
+        const bool more = prefetch && ni + 1 < nImages && ni + 1 != warm;
         for (int i = 0; i < n; i++) {
           const int k = R.members[i];
           left[i] = image(k, ni, 0); right[i] = image(k, ni, 1);

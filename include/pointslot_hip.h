@@ -219,7 +219,10 @@ int ps_match_bruteforce(ps_matcher* m, ps_bf_problem* probs, int nprob, float nn
  *   match_of_train[j] : out, index of the query assigned to slot j; -1 where the call leaves the slot alone (the caller keeps
  *                       its pointer); -2 where the call assigned the slot and the rotation check then reset it to NULL
  *                       (ORBmatcher.cc:1742-1750: the caller writes NULL)
- *   nmatches          : out, the return value */
+ *   nmatches          : out, the return value
+ * A search window may hold any number of candidates in the reference.  Here a window of more than 256 makes its problem run a
+ * second time with a wider candidate store (1024 per window, frames of up to 8191 features); only a problem that exceeds that as
+ * well fails - nmatches = -1, match_of_train untouched - and the call returns PS_ERR_CAPACITY after serving all other problems. */
 typedef struct ps_proj_train {
   int32_t n;
   const float* x; const float* y; const int32_t* octave; const float* angle; const float* u_right; const uint8_t* desc;

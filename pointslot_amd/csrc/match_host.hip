@@ -3,6 +3,7 @@
 // Replaces ORBmatcher::SearchByBruceMatching / DescriptorDistance — /root/reference/src/ORBmatcher.cc.
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <string.h>
 #include <vector>
@@ -13,7 +14,7 @@ extern "C" {
 void psk_bf_launch(const BfBlock*, int, const BfProb*, int, const uint8_t*, const float*, const uint8_t*, const uint8_t*,
                    const float*, uint32_t*, int32_t*, int32_t*, float, int, hipStream_t);
 void psk_hamming_matrix_launch(const uint8_t*, int, const uint8_t*, int, uint16_t*, hipStream_t);
-void psk_pj_launch(const PjArrays*, int, int, int, hipStream_t);
+void psk_pj_launch(const PjArrays*, int, int, int, int, hipStream_t);
 void psk_fuse_launch(const FuArrays*, int, int, hipStream_t);
 void psk_distinctive_launch(const uint8_t*, const int32_t*, int32_t*, int, hipStream_t);
 }
@@ -25,6 +26,8 @@ struct ps_matcher {
   size_t d_bytes = 0;
   uint8_t* h_buf = nullptr;   // pinned staging of the same size
   size_t h_bytes = 0;
+  uint8_t* d_wide = nullptr;  // second arena, only for the wide re-run of search problems whose windows overflowed the candidate store
+  size_t d_wide_bytes = 0;
 };
 
 namespace {
@@ -71,6 +74,7 @@ void ps_matcher_destroy(ps_matcher* m) {
   hipSetDevice(m->device);
   if (m->stream) { hipStreamSynchronize(m->stream); hipStreamDestroy(m->stream); }
   if (m->d_buf) hipFree(m->d_buf);
+  if (m->d_wide) hipFree(m->d_wide);
   if (m->h_buf) hipHostFree(m->h_buf);
   delete m;
 }
@@ -190,7 +194,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   const size_t o_qminl = take(NQ * 4), o_qmaxl = take(NQ * 4), o_qdesc = take(NQ * 32), o_qobs = take(NQ), o_qang = take(NQ * 4);
   const size_t o_qxw = take(NQ * 12), o_qoct = take(NQ * 4);
   const size_t in_bytes = off;
-  const size_t o_match = take(NT * 4), o_nm = take((size_t)nprob * 4), o_ovf = take(4);
+  const size_t o_match = take(NT * 4), o_nm = take((size_t)nprob * 4), o_ovf = take((size_t)nprob * 4);
   const size_t out_end = off;
   const size_t o_cand = take(NQ * PS_PJ_CAP * 4), o_ncand = take(NQ * 4), o_qbest = take(NQ * 4), o_qbin = take(NQ), o_tt = take(NQ * 16);
   int rc = ensure(m, off);
@@ -211,7 +215,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
     const size_t t0 = toff[p], q0 = qoff[p];
     PjProb& d = hp[p];
     memset(&d, 0, sizeof(d));
-    d.t_off = (int32_t)t0; d.nt = T.n; d.q_off = (int32_t)q0; d.nq = P.nq; d.grid_off = p * (NCELL + 1);
+    d.t_off = (int32_t)t0; d.nt = T.n; d.q_off = (int32_t)q0; d.c_off = (int32_t)q0; d.nq = P.nq; d.grid_off = p * (NCELL + 1);
     d.min_x = T.min_x; d.min_y = T.min_y; d.gw_inv = T.grid_w_inv; d.gh_inv = T.grid_h_inv;
     d.th_dist = P.th_dist; d.ratio_test = P.ratio_test; d.nn_ratio = P.nn_ratio; d.check_ori = P.check_orientation;
     d.use_bbox = P.use_bbox; d.frame_mode = P.frame_mode;
@@ -253,7 +257,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   PS_HIP(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, m->stream));
   if (prof) PS_HIP(hipStreamSynchronize(m->stream));
   const auto tp2 = std::chrono::steady_clock::now();
-  PS_HIP(hipMemsetAsync(D + o_ovf, 0, 4, m->stream));
+  PS_HIP(hipMemsetAsync(D + o_ovf, 0, (size_t)nprob * 4, m->stream));
   PjArrays A;
   A.prob = (const PjProb*)(D + o_prob);
   A.tx = (const float*)(D + o_tx); A.ty = (const float*)(D + o_ty); A.toct = (const int32_t*)(D + o_toct);
@@ -266,7 +270,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   A.cand = (uint32_t*)(D + o_cand); A.ncand = (int32_t*)(D + o_ncand); A.match = (int32_t*)(D + o_match);
   A.nmatch = (int32_t*)(D + o_nm); A.overflow = (int32_t*)(D + o_ovf); A.qbest = (int32_t*)(D + o_qbest); A.qbin = D + o_qbin;
   A.ttop = (uint4*)(D + o_tt);
-  psk_pj_launch(&A, nprob, max_nq > 0 ? max_nq : 1, any_frame, m->stream);
+  psk_pj_launch(&A, nprob, max_nq > 0 ? max_nq : 1, any_frame, 0, m->stream);
   PS_HIP(hipGetLastError());
   if (prof) PS_HIP(hipStreamSynchronize(m->stream));
   const auto tp3 = std::chrono::steady_clock::now();
@@ -278,13 +282,63 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
     fprintf(stderr, "ps_search_by_projection %d problems, %.1f MB in: pack %.3f ms, upload %.3f, kernels %.3f, read-back %.3f\n", nprob, in_bytes / 1e6, ms(tp0, tp1),
             ms(tp1, tp2), ms(tp2, tp3), ms(tp3, tp4));
   }
-  if (*(const int32_t*)(H + o_ovf) > 0)
-    return ps_set_error(PS_ERR_CAPACITY, "a search window held more than %d candidates", PS_PJ_CAP);
+  // Problems with a window of more than PS_PJ_CAP candidates (dense imagery, the 2 * th retry at a coarse octave) run again with
+  // the wide key format - 1024 candidates per window, frames of up to 8191 features - in a compact candidate store of their own;
+  // the other problems of the batch keep their results.  A problem that overflows that too (or has more features) is the only one
+  // that fails: nmatches = -1, its match_of_train untouched, and the call returns PS_ERR_CAPACITY after serving the rest.
+  const int32_t* ovf = (const int32_t*)(H + o_ovf);
+  std::vector<int> wide, failed;
+  for (int p = 0; p < nprob; p++)
+    if (ovf[p] > 0) (probs[p].train.n <= PS_PJ_WIDE_MAX_N ? wide : failed).push_back(p);
+  std::vector<int32_t> wide_nm(wide.size(), 0);
+  if (!wide.empty()) {
+    size_t nq2 = 0;
+    int max_nq2 = 1, any_frame2 = 0;
+    std::vector<PjProb> sub(wide.size());
+    for (size_t i = 0; i < wide.size(); i++) {
+      sub[i] = hp[wide[i]];
+      sub[i].c_off = (int32_t)nq2;
+      nq2 += probs[wide[i]].nq;
+      max_nq2 = std::max(max_nq2, probs[wide[i]].nq);
+      any_frame2 |= probs[wide[i]].frame_mode;
+    }
+    size_t woff = 0;
+    auto wtake = [&](size_t bytes) { size_t r = woff; woff += al(bytes + 64); return r; };
+    const size_t w_prob = wtake(sizeof(PjProb) * sub.size()), w_nm = wtake(sub.size() * 4), w_ovf = wtake(sub.size() * 4), w_cand = wtake(nq2 * PS_PJ_CAP_WIDE * 4);
+    if (woff > m->d_wide_bytes) {
+      if (m->d_wide) hipFree(m->d_wide);
+      m->d_wide = nullptr; m->d_wide_bytes = 0;
+      PS_HIP(hipMalloc(&m->d_wide, woff));
+      m->d_wide_bytes = woff;
+    }
+    uint8_t* Wd = m->d_wide;
+    PS_HIP(hipMemcpyAsync(Wd + w_prob, sub.data(), sizeof(PjProb) * sub.size(), hipMemcpyHostToDevice, m->stream));
+    PS_HIP(hipMemsetAsync(Wd + w_ovf, 0, sub.size() * 4, m->stream));
+    // (pj_project runs again on these problems: it only repeats what it wrote; the queries it invalidated stay invalid)
+    PjArrays A2 = A;
+    A2.prob = (const PjProb*)(Wd + w_prob); A2.cand = (uint32_t*)(Wd + w_cand); A2.nmatch = (int32_t*)(Wd + w_nm); A2.overflow = (int32_t*)(Wd + w_ovf);
+    psk_pj_launch(&A2, (int)sub.size(), max_nq2, any_frame2, 1, m->stream);
+    PS_HIP(hipGetLastError());
+    std::vector<int32_t> ovf2(sub.size(), 0);
+    PS_HIP(hipMemcpyAsync(H + o_match, D + o_match, NT * 4, hipMemcpyDeviceToHost, m->stream));
+    PS_HIP(hipStreamSynchronize(m->stream));
+    PS_HIP(hipMemcpy(wide_nm.data(), Wd + w_nm, sub.size() * 4, hipMemcpyDeviceToHost));
+    PS_HIP(hipMemcpy(ovf2.data(), Wd + w_ovf, sub.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < wide.size(); i++)
+      if (ovf2[i] > 0) { failed.push_back(wide[i]); wide_nm[i] = -1; }
+  }
   for (int p = 0; p < nprob; p++) {
     ps_proj_problem& P = probs[p];
+    if (std::find(failed.begin(), failed.end(), p) != failed.end()) { P.nmatches = -1; continue; }
     if (P.train.n > 0) memcpy(P.match_of_train, H + o_match + toff[p] * 4, (size_t)P.train.n * 4);
     P.nmatches = ((const int32_t*)(H + o_nm))[p];
   }
+  for (size_t i = 0; i < wide.size(); i++)
+    if (wide_nm[i] >= 0) probs[wide[i]].nmatches = wide_nm[i];
+  if (!failed.empty())
+    return ps_set_error(PS_ERR_CAPACITY, "projection problem %d (and %zu more): a search window held more than %d candidates%s", failed[0], failed.size() - 1,
+                        probs[failed[0]].train.n <= PS_PJ_WIDE_MAX_N ? PS_PJ_CAP_WIDE : PS_PJ_CAP,
+                        probs[failed[0]].train.n <= PS_PJ_WIDE_MAX_N ? "" : " and the frame has more features than the wide candidate store indexes (8191)");
   return PS_OK;
 }
 

@@ -201,7 +201,7 @@ extern "C" void psk_hamming_matrix_launch(const uint8_t* q, int nq, const uint8_
 //   pj_project  : frame-to-frame variant only — float projection of the last frame's map points
 //   pj_gather   : one wave per query — grid window walk in the reference's order (ix, iy, cell order), static
 //                 filters (level, |dx|,|dy| < r, stereo uR gate, bbox), Hamming distance; candidates are
-//                 stored in traversal order as keys  dist << 23 | position << 15 | train index
+//                 stored in traversal order as keys  dist << 23 | position << IDXB | train index
 //   pj_resolve  : one wave per problem — the order-dependent part: queries in order, trains blocked by an
 //                 earlier assignment are skipped, best / second best by two wave-min reductions, ratio test,
 //                 rotation histogram
@@ -248,7 +248,12 @@ __global__ __launch_bounds__(256) void pj_project(PjArrays A) {
   if (!ok) A.qvalid[q] = 0;
 }
 
+// Candidate keys are  dist << 23 | position << IDXB | train index  with 23 - IDXB position bits: IDXB = 15 is the everyday format
+// (32 767 features per frame, 256 candidates per window); IDXB = 13 (8191 features, 1024 candidates) serves the problems whose
+// windows overflowed the first one, so that a dense window costs a second pass instead of the result.
+template <int IDXB>
 __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
+  constexpr int CAP = 1 << (23 - IDXB);
   const PjProb P = A.prob[blockIdx.y];
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (qi >= P.nq) return;
@@ -297,9 +302,9 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
         }
         const unsigned long long m = __ballot(pass);
         const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-        if (pass && pos < PS_PJ_CAP) {
-          const uint32_t key = ((uint32_t)dist << 23) | ((uint32_t)pos << 15) | (uint32_t)j;
-          A.cand[(size_t)q * PS_PJ_CAP + pos] = key;
+        if (pass && pos < CAP) {
+          const uint32_t key = ((uint32_t)dist << 23) | ((uint32_t)pos << IDXB) | (uint32_t)j;
+          A.cand[((size_t)P.c_off + qi) * CAP + pos] = key;
           if (!A.tocc[P.t_off + j]) {   // sorted insertion
             uint32_t kk = key;
 #pragma unroll
@@ -324,14 +329,17 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
     prev = top[r];
   }
   if (lane == 0) {
-    if (count > PS_PJ_CAP) { atomicAdd(A.overflow, 1); count = PS_PJ_CAP; }
+    if (count > CAP) { atomicAdd(&A.overflow[blockIdx.y], 1); count = CAP; }
     A.ncand[q] = count;
     A.ttop[q] = make_uint4(top[0], top[1], top[2], top[3]);
   }
 }
 
 #define PJ_TBL 8192
+template <int IDXB>
 __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
+  constexpr int CAP = 1 << (23 - IDXB);
+  constexpr uint32_t IDXM = (1u << IDXB) - 1u;
   __shared__ uint32_t blocked[1024];   // up to 32768 train features
   __shared__ int hist[32];
   __shared__ uint32_t newly[1024];     // trains blocked by this call
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
     int stale = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++)
-      if (tk[r] != 0xFFFFFFFFu) { const uint32_t j = tk[r] & 0x7FFF; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u) << r; }
+      if (tk[r] != 0xFFFFFFFFu) { const uint32_t j = tk[r] & IDXM; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u) << r; }
     unsigned long long pend = __builtin_amdgcn_ballot_w64(ncv > 0);
     // ---- queries whose outcome cannot depend on the other queries of the block are decided by all lanes at once ----
     // A query's choice among its four keys only changes when an EARLIER query of the block claims one of those trains.  Every
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
       const int want = P.ratio_test ? 2 : 1;
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        if (ncv > 0 && tk[r] != 0xFFFFFFFFu) atomicMin(&first_lane[(tk[r] & 0x7FFF) & (PJ_TBL - 1)], (uint32_t)lane);
+        if (ncv > 0 && tk[r] != 0xFFFFFFFFu) atomicMin(&first_lane[(tk[r] & IDXM) & (PJ_TBL - 1)], (uint32_t)lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         if (ncv > 0 && tk[r] != 0xFFFFFFFFu) {
-          const bool mine = first_lane[(tk[r] & 0x7FFF) & (PJ_TBL - 1)] == (uint32_t)lane;
+          const bool mine = first_lane[(tk[r] & IDXM) & (PJ_TBL - 1)] == (uint32_t)lane;
           clean = clean && mine;
           if (!((stale >> r) & 1)) {
             if (found == 0) best = tk[r]; else if (found == 1) second = tk[r];
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        if (ncv > 0 && tk[r] != 0xFFFFFFFFu) first_lane[(tk[r] & 0x7FFF) & (PJ_TBL - 1)] = 0xFFFFFFFFu;
+        if (ncv > 0 && tk[r] != 0xFFFFFFFFu) first_lane[(tk[r] & IDXM) & (PJ_TBL - 1)] = 0xFFFFFFFFu;
       // (fewer than four keys: they are ALL the candidates that were free at entry, a scan cannot find another one)
       const bool may_scan = ncv > 4 && tk[3] != 0xFFFFFFFFu && exclusive < want;
       // ... and so does everything after it: only the lanes before the first such query take the parallel path
@@ -433,9 +441,9 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
       clean = clean && ((before >> lane) & 1ull);
       {
         bool accept = clean && best != 0xFFFFFFFFu && (int)(best >> 23) <= P.th_dist;
-        const int bestIdx = (int)(best & 0x7FFF);
+        const int bestIdx = (int)(best & IDXM);
         if (accept && P.ratio_test && second != 0xFFFFFFFFu) {
-          const int l1 = loct[bestIdx], l2 = loct[second & 0x7FFF];
+          const int l1 = loct[bestIdx], l2 = loct[second & IDXM];
           if (l1 == l2 && (float)(int)(best >> 23) > __fmul_rn(P.nn_ratio, (float)(int)(second >> 23))) accept = false;
         }
         if (accept) {
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
         stale = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          if (tk[r] != 0xFFFFFFFFu) { const uint32_t j = tk[r] & 0x7FFF; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u) << r; }
+          if (tk[r] != 0xFFFFFFFFu) { const uint32_t j = tk[r] & IDXM; stale |= (int)((newly[j >> 5] >> (j & 31)) & 1u) << r; }
 #ifdef PS_PJ_PROFILE
         pj_clean += __popcll(__builtin_amdgcn_ballot_w64(clean)); pj_dirty += __popcll(pend); pj_serial_blocks += scanners ? 1 : 0;
 #endif
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
             const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)tk[r], i);
             if (key != 0xFFFFFFFFu) {
               bool taken = (sb >> r) & 1;
-              if (!taken && nacc > 0) taken = __builtin_amdgcn_ballot_w64(accidx == (int)(key & 0x7FFF)) != 0ull;
+              if (!taken && nacc > 0) taken = __builtin_amdgcn_ballot_w64(accidx == (int)(key & IDXM)) != 0ull;
               if (!taken) { if (found == 0) best = key; else second = key; found++; }
             }
           }
@@ -489,8 +497,8 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
       if (need_scan) {
         uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
         for (int c = lane; c < nc; c += 64) {
-          const uint32_t k = A.cand[(size_t)q * PS_PJ_CAP + c];
-          const uint32_t j = k & 0x7FFF;
+          const uint32_t k = A.cand[((size_t)P.c_off + qi) * CAP + c];
+          const uint32_t j = k & IDXM;
           if (((blocked[j >> 5] | newly[j >> 5]) >> (j & 31)) & 1u) continue;
           if (k < m1) { m2 = m1; m1 = k; } else if (k < m2) m2 = k;
         }
@@ -498,11 +506,11 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
         second = wave_min_u32(m1 == best ? m2 : m1);
       }
       if (best == 0xFFFFFFFFu) continue;
-      const int bestDist = (int)(best >> 23), bestIdx = (int)(best & 0x7FFF);
+      const int bestDist = (int)(best >> 23), bestIdx = (int)(best & IDXM);
       if (bestDist > P.th_dist) continue;
       if (P.ratio_test && second != 0xFFFFFFFFu) {
         const int d2 = (int)(second >> 23);
-        const int l1 = loct[bestIdx], l2 = loct[second & 0x7FFF];
+        const int l1 = loct[bestIdx], l2 = loct[second & IDXM];
         if (l1 == l2 && (float)bestDist > __fmul_rn(P.nn_ratio, (float)d2)) continue;
         // (no second candidate: bestLevel2 = -1 never equals an octave -> accepted)
       }
@@ -578,11 +586,16 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
 
 }  // namespace
 
-extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int any_frame_mode, hipStream_t st) {
+extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int any_frame_mode, int wide, hipStream_t st) {
   const PjArrays A = *arrays;
   if (any_frame_mode) hipLaunchKernelGGL(pj_project, dim3((max_nq + 255) / 256, nprob), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(pj_gather, dim3((max_nq + 3) / 4, nprob), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(pj_resolve, dim3(nprob), dim3(64), 0, st, A);
+  if (wide) {
+    hipLaunchKernelGGL(pj_gather<13>, dim3((max_nq + 3) / 4, nprob), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(pj_resolve<13>, dim3(nprob), dim3(64), 0, st, A);
+  } else {
+    hipLaunchKernelGGL(pj_gather<15>, dim3((max_nq + 3) / 4, nprob), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(pj_resolve<15>, dim3(nprob), dim3(64), 0, st, A);
+  }
 }
 
 // ================================================================================================

@@ -8,12 +8,15 @@ struct BfProb { int32_t q_off, nq, t_off, nt; };
 struct BfBlock { int32_t prob, q_first, q_count, pad; };
 
 // ---- windowed (projection) matching ----
-#define PS_PJ_CAP 256          // candidates kept per query (exceeding it is reported as PS_ERR_CAPACITY)
+#define PS_PJ_CAP 256          // candidates kept per query in the everyday key format
+#define PS_PJ_CAP_WIDE 1024    // ... in the wide format that re-runs problems whose windows overflowed (frames of <= PS_PJ_WIDE_MAX_N features)
+#define PS_PJ_WIDE_MAX_N 8191
 #define PS_GRID_COLS 64        // FRAME_GRID_COLS / ROWS, /root/reference/include/Frame.h:40-41
 #define PS_GRID_ROWS 48
 struct PjProb {
   int32_t t_off, nt;           // train features
   int32_t q_off, nq;           // queries
+  int32_t c_off;               // first query's slot in the candidate store (= q_off, except in the compact store of a wide re-run)
   int32_t grid_off;            // into cell_off (COLS*ROWS+1 entries per problem); cell_idx shares t_off
   float min_x, min_y, gw_inv, gh_inv;
   int32_t th_dist;             // TH_HIGH (100) or TH_HIGH_FORDYNAMIC (130)
@@ -42,7 +45,8 @@ struct PjArrays {
   const uint8_t* qdesc; const uint8_t* qobs; const float* qang;
   const float* qxw; const int32_t* qoct;     // frame mode
   // work / outputs
-  uint32_t* cand; int32_t* ncand; int32_t* match; int32_t* nmatch; int32_t* overflow;
+  uint32_t* cand; int32_t* ncand; int32_t* match; int32_t* nmatch;
+  int32_t* overflow;                         // per problem: queries whose window held more candidates than the key format stores
   int32_t* qbest;                            // per query: matched train (or -1), for the rotation pass
   uint4* ttop;                               // per query: the four smallest candidate keys among the trains free at entry (pj_gather)
   uint8_t* qbin;

@@ -185,6 +185,9 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
   if (tid < k) {
     s.prior_robust[tid] = 1;
     for (int c = 0; c < 3; c++) s.prior_obs[tid][c] = poses[(size_t)(P.v_off + tid) * 7 + c];
+    // g2o keeps the increment in a zero-initialised vector: when the very first factorisation of a problem fails the
+    // update is exp(0) (and rho = -inf: the damping is raised and the trial repeated) - never leftover LDS contents
+    for (int c = 0; c < 6; c++) { s.x[tid][c] = 0.0; s.xnew[tid][c] = 0.0; }
   }
   int cnt = 0;
   for (int o = 0; o < k; o++) {

@@ -16,7 +16,7 @@ extern "C" {
 hipStream_t psi_orb_stream(ps_orb*);
 const OrbPlan* psi_orb_plan(ps_orb*);
 int psi_orb_prepare(ps_orb*, int, int);
-void psk_pj_launch(const PjArrays*, int, int, int, hipStream_t);
+void psk_pj_launch(const PjArrays*, int, int, int, int, hipStream_t);
 void psk_pose_lm_launch(const PoProb*, int, const PoVertex*, const float*, const float*, const float*, const uint8_t*, uint8_t*,
                         double*, uint8_t*, double*, int32_t*, double*, hipStream_t);
 void psk_trk_begin(const TrkArrays*, int, hipStream_t);
@@ -90,7 +90,7 @@ size_t carve(ps_tracker* t, uint8_t* base) {
   A.traj = c.take<float>((size_t)A.max_steps * S * 16);
   A.stats = c.take<TrkStat>((size_t)A.max_steps * S);
   t->po_chi2 = c.take<double>(n); t->po_state = c.take<uint8_t>(n);
-  t->d_overflow = c.take<int32_t>(1);
+  t->d_overflow = c.take<int32_t>(S);   // per sequence, accumulated over the searches of all steps
   // windowed-matcher work arrays (one set: the three searches of a step run one after the other)
   uint8_t* ones = c.take<uint8_t>(n);
   uint32_t* cand = c.take<uint32_t>(n * PS_PJ_CAP);
@@ -128,15 +128,15 @@ int queue_chain(ps_tracker* t) {
   if (rc != PS_OK) return rc;
   mark();                                                       // stereo
   psk_trk_begin(A, t->step, st); mark();                        // glue
-  psk_pj_launch(&t->pj_mm1, S, cap, 1, st); mark();             // search
+  psk_pj_launch(&t->pj_mm1, S, cap, 1, 0, st); mark();             // search
   psk_trk_after_mm1(A, st); mark();                             // glue
-  psk_pj_launch(&t->pj_mm2, S, cap, 1, st); mark();             // search (the 2 * th retry; empty problems where it is not needed)
+  psk_pj_launch(&t->pj_mm2, S, cap, 1, 0, st); mark();             // search (the 2 * th retry; empty problems where it is not needed)
   psk_trk_after_mm(A, t->step, st); mark();                     // glue
   psk_pose_lm_launch(A->po_prob, S, A->po_vert, A->cur.xw, A->po_obs, A->po_is2, A->cur.mp_valid, A->cur.outlier, t->po_chi2, t->po_state,
                      A->po_pose, A->po_result, nullptr, st);
   mark();                                                       // pose
   psk_trk_after_pose1(A, t->step, st); mark();                  // glue
-  psk_pj_launch(&t->pj_lm, S, cap, 0, st); mark();              // search
+  psk_pj_launch(&t->pj_lm, S, cap, 0, 0, st); mark();              // search
   psk_trk_after_lm(A, st); mark();                              // glue
   psk_pose_lm_launch(A->po_prob, S, A->po_vert, A->cur.xw, A->po_obs, A->po_is2, A->cur.mp_valid, A->cur.outlier, t->po_chi2, t->po_state,
                      A->po_pose, A->po_result, nullptr, st);
@@ -260,9 +260,14 @@ int ps_tracker_fetch(ps_tracker* t, int first_step, int nsteps, float* tcw, ps_t
   const size_t S = t->A.S;
   if (tcw && nsteps) PS_HIP(hipMemcpy(tcw, t->A.traj + (size_t)first_step * S * 16, (size_t)nsteps * S * 64, hipMemcpyDeviceToHost));
   if (stats && nsteps) PS_HIP(hipMemcpy(stats, t->A.stats + (size_t)first_step * S, (size_t)nsteps * S * sizeof(TrkStat), hipMemcpyDeviceToHost));
-  int32_t ovf = 0;
-  PS_HIP(hipMemcpy(&ovf, t->d_overflow, 4, hipMemcpyDeviceToHost));
-  if (ovf > 0) return ps_set_error(PS_ERR_CAPACITY, "%d search window(s) held more than %d candidates", ovf, PS_PJ_CAP);
+  std::vector<int32_t> ovf(S, 0);
+  PS_HIP(hipMemcpy(ovf.data(), t->d_overflow, S * 4, hipMemcpyDeviceToHost));
+  long total = 0;
+  int first = -1;
+  for (size_t k = 0; k < S; k++) { total += ovf[k]; if (ovf[k] && first < 0) first = (int)k; }
+  if (total > 0)
+    return ps_set_error(PS_ERR_CAPACITY, "%ld search window(s) held more than %d candidates (first in sequence %d): use the per-call matcher, which re-runs such "
+                        "problems with the wide candidate store", total, PS_PJ_CAP, first);
   return PS_OK;
 }
 
@@ -271,7 +276,7 @@ int ps_tracker_reset(ps_tracker* t) {
   PS_HIP(hipSetDevice(t->cfg.device));
   PS_HIP(hipStreamSynchronize(t->stream));
   PS_HIP(hipMemsetAsync(t->A.seq, 0, sizeof(TrkSeq) * t->A.S, t->stream));
-  PS_HIP(hipMemsetAsync(t->d_overflow, 0, 4, t->stream));
+  PS_HIP(hipMemsetAsync(t->d_overflow, 0, sizeof(int32_t) * t->A.S, t->stream));
   t->step = 0;
   return PS_OK;
 }

@@ -67,7 +67,7 @@ __device__ __forceinline__ void set_identity(float* m) {
 }
 
 __device__ void fill_search_common(PjProb& d, const TrkArrays& A, int s, int nt, int nq) {
-  d.t_off = s * A.cap; d.nt = nt; d.q_off = s * A.cap; d.nq = nq; d.grid_off = s * (PS_TRK_NCELL + 1);
+  d.t_off = s * A.cap; d.nt = nt; d.q_off = s * A.cap; d.c_off = d.q_off; d.nq = nq; d.grid_off = s * (PS_TRK_NCELL + 1);
   d.min_x = 0.f; d.min_y = 0.f; d.gw_inv = A.cam.gw_inv; d.gh_inv = A.cam.gh_inv;
   d.fx = A.cam.fx; d.fy = A.cam.fy; d.cx = A.cam.cx; d.cy = A.cam.cy; d.mbf = A.cam.mbf; d.mb = A.cam.mb;
   d.bounds[0] = 0.f; d.bounds[1] = (float)A.cam.w; d.bounds[2] = 0.f; d.bounds[3] = (float)A.cam.h;

@@ -155,8 +155,10 @@ def _fill_train(p, F, keep):
     return n
 
 
-def _search_by_projection(self, problems):
-    """problems: list of dicts, see SearchByProjectionFrame / SearchByProjectionPoints for the two layouts."""
+def _search_by_projection(self, problems, partial_ok=False):
+    """problems: list of dicts, see SearchByProjectionFrame / SearchByProjectionPoints for the two layouts.  partial_ok: when a
+    problem overflows even the wide candidate store the call fails with PS_ERR_CAPACITY after serving all the others; with
+    partial_ok the results come back anyway, nmatches = -1 marking the problems that failed."""
     n = len(problems)
     arr = (_ProjProblem * n)()
     keep, outs = [], []
@@ -198,7 +200,9 @@ def _search_by_projection(self, problems):
         out = np.full(max(nt, 1), -1, np.int32)
         p.match_of_train = out.ctypes.data
         keep.append(a); outs.append((out, nt))
-    check(lib.ps_search_by_projection(self._h, arr, n))
+    rc = lib.ps_search_by_projection(self._h, arr, n)
+    if not (partial_ok and rc == -3):
+        check(rc)
     return [(arr[i].nmatches, outs[i][0][:outs[i][1]].copy()) for i in range(n)]
 
 

@@ -95,6 +95,50 @@ def test_search_by_projection_all_variants(check_ori):
     m.close()
 
 
+def _dense_window_problem(seed, n_dense, n_queries=40):
+    """a points-mode problem whose queries all project into one spot crowded with n_dense level-0 features: every search window
+    holds n_dense candidates (the reference's GetFeaturesInArea has no limit; the first candidate store here holds 256)"""
+    from pointslot_amd.matcher import build_grid
+    sc = synth.projection_scene(seed, n=n_dense + 300, m=n_queries)
+    rng = np.random.default_rng(seed)
+    tr = dict(sc["train"])
+    for k in ("x", "y", "octave", "u_right", "occupied"):
+        tr[k] = np.array(tr[k])
+    tr["x"][:n_dense] = (300 + rng.uniform(-3, 3, n_dense)).astype(np.float32)
+    tr["y"][:n_dense] = (150 + rng.uniform(-3, 3, n_dense)).astype(np.float32)
+    tr["octave"][:n_dense] = 0
+    tr["u_right"][:n_dense] = -1
+    tr["occupied"][:n_dense] = 0
+    tr["cell_off"], tr["cell_idx"] = build_grid(tr["x"], tr["y"], *tr["grid"])
+    q = {k: np.array(v) for k, v in sc["points_query"].items()}
+    q["proj_x"][:] = 300; q["proj_y"][:] = 150; q["proj_xr"][:] = 250; q["level"][:] = 0; q["view_cos"][:] = 0.9; q["valid"][:] = 1
+    # queries look like the dense features: real competition for the same trains, order dependence included
+    q["desc"] = np.array(tr["desc"])[rng.integers(0, n_dense, len(q["valid"]))].copy()
+    q["desc"][:, 0] ^= rng.integers(0, 4, len(q["valid"])).astype(np.uint8)
+    return {"train": tr, "scale_factors": sc["scale_factors"], "mode": "points", "query": q, "th": 1.0}
+
+
+def test_search_windows_beyond_the_first_candidate_store(matcher):
+    """one over-full window used to fail the whole batch.  Now such a problem runs again with the wide store and is
+    exact; only a window beyond 1024 candidates fails - that problem alone."""
+    frame, pts, _, _ = _scene_problems(0x51070020)
+    dense = _dense_window_problem(77, 700)
+    res = matcher.SearchByProjection([frame, dense, pts])
+    for pr, (n, out) in zip([frame, dense, pts], res):
+        no, oo = oracle_lib.search_projection_frame(pr, True) if pr["mode"] == "frame" else oracle_lib.search_projection_points(pr, 0.9)
+        assert n == no and np.array_equal(out, oo), (pr["mode"], n, no)
+    assert res[1][0] >= 20
+    hopeless = _dense_window_problem(78, 1300)
+    with pytest.raises(Exception, match="more than 1024 candidates"):
+        matcher.SearchByProjection([frame, hopeless])
+    res = matcher.SearchByProjection([frame, hopeless, dense], partial_ok=True)
+    assert res[1][0] == -1 and np.all(res[1][1] == -1)
+    for k in (0, 2):
+        pr = [frame, hopeless, dense][k]
+        no, oo = oracle_lib.search_projection_frame(pr, True) if pr["mode"] == "frame" else oracle_lib.search_projection_points(pr, 0.9)
+        assert res[k][0] == no and np.array_equal(res[k][1], oo)
+
+
 def test_matchers_with_empty_inputs(matcher):
     from pointslot_amd.matcher import build_grid
     p = synth.bruteforce_problem(3, 0, 12)                      # no queries
