@@ -95,6 +95,14 @@ int ps_orb_level_size(const ps_orb* h, int w, int hgt, int level, int32_t* w_l, 
 int ps_orb_extract(ps_orb* h, const uint8_t* img, int w, int hgt, int stride, ps_keypoint* kps,
                    uint8_t* desc, int cap, int* n, uint8_t* const* pyramid_out);
 
+/* The object features of a frame — Frame::ExtractObjORB -> OpencvORBDetector (/root/reference/src/Frame.cc:2623-2665):
+ * cv::ORB::create(1000, 1.2, 8, 19)->detectAndCompute(im, ObjMask, kp, descriptor).  SURVEY.md 8f-2: OpenCV's own ORB (Harris
+ * ranking, its own pyramid) is a different extractor; this entry point is the DECLARED STAND-IN - this library's pipeline on a
+ * handle created with (1000, 1.2, 8, 20, 5), keypoints whose level-0 pixel lies outside `mask` (zero bytes) dropped before the
+ * quadtree - so object keypoint sets differ from a true PointSLOT run.  mask == NULL: no mask. */
+int ps_orb_extract_masked(ps_orb* h, const uint8_t* img, const uint8_t* mask, int w, int hgt, int stride, int mask_stride,
+                          ps_keypoint* kps, uint8_t* desc, int cap, int* n);
+
 /* Batched, device-resident form of the same call: `nimg` images of identical size already in HBM
  * (image i at d_imgs + i * image_pitch, rows `stride` bytes apart).  Results stay in HBM inside the
  * handle; the call is asynchronous on `stream` (a hipStream_t, NULL = the handle's own stream). */

@@ -66,6 +66,10 @@ struct Extractor {
   std::vector<std::vector<KeyPoint>> kps;         // selected per level (level coords, oriented)
   std::vector<KeyPoint> out_kps;
   std::vector<uint8_t> out_desc;
+  // object-feature variant (the declared stand-in for cv::ORB + mask): candidates outside the mask are dropped
+  // before DistributeOctTree.  mask: level-0 image, non-zero = keep; nullptr = the plain extractor
+  const uint8_t* mask = nullptr;
+  int mask_stride = 0, img_w = 0, img_h = 0;
 };
 
 // ---- ctor tables: ORBextractor.cc:410-470 -------------------------------------------------------
@@ -522,6 +526,12 @@ void compute_keypoints(Extractor& E) {
         for (KeyPoint& kp : vKeysCell) {
           kp.x += j * wCell;
           kp.y += i * hCell;
+          if (E.mask) {   // the candidate's pixel in the level-0 image: cvRound(level coordinate * scale), clipped
+            const float sc = E.mvScaleFactor[level];
+            const int mx = std::min(std::max(cvRound((kp.x + minBorderX) * sc), 0), E.img_w - 1);
+            const int my = std::min(std::max(cvRound((kp.y + minBorderY) * sc), 0), E.img_h - 1);
+            if (E.mask[(size_t)my * E.mask_stride + mx] == 0) continue;
+          }
           vToDistributeKeys.push_back(kp);
         }
       }
@@ -652,6 +662,15 @@ int orc_orb_run(void* h, const uint8_t* img, int w, int hgt, int stride) {
   Extractor& E = *(Extractor*)h;
   if (!img || w <= 0 || hgt <= 0) { E.out_kps.clear(); E.out_desc.clear(); return 0; }
   run(E, img, w, hgt, stride);
+  return (int)E.out_kps.size();
+}
+// the object-feature stand-in: the same pipeline with the FAST candidates restricted to mask != 0 before the quadtree
+int orc_orb_run_masked(void* h, const uint8_t* img, int w, int hgt, int stride, const uint8_t* mask, int mask_stride) {
+  Extractor& E = *(Extractor*)h;
+  if (!img || w <= 0 || hgt <= 0) { E.out_kps.clear(); E.out_desc.clear(); return 0; }
+  E.mask = mask; E.mask_stride = mask_stride; E.img_w = w; E.img_h = hgt;
+  run(E, img, w, hgt, stride);
+  E.mask = nullptr;
   return (int)E.out_kps.size();
 }
 void orc_orb_result(void* h, void* kps28, uint8_t* desc) {

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
     while (pend) {
       const int i = __ffsll((long long)pend) - 1;
       pend &= pend - 1;
-      const int qi = q0 + i, q = P.q_off + qi;
+      const int qi = q0 + i;
       const int nc = __builtin_amdgcn_readlane(ncv, i);
       const int sb = __builtin_amdgcn_readlane(stale, i);
       // first (and, for the ratio test, second) of the four keys that nobody has claimed

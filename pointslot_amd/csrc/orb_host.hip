@@ -14,7 +14,7 @@
 
 extern "C" {
 void psk_orb_launch_pyramid(const OrbPlan*, int, uint8_t*, const uint8_t*, int, size_t, const int4*, int, hipStream_t);
-void psk_orb_launch_fast(const OrbPlan*, uint8_t*, int, hipStream_t);
+void psk_orb_launch_fast(const OrbPlan*, uint8_t*, int, const uint8_t*, int, size_t, hipStream_t);
 void psk_orb_launch_quadtree(const OrbPlan*, uint8_t*, int, hipStream_t);
 void psk_orb_launch_blur(const OrbPlan*, uint8_t*, int, hipStream_t);
 void psk_orb_launch_border(const OrbPlan*, uint8_t*, int, hipStream_t);
@@ -62,6 +62,9 @@ struct ps_orb {
   uint8_t* h_objkeys = nullptr;
   uint8_t* d_img = nullptr;       // staging for ps_orb_extract / ps_orb_extract_batch (host images)
   size_t d_img_bytes = 0;
+  // object-feature variant: masks of the images of the NEXT batch (ps_orb_extract_masked sets and clears it around its batch)
+  const uint8_t* d_mask = nullptr; int mask_stride = 0; size_t mask_pitch = 0;
+  uint8_t* d_mask_buf = nullptr; size_t d_mask_bytes = 0;
   uint8_t* h_frames = nullptr;    // pinned staging of ps_orb_stereo_fetch_frames
   size_t h_frames_bytes = 0;
   hipStream_t stream = nullptr;
@@ -315,7 +318,7 @@ int run_batch(ps_orb* h, const uint8_t* d_imgs, int nimg, int stride, size_t pit
       psk_orb_launch_border(P, arena, n, st);
     }
     if (tm) PS_HIP(hipEventRecord(ev[1], st));
-    psk_orb_launch_fast(P, arena, n, st);
+    psk_orb_launch_fast(P, arena, n, h->d_mask ? h->d_mask + (size_t)i0 * h->mask_pitch : nullptr, h->mask_stride, h->mask_pitch, st);
     if (tm) PS_HIP(hipEventRecord(ev[2], st));
     psk_orb_launch_quadtree(P, arena, n, st);
     if (tm) PS_HIP(hipEventRecord(ev[3], st));
@@ -366,6 +369,7 @@ void ps_orb_destroy(ps_orb* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   free_device(h);
   if (h->d_img) hipFree(h->d_img);
+  if (h->d_mask_buf) hipFree(h->d_mask_buf);
   for (int r = 0; r < ps_orb::RING; r++)
     for (int c = 0; c < ps_orb::MAXCHUNK; c++)
       for (int i = 0; i <= ST_COUNT; i++) if (h->ev[r][c][i]) hipEventDestroy(h->ev[r][c][i]);
@@ -476,6 +480,33 @@ int ps_orb_extract(ps_orb* h, const uint8_t* img, int w, int hgt, int stride, ps
     }
   }
   return PS_OK;
+}
+
+// The object features of a frame (Frame::ExtractObjORB -> OpencvORBDetector, /root/reference/src/Frame.cc:2623-2665): the
+// reference runs OpenCV's own cv::ORB::create(1000, 1.2, 8, 19)->detectAndCompute(im, ObjMask, kp, descriptor).  This entry point
+// is the declared stand-in of SURVEY.md 8f-2: THIS extractor's pipeline (a2-a8) on the image, with the FAST keypoints whose
+// level-0 pixel lies outside the mask dropped before DistributeOctTree, so that the per-level quotas are spent inside the mask.
+int ps_orb_extract_masked(ps_orb* h, const uint8_t* img, const uint8_t* mask, int w, int hgt, int stride, int mask_stride, ps_keypoint* kps,
+                          uint8_t* desc, int cap, int* n) {
+  if (!h || !n) return ps_set_error(PS_ERR_INVALID, "ps_orb_extract_masked: null argument");
+  *n = 0;
+  if (!img || w <= 0 || hgt <= 0) return PS_OK;
+  if (!mask) return ps_orb_extract(h, img, w, hgt, stride, kps, desc, cap, n, nullptr);   // detectAndCompute with an empty mask
+  if (stride < w || mask_stride < w) return ps_set_error(PS_ERR_INVALID, "stride < width");
+  PS_HIP(hipSetDevice(h->cfg.device));
+  const size_t mbytes = (size_t)mask_stride * hgt;
+  if (mbytes > h->d_mask_bytes) {
+    PS_HIP(hipStreamSynchronize(h->stream));
+    if (h->d_mask_buf) hipFree(h->d_mask_buf);
+    h->d_mask_buf = nullptr; h->d_mask_bytes = 0;
+    PS_HIP(hipMalloc(&h->d_mask_buf, mbytes));
+    h->d_mask_bytes = mbytes;
+  }
+  PS_HIP(hipMemcpyAsync(h->d_mask_buf, mask, mbytes, hipMemcpyHostToDevice, h->stream));
+  h->d_mask = h->d_mask_buf; h->mask_stride = mask_stride; h->mask_pitch = mbytes;
+  const int rc = ps_orb_extract(h, img, w, hgt, stride, kps, desc, cap, n, nullptr);
+  h->d_mask = nullptr;
+  return rc;
 }
 
 int ps_orb_extract_batch(ps_orb* h, const uint8_t* const* imgs, int nimg, int w, int hgt, int stride) {

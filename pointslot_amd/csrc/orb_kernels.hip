@@ -513,7 +513,8 @@ __global__ void fast_prof_dump() {
 #endif
 typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
 typedef short fs_s2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int QS, int nimg, int bpi) {
+__global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int QS, int nimg, int bpi,
+                                                         const uint8_t* masks, int mask_stride, size_t mask_pitch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform geometry stays on the scalar unit
   int img, lb;
@@ -717,7 +718,15 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   for (int i0 = 0; i0 < ncand; i0 += 64) {
     const int idx = i0 + lane;
     const int pv = idx < ncand ? list[idx] : 0;
-    const bool keep = (pv & 0x8000) != 0;
+    bool keep = (pv & 0x8000) != 0;
+    if (masks && keep) {
+      // object-feature variant (SURVEY.md 8f-2 stand-in): a keypoint whose pixel in the level-0 image - cvRound(level
+      // coordinate * scale), clipped - lies outside the mask never reaches the quadtree
+      const int px = (pv & 127) + 3 + ci_x * L.w_cell + PS_MINB, py = ((pv >> 7) & 127) + 3 + ci_y * L.h_cell + PS_MINB;
+      const int mx = min(max(__float2int_rn(__fmul_rn((float)px, L.scale)), 0), plan.img_w - 1);
+      const int my = min(max(__float2int_rn(__fmul_rn((float)py, L.scale)), 0), plan.img_h - 1);
+      keep = masks[(size_t)img * mask_pitch + (size_t)my * mask_stride + mx] != 0;
+    }
     const unsigned long long km = __ballot(keep);
     if (keep) {
       const int pos = total + __popcll(km & ltmask);
@@ -1387,7 +1396,7 @@ extern "C" void psk_orb_launch_level_fused(const OrbPlan* plan, int level, uint8
 extern "C" void psk_orb_launch_border(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   hipLaunchKernelGGL(orb_border, dim3(plan->border_blocks, nimg), dim3(256), 0, st, *plan, arena);
 }
-extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
+extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nimg, const uint8_t* masks, int mask_stride, size_t mask_pitch, hipStream_t st) {
   // LDS geometry from the largest cell window of the plan
   int mw = 0, mh = 0;
   for (int l = 0; l < plan->nlevels; l++) {
@@ -1400,7 +1409,7 @@ extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nim
   const int per_wave = (TR * TS + SS * (TR - 4) + 2 * LCAP + 16 + 3 + QS * (TR - 6) + 15) & ~15;
   const int bpi = (plan->n_cells + 3) / 4;
   hipLaunchKernelGGL(orb_fast_cells, PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)per_wave * 4, st, *plan, arena,
-                     TS, TR, SS, LCAP, QS, nimg, bpi);
+                     TS, TR, SS, LCAP, QS, nimg, bpi, masks, mask_stride, mask_pitch);
 #ifdef PS_FAST_PROFILE
   hipLaunchKernelGGL(fast_prof_dump, dim3(1), dim3(1024), 0, st);
 #endif

@@ -29,6 +29,8 @@ lib.ps_orb_level_size.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c
 lib.ps_orb_extract.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                ctypes.c_void_p]
+lib.ps_orb_extract_masked.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 lib.ps_orb_extract_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
 lib.ps_orb_batch_device_outputs.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
@@ -99,6 +101,21 @@ class ORBextractor:
         wl, hl = ctypes.c_int32(), ctypes.c_int32()
         check(lib.ps_orb_level_size(self._h, w, h, level, ctypes.byref(wl), ctypes.byref(hl)))
         return wl.value, hl.value
+
+    def detect_masked(self, image, mask):
+        """The object features of a frame (Frame::ExtractObjORB, /root/reference/src/Frame.cc:2623-2665) through the declared
+        stand-in for cv::ORB + mask (ps_orb_extract_masked): this extractor's pipeline, keypoints outside the mask (zero
+        bytes) dropped before the quadtree.  Returns (keypoints, descriptors)."""
+        image = np.ascontiguousarray(image); mask = np.ascontiguousarray(mask)
+        if image.dtype != np.uint8 or image.ndim != 2 or mask.shape != image.shape or mask.dtype != np.uint8:
+            raise AssertionError("image and mask must be CV_8UC1 of the same size")
+        h, w = image.shape
+        kps = np.zeros(self.capacity, KEYPOINT_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n = ctypes.c_int(0)
+        check(lib.ps_orb_extract_masked(self._h, image.ctypes.data, mask.ctypes.data, w, h, image.strides[0], mask.strides[0], kps.ctypes.data,
+                                        desc.ctypes.data, self.capacity, ctypes.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
 
     def __call__(self, image, mask=None):
         """operator()(image, mask /*ignored*/, keypoints, descriptors).  Returns (keypoints, descriptors);

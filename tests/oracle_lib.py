@@ -92,6 +92,16 @@ class OracleORB:
         self.L.orc_orb_result(self.h, kps.ctypes.data, desc.ctypes.data)
         return kps[:n], desc[:n]
 
+    def run_masked(self, img, mask):
+        img = np.ascontiguousarray(img); mask = np.ascontiguousarray(mask)
+        self.L.orc_orb_run_masked.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        n = self.L.orc_orb_run_masked(self.h, img.ctypes.data, img.shape[1], img.shape[0], img.strides[0], mask.ctypes.data, mask.strides[0])
+        self.last_n = n
+        kps = np.zeros(max(n, 1), KEYPOINT_DTYPE)
+        desc = np.zeros((max(n, 1), 32), np.uint8)
+        self.L.orc_orb_result(self.h, kps.ctypes.data, desc.ctypes.data)
+        return kps[:n], desc[:n]
+
     def level_dims(self, l):
         w, h = ctypes.c_int(), ctypes.c_int()
         self.L.orc_orb_level_dims(self.h, l, ctypes.byref(w), ctypes.byref(h))

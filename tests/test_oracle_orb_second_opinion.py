@@ -61,3 +61,30 @@ def test_fast_candidates_and_quadtree(runs, name):
         assert np.array_equal(np.stack([kp["x"], kp["y"], kp["response"]], 1).astype(np.int32), sel + np.array([so.EDGE - 3, so.EDGE - 3, 0], np.int32))
         total += len(sel)
     assert total >= 1900
+
+
+def test_masked_object_features_definition():
+    """the 8f-2 stand-in (oracle: orc_orb_run_masked): FAST candidates whose level-0 pixel lies outside the mask are dropped before
+    the quadtree - restated here on the second opinion's candidates"""
+    img = _images()["kitti"]
+    mask = np.zeros_like(img)
+    mask[80:330, 300:900] = 255
+    mask[100:200, 500:700] = 0                                   # a hole
+    orc = oracle_lib.OracleORB(1000)
+    kps, _ = orc.run_masked(img, mask)
+    sf, _ = so.scale_tables()
+    _, quota, _ = orc.tables()
+    total = 0
+    for l, lv in enumerate(so.pyramid(img)):
+        cand = so.fast_cells(lv)
+        lx = np.rint((cand[:, 0] + so.EDGE - 3).astype(np.float32) * sf[l]).astype(int).clip(0, img.shape[1] - 1)
+        ly = np.rint((cand[:, 1] + so.EDGE - 3).astype(np.float32) * sf[l]).astype(int).clip(0, img.shape[0] - 1)
+        cand = cand[mask[ly, lx] != 0]
+        h, w = lv.shape
+        sel = so.distribute(cand, so.EDGE - 3, w - so.EDGE + 3, so.EDGE - 3, h - so.EDGE + 3, int(quota[l])) if len(cand) else np.zeros((0, 3), np.int32)
+        kp = orc.level_keypoints(l)
+        assert len(kp) == len(sel), (l, len(kp), len(sel))
+        if len(sel):
+            assert np.array_equal(np.stack([kp["x"], kp["y"], kp["response"]], 1).astype(np.int32), sel + np.array([so.EDGE - 3, so.EDGE - 3, 0], np.int32))
+        total += len(sel)
+    assert total == len(kps) and total > 300

@@ -331,3 +331,36 @@ def test_randomised_extractor_sweep():
     r = subprocess.run([sys.executable, tool, "5", "14"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_object_features_masked_stand_in():
+    """SURVEY.md 8f-2, the declared stand-in for cv::ORB::create(1000, 1.2, 8, 19)->detectAndCompute(im, ObjMask, ...)
+    (Frame.cc:2623-2665): this extractor with the keypoints outside the instance mask dropped before the quadtree - bit-exact
+    against the CPU restatement of the same definition; a full mask equals the plain extractor, an empty one yields nothing."""
+    from pointslot_amd import sequence
+    from pointslot_amd.extractor import ORBextractor
+    seq = sequence.generate(n_frames=1, seed=9)
+    img = seq["left"][0]
+    mask = np.where((seq["seg"][0] != 0), 255, 0).astype(np.uint8)          # the two boxes' instance pixels
+    assert 2000 < (mask != 0).sum() < 40000
+    ex = ORBextractor(1000, 1.2, 8, 20, 5)
+    orc = OracleORB(1000)
+    big = np.zeros_like(mask); big[60:300, 200:1000] = 7                      # any non-zero value counts
+    for m in (mask, big):
+        kps, desc = ex.detect_masked(img, m)
+        ko, do = orc.run_masked(img, m)
+        assert len(kps) == len(ko) and len(kps) > 20
+        assert np.array_equal(kps.view(np.uint8), ko.view(np.uint8)) and np.array_equal(desc, do)
+        lx = np.clip(np.rint(kps["x"]).astype(int), 0, img.shape[1] - 1); ly = np.clip(np.rint(kps["y"]).astype(int), 0, img.shape[0] - 1)
+        assert np.all(m[ly, lx] != 0)                                          # every keypoint lies inside the mask
+    # the quota is spent inside the mask: more in-mask keypoints than the plain extractor leaves there
+    plain, _ = ex(img)
+    px = np.clip(np.rint(plain["x"]).astype(int), 0, img.shape[1] - 1); py = np.clip(np.rint(plain["y"]).astype(int), 0, img.shape[0] - 1)
+    kb, _ = ex.detect_masked(img, big)
+    assert len(kb) >= (big[py, px] != 0).sum()
+    full, dfull = ex.detect_masked(img, np.full_like(mask, 255))
+    pk, pd = ex(img)
+    assert np.array_equal(full.view(np.uint8), pk.view(np.uint8)) and np.array_equal(dfull, pd)
+    none, _ = ex.detect_masked(img, np.zeros_like(mask))
+    assert len(none) == 0
+    ex.close()
