@@ -479,9 +479,8 @@ __device__ __forceinline__ void wave_sync() {
 
 // One WAVE per FAST cell, four independent cells per workgroup, no workgroup barriers.
 //   A  the cell window (cell + 6) is copied to LDS with aligned dword loads
-//   B  every lane takes 4 horizontally adjacent pixels at a time (rows x 12 bytes from LDS, v_alignbyte) and applies
-//      a cheap necessary condition on the 8 even ring positions; survivors are compacted in raster order (__ballot +
-//      popcount prefix)
+//   B  every lane takes 4 horizontally adjacent pixels at a time (3 rows x 12 bytes from LDS) and applies a cheap necessary
+//      condition on the 4 compass points of the ring; survivors are compacted in raster order (ballot + mbcnt prefix)
 //   C  survivors are scored exactly (s > min_th <=> corner) and compacted again
 //   D  strict 3x3 NMS on the LDS score map, threshold fallback, raster-ordered emission into the cell's slots
 #define FAST_T 256
@@ -579,9 +578,7 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
   for (int t = lane; t < (SS * (ch + 2) + 3) / 4; t += 64) reinterpret_cast<uint32_t*>(smap)[t] = 0;
   wave_sync();
   FP_MARK(0);
-  // ---- B: cheap NECESSARY test on the 8 even ring positions, 4 pixels per lane and step.  Nine contiguous ring
-  // pixels always contain four consecutive even positions, so a pixel without 4 consecutive dark (or bright) even
-  // positions cannot be a corner at min_th; this rejects most pixels for ~1/3 of the full test's work. ----
+  // ---- B: cheap NECESSARY test on the 4 compass points of the ring, 4 pixels per lane and step (see below) ----
   const int ng = (cw + 3) >> 2, ntask = ch * ng;
   // exact for t < 65536 / ng: the error of the rounded-up reciprocal stays below 1 / ng (ntask is a few hundred)
   const uint32_t ng_recip = (65536u + (uint32_t)ng - 1u) / (uint32_t)ng;
@@ -600,43 +597,40 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     const int y = tv ? (int)(((uint32_t)t * ng_recip) >> 16) : 0, g = tv ? t - y * ng : 0;   // t / ng without the division sequence
     unsigned long long C[4];
     if (pass == 0) {
+    // rows -3, 0, +3 of the window hold the four compass points of the ring (N, E, S, W = ring positions 0, 4, 8, 12)
     uint32_t w[7][3];
 #pragma unroll
-    for (int r = 0; r < 7; r++) {
-      if (r == 2 || r == 4) continue;   // rows +-1 hold odd ring positions only
+    for (int r = 0; r < 7; r += 3) {
       const uint32_t* p = reinterpret_cast<const uint32_t*>(tile + (y + r) * TS + 4 * g);
       if (lshift == 0) {   // wave-uniform
-        w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
+        w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = r == 3 ? p[2] : 0u;
       } else {
-        const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+        const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = r == 3 ? p[3] : 0u;
         w[r][0] = __builtin_amdgcn_alignbyte(a1, a0, lshift);
         w[r][1] = __builtin_amdgcn_alignbyte(a2, a1, lshift);
         w[r][2] = __builtin_amdgcn_alignbyte(a3, a2, lshift);
       }
     }
-    // Two pixels per operation on packed u16.  "4 consecutive even positions all darker than v - th" is
-    //   min over the 8 windows of (max of the window) < v - th,  and for brighter  max over windows of (min) > v + th,
-    // so the ring values go through pk_max / pk_min trees untouched and the threshold enters in one packed subtraction.
+    // Two pixels per operation on packed u16.  Nine contiguous ring pixels always contain two ADJACENT compass points, so a
+    // corner at threshold t has two adjacent compass points both darker than v - t or both brighter than v + t:
+    //   min over the 4 adjacent pairs of (max of the pair) < v - t   or   max over the pairs of (min of the pair) > v + t.
+    // On natural images this rejects nearly as many pixels as the 8-even-position test it replaces (8.7 % vs 5.9 % pass at
+    // t = 20 on the KITTI frame) for a third of its operations; the ring values go through the pk_max / pk_min trees untouched
+    // and the threshold enters in one packed subtraction.
     uint32_t qpair[2];
 #pragma unroll
     for (int pq = 0; pq < 2; pq++) {
       const int i = 2 * pq;
 #define PAIR(r, b) __builtin_bit_cast(fs_us2, (b) <= 6 ? __builtin_amdgcn_perm(w[r][1], w[r][0], (uint32_t)(b) | 0x0c000c00u | ((uint32_t)((b) + 1) << 16)) \
                                                         : __builtin_amdgcn_perm(w[r][2], w[r][1], (uint32_t)((b) - 4) | 0x0c000c00u | ((uint32_t)((b) - 3) << 16)))
-      // even ring positions in OpenCV's order: (0,3) (2,2) (3,0) (2,-2) (0,-3) (-2,-2) (-3,0) (-2,2)
-      const fs_us2 P[8] = {PAIR(6, 3 + i), PAIR(5, 5 + i), PAIR(3, 6 + i), PAIR(1, 5 + i), PAIR(0, 3 + i), PAIR(1, 1 + i), PAIR(3, 0 + i), PAIR(5, 1 + i)};
+      const fs_us2 pN = PAIR(6, 3 + i), pE = PAIR(3, 6 + i), pS = PAIR(0, 3 + i), pW = PAIR(3, 0 + i);
       const fs_s2 cv = __builtin_bit_cast(fs_s2, PAIR(3, 3 + i));
 #undef PAIR
-      fs_us2 x2[8], n2[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) { x2[k] = __builtin_elementwise_max(P[k], P[(k + 1) & 7]); n2[k] = __builtin_elementwise_min(P[k], P[(k + 1) & 7]); }
-      fs_us2 M = __builtin_elementwise_max(x2[0], x2[2]), m = __builtin_elementwise_min(n2[0], n2[2]);
-#pragma unroll
-      for (int k = 1; k < 8; k++) {
-        M = __builtin_elementwise_min(M, __builtin_elementwise_max(x2[k], x2[(k + 2) & 7]));
-        m = __builtin_elementwise_max(m, __builtin_elementwise_min(n2[k], n2[(k + 2) & 7]));
-      }
-      // four consecutive darker <=> M < v - th <=> th < v - M; brighter <=> th < m - v: the pixel passes at every threshold
+      const fs_us2 M = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(pN, pE), __builtin_elementwise_max(pE, pS)),
+                                                 __builtin_elementwise_min(__builtin_elementwise_max(pS, pW), __builtin_elementwise_max(pW, pN)));
+      const fs_us2 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(pN, pE), __builtin_elementwise_min(pE, pS)),
+                                                 __builtin_elementwise_max(__builtin_elementwise_min(pS, pW), __builtin_elementwise_min(pW, pN)));
+      // two adjacent darker <=> M < v - th <=> th < v - M; brighter <=> th < m - v: the pixel passes at every threshold
       // below q = max(v - M, m - v), which does not depend on th - kept (one byte per pixel) for the minThFAST pass
       const fs_s2 zero2 = {0, 0};
       const fs_s2 qv = __builtin_elementwise_max(__builtin_elementwise_max(cv - __builtin_bit_cast(fs_s2, M), __builtin_bit_cast(fs_s2, m) - cv), zero2);
