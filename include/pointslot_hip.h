@@ -103,6 +103,25 @@ int ps_orb_extract(ps_orb* h, const uint8_t* img, int w, int hgt, int stride, ps
 int ps_orb_extract_masked(ps_orb* h, const uint8_t* img, const uint8_t* mask, int w, int hgt, int stride, int mask_stride,
                           ps_keypoint* kps, uint8_t* desc, int cap, int* n);
 
+/* ... and the detector itself: OpenCV 3.4.3's ORB_Impl::detectAndCompute (features2d/src/orb.cpp; firstLevel 0, WTA_K 2,
+ * HARRIS_SCORE, patchSize 31) restated for the GPU - INTER_LINEAR_EXACT pyramid and mask pyramid (threshold 254 above level 0),
+ * whole-image FAST-9/16 with non-maximum suppression, runByPixelsMask, runByImageBorder(edge_threshold), retainBest(2 N) by
+ * FAST score, Harris responses (7 x 7, k = 0.04), retainBest(N), intensity-centroid angles, 7 x 7 sigma-2 blur, 256-bit rBRIEF.
+ * Keypoints come out level by level in the order KeyPointsFilter::retainBest leaves them (std::nth_element / std::partition,
+ * executed on the host with the same library calls).  UNVERIFIABLE against OpenCV in the build image, like every OpenCV stage of
+ * the path; the CPU restatement it is tested against follows the same published source.
+ * Frame.cc:2625: cv::ORB::create(1000, 1.2, 8, 19) == ps_cvorb_create(1000, 1.2f, 8, 19, 20, device, &h). */
+typedef struct ps_cvorb ps_cvorb;
+int ps_cvorb_create(int nfeatures, float scale_factor, int nlevels, int edge_threshold, int fast_threshold, int device, ps_cvorb** out);
+void ps_cvorb_destroy(ps_cvorb* h);
+/* detectAndCompute(image, mask, keypoints, descriptors); mask == NULL: no mask (non-zero mask bytes keep a keypoint). */
+int ps_cvorb_detect_and_compute(ps_cvorb* h, const uint8_t* img, const uint8_t* mask, int w, int hgt, int stride, int mask_stride,
+                                ps_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* Test access to intermediates of the last call.  what: 0 level image (tight w x h), 1 blurred level, 2 level mask, 3 the FAST
+ * keypoints after the mask / border filters in raster order as float rows (x, y, score, Harris response), count in *n,
+ * 4 the level size as int32[2]. */
+int ps_cvorb_debug_read(ps_cvorb* h, int level, int what, void* out, size_t out_bytes, int* n);
+
 /* Batched, device-resident form of the same call: `nimg` images of identical size already in HBM
  * (image i at d_imgs + i * image_pitch, rows `stride` bytes apart).  Results stay in HBM inside the
  * handle; the call is asynchronous on `stream` (a hipStream_t, NULL = the handle's own stream). */

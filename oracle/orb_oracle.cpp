@@ -630,9 +630,281 @@ void run(Extractor& E, const uint8_t* img, int w, int h, int stride) {
   }
 }
 
+// =================================================================================================
+// cv::ORB::create(nfeatures, scaleFactor, nlevels, edgeThreshold)->detectAndCompute(image, mask, keypoints, descriptors)
+// as Frame::ExtractObjORB / OpencvORBDetector call it (/root/reference/src/Frame.cc:2623-2627): OpenCV's OWN
+// ORB - firstLevel 0, WTA_K 2, HARRIS_SCORE, patchSize 31, fastThreshold 20 - restated from OpenCV 3.4.3's
+// features2d/src/orb.cpp (ORB_Impl::detectAndCompute, computeKeyPoints, HarrisResponses, ICAngles, computeOrbDescriptors),
+// imgproc/src/resize.cpp (INTER_LINEAR_EXACT: resize_bitExact with ufixedpoint16 coefficients) and
+// features2d/src/keypoint.cpp (runByImageBorder, runByPixelsMask, retainBest).  UNVERIFIABLE HERE like every OpenCV stage of
+// this file (OpenCV is not in the image).  Known implementation dependence: KeyPointsFilter::retainBest leaves its survivors in
+// the order std::nth_element / std::partition produce - the restatement calls the same two algorithms of the same libstdc++.
+// =================================================================================================
+struct CvLevel { int w = 0, h = 0, stride = 0; float scale = 1.f; std::vector<uint8_t> pad, mask, blur; const uint8_t* roi() const { return pad.data() + (size_t)CV_BORDER * stride + CV_BORDER; } static const int CV_BORDER = 23; };
+
+// resize(src, dst, dsize, 0, 0, INTER_LINEAR_EXACT) on CV_8UC1: coefficients in 8.8 fixed point from IEEE-double source
+// coordinates, horizontal pass in 8.8 (u16), vertical pass in 16.16 (u32), one rounding (v + 2^15) >> 16
+void linear_exact_coeffs(int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& c0, std::vector<int>& c1, int& dmin, int& dmax) {
+  const double inv_scale = (double)dsize / ssize, scale = 1.0 / inv_scale;
+  ofs.assign(dsize, 0); c0.assign(dsize, 0); c1.assign(dsize, 0);
+  dmin = 0; dmax = dsize;
+  for (int val = 0; val < dsize; val++) {
+    const double fval = scale * ((double)val + 0.5) - 0.5;
+    const int ival = cvFloor(fval);
+    if (ival >= 0 && ssize > 1) {
+      if (ival < ssize - 1) {
+        ofs[val] = ival;
+        c1[val] = cvRound((fval - (double)ival) * 256.0);       // ufixedpoint16(softdouble)
+        c0[val] = 256 - c1[val];                                 // fixedpoint::one() - coeffs[1]
+      } else { ofs[val] = ssize - 1; dmax = std::min(dmax, val); }
+    } else dmin = std::max(dmin, val + 1);
+  }
+}
+void resize_linear_exact_8u(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride) {
+  std::vector<int> xo, xa0, xa1, yo, yb0, yb1;
+  int xmin, xmax, ymin, ymax;
+  linear_exact_coeffs(sw, dw, xo, xa0, xa1, xmin, xmax);
+  linear_exact_coeffs(sh, dh, yo, yb0, yb1, ymin, ymax);
+  auto hline = [&](int sy, std::vector<uint32_t>& out) {           // hlineResize<uint8_t, ufixedpoint16, 2>
+    const uint8_t* S = src + (size_t)sy * sstride;
+    out.resize(dw);
+    for (int x = 0; x < dw; x++) {
+      if (x < xmin) out[x] = (uint32_t)S[0] << 8;
+      else if (x >= xmax) out[x] = (uint32_t)S[sw - 1] << 8;
+      else out[x] = (uint32_t)xa0[x] * S[xo[x]] + (uint32_t)xa1[x] * S[xo[x] + 1];
+    }
+  };
+  std::vector<uint32_t> r0, r1;
+  for (int y = 0; y < dh; y++) {
+    uint8_t* D = dst + (size_t)y * dstride;
+    if (y < ymin || y >= ymax) {                                    // rows outside the source: the first / last row alone
+      hline(y < ymin ? 0 : sh - 1, r0);
+      for (int x = 0; x < dw; x++) D[x] = (uint8_t)std::min<uint32_t>((r0[x] + 128u) >> 8, 255u);
+      continue;
+    }
+    hline(yo[y], r0); hline(yo[y] + 1, r1);
+    for (int x = 0; x < dw; x++) {                                  // vlineResize: ufixedpoint16 * ufixedpoint16 -> 16.16, saturating cast
+      const uint64_t v = (uint64_t)r0[x] * (uint32_t)yb0[y] + (uint64_t)r1[x] * (uint32_t)yb1[y];
+      D[x] = (uint8_t)std::min<uint64_t>((v + 32768u) >> 16, 255u);
+    }
+  }
+}
+
+struct CvOrb {
+  int nfeatures = 1000, nlevels = 8, edgeThreshold = 19, fastThreshold = 20;
+  double scaleFactor = 1.2;
+  std::vector<CvLevel> levels;
+  std::vector<KeyPoint> kps;
+  std::vector<uint8_t> desc;
+  std::vector<std::vector<KeyPoint>> fast_all;   // diagnostics: per level, FAST keypoints after the mask / border filters (raster order), Harris in .angle
+};
+
+void cv_retain_best(std::vector<KeyPoint>& keypoints, int n_points) {   // KeyPointsFilter::retainBest (keypoint.cpp)
+  if (n_points >= 0 && keypoints.size() > (size_t)n_points) {
+    if (n_points == 0) { keypoints.clear(); return; }
+    std::nth_element(keypoints.begin(), keypoints.begin() + n_points - 1, keypoints.end(),
+                     [](const KeyPoint& a, const KeyPoint& b) { return a.response > b.response; });
+    const float ambiguous_response = keypoints[n_points - 1].response;
+    auto new_end = std::partition(keypoints.begin() + n_points, keypoints.end(), [ambiguous_response](const KeyPoint& k) { return k.response >= ambiguous_response; });
+    keypoints.resize(new_end - keypoints.begin());
+  }
+}
+
+void cv_orb_run(CvOrb& O, const uint8_t* img, int w, int h, int stride, const uint8_t* mask, int mask_stride) {
+  const int B = CvLevel::CV_BORDER;   // max(edgeThreshold, descPatchSize = ceil(15 sqrt 2) = 22, HARRIS_BLOCK_SIZE / 2) + 1
+  O.levels.assign(O.nlevels, CvLevel());
+  O.kps.clear(); O.desc.clear();
+  // ---- pyramid: level l is resized from level l - 1 (level 1 from the image), REFLECT_101 border; the mask likewise with
+  // a zero border and, above level 0, threshold(254, TOZERO) ----
+  for (int l = 0; l < O.nlevels; l++) {
+    CvLevel& L = O.levels[l];
+    L.scale = (float)std::pow(O.scaleFactor, (double)l);            // getScale(level, firstLevel = 0, scaleFactor)
+    const float inv_scale = 1.0f / L.scale;
+    L.w = cvRound(w * inv_scale); L.h = cvRound(h * inv_scale);
+    L.stride = L.w + 2 * B;
+    L.pad.assign((size_t)L.stride * (L.h + 2 * B), 0);
+    uint8_t* roi = L.pad.data() + (size_t)B * L.stride + B;
+    if (l == 0) for (int y = 0; y < h; y++) std::memcpy(roi + (size_t)y * L.stride, img + (size_t)y * stride, w);
+    else resize_linear_exact_8u(O.levels[l - 1].roi(), O.levels[l - 1].w, O.levels[l - 1].h, O.levels[l - 1].stride, roi, L.w, L.h, L.stride);
+    for (int y = -B; y < L.h + B; y++)
+      for (int x = -B; x < L.w + B; x++)
+        if (y < 0 || y >= L.h || x < 0 || x >= L.w) roi[(ptrdiff_t)y * L.stride + x] = roi[(ptrdiff_t)reflect101(y, L.h) * L.stride + reflect101(x, L.w)];
+    if (mask) {
+      L.mask.assign((size_t)L.w * L.h, 0);
+      if (l == 0) for (int y = 0; y < h; y++) std::memcpy(&L.mask[(size_t)y * w], mask + (size_t)y * mask_stride, w);
+      else {
+        resize_linear_exact_8u(O.levels[l - 1].mask.data(), O.levels[l - 1].w, O.levels[l - 1].h, O.levels[l - 1].w, L.mask.data(), L.w, L.h, L.w);
+        for (uint8_t& m : L.mask) m = m > 254 ? m : 0;
+      }
+    }
+  }
+  // ---- computeKeyPoints ----
+  std::vector<int> nfeaturesPerLevel(O.nlevels);
+  {
+    const float factor = (float)(1.0 / O.scaleFactor);
+    float ndesired = O.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)O.nlevels));
+    int sum = 0;
+    for (int l = 0; l < O.nlevels - 1; l++) { nfeaturesPerLevel[l] = cvRound(ndesired); sum += nfeaturesPerLevel[l]; ndesired *= factor; }
+    nfeaturesPerLevel[O.nlevels - 1] = std::max(O.nfeatures - sum, 0);
+  }
+  std::vector<int> umax(HALF_PATCH_SIZE + 2);
+  {
+    int v, v0, vmax = cvFloor(HALF_PATCH_SIZE * std::sqrt(2.f) / 2 + 1), vmin = cvCeil(HALF_PATCH_SIZE * std::sqrt(2.f) / 2);
+    for (v = 0; v <= vmax; ++v) umax[v] = cvRound(std::sqrt((double)HALF_PATCH_SIZE * HALF_PATCH_SIZE - v * v));
+    for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
+  }
+  std::vector<KeyPoint> all;
+  std::vector<int> counters(O.nlevels);
+  O.fast_all.assign(O.nlevels, {});
+  for (int l = 0; l < O.nlevels; l++) {
+    const CvLevel& L = O.levels[l];
+    std::vector<KeyPoint> kp;
+    fast9_16_nms(L.roi(), L.w, L.h, L.stride, O.fastThreshold, kp);                // FastFeatureDetector::detect ...
+    if (mask) {                                                                      // ... then KeyPointsFilter::runByPixelsMask
+      std::vector<KeyPoint> in;
+      for (const KeyPoint& k : kp) if (L.mask[(size_t)(int)(k.y + 0.5f) * L.w + (int)(k.x + 0.5f)] != 0) in.push_back(k);
+      kp.swap(in);
+    }
+    {                                                                                // KeyPointsFilter::runByImageBorder(edgeThreshold)
+      std::vector<KeyPoint> in;
+      const int b = O.edgeThreshold;
+      if (L.h > 2 * b && L.w > 2 * b)
+        for (const KeyPoint& k : kp) if (k.x >= b && k.x < L.w - b && k.y >= b && k.y < L.h - b) in.push_back(k);
+      kp.swap(in);
+    }
+    O.fast_all[l] = kp;
+    cv_retain_best(kp, 2 * nfeaturesPerLevel[l]);                                   // HARRIS_SCORE: twice the quota by FAST score
+    counters[l] = (int)kp.size();
+    for (KeyPoint& k : kp) { k.octave = l; k.size = PATCH_SIZE * L.scale; }
+    all.insert(all.end(), kp.begin(), kp.end());
+  }
+  if (all.empty()) return;
+  // HarrisResponses(imagePyramid, layerInfo, allKeypoints, 7, 0.04f)
+  auto harris = [&](const KeyPoint& k) {
+    const CvLevel& L = O.levels[k.octave];
+    const int blockSize = 7, r = blockSize / 2, step = L.stride;
+    const float scale = 1.f / ((1 << 2) * blockSize * 255.f), scale_sq_sq = scale * scale * scale * scale;
+    const uint8_t* ptr0 = L.roi() + (ptrdiff_t)(cvRound(k.y) - r) * step + cvRound(k.x) - r;
+    int a = 0, b = 0, c = 0;
+    for (int i = 0; i < blockSize; i++)
+      for (int j = 0; j < blockSize; j++) {
+        const uint8_t* ptr = ptr0 + i * step + j;
+        const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-step + 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[step - 1]);
+        const int Iy = (ptr[step] - ptr[-step]) * 2 + (ptr[step - 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[-step + 1]);
+        a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+      }
+    return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+  };
+  for (int l = 0; l < O.nlevels; l++) for (KeyPoint& k : O.fast_all[l]) { KeyPoint t = k; t.octave = l; k.angle = harris(t); }
+  for (KeyPoint& k : all) k.response = harris(k);
+  std::vector<KeyPoint> best;
+  int offset = 0;
+  for (int l = 0; l < O.nlevels; l++) {
+    std::vector<KeyPoint> kp(all.begin() + offset, all.begin() + offset + counters[l]);
+    offset += counters[l];
+    cv_retain_best(kp, nfeaturesPerLevel[l]);                                       // cull to the quota by the Harris score
+    best.insert(best.end(), kp.begin(), kp.end());
+  }
+  // ICAngles, then pt *= scale
+  for (KeyPoint& k : best) {
+    const CvLevel& L = O.levels[k.octave];
+    const uint8_t* center = L.roi() + (ptrdiff_t)cvRound(k.y) * L.stride + cvRound(k.x);
+    int m_01 = 0, m_10 = 0;
+    for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+    for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+      int v_sum = 0, d = umax[v];
+      for (int u = -d; u <= d; ++u) {
+        const int val_plus = center[u + v * L.stride], val_minus = center[u - v * L.stride];
+        v_sum += (val_plus - val_minus);
+        m_10 += u * (val_plus + val_minus);
+      }
+      m_01 += v * v_sum;
+    }
+    k.angle = fast_atan2((float)m_01, (float)m_10);
+  }
+  for (KeyPoint& k : best) { const float sc = O.levels[k.octave].scale; k.x *= sc; k.y *= sc; }
+  // ---- descriptors: GaussianBlur(7 x 7, sigma 2, REFLECT_101) of every level, then computeOrbDescriptors (WTA_K = 2) ----
+  int kq[7];
+  gaussian_kernel_q8(kq);
+  // (OpenCV blurs every level in place inside the padded pyramid buffer: the border around it keeps the unblurred REFLECT_101
+  // copies, which computeOrbDescriptors reads for pattern points that fall outside the level - blur is a padded plane too)
+  for (CvLevel& L : O.levels) {
+    L.blur = L.pad;
+    uint8_t* broi = L.blur.data() + (size_t)B * L.stride + B;
+    std::vector<uint16_t> hbuf((size_t)L.w * (L.h + 6));
+    for (int y = -3; y < L.h + 3; y++) {
+      const uint8_t* row = L.roi() + (ptrdiff_t)y * L.stride;     // rows / columns beyond the image: the REFLECT_101 border (23 >= 3)
+      for (int x = 0; x < L.w; x++) {
+        uint32_t sm = 0;
+        for (int i = 0; i < 7; i++) sm += (uint32_t)kq[i] * row[x + i - 3];
+        hbuf[(size_t)(y + 3) * L.w + x] = (uint16_t)std::min<uint32_t>(sm, 65535u);
+      }
+    }
+    for (int y = 0; y < L.h; y++)
+      for (int x = 0; x < L.w; x++) {
+        uint32_t sm = 0;
+        for (int j = 0; j < 7; j++) sm += (uint32_t)kq[j] * hbuf[(size_t)(y + j) * L.w + x];
+        broi[(size_t)y * L.stride + x] = (uint8_t)std::min<uint32_t>((sm + 32768u) >> 16, 255u);
+      }
+  }
+  O.kps = best;
+  O.desc.assign(best.size() * 32, 0);
+  for (size_t j = 0; j < best.size(); j++) {
+    const KeyPoint& kpt = best[j];
+    const CvLevel& L = O.levels[kpt.octave];
+    const float scale = 1.f / L.scale;
+    float angle = kpt.angle;
+    angle *= (float)(M_PI / 180.f);
+    const float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+    const uint8_t* center = L.blur.data() + (ptrdiff_t)(B + cvRound(kpt.y * scale)) * L.stride + B + cvRound(kpt.x * scale);
+    const int* pat = kPattern;
+    auto get = [&](int idx) -> int {
+      const float x = pat[idx * 2] * a - pat[idx * 2 + 1] * b, y = pat[idx * 2] * b + pat[idx * 2 + 1] * a;
+      return center[cvRound(y) * L.stride + cvRound(x)];
+    };
+    for (int i = 0; i < 32; ++i, pat += 32) {
+      int val = 0;
+      for (int t = 0; t < 8; t++) { const int t0 = get(2 * t), t1 = get(2 * t + 1); val |= (t0 < t1) << t; }
+      O.desc[j * 32 + i] = (uint8_t)val;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// cv::ORB::create(nfeatures, scaleFactor, nlevels, edgeThreshold)->detectAndCompute(image, mask, ...): see cv_orb_run above
+void* orc_cvorb_create(int nfeatures, float scaleFactor, int nlevels, int edgeThreshold, int fastThreshold) {
+  CvOrb* O = new CvOrb();
+  O->nfeatures = nfeatures; O->scaleFactor = (double)scaleFactor; O->nlevels = nlevels; O->edgeThreshold = edgeThreshold; O->fastThreshold = fastThreshold;
+  return O;
+}
+void orc_cvorb_destroy(void* h) { delete (CvOrb*)h; }
+int orc_cvorb_run(void* h, const uint8_t* img, int w, int hgt, int stride, const uint8_t* mask, int mask_stride) {
+  CvOrb& O = *(CvOrb*)h;
+  cv_orb_run(O, img, w, hgt, stride, mask, mask_stride);
+  return (int)O.kps.size();
+}
+void orc_cvorb_result(void* h, void* kps28, uint8_t* desc) {
+  CvOrb& O = *(CvOrb*)h;
+  if (!O.kps.empty()) { std::memcpy(kps28, O.kps.data(), O.kps.size() * sizeof(KeyPoint)); std::memcpy(desc, O.desc.data(), O.desc.size()); }
+}
+void orc_cvorb_level_dims(void* h, int level, int* w, int* hgt) { CvOrb& O = *(CvOrb*)h; *w = O.levels[level].w; *hgt = O.levels[level].h; }
+// level image without the border (tight w x h); what = 0 image, 1 blurred, 2 mask (zeros when no mask was given)
+void orc_cvorb_level_plane(void* h, int level, int what, uint8_t* out) {
+  const CvLevel& L = ((CvOrb*)h)->levels[level];
+  for (int y = 0; y < L.h; y++)
+    for (int x = 0; x < L.w; x++)
+      out[(size_t)y * L.w + x] = what == 0 ? L.roi()[(ptrdiff_t)y * L.stride + x]
+                               : (what == 1 ? L.blur[(size_t)(CvLevel::CV_BORDER + y) * L.stride + CvLevel::CV_BORDER + x] : (L.mask.empty() ? 0 : L.mask[(size_t)y * L.w + x]));
+}
+// FAST keypoints of a level after the mask and border filters, raster order: rows of (x, y, FAST score, Harris response) floats
+int orc_cvorb_level_fast(void* h, int level, float* out, int cap) {
+  const std::vector<KeyPoint>& v = ((CvOrb*)h)->fast_all[level];
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) { out[4 * i] = v[i].x; out[4 * i + 1] = v[i].y; out[4 * i + 2] = v[i].response; out[4 * i + 3] = v[i].angle; }
+  return (int)v.size();
+}
 
 void* orc_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) {
   Extractor* E = new Extractor();

@@ -1,0 +1,259 @@
+// Host side of the object-feature detector (include/pointslot_hip.h: ps_cvorb_*): OpenCV's own ORB as the reference calls it
+//   cv::ORB::create(1000, 1.2, 8, 19)->detectAndCompute(im, ObjMask, kp, descriptor)      /root/reference/src/Frame.cc:2623-2627
+// restated from OpenCV 3.4.3 (features2d/src/orb.cpp) - SURVEY.md 8f-2; unverifiable against OpenCV in this image.  Plan
+// (level sizes, INTER_LINEAR_EXACT coefficient tables), kernel orchestration, and the two KeyPointsFilter::retainBest steps,
+// which run here with std::nth_element / std::partition because their output order is whatever those algorithms leave.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "../../include/pointslot_hip.h"
+#include "cvorb_plan.h"
+#include "ps_common.h"
+
+extern "C" {
+void psk_cv_level0(const CvLevelDev*, const uint8_t*, int, const uint8_t*, int, hipStream_t);
+void psk_cv_resize(const CvLevelDev*, const CvLevelDev*, const int4*, const int4*, hipStream_t);
+void psk_cv_detect(const CvLevelDev*, int, int, int, int32_t*, hipStream_t);
+void psk_cv_blur(const CvLevelDev*, const int*, hipStream_t);
+void psk_cv_describe(const CvPlanDev*, const CvSel*, int, void*, uint8_t*, hipStream_t);
+}
+
+struct ps_cvorb {
+  int nfeatures, nlevels, edge, fast_th, device;
+  double scale_factor;
+  hipStream_t stream = nullptr;
+  int w = 0, h = 0;
+  bool planned = false;
+  CvPlanDev plan;                      // device pointers inside
+  std::vector<int> cap;                // candidate capacity per level
+  std::vector<int> quota;              // nfeaturesPerLevel
+  uint8_t* d_buf = nullptr;            // one arena: planes, tables, candidates, selections, outputs
+  uint8_t* d_img = nullptr; uint8_t* d_mask = nullptr;   // staged inputs
+  int4* d_xtab[CV_MAX_LEVELS] = {}; int4* d_ytab[CV_MAX_LEVELS] = {};
+  int32_t* d_total = nullptr;          // [nlevels]
+  CvSel* d_sel = nullptr; ps_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr;
+  int sel_cap = 0;
+  int kq[7];
+  // last call (for ps_cvorb_debug_read)
+  std::vector<std::vector<float>> last_cand;   // per level: rows of 4 floats
+  bool last_had_mask = false;
+};
+
+namespace {
+inline int cv_round(double v) { return (int)nearbyint(v); }
+inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
+inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
+
+// interpolationLinear<ufixedpoint16>::getCoeffs (resize.cpp): source offset and 8.8 weights per destination index
+void exact_table(int ssize, int dsize, std::vector<int4>& tab) {
+  const double inv_scale = (double)dsize / ssize, scale = 1.0 / inv_scale;
+  tab.assign(dsize, int4{0, 0, 0, 0});
+  int dmin = 0, dmax = dsize;
+  for (int val = 0; val < dsize; val++) {
+    const double fval = scale * ((double)val + 0.5) - 0.5;
+    const int ival = cv_floor(fval);
+    if (ival >= 0 && ssize > 1) {
+      if (ival < ssize - 1) {
+        const int c1 = cv_round((fval - (double)ival) * 256.0);
+        tab[val] = int4{ival, 256 - c1, c1, 0};
+      } else { tab[val] = int4{ssize - 1, 0, 0, 0}; dmax = std::min(dmax, val); }
+    } else dmin = std::max(dmin, val + 1);
+  }
+  for (int val = 0; val < dsize; val++) tab[val].w = val < dmin ? 1 : (val >= dmax ? 2 : 0);
+}
+
+void retain_best(std::vector<CvSel>& kp, int n_points) {   // KeyPointsFilter::retainBest (features2d/src/keypoint.cpp)
+  if (n_points >= 0 && kp.size() > (size_t)n_points) {
+    if (n_points == 0) { kp.clear(); return; }
+    std::nth_element(kp.begin(), kp.begin() + n_points - 1, kp.end(), [](const CvSel& a, const CvSel& b) { return a.response > b.response; });
+    const float ambiguous_response = kp[n_points - 1].response;
+    auto new_end = std::partition(kp.begin() + n_points, kp.end(), [ambiguous_response](const CvSel& k) { return k.response >= ambiguous_response; });
+    kp.resize(new_end - kp.begin());
+  }
+}
+
+int build_plan(ps_cvorb* h, int w, int hgt) {
+  if (h->d_buf) { hipFree(h->d_buf); h->d_buf = nullptr; }
+  CvPlanDev& P = h->plan;
+  memset(&P, 0, sizeof(P));
+  P.nlevels = h->nlevels;
+  {   // umax of the circular patch (orb.cpp computeKeyPoints)
+    const int hp = 15;
+    int v, v0, vmax = cv_floor(hp * sqrtf(2.f) / 2 + 1), vmin = cv_ceil(hp * sqrtf(2.f) / 2);
+    for (v = 0; v <= vmax; ++v) P.umax[v] = cv_round(sqrt((double)hp * hp - v * v));
+    for (v = hp, v0 = 0; v >= vmin; --v) { while (P.umax[v0] == P.umax[v0 + 1]) ++v0; P.umax[v] = v0; ++v0; }
+  }
+  h->quota.assign(h->nlevels, 0);
+  {
+    const float factor = (float)(1.0 / h->scale_factor);
+    float ndesired = h->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)h->nlevels));
+    int sum = 0;
+    for (int l = 0; l < h->nlevels - 1; l++) { h->quota[l] = cv_round(ndesired); sum += h->quota[l]; ndesired *= factor; }
+    h->quota[h->nlevels - 1] = std::max(h->nfeatures - sum, 0);
+  }
+  std::vector<std::vector<int4>> xt(h->nlevels), yt(h->nlevels);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += al(bytes + 64); return r; };
+  struct Ofs { size_t pad, blur, mask, score, rowcnt, rowoff, cand, xtab, ytab; };
+  std::vector<Ofs> ofs(h->nlevels);
+  h->cap.assign(h->nlevels, 0);
+  for (int l = 0; l < h->nlevels; l++) {
+    CvLevelDev& L = P.lv[l];
+    L.scale = (float)pow(h->scale_factor, (double)l);
+    const float inv_scale = 1.0f / L.scale;
+    L.w = cv_round(w * inv_scale); L.h = cv_round(hgt * inv_scale);
+    if (L.w <= 2 * h->edge || L.h <= 2 * h->edge || L.w <= 2 * 16 || L.h <= 2 * 16)
+      return ps_set_error(PS_ERR_INVALID, "image %dx%d: level %d is %dx%d, too small for the detector", w, hgt, l, L.w, L.h);
+    L.stride = (int)((L.w + 2 * CV_BORDER + 63) / 64 * 64);
+    h->cap[l] = ((L.w + 1) / 2) * ((L.h + 1) / 2);            // strict 3 x 3 maxima: at most one per 2 x 2 block
+    ofs[l].pad = take((size_t)L.stride * (L.h + 2 * CV_BORDER)); ofs[l].blur = take((size_t)L.stride * (L.h + 2 * CV_BORDER)); ofs[l].mask = take((size_t)L.w * L.h);
+    ofs[l].score = take((size_t)L.w * L.h); ofs[l].rowcnt = take((size_t)L.h * 4); ofs[l].rowoff = take((size_t)L.h * 4);
+    ofs[l].cand = take((size_t)h->cap[l] * 16);
+    if (l > 0) {
+      exact_table(P.lv[l - 1].w, L.w, xt[l]); exact_table(P.lv[l - 1].h, L.h, yt[l]);
+      ofs[l].xtab = take(xt[l].size() * 16); ofs[l].ytab = take(yt[l].size() * 16);
+    }
+  }
+  const size_t o_img = take((size_t)w * hgt), o_mask = take((size_t)w * hgt), o_total = take(h->nlevels * 4);
+  h->sel_cap = 0;
+  for (int l = 0; l < h->nlevels; l++) h->sel_cap += h->cap[l];   // ties may keep more than the quota; bounded by the candidates
+  h->sel_cap = std::min(h->sel_cap, 16 * h->nfeatures + 4096);
+  const size_t o_sel = take((size_t)h->sel_cap * sizeof(CvSel)), o_kps = take((size_t)h->sel_cap * sizeof(ps_keypoint)), o_desc = take((size_t)h->sel_cap * 32);
+  PS_HIP(hipMalloc(&h->d_buf, off));
+  PS_HIP(hipMemsetAsync(h->d_buf, 0, off, h->stream));
+  uint8_t* D = h->d_buf;
+  for (int l = 0; l < h->nlevels; l++) {
+    CvLevelDev& L = P.lv[l];
+    L.pad = D + ofs[l].pad; L.blur = D + ofs[l].blur; L.mask = D + ofs[l].mask; L.score = D + ofs[l].score;
+    L.rowcnt = (int32_t*)(D + ofs[l].rowcnt); L.rowoff = (int32_t*)(D + ofs[l].rowoff); L.cand = (float4*)(D + ofs[l].cand);
+    if (l > 0) {
+      h->d_xtab[l] = (int4*)(D + ofs[l].xtab); h->d_ytab[l] = (int4*)(D + ofs[l].ytab);
+      PS_HIP(hipMemcpyAsync(h->d_xtab[l], xt[l].data(), xt[l].size() * 16, hipMemcpyHostToDevice, h->stream));
+      PS_HIP(hipMemcpyAsync(h->d_ytab[l], yt[l].data(), yt[l].size() * 16, hipMemcpyHostToDevice, h->stream));
+    }
+  }
+  h->d_img = D + o_img; h->d_mask = D + o_mask; h->d_total = (int32_t*)(D + o_total);
+  h->d_sel = (CvSel*)(D + o_sel); h->d_kps = (ps_keypoint*)(D + o_kps); h->d_desc = D + o_desc;
+  PS_HIP(hipStreamSynchronize(h->stream));   // the tables above are read from vectors that go out of scope
+  h->w = w; h->h = hgt; h->planned = true;
+  return PS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ps_cvorb_create(int nfeatures, float scale_factor, int nlevels, int edge_threshold, int fast_threshold, int device, ps_cvorb** out) {
+  if (!out) return ps_set_error(PS_ERR_INVALID, "null argument");
+  if (nfeatures < 1 || !(scale_factor > 1.f) || nlevels < 1 || nlevels > CV_MAX_LEVELS || edge_threshold < 3 || edge_threshold > CV_BORDER - 4 || fast_threshold < 1 || fast_threshold > 254)
+    return ps_set_error(PS_ERR_INVALID, "ps_cvorb_create: unsupported configuration (1..8 levels, edge threshold 3..19)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ps_set_error(PS_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return ps_set_error(PS_ERR_INVALID, "bad device ordinal");
+  PS_HIP(hipSetDevice(device));
+  ps_cvorb* h = new ps_cvorb();
+  h->nfeatures = nfeatures; h->nlevels = nlevels; h->edge = edge_threshold; h->fast_th = fast_threshold; h->device = device;
+  h->scale_factor = (double)scale_factor;   // ORB::create takes a float, ORB_Impl keeps a double
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return ps_set_error(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  {   // getGaussianKernel(7, 2) in 8.8 fixed point
+    double v[7], sum = 0;
+    for (int i = 0; i < 7; i++) { const double x = i - 3; v[i] = exp(-0.5 * x * x / 4.0); sum += v[i]; }
+    for (int i = 0; i < 7; i++) h->kq[i] = cv_round(v[i] / sum * 256.0);
+  }
+  *out = h;
+  return PS_OK;
+}
+
+void ps_cvorb_destroy(ps_cvorb* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
+  if (h->d_buf) hipFree(h->d_buf);
+  delete h;
+}
+
+int ps_cvorb_detect_and_compute(ps_cvorb* h, const uint8_t* img, const uint8_t* mask, int w, int hgt, int stride, int mask_stride, ps_keypoint* kps,
+                                uint8_t* desc, int cap, int* n) {
+  if (!h || !n) return ps_set_error(PS_ERR_INVALID, "ps_cvorb_detect_and_compute: null argument");
+  *n = 0;
+  if (!img || w <= 0 || hgt <= 0) return PS_OK;
+  if (stride < w || (mask && mask_stride < w)) return ps_set_error(PS_ERR_INVALID, "stride < width");
+  PS_HIP(hipSetDevice(h->device));
+  if (!h->planned || h->w != w || h->h != hgt) {
+    int rc = build_plan(h, w, hgt);
+    if (rc != PS_OK) return rc;
+  }
+  hipStream_t st = h->stream;
+  PS_HIP(hipMemcpy2DAsync(h->d_img, w, img, stride, w, hgt, hipMemcpyHostToDevice, st));
+  if (mask) PS_HIP(hipMemcpy2DAsync(h->d_mask, w, mask, mask_stride, w, hgt, hipMemcpyHostToDevice, st));
+  CvPlanDev P = h->plan;
+  if (!mask) for (int l = 0; l < P.nlevels; l++) P.lv[l].mask = nullptr;
+  h->last_had_mask = mask != nullptr;
+  // pyramid, detection
+  psk_cv_level0(&P.lv[0], h->d_img, w, mask ? h->d_mask : nullptr, w, st);
+  for (int l = 1; l < P.nlevels; l++) psk_cv_resize(&P.lv[l], &P.lv[l - 1], h->d_xtab[l], h->d_ytab[l], st);
+  for (int l = 0; l < P.nlevels; l++) psk_cv_detect(&P.lv[l], h->fast_th, h->edge, h->cap[l], h->d_total + l, st);
+  for (int l = 0; l < P.nlevels; l++) psk_cv_blur(&P.lv[l], h->kq, st);   // (independent of the selection: queued before the host waits)
+  PS_HIP(hipGetLastError());
+  std::vector<int32_t> total(P.nlevels, 0);
+  PS_HIP(hipMemcpyAsync(total.data(), h->d_total, P.nlevels * 4, hipMemcpyDeviceToHost, st));
+  PS_HIP(hipStreamSynchronize(st));
+  // KeyPointsFilter::retainBest twice per level, in the order computeKeyPoints applies them
+  h->last_cand.assign(P.nlevels, {});
+  std::vector<CvSel> selected;
+  for (int l = 0; l < P.nlevels; l++) {
+    const int cnt = std::min(total[l], h->cap[l]);
+    std::vector<float>& c = h->last_cand[l];
+    c.resize((size_t)cnt * 4);
+    if (cnt > 0) PS_HIP(hipMemcpy(c.data(), P.lv[l].cand, (size_t)cnt * 16, hipMemcpyDeviceToHost));
+    // (the level field is constant inside this loop: it carries the candidate's index through the first selection, so that the
+    // Harris response computed with the candidate can be attached afterwards, as HarrisResponses does)
+    std::vector<CvSel> kp(cnt);
+    for (int i = 0; i < cnt; i++) kp[i] = CvSel{(int)c[4 * i], (int)c[4 * i + 1], i, c[4 * i + 2]};
+    retain_best(kp, 2 * h->quota[l]);                       // by FAST score: twice the quota (HARRIS_SCORE)
+    for (CvSel& k : kp) k.response = c[4 * (size_t)k.level + 3];   // HarrisResponses
+    retain_best(kp, h->quota[l]);                           // cull to the quota by the Harris score
+    for (CvSel& k : kp) { k.level = l; selected.push_back(k); }
+  }
+  const int nsel = (int)selected.size();
+  if (nsel > h->sel_cap) return ps_set_error(PS_ERR_CAPACITY, "%d keypoints selected, internal capacity %d", nsel, h->sel_cap);
+  *n = nsel;
+  if (nsel == 0) return PS_OK;
+  if (nsel > cap) return ps_set_error(PS_ERR_CAPACITY, "%d keypoints, caller capacity %d", nsel, cap);
+  if (!kps || !desc) return ps_set_error(PS_ERR_INVALID, "null output buffer");
+  PS_HIP(hipMemcpyAsync(h->d_sel, selected.data(), (size_t)nsel * sizeof(CvSel), hipMemcpyHostToDevice, st));
+  psk_cv_describe(&P, h->d_sel, nsel, h->d_kps, h->d_desc, st);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipMemcpyAsync(kps, h->d_kps, (size_t)nsel * sizeof(ps_keypoint), hipMemcpyDeviceToHost, st));
+  PS_HIP(hipMemcpyAsync(desc, h->d_desc, (size_t)nsel * 32, hipMemcpyDeviceToHost, st));
+  PS_HIP(hipStreamSynchronize(st));
+  return PS_OK;
+}
+
+// Test access to intermediates of the last call.  what: 0 level image (tight w x h), 1 blurred level, 2 level mask,
+// 3 the FAST keypoints after the mask / border filters as float rows (x, y, score, Harris), count in *n; 4: level size as int32[2]
+int ps_cvorb_debug_read(ps_cvorb* h, int level, int what, void* out, size_t out_bytes, int* n) {
+  if (!h || !h->planned || level < 0 || level >= h->nlevels || !out) return ps_set_error(PS_ERR_INVALID, "ps_cvorb_debug_read: bad argument");
+  PS_HIP(hipSetDevice(h->device));
+  PS_HIP(hipDeviceSynchronize());
+  const CvLevelDev& L = h->plan.lv[level];
+  if (what == 4) { if (out_bytes < 8) return ps_set_error(PS_ERR_CAPACITY, "buffer too small"); ((int32_t*)out)[0] = L.w; ((int32_t*)out)[1] = L.h; return PS_OK; }
+  if (what == 3) {
+    const std::vector<float>& c = h->last_cand[level];
+    if (c.size() * 4 > out_bytes) return ps_set_error(PS_ERR_CAPACITY, "buffer too small");
+    if (!c.empty()) memcpy(out, c.data(), c.size() * 4);
+    if (n) *n = (int)(c.size() / 4);
+    return PS_OK;
+  }
+  if ((size_t)L.w * L.h > out_bytes) return ps_set_error(PS_ERR_CAPACITY, "buffer too small");
+  if (what == 0) PS_HIP(hipMemcpy2D(out, L.w, L.pad + (size_t)CV_BORDER * L.stride + CV_BORDER, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+  else if (what == 1) PS_HIP(hipMemcpy2D(out, L.w, L.blur + (size_t)CV_BORDER * L.stride + CV_BORDER, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+  else if (what == 2) { if (h->last_had_mask) PS_HIP(hipMemcpy(out, L.mask, (size_t)L.w * L.h, hipMemcpyDeviceToHost)); else memset(out, 0, (size_t)L.w * L.h); }
+  else return ps_set_error(PS_ERR_INVALID, "unknown `what` %d", what);
+  return PS_OK;
+}
+
+}  // extern "C"

@@ -7,6 +7,7 @@
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
 #include "Optimizer.h"
+#include "ObjectORB.h"
 
 int main(int argc, char** argv) {
   if (argc < 5) { std::fprintf(stderr, "usage\n"); return 2; }
@@ -36,6 +37,16 @@ int main(int argc, char** argv) {
     for (int j = 0; j < n; j += 89)
       if (D[(size_t)i * n + j] != ORB_SLAM2::ORBmatcher::DescriptorDistance(mDescriptors.row(i), mDescriptors.row(j))) return 1;
   (void)ORB_SLAM2::Optimizer::handle(0);
+  // Frame::ExtractObjORB -> OpencvORBDetector(left, LeftObjMask, keypoints_1, descriptors_1) (Frame.cc:2623-2651): the left half masked
+  pscv::Mat objMask(h, w, 0);
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) objMask.at<unsigned char>(y, x) = (x > w / 8 && x < w / 2 && y > h / 6) ? 255 : 0;
+  std::vector<pscv::KeyPoint> keypoints_1;
+  pscv::Mat descriptors_1;
+  ORB_SLAM2::OpencvORBDetector(image, objMask, keypoints_1, descriptors_1);
+  std::printf("object keypoints %zu\n", keypoints_1.size());
+  if (keypoints_1.empty()) return 1;
+  f = std::fopen((pre + ".okps").c_str(), "wb"); std::fwrite(keypoints_1.data(), 28, keypoints_1.size(), f); std::fclose(f);
+  f = std::fopen((pre + ".odesc").c_str(), "wb"); std::fwrite(descriptors_1.data, 32, keypoints_1.size(), f); std::fclose(f);
   delete mpORBextractorLeft;
   std::printf("shim smoke ok\n");
   return 0;

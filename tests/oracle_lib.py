@@ -132,6 +132,59 @@ class OracleORB:
         return out[:n]
 
 
+class OracleCvORB:
+    """the CPU restatement of cv::ORB::create(...)->detectAndCompute(image, mask, ...) (oracle/orb_oracle.cpp: cv_orb_run)"""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, edge=19, fast_th=20):
+        self.L = lib()
+        self.L.orc_cvorb_create.restype = ctypes.c_void_p
+        self.L.orc_cvorb_create.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        self.L.orc_cvorb_destroy.argtypes = [ctypes.c_void_p]
+        self.L.orc_cvorb_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        self.L.orc_cvorb_result.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.L.orc_cvorb_level_dims.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.L.orc_cvorb_level_plane.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        self.L.orc_cvorb_level_fast.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        self.nlevels = nlevels
+        self.h = ctypes.c_void_p(self.L.orc_cvorb_create(nfeatures, scale, nlevels, edge, fast_th))
+
+    def __del__(self):
+        try:
+            self.L.orc_cvorb_destroy(self.h)
+        except Exception:
+            pass
+
+    def run(self, img, mask=None):
+        img = np.ascontiguousarray(img)
+        mp, ms = None, 0
+        if mask is not None:
+            mask = np.ascontiguousarray(mask)
+            mp, ms = mask.ctypes.data, mask.strides[0]
+        n = self.L.orc_cvorb_run(self.h, img.ctypes.data, img.shape[1], img.shape[0], img.strides[0], mp, ms)
+        kps = np.zeros(max(n, 1), KEYPOINT_DTYPE)
+        desc = np.zeros((max(n, 1), 32), np.uint8)
+        self.L.orc_cvorb_result(self.h, kps.ctypes.data, desc.ctypes.data)
+        return kps[:n], desc[:n]
+
+    def level_dims(self, l):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        self.L.orc_cvorb_level_dims(self.h, l, ctypes.byref(w), ctypes.byref(h))
+        return w.value, h.value
+
+    def plane(self, l, what):
+        w, h = self.level_dims(l)
+        out = np.zeros((h, w), np.uint8)
+        self.L.orc_cvorb_level_plane(self.h, l, what, out.ctypes.data)
+        return out
+
+    def fast(self, l):
+        w, h = self.level_dims(l)
+        cap = ((w + 1) // 2) * ((h + 1) // 2)
+        out = np.zeros((cap, 4), np.float32)
+        n = self.L.orc_cvorb_level_fast(self.h, l, out.ctypes.data, cap)
+        return out[:n]
+
+
 def stereo_match(left, right, mb, mbf):
     """left / right: OracleORB objects after run().  Returns (kept, u_right, depth)."""
     L = lib()

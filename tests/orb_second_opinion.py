@@ -270,3 +270,74 @@ def distribute(keys, min_x, max_x, min_y, max_y, n_wanted):
                 best = k
         out.append(best)
     return np.array(out, np.int32).reshape(-1, 3)
+
+
+# ---- cv::ORB (the object-feature detector): the stages that differ from ORBextractor ------------------------
+def _exact_coefficients(n_dst, n_src):
+    """resize(INTER_LINEAR_EXACT), 8-bit: source offset, 8.8 weights, and the range of destination indices with two source samples"""
+    scale = 1.0 / (n_dst / n_src)
+    f = scale * (np.arange(n_dst, dtype=np.float64) + 0.5) - 0.5
+    i = np.floor(f).astype(np.int64)
+    c1 = np.rint((f - i) * 256.0).astype(np.int64)
+    before = i < 0
+    after = i >= n_src - 1
+    return np.clip(i, 0, n_src - 2), 256 - c1, c1, before, after
+
+
+def resize_linear_exact_u8(src, dw, dh):
+    sh, sw = src.shape
+    xo, a0, a1, xb, xa = _exact_coefficients(dw, sw)
+    yo, b0, b1, yb, ya = _exact_coefficients(dh, sh)
+    S = src.astype(np.int64)
+    hor = S[:, xo] * a0 + S[:, xo + 1] * a1
+    hor[:, xb] = S[:, :1] << 8
+    hor[:, xa] = S[:, -1:] << 8
+    out = (hor[yo] * b0[:, None] + hor[yo + 1] * b1[:, None] + 32768) >> 16
+    out[yb] = (hor[0] + 128) >> 8
+    out[ya] = (hor[-1] + 128) >> 8
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def cv_pyramid(img, nlevels=8, scale=1.2):
+    """cv::ORB's pyramid: level l = INTER_LINEAR_EXACT resize of level l - 1 to cvRound(size / (float)pow(scaleFactor, l))"""
+    sf = np.float64(np.float32(scale))
+    h, w = img.shape
+    levels = [np.ascontiguousarray(img)]
+    for l in range(1, nlevels):
+        inv = np.float32(1.0) / np.float32(sf ** l)
+        levels.append(resize_linear_exact_u8(levels[-1], cv_round(np.float32(w) * inv), cv_round(np.float32(h) * inv)))
+    return levels
+
+
+def cv_fast(level_img, threshold=20, edge=19, mask=None):
+    """cv::FAST(threshold, nonmaxSuppression) on the whole level, then runByPixelsMask and runByImageBorder(edge): (x, y, score)"""
+    s = fast_score_map(level_img)
+    h, w = s.shape
+    c = np.where(s >= threshold, s, 0)
+    p = np.pad(c, 1)
+    keep = c > 0
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            if dx or dy:
+                keep &= c > p[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+    if mask is not None:
+        keep &= mask != 0
+    inner = np.zeros_like(keep)
+    inner[edge:h - edge, edge:w - edge] = True
+    ys, xs = np.nonzero(keep & inner)
+    return np.stack([xs, ys, c[ys, xs]], 1).astype(np.int32)
+
+
+def cv_harris(level_img, xs, ys):
+    """HarrisResponses(blockSize 7, k 0.04) as float32 arithmetic in the order orb.cpp writes it"""
+    I = np.pad(level_img.astype(np.int64), 8, mode="reflect")
+    out = np.zeros(len(xs), np.float32)
+    scale = np.float32(1.0) / (np.float32(28) * np.float32(255.0))
+    s4 = scale * scale * scale * scale
+    for n, (x, y) in enumerate(zip(xs, ys)):
+        blk = I[y + 8 - 4:y + 8 + 5, x + 8 - 4:x + 8 + 5]        # 9 x 9 around the point
+        Ix = (blk[1:-1, 2:] - blk[1:-1, :-2]) * 2 + (blk[:-2, 2:] - blk[:-2, :-2]) + (blk[2:, 2:] - blk[2:, :-2])
+        Iy = (blk[2:, 1:-1] - blk[:-2, 1:-1]) * 2 + (blk[2:, :-2] - blk[:-2, :-2]) + (blk[2:, 2:] - blk[:-2, 2:])
+        a, b, c = np.float32(int((Ix * Ix).sum())), np.float32(int((Iy * Iy).sum())), np.float32(int((Ix * Iy).sum()))
+        out[n] = (a * b - c * c - np.float32(0.04) * (a + b) * (a + b)) * s4
+    return out

@@ -88,3 +88,40 @@ def test_masked_object_features_definition():
             assert np.array_equal(np.stack([kp["x"], kp["y"], kp["response"]], 1).astype(np.int32), sel + np.array([so.EDGE - 3, so.EDGE - 3, 0], np.int32))
         total += len(sel)
     assert total == len(kps) and total > 300
+
+
+def test_cv_orb_stages_second_opinion():
+    """the restatement of OpenCV's own ORB (object features): INTER_LINEAR_EXACT pyramid, whole-image FAST with the
+    mask / border filters, and the Harris responses against the numpy statement of the same definitions"""
+    img = _images()["kitti"]
+    mask = np.zeros_like(img)
+    mask[60:330, 250:1000] = 255
+    orc = oracle_lib.OracleCvORB()
+    kps, desc = orc.run(img, mask)
+    assert 900 <= len(kps) <= 1100
+    levels = so.cv_pyramid(img)
+    mlevels = [mask]
+    for l in range(1, 8):
+        m = so.resize_linear_exact_u8(mlevels[-1], levels[l].shape[1], levels[l].shape[0])
+        mlevels.append(np.where(m > 254, m, 0).astype(np.uint8))
+    for l, lv in enumerate(levels):
+        assert orc.level_dims(l) == (lv.shape[1], lv.shape[0])
+        assert np.array_equal(orc.plane(l, 0), lv), "level %d image" % l
+        assert np.array_equal(orc.plane(l, 1), so.gaussian_blur7(lv)), "level %d blurred" % l
+        assert np.array_equal(orc.plane(l, 2), mlevels[l]), "level %d mask" % l
+        f = orc.fast(l)
+        mine = so.cv_fast(lv, 20, 19, mlevels[l])
+        assert np.array_equal(f[:, :3].astype(np.int32), mine), "level %d FAST keypoints" % l
+        hr = so.cv_harris(lv, mine[:, 0], mine[:, 1])
+        assert np.array_equal(f[:, 3].view(np.uint32), hr.view(np.uint32)), "level %d Harris responses" % l
+    # per level: the quota's best by Harris response among the 2 x quota best by FAST score (as sets: the order is std::nth_element's)
+    sf = np.array([np.float32(np.float64(np.float32(1.2)) ** l) for l in range(8)], np.float32)
+    for l in range(8):
+        sel = kps[kps["octave"] == l]
+        if len(sel) == 0:
+            continue
+        f = orc.fast(l)
+        lx = np.rint(sel["x"] / sf[l]).astype(int); ly = np.rint(sel["y"] / sf[l]).astype(int)
+        table = {(int(x), int(y)): (s, hsc) for x, y, s, hsc in f}
+        assert all((x, y) in table for x, y in zip(lx, ly))
+        assert np.array_equal(np.array([table[(x, y)][1] for x, y in zip(lx, ly)], np.float32).view(np.uint32), sel["response"].view(np.uint32))

@@ -24,10 +24,9 @@ def test_shim_compiles_and_links():
 
 @pytest.mark.gpu
 def test_shim_runs_and_matches_oracle(tmp_path):
-    from oracle_lib import OracleORB, KEYPOINT_DTYPE
+    from oracle_lib import OracleORB, OracleCvORB, KEYPOINT_DTYPE
     from pointslot_amd import synth
-    if not os.path.exists(EXE):
-        _build()
+    _build()          # always: a binary that travelled with the snapshot may predate the headers
     left, _ = synth.stereo_pair(w=800, h=300)
     raw = tmp_path / "img.raw"
     left.tofile(raw)
@@ -39,3 +38,11 @@ def test_shim_runs_and_matches_oracle(tmp_path):
     ko, do = OracleORB(1000).run(left)
     assert np.array_equal(kps.view(np.uint8), ko.view(np.uint8))
     assert np.array_equal(desc, do)
+    # OpencvORBDetector(im, ObjMask, kp, descriptor) == cv::ORB::create(1000, 1.2, 8, 19)->detectAndCompute (the CPU restatement of it)
+    okps = np.fromfile(tmp_path / "o.okps", KEYPOINT_DTYPE)
+    odesc = np.fromfile(tmp_path / "o.odesc", np.uint8).reshape(-1, 32)
+    mask = np.zeros_like(left)
+    mask[300 // 6 + 1:, 800 // 8 + 1:800 // 2] = 255
+    ko, do = OracleCvORB().run(left, mask)
+    assert len(okps) == len(ko) and len(ko) > 100
+    assert np.array_equal(okps.view(np.uint8), ko.view(np.uint8)) and np.array_equal(odesc, do)
