@@ -190,7 +190,7 @@ class ObjectState {
 // ---- a21: an object edge the reference defines and never instantiates (g2o_Object.cc:404-480), kept for API
 // compatibility.  Vertices: a cuboid (object-to-world pose) and a point in the object frame; Tcw is a constant of the edge.
 // With Tcw = I the residual and both Jacobians are those of EdgeStereoSE3ProjectXYZ on (Tco, point) - the edge of
-// Optimizer::ObjectLocalBundleAdjustment that the ba_* kernels implement (tests/test_oracle_opt.py checks the reduction). ----
+// Optimizer::ObjectLocalBundleAdjustment that the ba_* kernels implement (tests/test_object_state.py checks the reduction). ----
 struct EdgeStereoDynamicPointAndCuboid {
   SE3Quat Tcw;
   Matrix3d Kalib;
