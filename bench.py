@@ -470,8 +470,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sequences", type=int, default=256, help="independent stereo sequences tracked in lockstep per GPU")
-    ap.add_argument("--groups", type=int, default=2, help="lockstep groups per GPU (one tracker handle and stream each)")
+    ap.add_argument("--sequences", type=int, default=512, help="independent stereo sequences tracked in lockstep per GPU")
+    ap.add_argument("--groups", type=int, default=1, help="lockstep groups per GPU (one tracker handle and stream each)")
     ap.add_argument("--texture", choices=["kitti", "synthetic"], default="kitti", help="texture of the generated sequences of the headline run")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the headline loop")

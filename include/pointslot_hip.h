@@ -51,6 +51,11 @@ int ps_debug_poison_lds(int device, uint32_t pattern);
 /* Diagnostic: measured FP64 matrix-core rate of `device` in TFLOP/s (a loop of independent v_mfma_f64_16x16x4_f64 on every CU).
  * The local hardware guide has no FP64 MFMA peak; this is the denominator of the object-BA roofline. */
 int ps_debug_mfma_f64_peak(int device, double* tflops);
+/* Diagnostic: `repeats` launches of a streaming kernel that touches exactly `bytes` of a fresh buffer once per launch - mode 0 reads
+ * 16 B per lane, 1 reads 4 B per lane, 2 writes 4 B per lane, 3 writes 16 B per lane (kernel names traffic_read / traffic_write).
+ * Run under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` it calibrates those counters for the access widths the kernels of this
+ * library use (the hardware guide only calibrates 16-byte reads); tools/pmc_traffic.sh applies the factors. */
+int ps_debug_traffic_kernel(int device, int mode, size_t bytes, int repeats);
 /* Page-locked host memory for image and result buffers: copies from/to it are asynchronous and run at full PCIe rate
  * (ps_orb_extract_batch reads the caller's image buffers directly).  NULL on failure (ps_last_error has the text). */
 void* ps_pinned_alloc(size_t bytes);

@@ -40,9 +40,49 @@ __global__ __launch_bounds__(256) void mfma_f64_loop(double* sink, int iters) {
   for (int i = 0; i < 8; i++) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
   if (s == 12345.678) sink[0] = s;   // keeps the loop alive
 }
+// Known-byte streaming kernels for calibrating the PMC byte counters (MI355X_MICROARCH.md, section HBM: FETCH_SIZE / WRITE_SIZE
+// are only calibrated for 16 B / lane reads; "calibrate on a known byte count in your own access pattern"): every lane reads (or
+// writes) `words` consecutive 4-byte or 16-byte elements of a buffer exactly once, wave-coalesced.
+template <typename T> __global__ __launch_bounds__(256) void traffic_read(const T* src, size_t n, uint32_t* sink) {
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const T v = src[i];
+    acc ^= ((const uint32_t*)&v)[0];
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+template <typename T> __global__ __launch_bounds__(256) void traffic_write(T* dst, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    T v;
+    for (size_t k = 0; k < sizeof(T) / 4; k++) ((uint32_t*)&v)[k] = seed + (uint32_t)i;
+    dst[i] = v;
+  }
+}
 }  // namespace
 
 extern "C" {
+int ps_debug_traffic_kernel(int device, int mode, size_t bytes, int repeats) {
+  PS_HIP(hipSetDevice(device));
+  if (mode < 0 || mode > 3 || bytes < 1024 || repeats < 1) return ps_set_error(PS_ERR_INVALID, "ps_debug_traffic_kernel: mode 0..3, bytes >= 1024");
+  bytes &= ~(size_t)1023;
+  uint8_t* buf = nullptr;
+  uint32_t* sink = nullptr;
+  PS_HIP(hipMalloc(&buf, bytes));
+  PS_HIP(hipMalloc(&sink, 4));
+  PS_HIP(hipMemset(buf, 1, bytes));
+  PS_HIP(hipDeviceSynchronize());
+  const int blocks = 256 * 16;
+  for (int r = 0; r < repeats; r++) {
+    if (mode == 0) hipLaunchKernelGGL(traffic_read<uint4>, dim3(blocks), dim3(256), 0, 0, (const uint4*)buf, bytes / 16, sink);
+    else if (mode == 1) hipLaunchKernelGGL(traffic_read<uint32_t>, dim3(blocks), dim3(256), 0, 0, (const uint32_t*)buf, bytes / 4, sink);
+    else if (mode == 2) hipLaunchKernelGGL(traffic_write<uint32_t>, dim3(blocks), dim3(256), 0, 0, (uint32_t*)buf, bytes / 4, (uint32_t)r);
+    else hipLaunchKernelGGL(traffic_write<uint4>, dim3(blocks), dim3(256), 0, 0, (uint4*)buf, bytes / 16, (uint32_t)r);
+  }
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipDeviceSynchronize());
+  hipFree(buf); hipFree(sink);
+  return PS_OK;
+}
 int ps_debug_mfma_f64_peak(int device, double* tflops) {
   if (!tflops) return ps_set_error(PS_ERR_INVALID, "null argument");
   PS_HIP(hipSetDevice(device));
