@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include "ba_plan.h"
 #include "ps_common.h"
@@ -50,8 +51,10 @@ struct Layout {   // byte offsets in the arena; [0, host_end) is mirrored in pin
 };
 }  // namespace
 
+extern "C" std::mutex* psi_optimizer_mutex(ps_optimizer* m);
 extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int nprob) {
   if (!m || !probs || nprob < 1) return ps_set_error(PS_ERR_INVALID, "ps_object_ba_batch: bad argument");
+  std::lock_guard<std::mutex> lock(*psi_optimizer_mutex(m));   // a handle may be shared by the tracking and the object-mapping thread
   PS_HIP(hipSetDevice(psi_optimizer_device(m)));
   hipStream_t st = psi_optimizer_stream(m);
   BaCtx* ctx = psi_optimizer_ba_ctx(m);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <string.h>
 #include <vector>
 #include "match_plan.h"
@@ -20,6 +21,7 @@ void psk_distinctive_launch(const uint8_t*, const int32_t*, int32_t*, int, hipSt
 }
 
 struct ps_matcher {
+  std::mutex mu;              // calls on one handle are serialised (a handle may be shared by threads)
   int device = 0;
   hipStream_t stream = nullptr;
   uint8_t* d_buf = nullptr;   // one growable device arena
@@ -81,6 +83,7 @@ void ps_matcher_destroy(ps_matcher* m) {
 
 int ps_hamming_matrix(ps_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out) {
   if (!m || !q || !t || !out || nq < 1 || nt < 1) return ps_set_error(PS_ERR_INVALID, "ps_hamming_matrix: bad argument");
+  std::lock_guard<std::mutex> lock(m->mu);
   PS_HIP(hipSetDevice(m->device));
   const size_t oq = 0, ot = al((size_t)nq * 32), oo = ot + al((size_t)nt * 32), total = oo + al((size_t)nq * nt * 2);
   int rc = ensure(m, total);
@@ -98,6 +101,7 @@ int ps_hamming_matrix(ps_matcher* m, const uint8_t* q, int nq, const uint8_t* t,
 
 int ps_match_bruteforce(ps_matcher* m, ps_bf_problem* probs, int nprob, float nn_ratio, int check_orientation) {
   if (!m || !probs || nprob < 1) return ps_set_error(PS_ERR_INVALID, "ps_match_bruteforce: bad argument");
+  std::lock_guard<std::mutex> lock(m->mu);
   PS_HIP(hipSetDevice(m->device));
   size_t tq = 0, tt = 0;
   std::vector<BfProb> dp(nprob);
@@ -165,6 +169,7 @@ int ps_match_bruteforce(ps_matcher* m, ps_bf_problem* probs, int nprob, float nn
 // The three ORBmatcher::SearchByProjection overloads (see include/pointslot_hip.h for the field mapping).
 int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   if (!m || !probs || nprob < 1) return ps_set_error(PS_ERR_INVALID, "ps_search_by_projection: bad argument");
+  std::lock_guard<std::mutex> lock(m->mu);
   PS_HIP(hipSetDevice(m->device));
   size_t NT = 0, NQ = 0;
   int max_nq = 0, any_frame = 0;
@@ -349,6 +354,7 @@ int ps_distinctive_descriptors(ps_matcher* m, const uint8_t* desc, const int32_t
   if (total > 0 && !desc) return ps_set_error(PS_ERR_INVALID, "null descriptors");
   for (int p = 0; p < npoints; p++)
     if (off[p + 1] < off[p] || off[p + 1] - off[p] > 128) return ps_set_error(PS_ERR_CAPACITY, "point %d: 0..128 observations supported", p);
+  std::lock_guard<std::mutex> lock(m->mu);
   PS_HIP(hipSetDevice(m->device));
   const size_t o_desc = 0, o_off = al((size_t)total * 32 + 32), o_best = o_off + al((size_t)(npoints + 1) * 4), end = o_best + al((size_t)npoints * 4);
   int rc = ensure(m, end);
@@ -367,6 +373,7 @@ int ps_distinctive_descriptors(ps_matcher* m, const uint8_t* desc, const int32_t
 
 int ps_fuse_search(ps_matcher* m, ps_fuse_problem* probs, int nprob) {
   if (!m || !probs || nprob < 1) return ps_set_error(PS_ERR_INVALID, "ps_fuse_search: bad argument");
+  std::lock_guard<std::mutex> lock(m->mu);
   PS_HIP(hipSetDevice(m->device));
   size_t NT = 0, NQ = 0;
   int max_nq = 0;

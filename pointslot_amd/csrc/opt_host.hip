@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include "opt_plan.h"
 #include "ps_common.h"
@@ -17,6 +18,9 @@ extern "C" void psk_pose_lm_launch(const PoProb*, int, const PoVertex*, const fl
 struct BaCtx { uint8_t* d_buf = nullptr; size_t d_bytes = 0; uint8_t* h_buf = nullptr; size_t h_bytes = 0; };
 
 struct ps_optimizer {
+  // One handle may be shared by threads (the shim's process-wide handle serves PoseOptimization on the tracking thread and
+  // ObjectLocalBundleAdjustment on the ObjectLocalMapping thread, ObjectLocalMapping.cpp:375-377): calls on it are serialised
+  std::mutex mu;
   BaCtx ba;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -170,6 +174,7 @@ int psi_optimizer_device(ps_optimizer* m) { return m->device; }
 hipStream_t psi_optimizer_stream(ps_optimizer* m) { return m->stream; }
 BaCtx* psi_optimizer_ba_ctx(ps_optimizer* m) { return &m->ba; }
 void psi_optimizer_set_ms(ps_optimizer* m, float ms) { m->last_kernel_ms = ms; }
+std::mutex* psi_optimizer_mutex(ps_optimizer* m) { return &m->mu; }
 
 int ps_optimizer_last_kernel_ms(const ps_optimizer* m, float* ms) {
   if (!m || !ms) return ps_set_error(PS_ERR_INVALID, "null argument");
@@ -196,6 +201,7 @@ int ps_optimizer_get_trace(const ps_optimizer* m, int problem, double* chi2_lamb
 
 int ps_pose_optimize_batch(ps_optimizer* m, ps_pose_problem* probs, int nprob) {
   if (!m || !probs || nprob < 1) return ps_set_error(PS_ERR_INVALID, "ps_pose_optimize_batch: bad argument");
+  std::lock_guard<std::mutex> lock(m->mu);
   PS_HIP(hipSetDevice(m->device));
   std::vector<PoView> pv(nprob);
   std::vector<Se3> poses(nprob);
@@ -221,6 +227,7 @@ int ps_pose_optimize_batch(ps_optimizer* m, ps_pose_problem* probs, int nprob) {
 
 int ps_cfse3_optimize_batch(ps_optimizer* m, ps_cfse3_problem* probs, int nprob) {
   if (!m || !probs || nprob < 1) return ps_set_error(PS_ERR_INVALID, "ps_cfse3_optimize_batch: bad argument");
+  std::lock_guard<std::mutex> lock(m->mu);
   PS_HIP(hipSetDevice(m->device));
   std::vector<PoView> pv;
   std::vector<Se3> poses;
@@ -286,6 +293,7 @@ int ps_dynamic_discrimination_batch(ps_optimizer* h, ps_dyn_problem* probs, int 
     if (P.n > 0 && (!P.valid || !P.po || !P.obs || !P.inv_sigma2)) return ps_set_error(PS_ERR_INVALID, "problem %d: null array", p);
     N += P.n;
   }
+  std::lock_guard<std::mutex> lock(h->mu);
   PS_HIP(hipSetDevice(h->device));
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t r = off; off += al(bytes + 64); return r; };

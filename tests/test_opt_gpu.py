@@ -195,3 +195,74 @@ def test_randomised_optimiser_sweep():
     r = subprocess.run([sys.executable, tool, "7", "30"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_one_handle_shared_by_two_threads(opt):
+    """The shim keeps ONE process-wide optimiser handle (host/Optimizer.h): PoseOptimization runs on the tracking thread and
+    ObjectLocalBundleAdjustment on the ObjectLocalMapping thread (/root/reference/src/ObjectLocalMapping.cpp:375-377).  Calls on a
+    handle are serialised inside the library: two threads hammering the same handle get exactly the single-threaded results."""
+    import threading
+    frames = [synth.pose_problem(0x51070003 + k) for k in range(6)]
+    graphs = [synth.object_ba_problem(0x51070046, n_kf=12, n_pts=60, p_vis=0.7, perturb_axis="z"),
+              synth.object_ba_problem(0x51070047, n_kf=9, n_pts=33, p_vis=0.5, mono_frac=0.3)]
+    ref_pose = opt.PoseOptimization(frames)
+    ref_ba = opt.ObjectLocalBundleAdjustment(graphs)
+    errors = []
+
+    def pose_loop():
+        try:
+            for _ in range(12):
+                res = opt.PoseOptimization(frames)
+                for (r, t, o), (r0, t0, o0) in zip(res, ref_pose):
+                    assert r == r0 and np.array_equal(t, t0) and np.array_equal(o, o0)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    def ba_loop():
+        try:
+            for _ in range(6):
+                res = opt.ObjectLocalBundleAdjustment(graphs)
+                for a, b in zip(res, ref_ba):
+                    assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"]) and np.array_equal(a["erase"], b["erase"])
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=pose_loop), threading.Thread(target=ba_loop), threading.Thread(target=pose_loop)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:1]
+
+
+def test_capacity_limits_are_reported_not_hidden(opt):
+    """DESIGN.md section 3 lists the capacity limits of this build; each is an error code, and the handle keeps working afterwards."""
+    from pointslot_amd._lib import PointslotError, PS_ERR_CAPACITY, PS_ERR_INVALID
+    from pointslot_amd.extractor import ORBextractor
+    big = synth.object_ba_problem(0x51070049, n_kf=130, n_pts=20, p_vis=0.3)        # 129 free poses > 128
+    with pytest.raises(PointslotError) as e:
+        opt.ObjectLocalBundleAdjustment([big])
+    assert e.value.code == PS_ERR_CAPACITY
+    ok = synth.object_ba_problem(0x51070044, n_kf=5, n_pts=14, p_vis=0.8, outlier_frac=0.0)
+    assert opt.ObjectLocalBundleAdjustment([ok])[0]["iterations"] > 0                # the handle is still usable
+    f = {"objs": [dict(xo=np.zeros((3, 3), np.float32), obs=np.zeros((3, 3), np.float32), inv_sigma2=np.ones(3, np.float32), valid=np.ones(3, np.uint8),
+                       pose7=np.array([0, 0, 5, 0, 0, 0, 1.0]))] * 17, "K": synth.pose_problem(1, 20)["K"]}
+    with pytest.raises(PointslotError) as e:                                         # 17 objects in one CFSE3 graph > 16
+        opt.CFSE3ObjStateOptimization([f])
+    assert e.value.code == PS_ERR_INVALID
+    left, right = synth.stereo_pair()
+    ex = ORBextractor(30000, 1.2, 8, 20, 5)                                          # per-level quota 6513 > 2044 (quadtree node table)
+    with pytest.raises(PointslotError) as e:
+        ex(left)
+    assert e.value.code == PS_ERR_INVALID
+    ex.close()
+    ex = ORBextractor(4500, 1.2, 8, 20, 5, max_batch=2)                              # fits the extractor, but > 4096 keypoints per image in the stereo matcher
+    import torch
+    d = torch.from_numpy(np.stack([left, right])).cuda()
+    ex.extract_batch_device(d.data_ptr(), 2, left.shape[1], left.shape[0], left.shape[1], left.size)
+    with pytest.raises(PointslotError) as e:
+        ex.stereo_match_batch(1, 0.53, 384.4)
+    assert e.value.code == PS_ERR_CAPACITY
+    kps, desc = ex.fetch(0)                                                           # extraction results are intact
+    assert len(kps) > 2000
+    ex.close()

@@ -83,3 +83,60 @@ def test_device_tracker_images_in_hbm_and_reset():
     assert np.array_equal(tcw_a.view(np.uint32), tcw_b.view(np.uint32))
     assert np.array_equal(st_a.view(np.int32), st_b.view(np.int32))
     trk.close()
+
+
+@pytest.mark.gpu
+def test_154_frames_against_the_cpu_restatement():
+    """BASELINE config 5 length: 154 frames of one sequence (800 x 300 to keep the CPU side to seconds) through the device-resident
+    chain and through the CPU restatement of the same loop.  Over that distance the camera leaves the initial keyframe's map and the
+    slice tracks on temporal points alone (no keyframe insertion in localisation mode): both drift the same way - every frame's
+    counts are equal and the poses stay within the float32 / FP64-LM tolerance of each other all along."""
+    from oracle_backend import OracleBackend
+    from pointslot_amd import sequence
+    from pointslot_amd.tracker import StereoOdometry
+    from pointslot_amd.tracker_device import LockstepTracker
+    n = 154
+    seq = sequence.generate(n_frames=n, seed=3, w=800, h=300, step=0.05)
+    h, w = seq["left"][0].shape
+    trk = LockstepTracker(1, seq["K"], seq["bf"], w, h, max_steps=n)
+    for i in range(n):
+        trk.step([np.ascontiguousarray(seq["left"][i])], [np.ascontiguousarray(seq["right"][i])])
+    tcw, st = trk.fetch()
+    trk.close()
+    vo = StereoOdometry(OracleBackend(), seq["K"], seq["bf"], w, h)
+    for i in range(n):
+        vo.track(seq["left"][i], seq["right"][i])
+    worst, worst_rel, differ, first = 0.0, 0.0, 0, None
+    prev = None
+    for i in range(n):
+        a = vo.trajectory[i]
+        assert (a is not None) == bool(st["tracked"][i, 0]), i
+        if a is None:
+            prev = None
+            continue
+        g = tcw[i, 0]
+        worst = max(worst, float(np.abs(a - g).max()))
+        if prev is not None:   # frame-to-frame motion T_i T_{i-1}^-1 of the two runs
+            ra = a.astype(np.float64) @ np.linalg.inv(prev[0].astype(np.float64)); rg = g.astype(np.float64) @ np.linalg.inv(prev[1].astype(np.float64))
+            worst_rel = max(worst_rel, float(np.abs(ra - rg).max()))
+        prev = (a, g)
+        if i > 0 and "matches" in vo.stats[i]:
+            d = abs(vo.stats[i]["matches"] - int(st["matches"][i, 0])) + abs(vo.stats[i]["map_matches"] - int(st["map_matches"][i, 0]))
+            # The poses of the two runs differ in the last float32 digits (FP64 LM, different summation order), and in pure
+            # visual-odometry mode every frame's temporal points are rebuilt from the previous pose, so the difference performs a
+            # random walk.  Matching is discrete: sooner or later a projection lands on the other side of a window edge or a
+            # chi-square on the other side of its threshold, and ONE match differs.
+            assert d <= 3, (i, vo.stats[i], st[i, 0])
+            if d:
+                differ += 1
+                first = i if first is None else first
+    assert st["tracked"].sum() >= n - 2
+    drift = float(np.abs(-(tcw[-1, 0, :3, :3].T @ tcw[-1, 0, :3, 3]) - seq["twc"][-1][:, 3]).max())
+    # two equally valid runs of a drifting estimator (measured: identical counts for 110 frames, then single matches differ; the
+    # poses drift 2 mm apart over 154 frames while both are 0.2 m from the truth): they stay far closer to each other than either is
+    # to the truth
+    assert worst_rel < 5e-3, worst_rel
+    assert worst < 5e-3 and worst < 0.1 * max(drift, 0.02), (worst, drift)
+    assert first is None or first >= 20, first        # identical counts for the first frames at least
+    print("154 frames: max |Tcw diff| %.3g, max frame-to-frame motion diff %.3g, %d tracked, %d frames with a differing match count (first: %s), final position error %.3f m" % (
+        worst, worst_rel, int(st["tracked"].sum()), differ, first, float(np.abs(-(tcw[-1, 0, :3, :3].T @ tcw[-1, 0, :3, 3]) - seq["twc"][-1][:, 3]).max())))
