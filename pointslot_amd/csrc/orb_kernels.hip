@@ -438,37 +438,21 @@ __global__ __launch_bounds__(256) void orb_border(OrbPlan plan, uint8_t* arena) 
 // candidate area [3, w-4] x [3, h-4] score 0 (FAST runs on the cell ROI).  Hence:
 //   keypoint_t(p) = s(p) > t  AND  s(p) > s(n) for all in-cell neighbours n,
 // the cell uses t = iniThFAST unless that yields no keypoint, then minThFAST (ORBextractor.cc:809-816).
+//
+// One WAVE per FAST cell, four independent cells per workgroup, no workgroup barriers.
+//   A  the cell window (cell + 6) goes to LDS shifted to its own origin (8-byte loads, DPP + v_alignbyte)
+//   B  necessary test on the 4 compass points of the ring, 4 horizontally adjacent pixels per lane and step on packed u16.
+//      Nine contiguous ring pixels always contain two ADJACENT compass points, so a corner at threshold t has two adjacent
+//      compass points both darker than v - t or both brighter than v + t.  "Some adjacent pair is below x" is
+//      (N < x or S < x) and (E < x or W < x), i.e. max(min(N, S), min(E, W)) < x: three packed operations per polarity.
+//      A pixel that passes as dark goes to the dark list, as bright to the bright list (both: to both).  The lists are
+//      unordered (slot-major within a step): two v_mbcnt and one address per (slot, polarity).
+//   C  exact score of the listed pixels, TWO per lane: a list entry has one polarity, and with r' = 255 - r, v' = 255 - v
+//      for bright entries both polarities are  v' - min over the 16 arcs of (max of the arc's 9 values)  on packed u16 halves.
+//      A dark and a bright 9-arc cannot coexist on a 16-ring, so a pixel listed twice is a corner in at most one list.
+//   D  strict 3x3 NMS on the LDS score map, threshold fallback, raster-ordered emission into the cell's slots: the
+//      kept pixels set bits in a per-row bitmap, a row-count prefix gives every keypoint its raster rank.
 // ------------------------------------------------------------------------------------------------
-// Exact score of a pixel that is known to be a corner at min_th: s = max over the 16 nine-pixel arcs of
-// min |signed diff| (see above).  c points at the pixel inside the LDS tile.
-typedef unsigned short fsc_us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int fast_score_exact(const uint8_t* c, int ts) {
-  // With r_k the ring values:  dark  = v - min over the 16 arcs of (max of the arc's 9 values),
-  //                            bright = max over arcs of (min of 9) - v,   s = max(dark, bright).
-  // Both trees run at once on packed u16: low half r_k, high half 255 - r_k (min r = 255 - max (255 - r)).
-  const int v = c[0];
-  const int off[16] = {3 * ts, 3 * ts + 1, 2 * ts + 2, ts + 3, 3, -ts + 3, -2 * ts + 2, -3 * ts + 1,
-                       -3 * ts, -3 * ts - 1, -2 * ts - 2, -ts - 3, -3, ts - 3, 2 * ts - 2, 3 * ts - 1};
-  fsc_us2 x[16], m2[16], m4[16], m8[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const uint32_t r = c[off[i]];
-    x[i] = __builtin_bit_cast(fsc_us2, (r | (r << 16)) ^ 0x00FF0000u);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; i++) m2[i] = __builtin_elementwise_max(x[i], x[(i + 1) & 15]);
-#pragma unroll
-  for (int i = 0; i < 16; i++) m4[i] = __builtin_elementwise_max(m2[i], m2[(i + 2) & 15]);
-#pragma unroll
-  for (int i = 0; i < 16; i++) m8[i] = __builtin_elementwise_max(m4[i], m4[(i + 4) & 15]);
-  fsc_us2 best = __builtin_elementwise_max(m8[0], x[8]);
-#pragma unroll
-  for (int i = 1; i < 16; i++) best = __builtin_elementwise_min(best, __builtin_elementwise_max(m8[i], x[(i + 8) & 15]));
-  const uint32_t bb = __builtin_bit_cast(uint32_t, best);
-  const int minmax9 = (int)(bb & 0xFFFFu), maxmin9 = 255 - (int)(bb >> 16);
-  return max(v - minmax9, maxmin9 - v);
-}
-
 // wave-level phase separator: LDS traffic of one wave is processed in order, the fence only keeps the
 // compiler from moving accesses across it (no workgroup barrier anywhere in this kernel)
 __device__ __forceinline__ void wave_sync() {
@@ -476,61 +460,61 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-
-// One WAVE per FAST cell, four independent cells per workgroup, no workgroup barriers.
-//   A  the cell window (cell + 6) is copied to LDS with aligned dword loads
-//   B  every lane takes 4 horizontally adjacent pixels at a time (3 rows x 12 bytes from LDS) and applies a cheap necessary
-//      condition on the 4 compass points of the ring; survivors are compacted in raster order (ballot + mbcnt prefix)
-//   C  survivors are scored exactly (s > min_th <=> corner) and compacted again
-//   D  strict 3x3 NMS on the LDS score map, threshold fallback, raster-ordered emission into the cell's slots
-#define FAST_T 256
-#ifdef PS_FAST_PROFILE   // developer build: core-clock cycles per phase summed over all cell-waves, printed after the launch
-#define FP_MAXW 262144
-__device__ unsigned long long g_fast_prof[FP_MAXW * 10];
-#define FP_DECL long long fp_t = clock64(); unsigned long long fp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define FP_MARK(k) do { const long long _n = clock64(); fp_acc[k] += (unsigned long long)(_n - fp_t); fp_t = _n; } while (0)
-#define FP_COUNT(k, v) (fp_acc[k] += (unsigned long long)(v))
-#define FP_FLUSH() do { const int _w = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave; if (lane == 0 && _w < FP_MAXW) for (int _k = 0; _k < 10; _k++) g_fast_prof[_w * 10 + _k] = fp_acc[_k]; } while (0)
-__global__ void fast_prof_dump() {
-  __shared__ unsigned long long acc[10];
-  if (threadIdx.x < 10) acc[threadIdx.x] = 0;
-  __syncthreads();
-  unsigned long long a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int w = threadIdx.x; w < FP_MAXW; w += blockDim.x)
-    for (int k = 0; k < 10; k++) { a[k] += g_fast_prof[w * 10 + k]; g_fast_prof[w * 10 + k] = 0; }
-  for (int k = 0; k < 10; k++) atomicAdd(&acc[k], a[k]);
-  __syncthreads();
-  if (threadIdx.x == 0)
-    printf("fast cycles: A %llu B %llu C %llu D %llu emit %llu | waves %llu nsurv %llu ncand %llu pass2 %llu kp %llu\n", acc[0], acc[1], acc[2], acc[3], acc[4],
-           acc[5], acc[6], acc[7], acc[8], acc[9]);
+// inclusive prefix sum over the 64 lanes (Kogge-Stone inside the 16-lane DPP rows, then the two row broadcasts)
+__device__ __forceinline__ int wave_scan_inclusive(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+  return v;
 }
-#else
-#define FP_DECL
-#define FP_MARK(k)
-#define FP_COUNT(k, v)
-#define FP_FLUSH()
-#endif
+
+#define FAST_T 256
 typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
 typedef short fs_s2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TS, int TR, int SS, int LCAP, int QS, int nimg, int bpi,
+
+// LDS layout of one cell-wave (bytes; every region 16-byte aligned).  TR = window rows of the plan's tallest cell.
+struct FastLds { int smap, bmp, list, cap, total; };
+__host__ __device__ __forceinline__ FastLds fast_lds(int TS, int TR, int SS, int LCAP) {
+  FastLds f;
+  int o = (TR * TS + 15) & ~15;
+  f.smap = o; o += (SS * (TR - 4) + 15) & ~15;         // score map with a zero ring: (rows + 2) x SS
+  f.bmp = o; o += (8 * (TR - 6) + 15) & ~15;           // kept-keypoint bitmap, one u64 per cell row
+  // survivor entries: dark from the front, bright from the back.  Sized for 60 % of the cell (a step can add 512); a cell
+  // that would overflow it is scored in several rounds (exact, slower: see the kernel)
+  f.cap = ((LCAP * 3 / 5 > 640 ? LCAP * 3 / 5 : 640) + 7) & ~7;
+  f.list = o; o += 2 * f.cap;
+  f.total = o;
+  return f;
+}
+
+// TS: LDS row stride of the window; 1 << LG: 4-pixel groups per cell row (8: cells up to 32 px wide, 16: up to 64);
+// MAXROWS: window rows the loader is unrolled for.
+template <int TS, int LG, int MAXROWS>
+__global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TR, int SS, int LCAP, int nimg, int bpi,
                                                          const uint8_t* masks, int mask_stride, size_t mask_pitch) {
+  constexpr int NG = 1 << LG, RPS = 64 >> LG;          // groups per row = loader lanes per row; rows per 64-lane step
+  constexpr int NPASS = (MAXROWS + RPS - 1) / RPS;
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform geometry stays on the scalar unit
   int img, lb;
   if (!xcd_image_block(nimg, img, lb)) return;
   const int cell = lb * 4 + wave;
   if (cell >= plan.n_cells) return;
-  const int per_wave = TR * TS + SS * (TR - 4) + 2 * LCAP + 16 + 3 + QS * (TR - 6);   // same expression as the launcher
-  uint8_t* tile = fast_smem + (size_t)wave * ((per_wave + 15) & ~15);
-  uint8_t* smap = tile + TR * TS;
-  uint16_t* list = reinterpret_cast<uint16_t*>(smap + ((SS * (TR - 4) + 1) & ~1));
-  uint8_t* qmap = tile + ((TR * TS + SS * (TR - 4) + 2 * LCAP + 16 + 3) & ~3);   // per pixel: the largest threshold that still passes the necessary test
+  const FastLds F = fast_lds(TS, TR, SS, LCAP);
+  uint8_t* tile = fast_smem + (size_t)wave * F.total;
+  uint8_t* smap = tile + F.smap;
+  unsigned long long* bmp = reinterpret_cast<unsigned long long*>(tile + F.bmp);
+  uint16_t* list = reinterpret_cast<uint16_t*>(tile + F.list);
+  const int CAP = F.cap;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
   int level = 0;
 #pragma unroll
   for (int l = 1; l < PS_ORB_MAX_LEVELS; l++)
     if (l < plan.nlevels && cell >= plan.lv[l].cell_base) level = l;
-  const OrbLevel L = plan.lv[level];
+  const OrbLevel& L = plan.lv[level];
   const int ci = cell - L.cell_base;
   const int ci_y = ci / L.n_cols, ci_x = ci - ci_y * L.n_cols;
   int32_t* cellcnt = reinterpret_cast<int32_t*>(base + plan.cellcnt_off);
@@ -542,203 +526,213 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     if (lane == 0) cellcnt[cell] = 0;
     return;
   }
-  // ---- A: window -> LDS (aligned dwords), score map cleared ----
-  FP_DECL;
-  FP_COUNT(5, 1);
-  const int shift = (PS_EDGE + iniX) & 3;   // plane origins are 256-B aligned, strides multiples of 64
-  const uint8_t* ga = base + L.plane_off + (size_t)(PS_EDGE + iniY) * L.stride + (PS_EDGE + iniX - shift);
-  const int nd = (shift + ww + 3) >> 2;
-  int lshift = shift;                       // byte offset of the window inside the LDS rows
-  if (TR <= 40 && nd <= 16) {
-    // 16 lanes per row, 4 rows per step; every load is issued before the first LDS store so that the window costs one
-    // memory round trip instead of one per step (windows of the usual 30-px cells: <= 40 rows, <= 16 dwords)
-    const int wr = lane >> 4, wd = lane & 15;
-    const bool wact = wd < nd;
-    const uint8_t* gp = ga + (size_t)wr * L.stride + 4 * (wact ? wd : 0);
-    uint32_t tmp[10];
+  const int ry = lane >> LG, g = lane & (NG - 1);
+  // ---- A: window -> LDS.  NG lanes per row, 8 bytes per lane, RPS rows per pass; every load is issued before the first
+  // LDS store so that the window costs one memory round trip.  The rows land shifted to the window's own origin (the next
+  // dword of the row comes from the neighbouring lane of the 16-lane DPP row), so that the later stages read aligned dwords. ----
+  {
+    const int shift = (PS_EDGE + iniX) & 3;   // plane origins are 256-B aligned, strides multiples of 64
+    const uint8_t* ga = base + L.plane_off + (size_t)(PS_EDGE + iniY) * L.stride + (PS_EDGE + iniX - shift);
+    const bool wact = 8 * g < shift + ww + 4;            // this lane's 8 bytes hold window bytes (or the dword that follows them)
+    const uint8_t* gp = ga + (wact ? 8 * g : 0);
+    uint2 tmp[NPASS];
 #pragma unroll
-    for (int i = 0; i < 10; i++) {
-      const int y = min(4 * i + wr, wh - 1) - wr;
-      tmp[i] = *reinterpret_cast<const uint32_t*>(gp + (ptrdiff_t)y * L.stride);
+    for (int i = 0; i < NPASS; i++) {
+      const int y = min(RPS * i + ry, wh - 1);
+      tmp[i] = *reinterpret_cast<const uint2*>(gp + (size_t)y * L.stride);
     }
-    // the window goes into LDS already shifted to its own origin (next dword of the row from the neighbouring lane of the
-    // 16-lane DPP row): the later stages read aligned dwords and skip the per-row v_alignbyte
+    // the score map (zero ring included) is cleared while the loads are in flight
+    for (int t = lane; t < (SS * (ch + 2) + 15) / 16; t += 64) reinterpret_cast<uint4*>(smap)[t] = make_uint4(0, 0, 0, 0);
+    const bool wst = 8 * g < TS;
 #pragma unroll
-    for (int i = 0; i < 10; i++) {
-      const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tmp[i], 0x101 /* row_shl:1 */, 0xF, 0xF, true);
-      if (wact && 4 * i + wr < wh) *reinterpret_cast<uint32_t*>(tile + (4 * i + wr) * TS + 4 * wd) = __builtin_amdgcn_alignbyte(nxt, tmp[i], (uint32_t)shift);
-    }
-    lshift = 0;
-  } else {
-    for (int t = lane; t < wh * nd; t += 64) {
-      const int y = t / nd, dd = t - y * nd;
-      *reinterpret_cast<uint32_t*>(tile + y * TS + 4 * dd) = *reinterpret_cast<const uint32_t*>(ga + (size_t)y * L.stride + 4 * dd);
+    for (int i = 0; i < NPASS; i++) {
+      const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tmp[i].x, 0x101 /* row_shl:1 */, 0xF, 0xF, true);
+      uint2 o;
+      o.x = __builtin_amdgcn_alignbyte(tmp[i].y, tmp[i].x, (uint32_t)shift);
+      o.y = __builtin_amdgcn_alignbyte(nxt, tmp[i].y, (uint32_t)shift);
+      if (wst && RPS * i + ry < wh) *reinterpret_cast<uint2*>(tile + (RPS * i + ry) * TS + 8 * g) = o;
     }
   }
-  for (int t = lane; t < (SS * (ch + 2) + 3) / 4; t += 64) reinterpret_cast<uint32_t*>(smap)[t] = 0;
   wave_sync();
-  FP_MARK(0);
-  // ---- B: cheap NECESSARY test on the 4 compass points of the ring, 4 pixels per lane and step (see below) ----
-  const int ng = (cw + 3) >> 2, ntask = ch * ng;
-  // exact for t < 65536 / ng: the error of the rounded-up reciprocal stays below 1 / ng (ntask is a few hundred)
-  const uint32_t ng_recip = (65536u + (uint32_t)ng - 1u) / (uint32_t)ng;
-  const unsigned long long ltmask = (1ull << lane) - 1ull;
-  uint32_t* slots = reinterpret_cast<uint32_t*>(base + plan.cand_base) + L.cand_off + (size_t)ci * L.cell_cap;
+  // pixels of a lane's group that lie inside the cell (cell width is not a multiple of 4)
+  unsigned long long VX[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) VX[i] = __builtin_amdgcn_ballot_w64(4 * g + i < cw);
   int total = 0;
-  // Two passes at most: first with iniThFAST — a keypoint at threshold t only competes with neighbours that are corners
+  // Two passes at most: first with iniThFAST - a keypoint at threshold t only competes with neighbours that are corners
   // at t, so when the cell has a keypoint at iniThFAST (the common case) the many weak corners between minThFAST and
   // iniThFAST never need a score.  Only a cell without one repeats the pipeline at minThFAST (ORBextractor.cc:809-816).
   for (int pass = 0; pass < 2; pass++) {
-  const int th = pass == 0 ? plan.ini_th : plan.min_th;
-  int nsurv = 0;
-  for (int t0 = 0; t0 < ntask; t0 += 64) {
-    const int t = t0 + lane;
-    const bool tv = t < ntask;
-    const int y = tv ? (int)(((uint32_t)t * ng_recip) >> 16) : 0, g = tv ? t - y * ng : 0;   // t / ng without the division sequence
-    unsigned long long C[4];
-    if (pass == 0) {
-    // rows -3, 0, +3 of the window hold the four compass points of the ring (N, E, S, W = ring positions 0, 4, 8, 12)
-    uint32_t w[7][3];
+    const int th = pass == 0 ? plan.ini_th : plan.min_th;
+    // ---- B + C.  B fills the survivor region step by step; C scores what is listed.  One round unless the region
+    // would overflow (more than 60 % of the cell's pixels listed: noise), then C runs on what is there and B goes on. ----
+    int nd = 0, nb = 0, y0 = 0;
+    bool flushed = false;
+    const uint8_t* rp = tile + ry * TS + 4 * g;          // window row of the lane's N points; the centre row is 3 below
+    uint32_t val = (uint32_t)((ry << 7) | (4 * g));      // list entry of the lane's first pixel: y << 7 | x
+    for (;;) {
+      bool full = false;
+      for (; y0 < ch; y0 += RPS, rp += RPS * TS, val += RPS << 7) {
+        const int nl = (ch - y0) << LG;                  // lanes whose row is inside the cell
+        const unsigned long long rv = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
+        const uint32_t n0 = reinterpret_cast<const uint32_t*>(rp)[0], n1 = reinterpret_cast<const uint32_t*>(rp)[1];
+        const uint32_t c0 = reinterpret_cast<const uint32_t*>(rp + 3 * TS)[0], c1 = reinterpret_cast<const uint32_t*>(rp + 3 * TS)[1],
+                       c2 = reinterpret_cast<const uint32_t*>(rp + 3 * TS)[2];
+        const uint32_t s0 = reinterpret_cast<const uint32_t*>(rp + 6 * TS)[0], s1 = reinterpret_cast<const uint32_t*>(rp + 6 * TS)[1];
+        unsigned long long DK[4], BR[4], VR[4];
 #pragma unroll
-    for (int r = 0; r < 7; r += 3) {
-      const uint32_t* p = reinterpret_cast<const uint32_t*>(tile + (y + r) * TS + 4 * g);
-      if (lshift == 0) {   // wave-uniform
-        w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = r == 3 ? p[2] : 0u;
-      } else {
-        const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = r == 3 ? p[3] : 0u;
-        w[r][0] = __builtin_amdgcn_alignbyte(a1, a0, lshift);
-        w[r][1] = __builtin_amdgcn_alignbyte(a2, a1, lshift);
-        w[r][2] = __builtin_amdgcn_alignbyte(a3, a2, lshift);
-      }
-    }
-    // Two pixels per operation on packed u16.  Nine contiguous ring pixels always contain two ADJACENT compass points, so a
-    // corner at threshold t has two adjacent compass points both darker than v - t or both brighter than v + t:
-    //   min over the 4 adjacent pairs of (max of the pair) < v - t   or   max over the pairs of (min of the pair) > v + t.
-    // On natural images this rejects nearly as many pixels as the 8-even-position test it replaces (8.7 % vs 5.9 % pass at
-    // t = 20 on the KITTI frame) for a third of its operations; the ring values go through the pk_max / pk_min trees untouched
-    // and the threshold enters in one packed subtraction.
-    uint32_t qpair[2];
+        for (int i = 0; i < 4; i++) VR[i] = VX[i] & rv;
 #pragma unroll
-    for (int pq = 0; pq < 2; pq++) {
-      const int i = 2 * pq;
-#define PAIR(r, b) __builtin_bit_cast(fs_us2, (b) <= 6 ? __builtin_amdgcn_perm(w[r][1], w[r][0], (uint32_t)(b) | 0x0c000c00u | ((uint32_t)((b) + 1) << 16)) \
-                                                        : __builtin_amdgcn_perm(w[r][2], w[r][1], (uint32_t)((b) - 4) | 0x0c000c00u | ((uint32_t)((b) - 3) << 16)))
-      const fs_us2 pN = PAIR(6, 3 + i), pE = PAIR(3, 6 + i), pS = PAIR(0, 3 + i), pW = PAIR(3, 0 + i);
-      const fs_s2 cv = __builtin_bit_cast(fs_s2, PAIR(3, 3 + i));
+        for (int pq = 0; pq < 2; pq++) {
+          // bytes (b, b + 1) of the 8-byte pair {hi, lo} as packed u16
+#define PAIR(hi, lo, b) __builtin_bit_cast(fs_us2, __builtin_amdgcn_perm(hi, lo, (uint32_t)(b) | 0x0c000c00u | ((uint32_t)((b) + 1) << 16)))
+          const fs_us2 pN = PAIR(n1, n0, 3 + 2 * pq), pS = PAIR(s1, s0, 3 + 2 * pq), pW = PAIR(c1, c0, 2 * pq);
+          const fs_us2 pE = pq == 0 ? PAIR(c1, c0, 6) : PAIR(c2, c1, 4);
+          const fs_s2 cv = __builtin_bit_cast(fs_s2, PAIR(c1, c0, 3 + 2 * pq));
 #undef PAIR
-      const fs_us2 M = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(pN, pE), __builtin_elementwise_max(pE, pS)),
-                                                 __builtin_elementwise_min(__builtin_elementwise_max(pS, pW), __builtin_elementwise_max(pW, pN)));
-      const fs_us2 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(pN, pE), __builtin_elementwise_min(pE, pS)),
-                                                 __builtin_elementwise_max(__builtin_elementwise_min(pS, pW), __builtin_elementwise_min(pW, pN)));
-      // two adjacent darker <=> M < v - th <=> th < v - M; brighter <=> th < m - v: the pixel passes at every threshold
-      // below q = max(v - M, m - v), which does not depend on th - kept (one byte per pixel) for the minThFAST pass
-      const fs_s2 zero2 = {0, 0};
-      const fs_s2 qv = __builtin_elementwise_max(__builtin_elementwise_max(cv - __builtin_bit_cast(fs_s2, M), __builtin_bit_cast(fs_s2, m) - cv), zero2);
-      qpair[pq] = __builtin_bit_cast(uint32_t, qv);
-      const fs_s2 thv = {(short)th, (short)th};
-      const uint32_t rr = __builtin_bit_cast(uint32_t, thv - qv);     // < 0: passes
-      C[i] = __builtin_amdgcn_ballot_w64(tv && (4 * g + i) < cw && (rr & 0x8000u) != 0);
-      C[i + 1] = __builtin_amdgcn_ballot_w64(tv && (4 * g + i + 1) < cw && (rr & 0x80000000u) != 0);
+          const fs_us2 M = __builtin_elementwise_max(__builtin_elementwise_min(pN, pS), __builtin_elementwise_min(pE, pW));
+          const fs_us2 m = __builtin_elementwise_min(__builtin_elementwise_max(pN, pS), __builtin_elementwise_max(pE, pW));
+          const fs_s2 dd = cv - __builtin_bit_cast(fs_s2, M);         // > th: two adjacent compass points darker than v - th
+          const fs_s2 bb = __builtin_bit_cast(fs_s2, m) - cv;         // > th: two adjacent compass points brighter than v + th
+          DK[2 * pq] = __builtin_amdgcn_ballot_w64((int)dd.x > th) & VR[2 * pq];
+          DK[2 * pq + 1] = __builtin_amdgcn_ballot_w64((int)dd.y > th) & VR[2 * pq + 1];
+          BR[2 * pq] = __builtin_amdgcn_ballot_w64((int)bb.x > th) & VR[2 * pq];
+          BR[2 * pq + 1] = __builtin_amdgcn_ballot_w64((int)bb.y > th) & VR[2 * pq + 1];
+        }
+        int nstep = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) nstep += __popcll(DK[i]) + __popcll(BR[i]);
+        if (nd + nb + nstep > CAP) { full = true; break; }   // (a step adds at most 512 entries <= CAP: an empty region always takes it)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if (DK[i]) {                                   // wave-uniform
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(DK[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)DK[i], (uint32_t)nd));
+            if (__builtin_amdgcn_inverse_ballot_w64(DK[i])) list[pos] = (uint16_t)(val | i);
+            nd += __popcll(DK[i]);
+          }
+          if (BR[i]) {
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(BR[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)BR[i], (uint32_t)nb));
+            if (__builtin_amdgcn_inverse_ballot_w64(BR[i])) list[CAP - 1 - (int)pos] = (uint16_t)(val | i);
+            nb += __popcll(BR[i]);
+          }
+        }
+      }
+      wave_sync();
+      // ---- C: exact scores, two entries per lane: entry k of the concatenation [dark entries, bright entries] ----
+      const int ntot = nd + nb;
+      for (int i0 = 0; i0 < ntot; i0 += 128) {
+        uint32_t p[2], polm = 0;
+        const uint8_t* q[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int kk = min(i0 + 64 * e + lane, ntot - 1);   // lanes beyond the end repeat the last entry (their result is dropped)
+          const bool bright = kk >= nd;
+          p[e] = list[bright ? CAP - 1 + nd - kk : kk];
+          if (bright) polm |= 0xFFu << (16 * e);
+          q[e] = tile + (p[e] >> 7) * TS + (p[e] & 127u);     // window position of the pixel's 7 x 7 neighbourhood
+        }
+        // ring offsets from q (centre at (3, 3)): position 0 is (dx, dy) = (0, +3), then as OpenCV's table
+        constexpr int RO[16] = {6 * TS + 3, 6 * TS + 4, 5 * TS + 5, 4 * TS + 6, 3 * TS + 6, 2 * TS + 6, 1 * TS + 5, 0 * TS + 4,
+                                0 * TS + 3, 0 * TS + 2, 1 * TS + 1, 2 * TS + 0, 3 * TS + 0, 4 * TS + 0, 5 * TS + 1, 6 * TS + 2};
+        fs_us2 x[16], m2[16], m4[16], m8[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          x[i] = __builtin_bit_cast(fs_us2, ((uint32_t)q[0][RO[i]] | ((uint32_t)q[1][RO[i]] << 16)) ^ polm);
+        const fs_s2 cv = __builtin_bit_cast(fs_s2, ((uint32_t)q[0][3 * TS + 3] | ((uint32_t)q[1][3 * TS + 3] << 16)) ^ polm);
+#pragma unroll
+        for (int i = 0; i < 16; i++) m2[i] = __builtin_elementwise_max(x[i], x[(i + 1) & 15]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) m4[i] = __builtin_elementwise_max(m2[i], m2[(i + 2) & 15]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) m8[i] = __builtin_elementwise_max(m4[i], m4[(i + 4) & 15]);
+        // nine-pixel arc i = positions i .. i + 8 = the eight from i and the eight from i + 1
+        fs_us2 best = __builtin_elementwise_max(m8[0], m8[1]);
+#pragma unroll
+        for (int i = 1; i < 16; i++) best = __builtin_elementwise_min(best, __builtin_elementwise_max(m8[i], m8[(i + 1) & 15]));
+        const fs_s2 sc = cv - __builtin_bit_cast(fs_s2, best);
+        if ((int)sc.x > th && i0 + lane < ntot) smap[((p[0] >> 7) + 1) * SS + (p[0] & 127u) + 1] = (uint8_t)sc.x;
+        if ((int)sc.y > th && i0 + 64 + lane < ntot) smap[((p[1] >> 7) + 1) * SS + (p[1] & 127u) + 1] = (uint8_t)sc.y;
+      }
+      if (!full) break;
+      wave_sync();
+      nd = nb = 0;
+      flushed = true;
     }
-    if (tv) *reinterpret_cast<uint32_t*>(qmap + y * QS + 4 * g) = __builtin_amdgcn_perm(qpair[1], qpair[0], 0x06040200u);
-    } else {
-      const uint32_t qq = tv ? *reinterpret_cast<const uint32_t*>(qmap + y * QS + 4 * g) : 0u;
-#pragma unroll
-      for (int i = 0; i < 4; i++) C[i] = __builtin_amdgcn_ballot_w64(tv && (4 * g + i) < cw && (int)((qq >> (8 * i)) & 0xFFu) > th);
-    }
-    // raster-ordered compaction: order (lane, slot)
-    // survivors in lower lanes: v_mbcnt counts the mask bits below the lane and adds an accumulator, two instructions per mask
-    uint32_t lower_u = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      lower_u = __builtin_amdgcn_mbcnt_hi((uint32_t)(C[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)C[i], lower_u));
-    const int lower = (int)lower_u;
-    int own = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if ((C[i] >> lane) & 1ull) {
-        const int pos = nsurv + lower + own;
-        if (pos < LCAP) list[pos] = (uint16_t)((y << 7) | (4 * g + i));   // y and x in seven bits each (PS_FAST_WIN <= 72), bit 15 stays free: no division later
-        own++;
+    wave_sync();
+    // ---- D: strict 3x3 NMS of the corners at th (the non-zero entries of the score map: scores do not depend on th, and
+    // only scores above the current or an earlier, higher th were written) ----
+    unsigned long long anykp = 0;
+    unsigned long long rowbits = 0;                      // several rounds: lane = cell row
+    if (!flushed) {
+      const int ntot = nd + nb;
+      for (int i0 = 0; i0 < ntot; i0 += 64) {
+        const int k = i0 + lane;
+        bool lmax = false;
+        if (k < ntot) {
+          const int li = k >= nd ? CAP - 1 + nd - k : k;
+          const int pp = list[li];
+          const uint8_t* m = smap + ((pp >> 7) + 1) * SS + (pp & 127) + 1;
+          const int s = m[0];
+          lmax = s > m[-1] && s > m[1] && s > m[-SS - 1] && s > m[-SS] && s > m[-SS + 1] && s > m[SS - 1] && s > m[SS] && s > m[SS + 1];
+          if (lmax) list[li] = (uint16_t)(pp | 0x8000); // bit 15: survives the NMS (a pixel listed twice is marked twice)
+        }
+        anykp |= __builtin_amdgcn_ballot_w64(lmax);
+      }
+    } else if (lane < ch) {
+      for (int x = 0; x < cw; x++) {
+        const uint8_t* m = smap + (lane + 1) * SS + x + 1;
+        const int s = m[0];
+        if (s > m[-1] && s > m[1] && s > m[-SS - 1] && s > m[-SS] && s > m[-SS + 1] && s > m[SS - 1] && s > m[SS] && s > m[SS + 1])
+          rowbits |= 1ull << x;
       }
     }
-    nsurv += __popcll(C[0]) + __popcll(C[1]) + __popcll(C[2]) + __popcll(C[3]);
-  }
-  nsurv = min(nsurv, LCAP);
-  wave_sync();
-  FP_MARK(1);
-  FP_COUNT(6, nsurv);
-  if (pass == 1) FP_COUNT(8, 1);
-  // ---- C: exact score of the survivors; s > min_th <=> corner.  The list is compacted in place (a chunk is read
-  // before anything is written, and writes never run ahead of the reads). ----
-  int ncand = 0;
-  for (int i0 = 0; i0 < nsurv; i0 += 64) {
-    const int idx = i0 + lane;
-    int p = 0, sc = 0;
-    if (idx < nsurv) {
-      p = list[idx];
-      const int y = (p >> 7) & 127, x = p & 127;
-      sc = fast_score_exact(tile + (y + 3) * TS + lshift + x + 3, TS);
-      if (sc > th) smap[(y + 1) * SS + x + 1] = (uint8_t)sc;
+    if (flushed) anykp = __builtin_amdgcn_ballot_w64(rowbits != 0);
+    if (!anykp && pass == 0) continue;   // no keypoint at iniThFAST: run the cell again at minThFAST
+    // ---- emission in raster order: bitmap of the kept pixels, one row per lane; the row counts' prefix is the rank ----
+    const int mx0 = ci_x * L.w_cell + 3, my0 = ci_y * L.h_cell + 3;   // cell pixel (0, 0) relative to (minBorderX, minBorderY)
+    if (!flushed) {
+      if (lane < ch) bmp[lane] = 0;
+      wave_sync();
+      const int ntot = nd + nb;
+      for (int i0 = 0; i0 < ntot; i0 += 64) {
+        const int k = i0 + lane;
+        const int pv = k < ntot ? list[k >= nd ? CAP - 1 + nd - k : k] : 0;
+        if (pv & 0x8000) atomicOr(&bmp[(pv >> 7) & 127], 1ull << (pv & 127));
+      }
+      wave_sync();
+      rowbits = lane < ch ? bmp[lane] : 0ull;
     }
-    const unsigned long long cm = __builtin_amdgcn_ballot_w64(sc > th);
-    wave_sync();
-    if (sc > th) list[ncand + __popcll(cm & ltmask)] = (uint16_t)p;
-    ncand += __popcll(cm);
-  }
-  wave_sync();
-  FP_MARK(2);
-  FP_COUNT(7, ncand);
-  // ---- D: per-cell NMS and emission (every listed pixel is a corner at th) ----
-  unsigned long long anykp = 0;
-  for (int i0 = 0; i0 < ncand; i0 += 64) {
-    const int idx = i0 + lane;
-    uint8_t f = 0;
-    if (idx < ncand) {
-      const int p = list[idx];
-      const int y = (p >> 7) & 127, x = p & 127;
-      const uint8_t* m = smap + (y + 1) * SS + x + 1;
-      const int s = m[0];
-      const bool lmax = s > m[-1] && s > m[1] && s > m[-SS - 1] && s > m[-SS] && s > m[-SS + 1] &&
-                        s > m[SS - 1] && s > m[SS] && s > m[SS + 1];
-      f = lmax ? 1 : 0;
-      if (lmax) list[idx] = (uint16_t)(p | 0x8000);   // bit 15: survives the NMS
-    }
-    anykp |= __builtin_amdgcn_ballot_w64(f != 0);
-  }
-  wave_sync();
-  FP_MARK(3);
-  if (!anykp && pass == 0) continue;   // no keypoint at iniThFAST: run the cell again at minThFAST
-  for (int i0 = 0; i0 < ncand; i0 += 64) {
-    const int idx = i0 + lane;
-    const int pv = idx < ncand ? list[idx] : 0;
-    bool keep = (pv & 0x8000) != 0;
-    if (masks && keep) {
+    if (masks) {
       // object-feature variant (SURVEY.md 8f-2 stand-in): a keypoint whose pixel in the level-0 image - cvRound(level
       // coordinate * scale), clipped - lies outside the mask never reaches the quadtree
-      const int px = (pv & 127) + 3 + ci_x * L.w_cell + PS_MINB, py = ((pv >> 7) & 127) + 3 + ci_y * L.h_cell + PS_MINB;
-      const int mx = min(max(__float2int_rn(__fmul_rn((float)px, L.scale)), 0), plan.img_w - 1);
-      const int my = min(max(__float2int_rn(__fmul_rn((float)py, L.scale)), 0), plan.img_h - 1);
-      keep = masks[(size_t)img * mask_pitch + (size_t)my * mask_stride + mx] != 0;
+      unsigned long long w = rowbits;
+      while (w) {
+        const int x = __ffsll((long long)w) - 1;
+        w &= w - 1;
+        const int px = x + mx0 + PS_MINB, py = lane + my0 + PS_MINB;
+        const int mx = min(max(__float2int_rn(__fmul_rn((float)px, L.scale)), 0), plan.img_w - 1);
+        const int my = min(max(__float2int_rn(__fmul_rn((float)py, L.scale)), 0), plan.img_h - 1);
+        if (masks[(size_t)img * mask_pitch + (size_t)my * mask_stride + mx] == 0) rowbits &= ~(1ull << x);
+      }
     }
-    const unsigned long long km = __ballot(keep);
-    if (keep) {
-      const int pos = total + __popcll(km & ltmask);
-      const int p = pv & 0x7FFF;
-      const int y = (p >> 7) & 127, x = p & 127;
-      const int s = smap[(y + 1) * SS + x + 1];
-      // coordinates relative to (minBorderX, minBorderY): local + j*wCell (ORBextractor.cc:822-824)
-      const uint32_t xr = (uint32_t)(x + 3 + ci_x * L.w_cell), yr = (uint32_t)(y + 3 + ci_y * L.h_cell);
-      if (pos < L.cell_cap) slots[pos] = xr | (yr << 12) | ((uint32_t)s << 24);
+    {
+      const int c = __popcll(rowbits);
+      const int inc = wave_scan_inclusive(c);
+      total = __builtin_amdgcn_readlane(inc, 63);
+      int pos = inc - c;
+      uint32_t* slots = reinterpret_cast<uint32_t*>(base + plan.cand_base) + L.cand_off + (size_t)ci * L.cell_cap;
+      while (rowbits) {
+        const int x = __ffsll((long long)rowbits) - 1;
+        rowbits &= rowbits - 1;
+        const int s = smap[(lane + 1) * SS + x + 1];
+        // coordinates relative to (minBorderX, minBorderY): local + j*wCell (ORBextractor.cc:822-824)
+        if (pos < L.cell_cap) slots[pos] = (uint32_t)(x + mx0) | ((uint32_t)(lane + my0) << 12) | ((uint32_t)s << 24);
+        pos++;
+      }
     }
-    total += __popcll(km);
-  }
-  FP_MARK(4);
-  FP_COUNT(9, total);
-  break;
+    break;
   }   // pass
   if (lane == 0) cellcnt[cell] = min(total, L.cell_cap);
-  FP_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1397,16 +1391,18 @@ extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nim
     mw = plan->lv[l].w_cell + 6 > mw ? plan->lv[l].w_cell + 6 : mw;
     mh = plan->lv[l].h_cell + 6 > mh ? plan->lv[l].h_cell + 6 : mh;
   }
-  const int TS = (mw + 16 + 3) & ~3, TR = mh, SS = (mw - 6 + 2 + 3) & ~3;
+  const int TR = mh, SS = (mw - 6 + 2 + 3) & ~3;
   const int LCAP = (mw - 6) * (mh - 6);
-  const int QS = (mw - 6 + 3) & ~3;
-  const int per_wave = (TR * TS + SS * (TR - 4) + 2 * LCAP + 16 + 3 + QS * (TR - 6) + 15) & ~15;
   const int bpi = (plan->n_cells + 3) / 4;
-  hipLaunchKernelGGL(orb_fast_cells, PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)per_wave * 4, st, *plan, arena,
-                     TS, TR, SS, LCAP, QS, nimg, bpi, masks, mask_stride, mask_pitch);
-#ifdef PS_FAST_PROFILE
-  hipLaunchKernelGGL(fast_prof_dump, dim3(1), dim3(1024), 0, st);
-#endif
+  if (mw <= 38 && mh <= 48) {      // cells up to 32 px wide (30-px cells of the usual image sizes): 8 groups per row, 8 rows per step
+    const FastLds F = fast_lds(40, TR, SS, LCAP);
+    hipLaunchKernelGGL((orb_fast_cells<40, 3, 48>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, TR, SS, LCAP,
+                       nimg, bpi, masks, mask_stride, mask_pitch);
+  } else {                         // up to PS_FAST_WIN: 16 groups per row, 4 rows per step
+    const FastLds F = fast_lds(72, TR, SS, LCAP);
+    hipLaunchKernelGGL((orb_fast_cells<72, 4, 68>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, TR, SS, LCAP,
+                       nimg, bpi, masks, mask_stride, mask_pitch);
+  }
 }
 extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   // smallest node capacity that holds every level (quota + 4 nodes, 4 * n_ini initial children, cells / 3 for the gather table)

@@ -8,7 +8,7 @@
 #define PS_EDGE 19          // EDGE_THRESHOLD, /root/reference/src/ORBextractor.cc:74
 #define PS_MINB 16          // minBorderX/Y = EDGE_THRESHOLD - 3, ORBextractor.cc:773-774
 #define PS_QT_NCAP 2048     // largest node capacity of the quadtree kernel (per-level quota + 4 must fit; 149 KB of LDS)
-#define PS_FAST_WIN 72      // max FAST cell window edge (cell + 6)
+#define PS_FAST_WIN 66      // max FAST cell window edge (cell + 6): a cell is at most 60 px (ceil(width / floor(width / 30)))
 
 struct OrbLevel {
   int32_t w, h;             // level image size (ORBextractor.cc:1112)

@@ -112,6 +112,31 @@ def test_batch_device_matches_single(images):
         assert np.array_equal(dg, do)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "salt", "mixed"])
+def test_noise_images_take_the_multi_round_path(kind):
+    """white noise lists most pixels of a FAST cell as dark AND bright survivors: the survivor region of orb_fast_cells
+    overflows and the cell is scored in several rounds with the row-wise NMS - every stage stays bit-exact"""
+    from pointslot_amd.extractor import ORBextractor
+    rng = np.random.default_rng(11)
+    h, w = 375, 1242
+    if kind == "uniform":
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == "salt":
+        img = np.where(rng.random((h, w)) < 0.5, 20, 235).astype(np.uint8)
+    else:   # left half noise, right half flat with a few corners: cells of both kinds in one launch
+        img = np.full((h, w), 128, np.uint8)
+        img[:, : w // 2] = rng.integers(0, 256, (h, w // 2), dtype=np.uint8)
+        img[50:200, 800:1000] = 30
+    ex = ORBextractor(2000, 1.2, 8, 20, 5)
+    orc = OracleORB(2000)
+    kg, dg = ex(img)
+    ko, do = orc.run(img)
+    _compare_stages(ex, orc, img, kind)
+    assert len(kg) == len(ko) and len(kg) > 100
+    assert np.array_equal(kg.view(np.uint8), ko.view(np.uint8)) and np.array_equal(dg, do)
+    ex.close()
+
+
 @pytest.mark.parametrize("shape,nfeatures,nlevels,ths,scale", [
     ((480, 640), 1500, 8, (20, 7), 1.2),
     ((300, 800), 500, 8, (20, 5), 1.2),
