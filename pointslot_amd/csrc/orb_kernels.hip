@@ -482,9 +482,10 @@ __host__ __device__ __forceinline__ FastLds fast_lds(int TS, int TR, int SS, int
   int o = (TR * TS + 15) & ~15;
   f.smap = o; o += (SS * (TR - 4) + 15) & ~15;         // score map with a zero ring: (rows + 2) x SS
   f.bmp = o; o += (8 * (TR - 6) + 15) & ~15;           // kept-keypoint bitmap, one u64 per cell row
-  // survivor entries: dark from the front, bright from the back.  Sized for 60 % of the cell (a step can add 512); a cell
-  // that would overflow it is scored in several rounds (exact, slower: see the kernel)
-  f.cap = ((LCAP * 3 / 5 > 640 ? LCAP * 3 / 5 : 640) + 7) & ~7;
+  // survivor entries: dark from the front, bright from the back.  Sized for 9/16 of the cell's pixels (a step can add 512);
+  // a cell that would overflow it is scored in several rounds (exact, slower: see the kernel).  With the 32 x 40 cells of
+  // 1242 x 375 a wave takes 5120 bytes: 8 workgroups per CU.
+  f.cap = ((LCAP * 9 / 16 > 640 ? LCAP * 9 / 16 : 640) + 7) & ~7;
   f.list = o; o += 2 * f.cap;
   f.total = o;
   return f;
@@ -492,8 +493,11 @@ __host__ __device__ __forceinline__ FastLds fast_lds(int TS, int TR, int SS, int
 
 // TS: LDS row stride of the window; 1 << LG: 4-pixel groups per cell row (8: cells up to 32 px wide, 16: up to 64);
 // MAXROWS: window rows the loader is unrolled for.
+#ifndef PS_FAST_WAVES
+#define PS_FAST_WAVES 8        // waves per SIMD the register allocation aims at (the LDS of the usual cells admits 8 workgroups per CU)
+#endif
 template <int TS, int LG, int MAXROWS>
-__global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TR, int SS, int LCAP, int nimg, int bpi,
+__global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_WAVES, 8))) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TR, int SS, int LCAP, int nimg, int bpi,
                                                          const uint8_t* masks, int mask_stride, size_t mask_pitch) {
   constexpr int NG = 1 << LG, RPS = 64 >> LG;          // groups per row = loader lanes per row; rows per 64-lane step
   constexpr int NPASS = (MAXROWS + RPS - 1) / RPS;
@@ -554,16 +558,19 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     }
   }
   wave_sync();
-  // pixels of a lane's group that lie inside the cell (cell width is not a multiple of 4)
-  unsigned long long VX[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) VX[i] = __builtin_amdgcn_ballot_w64(4 * g + i < cw);
   int total = 0;
   // Two passes at most: first with iniThFAST - a keypoint at threshold t only competes with neighbours that are corners
   // at t, so when the cell has a keypoint at iniThFAST (the common case) the many weak corners between minThFAST and
   // iniThFAST never need a score.  Only a cell without one repeats the pipeline at minThFAST (ORBextractor.cc:809-816).
   for (int pass = 0; pass < 2; pass++) {
     const int th = pass == 0 ? plan.ini_th : plan.min_th;
+    // per-lane packed thresholds: a pixel of the lane's group beyond the cell's width (not a multiple of 4) never passes
+    fs_s2 thv[2];
+#pragma unroll
+    for (int pq = 0; pq < 2; pq++) {
+      thv[pq].x = (short)(4 * g + 2 * pq < cw ? th : 0x7FFF);
+      thv[pq].y = (short)(4 * g + 2 * pq + 1 < cw ? th : 0x7FFF);
+    }
     // ---- B + C.  B fills the survivor region step by step; C scores what is listed.  One round unless the region
     // would overflow (more than 60 % of the cell's pixels listed: noise), then C runs on what is there and B goes on. ----
     int nd = 0, nb = 0, y0 = 0;
@@ -573,15 +580,15 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
     for (;;) {
       bool full = false;
       for (; y0 < ch; y0 += RPS, rp += RPS * TS, val += RPS << 7) {
-        const int nl = (ch - y0) << LG;                  // lanes whose row is inside the cell
+        // lanes whose row lies below the cell read rows of the window that exist in LDS but mean nothing: masked out (a ballot
+        // inside a lane-dependent branch would make every count that follows lane-dependent)
+        const int nl = (ch - y0) << LG;
         const unsigned long long rv = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
         const uint32_t n0 = reinterpret_cast<const uint32_t*>(rp)[0], n1 = reinterpret_cast<const uint32_t*>(rp)[1];
         const uint32_t c0 = reinterpret_cast<const uint32_t*>(rp + 3 * TS)[0], c1 = reinterpret_cast<const uint32_t*>(rp + 3 * TS)[1],
                        c2 = reinterpret_cast<const uint32_t*>(rp + 3 * TS)[2];
         const uint32_t s0 = reinterpret_cast<const uint32_t*>(rp + 6 * TS)[0], s1 = reinterpret_cast<const uint32_t*>(rp + 6 * TS)[1];
-        unsigned long long DK[4], BR[4], VR[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) VR[i] = VX[i] & rv;
+        unsigned long long DK[4], BR[4];
 #pragma unroll
         for (int pq = 0; pq < 2; pq++) {
           // bytes (b, b + 1) of the 8-byte pair {hi, lo} as packed u16
@@ -594,10 +601,10 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
           const fs_us2 m = __builtin_elementwise_min(__builtin_elementwise_max(pN, pS), __builtin_elementwise_max(pE, pW));
           const fs_s2 dd = cv - __builtin_bit_cast(fs_s2, M);         // > th: two adjacent compass points darker than v - th
           const fs_s2 bb = __builtin_bit_cast(fs_s2, m) - cv;         // > th: two adjacent compass points brighter than v + th
-          DK[2 * pq] = __builtin_amdgcn_ballot_w64((int)dd.x > th) & VR[2 * pq];
-          DK[2 * pq + 1] = __builtin_amdgcn_ballot_w64((int)dd.y > th) & VR[2 * pq + 1];
-          BR[2 * pq] = __builtin_amdgcn_ballot_w64((int)bb.x > th) & VR[2 * pq];
-          BR[2 * pq + 1] = __builtin_amdgcn_ballot_w64((int)bb.y > th) & VR[2 * pq + 1];
+          DK[2 * pq] = __builtin_amdgcn_ballot_w64(dd.x > thv[pq].x) & rv;
+          DK[2 * pq + 1] = __builtin_amdgcn_ballot_w64(dd.y > thv[pq].y) & rv;
+          BR[2 * pq] = __builtin_amdgcn_ballot_w64(bb.x > thv[pq].x) & rv;
+          BR[2 * pq + 1] = __builtin_amdgcn_ballot_w64(bb.y > thv[pq].y) & rv;
         }
         int nstep = 0;
 #pragma unroll
@@ -634,21 +641,23 @@ __global__ __launch_bounds__(FAST_T) void orb_fast_cells(OrbPlan plan, uint8_t* 
         // ring offsets from q (centre at (3, 3)): position 0 is (dx, dy) = (0, +3), then as OpenCV's table
         constexpr int RO[16] = {6 * TS + 3, 6 * TS + 4, 5 * TS + 5, 4 * TS + 6, 3 * TS + 6, 2 * TS + 6, 1 * TS + 5, 0 * TS + 4,
                                 0 * TS + 3, 0 * TS + 2, 1 * TS + 1, 2 * TS + 0, 3 * TS + 0, 4 * TS + 0, 5 * TS + 1, 6 * TS + 2};
-        fs_us2 x[16], m2[16], m4[16], m8[16];
+        fs_us2 x[16];
 #pragma unroll
         for (int i = 0; i < 16; i++)
           x[i] = __builtin_bit_cast(fs_us2, ((uint32_t)q[0][RO[i]] | ((uint32_t)q[1][RO[i]] << 16)) ^ polm);
         const fs_s2 cv = __builtin_bit_cast(fs_s2, ((uint32_t)q[0][3 * TS + 3] | ((uint32_t)q[1][3 * TS + 3] << 16)) ^ polm);
+        // max of each of the 16 nine-pixel arcs from running maxima of the two 8-blocks (suffix S, prefix P): the arc that starts
+        // at i < 8 is the block-0 suffix from i and the block-1 prefix up to i; the arc that starts at i + 8 wraps the other way
+        fs_us2 S0[8], P0[8], S1[8], P1[8];
+        S0[7] = x[7]; P0[0] = x[0]; S1[7] = x[15]; P1[0] = x[8];
 #pragma unroll
-        for (int i = 0; i < 16; i++) m2[i] = __builtin_elementwise_max(x[i], x[(i + 1) & 15]);
+        for (int i = 6; i >= 0; i--) { S0[i] = __builtin_elementwise_max(x[i], S0[i + 1]); S1[i] = __builtin_elementwise_max(x[8 + i], S1[i + 1]); }
 #pragma unroll
-        for (int i = 0; i < 16; i++) m4[i] = __builtin_elementwise_max(m2[i], m2[(i + 2) & 15]);
+        for (int i = 1; i < 8; i++) { P0[i] = __builtin_elementwise_max(x[i], P0[i - 1]); P1[i] = __builtin_elementwise_max(x[8 + i], P1[i - 1]); }
+        fs_us2 best = __builtin_elementwise_min(__builtin_elementwise_max(S0[0], P1[0]), __builtin_elementwise_max(S1[0], P0[0]));
 #pragma unroll
-        for (int i = 0; i < 16; i++) m8[i] = __builtin_elementwise_max(m4[i], m4[(i + 4) & 15]);
-        // nine-pixel arc i = positions i .. i + 8 = the eight from i and the eight from i + 1
-        fs_us2 best = __builtin_elementwise_max(m8[0], m8[1]);
-#pragma unroll
-        for (int i = 1; i < 16; i++) best = __builtin_elementwise_min(best, __builtin_elementwise_max(m8[i], m8[(i + 1) & 15]));
+        for (int i = 1; i < 8; i++)
+          best = __builtin_elementwise_min(best, __builtin_elementwise_min(__builtin_elementwise_max(S0[i], P1[i]), __builtin_elementwise_max(S1[i], P0[i])));
         const fs_s2 sc = cv - __builtin_bit_cast(fs_s2, best);
         if ((int)sc.x > th && i0 + lane < ntot) smap[((p[0] >> 7) + 1) * SS + (p[0] & 127u) + 1] = (uint8_t)sc.x;
         if ((int)sc.y > th && i0 + 64 + lane < ntot) smap[((p[1] >> 7) + 1) * SS + (p[1] & 127u) + 1] = (uint8_t)sc.y;
