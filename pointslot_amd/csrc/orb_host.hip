@@ -230,6 +230,7 @@ int build_plan(ps_orb* h, int w, int hgt) {
       return ps_set_error(PS_ERR_INVALID, "feature quota %d exceeds the quadtree node capacity", L.quota);
     L.sel_off = sel;
     L.sel_cap = (L.quota + 3 > 4 * L.n_ini ? L.quota + 3 : 4 * L.n_ini) + 1;
+    L.sel_cap = (L.sel_cap + 3) & ~3;      // levels start at multiples of four slots: a wave of orb_describe (four keypoints) never straddles two
     sel += L.sel_cap;
     L.scale = h->scale[l];
     L.inv_scale = h->inv_scale[l];

@@ -1150,9 +1150,22 @@ __global__ __launch_bounds__(256) void orb_blur(OrbPlan plan, uint8_t* arena) {
 // Orientation + descriptor: ORBextractor.cc:77-104 (IC_Angle, cv::fastAtan2), :108-147
 // (computeOrbDescriptor), :1095-1101 (scaling), one wave per selected keypoint.
 // ------------------------------------------------------------------------------------------------
-__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
+constexpr int8_t k_pattern[1024] = {
 #include "orb_pattern.inc"
 };
+// the pattern as floats, [test within the lane's sixteen][lane of the 16-lane group] x (x0, y0, x1, y1): lane l of a group owns
+// tests 16 l .. 16 l + 15 (two descriptor bytes); a load instruction reads 16 consecutive float4
+struct PatF { float4 v[16][16]; };
+constexpr PatF make_patf() {
+  PatF t{};
+  for (int lane = 0; lane < 16; lane++)
+    for (int j = 0; j < 16; j++) {
+      const int8_t* p = k_pattern + 4 * (16 * lane + j);
+      t.v[j][lane].x = (float)p[0]; t.v[j][lane].y = (float)p[1]; t.v[j][lane].z = (float)p[2]; t.v[j][lane].w = (float)p[3];
+    }
+  return t;
+}
+__constant__ PatF c_patf = make_patf();
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   // OpenCV 3.4 atan_f32 (mathfuncs_core.simd.hpp), evaluated without FMA contraction
@@ -1183,83 +1196,93 @@ struct PsKeyPoint { float x, y, size, angle, response; int32_t octave, class_id;
 // libm except for one argument in ~1e8): two-term Cody-Waite reduction by pi/2 and the classic degree-13/12 kernels on
 // [-pi/4, pi/4], evaluated with explicit FMAs.  A third of the instructions of the general-purpose library routines, which carry
 // a Payne-Hanek path and double-double arithmetic for arguments this kernel never sees.
-__device__ __forceinline__ void sincos_0_2pi(double x, double& sn, double& cs) {
-  const double kd = __builtin_rint(x * 0.63661977236758134308);          // x * 2 / pi
+__device__ __forceinline__ void sincos_0_2pi(double x, double& sn, double& cs, const double* C) {
+  const double kd = __builtin_rint(x * C[0]);                             // x * 2 / pi
   const int k = (int)kd;
-  double r = __builtin_fma(-kd, 1.57079632673412561417e+00, x);
-  r = __builtin_fma(-kd, 6.07710050650619224932e-11, r);
+  double r = __builtin_fma(-kd, C[1], x);
+  r = __builtin_fma(-kd, C[2], r);
   const double z = r * r;
-  double ps = 1.58962301576546568060e-10;
-  ps = __builtin_fma(ps, z, -2.50507477628578072866e-8);
-  ps = __builtin_fma(ps, z, 2.75573136213857245213e-6);
-  ps = __builtin_fma(ps, z, -1.98412698295895385996e-4);
-  ps = __builtin_fma(ps, z, 8.33333333332211858878e-3);
-  ps = __builtin_fma(ps, z, -1.66666666666666307295e-1);
+  double ps = C[3];
+  ps = __builtin_fma(ps, z, C[4]);
+  ps = __builtin_fma(ps, z, C[5]);
+  ps = __builtin_fma(ps, z, C[6]);
+  ps = __builtin_fma(ps, z, C[7]);
+  ps = __builtin_fma(ps, z, C[8]);
   const double s0 = __builtin_fma(r * z, ps, r);
-  double pc = -1.13585365213876817300e-11;
-  pc = __builtin_fma(pc, z, 2.08757008419747316778e-9);
-  pc = __builtin_fma(pc, z, -2.75573141792967388112e-7);
-  pc = __builtin_fma(pc, z, 2.48015872888517045348e-5);
-  pc = __builtin_fma(pc, z, -1.38888888888730564116e-3);
-  pc = __builtin_fma(pc, z, 4.16666666666665929218e-2);
+  double pc = C[9];
+  pc = __builtin_fma(pc, z, C[10]);
+  pc = __builtin_fma(pc, z, C[11]);
+  pc = __builtin_fma(pc, z, C[12]);
+  pc = __builtin_fma(pc, z, C[13]);
+  pc = __builtin_fma(pc, z, C[14]);
   const double c0 = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
   const double ss = (k & 1) ? c0 : s0, cc = (k & 1) ? s0 : c0;
   sn = (k & 2) ? -ss : ss;
   cs = ((k + 1) & 2) ? -cc : cc;
 }
 
-// IC_Angle item table: item t = lane + 64 i covers row v = (t >> 3) - 15, columns u0 .. u0 + 3 with u0 = 4 (t & 7) - 15 of
-// the 31 x 31 patch; x = byte mask of the columns inside the disc (|u| <= umax[|v|], ORBextractor.cc:452-468), y = the same
-// bytes times (u + 15).
-struct IcTab { uint2 v[4][64]; };
+// IC_Angle item table for a 16-lane group: lane l = 4 r + c takes, in step j, the eight pixels of row v = 4 j + r - 15 at columns
+// u0 .. u0 + 7, u0 = 8 c - 15, of the 31 x 31 patch; x, y = byte masks of the columns inside the disc (|u| <= umax[|v|],
+// ORBextractor.cc:452-468; row 16 and column 16 do not exist: zero), z, w = the same bytes times (u + 15).
+struct IcTab { uint4 v[8][16]; };
 constexpr IcTab make_ictab() {
   IcTab tb{};
   const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-  for (int i = 0; i < 4; i++)
-    for (int lane = 0; lane < 64; lane++) {
-      const int t = lane + 64 * i;
-      uint32_t m = 0, um = 0;
-      if (t < 248) {
-        const int v = (t >> 3) - 15, u0 = 4 * (t & 7) - 15;
+  for (int j = 0; j < 8; j++)
+    for (int l = 0; l < 16; l++) {
+      const int v = 4 * j + (l >> 2) - 15, u0 = 8 * (l & 3) - 15;
+      uint32_t m[2] = {0, 0}, um[2] = {0, 0};
+      if (v <= 15) {
         const int um_row = umax[v < 0 ? -v : v];
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 8; k++) {
           const int u = u0 + k, au = u < 0 ? -u : u;
-          if (au <= um_row) { m |= 1u << (8 * k); um |= (uint32_t)(u + 15) << (8 * k); }
+          if (au <= um_row) { m[k >> 2] |= 1u << (8 * (k & 3)); um[k >> 2] |= (uint32_t)(u + 15) << (8 * (k & 3)); }
         }
       }
-      tb.v[i][lane].x = m; tb.v[i][lane].y = um;
+      tb.v[j][l].x = m[0]; tb.v[j][l].y = m[1]; tb.v[j][l].z = um[0]; tb.v[j][l].w = um[1];
     }
   return tb;
 }
 __constant__ IcTab c_ictab = make_ictab();
 
-// wave-wide integer sum with DPP (no LDS round trips): xor-1, xor-2, half-row mirror, row mirror, then the four rows
-__device__ __forceinline__ int wave_sum_i32(int v) {
+// coefficients of sincos_0_2pi, read with scalar loads (a 64-bit literal would cost two vector moves per use)
+__constant__ double c_sincos[16] = {0.63661977236758134308, 1.57079632673412561417e+00, 6.07710050650619224932e-11,
+                                    1.58962301576546568060e-10, -2.50507477628578072866e-8, 2.75573136213857245213e-6,
+                                    -1.98412698295895385996e-4, 8.33333333332211858878e-3, -1.66666666666666307295e-1,
+                                    -1.13585365213876817300e-11, 2.08757008419747316778e-9, -2.75573141792967388112e-7,
+                                    2.48015872888517045348e-5, -1.38888888888730564116e-3, 4.16666666666665929218e-2, 0.0};
+
+// sum over the 16 lanes of a DPP row, left in every lane of the row: xor-1, xor-2, half-row mirror, row mirror
+__device__ __forceinline__ int row_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
   v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
-  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+  return v;
 }
 
+typedef float ds_f2 __attribute__((ext_vector_type(2)));
+// FOUR keypoints per wave, one per 16-lane DPP row: the angle (atan2, double-precision sincos) is the same ~100 instructions
+// whether 16 or 64 lanes share a keypoint, and the reductions stay inside a DPP row.  Levels start at multiples of four
+// slots (orb_host.hip), so a wave's four slots belong to one level and the level geometry stays on the scalar unit.
 __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena, PsKeyPoint* out_kps,
                                                    uint8_t* out_desc, int32_t* out_counts, int nimg, int bpi) {
   int img, lb;
   if (!xcd_image_block(nimg, img, lb)) return;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the level lookup on the scalar unit
-  const int slot = lb * 4 + wv;
-  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slot0 = (lb * 4 + wv) * 4;
+  const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
   const int32_t* selcnt = reinterpret_cast<const int32_t*>(base + plan.selcnt_off);
-  if (slot >= plan.sel_total) return;
+  if (slot0 >= plan.sel_total) return;
   int level = 0;
 #pragma unroll
   for (int l = 1; l < PS_ORB_MAX_LEVELS; l++)
-    if (l < plan.nlevels && slot >= plan.lv[l].sel_off) level = l;
-  const OrbLevel L = plan.lv[level];
-  const int k = slot - L.sel_off;
+    if (l < plan.nlevels && slot0 >= plan.lv[l].sel_off) level = l;
+  const OrbLevel& L = plan.lv[level];
+  const int k0 = slot0 - L.sel_off, k = k0 + grp;
   // the slot is read before the counts are known (it always exists), so the two round trips overlap
-  const uint32_t e = (reinterpret_cast<const uint32_t*>(base + plan.sel_base) + L.sel_off)[min(k, L.sel_cap - 1)];
+  uint32_t e = (reinterpret_cast<const uint32_t*>(base + plan.sel_base) + L.sel_off)[min(k, L.sel_cap - 1)];
   int offset = 0, total = 0;
 #pragma unroll
   for (int l = 0; l < PS_ORB_MAX_LEVELS; l++) {
@@ -1269,89 +1292,114 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
       total += c;
     }
   }
-  if (slot == 0 && lane == 0) out_counts[img] = min(total, plan.kp_cap);
-  if (k >= selcnt[level]) return;
+  if (slot0 == 0 && lane == 0) out_counts[img] = min(total, plan.kp_cap);
+  const int cnt = selcnt[level];
+  if (k0 >= cnt) return;
   const int oi = offset + k;
-  if (oi >= plan.kp_cap) return;
+  const bool valid = k < cnt && oi < plan.kp_cap;
+  if (!valid) e = 19u | (19u << 12);       // an empty slot's row computes on a position whose loads stay inside the level; it stores nothing
   const int kx = e & 0xFFF, ky = (e >> 12) & 0xFFF, sc = e >> 24;
 
   // ---- the 39 x 39 neighbourhood of the blurred level that the steered pattern can reach (|coordinate| <= 18.4 before
-  // rounding) goes to LDS with row-coalesced dword loads: the 512 byte gathers of the tests would otherwise touch ~30
-  // cache lines per load instruction and the kernel is bound by the L1 tag rate.  Issued first, consumed last. ----
-  __shared__ uint32_t patch_all[4][40 * 12];
-  uint32_t* patch = patch_all[wv];
+  // rounding) goes to LDS with row-coalesced loads: the 512 byte gathers of the tests would otherwise touch ~30 cache lines
+  // per load instruction.  Four lanes x 12 bytes per row, four rows per step, ten steps.  Issued first, consumed last. ----
+  __shared__ uint32_t patch_all[16][40 * 12];
+  uint32_t* patch = patch_all[wv * 4 + grp];
   const int pshift = (kx - 19) & 3;
+  const int r4 = l16 >> 2, c4 = l16 & 3;
+  uint32_t tmp[10][3];
   {
-    // 16 lanes per row (11 dwords used), 4 rows per step, 10 steps
-    const int pr = lane >> 4, pd = min(lane & 15, 10);
-    const uint8_t* prow = base + L.blur_off + (size_t)(ky - 19 + pr) * L.bstride + (kx - 19 - pshift) + 4 * pd;
-    uint32_t tmp[10];
+    const uint32_t loff = L.blur_off + (uint32_t)((ky - 19 + r4) * L.bstride + (kx - 19 - pshift) + 12 * c4);
+    const uint32_t s4 = 4u * (uint32_t)L.bstride;
 #pragma unroll
-    for (int i = 0; i < 10; i++) tmp[i] = *reinterpret_cast<const uint32_t*>(prow + (size_t)min(4 * i, 38 - pr) * L.bstride);
-#pragma unroll
-    for (int i = 0; i < 10; i++) patch[(4 * i + pr) * 12 + pd] = tmp[i];   // rows 39 (i = 9, pr = 3) is a duplicate of row 38 and never read
-  }
-  // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the disc ----
-  const uint8_t* center = base + L.plane_off + (size_t)(PS_EDGE + ky) * L.stride + PS_EDGE + kx;
-  int m10 = 0, m01 = 0;
-  // 31 rows x 8 groups of 4 columns = 248 items, 4 per lane: one (unaligned) dword load per item; the disc mask and the
-  // column weights (u + 15, as bytes) come from a per-lane table so that an item costs three v_dot4_u32_u8 and a mad:
-  //   m10 = sum (u + 15) I - 15 sum I,   m01 = sum_rows v * (row sum)
-  {
-    uint32_t pix[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int t = min(lane + 64 * i, 247);
-      pix[i] = *reinterpret_cast<const uint32_t*>(center + (ptrdiff_t)((t >> 3) - 15) * L.stride + (4 * (t & 7) - 15));
+    for (int i = 0; i < 10; i++) {
+      // row 39 (i = 9, r4 = 3) does not exist in the neighbourhood: that lane repeats row 38 (never read)
+      const uint32_t o = i < 9 ? loff + (uint32_t)i * s4 : loff + 9u * s4 - (r4 == 3 ? (uint32_t)L.bstride : 0u);
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(base + o);
+      tmp[i][0] = p[0]; tmp[i][1] = p[1]; tmp[i][2] = p[2];
     }
+  }
+  // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the disc.  32 rows x 4 groups of 8 columns = 128 items, 8 per lane: one
+  // (unaligned) 8-byte load per item; disc mask and column weights (u + 15, as bytes) from a table, so an item costs four
+  // v_dot4_u32_u8 and a multiply-add:  m10 = sum (u + 15) I - 15 sum I,   m01 = sum_rows v * (row sum) ----
+  int m10, m01 = 0;
+  {
+    const uint32_t coff = L.plane_off + (uint32_t)((PS_EDGE + ky - 15 + r4) * L.stride + PS_EDGE + kx - 15 + 8 * c4);
+    const uint32_t s4 = 4u * (uint32_t)L.stride;
+    uint2 pix[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) pix[j] = *reinterpret_cast<const uint2*>(base + (coff + (uint32_t)j * s4));
     int s0 = 0;
     uint32_t acc = 0;
+    const int v0 = r4 - 15;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const uint2 mk = c_ictab.v[i][lane];
-      const int t = min(lane + 64 * i, 247);
-      const uint32_t sr = __builtin_amdgcn_udot4(pix[i], mk.x, 0u, false);
-      acc = __builtin_amdgcn_udot4(pix[i], mk.y, acc, false);
+    for (int j = 0; j < 8; j++) {
+      const uint4 mk = c_ictab.v[j][l16];
+      const uint32_t sr = __builtin_amdgcn_udot4(pix[j].y, mk.y, __builtin_amdgcn_udot4(pix[j].x, mk.x, 0u, false), false);
+      acc = __builtin_amdgcn_udot4(pix[j].y, mk.w, __builtin_amdgcn_udot4(pix[j].x, mk.z, acc, false), false);
       s0 += (int)sr;
-      m01 += ((t >> 3) - 15) * (int)sr;
+      m01 += (v0 + 4 * j) * (int)sr;
     }
     m10 = (int)acc - 15 * s0;
   }
-  m10 = wave_sum_i32(m10);
-  m01 = wave_sum_i32(m01);
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    uint32_t* d = patch + (4 * i + r4) * 12 + 3 * c4;
+    d[0] = tmp[i][0]; d[1] = tmp[i][1]; d[2] = tmp[i][2];
+  }
+  m10 = row_sum_i32(m10);
+  m01 = row_sum_i32(m01);
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-  // ---- steered BRIEF on the blurred level: lane handles tests 4*lane .. 4*lane+3 ----
+  // ---- steered BRIEF on the blurred level: lane l of the row handles tests 16 l .. 16 l + 15 ----
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float arad = __fmul_rn(angle, factorPI);
   double sn_d, cs_d;
-  sincos_0_2pi((double)arad, sn_d, cs_d);
+  sincos_0_2pi((double)arad, sn_d, cs_d, c_sincos);
   const float a = (float)cs_d, b = (float)sn_d;
   wave_sync();
-  const uint8_t* bc = reinterpret_cast<const uint8_t*>(patch) + 19 * 48 + 19 + pshift;
-  uint32_t nib = 0;
-  const int4 pw = reinterpret_cast<const int4*>(c_pattern)[lane];   // this lane's 4 tests x (x0,y0,x1,y1) int8
-  const int pws[4] = {pw.x, pw.y, pw.z, pw.w};
+  // A point (x, y) of the pattern samples the blurred patch at row cvRound(x b + y a), column cvRound(x a - y b)
+  // (ORBextractor.cc:115-120), every product and the sum rounded to float.  Two floats per instruction: {x b, x a} + {y a, -(y b)}
+  // (negation is exact); cvRound by adding 1.5 * 2^23, whose float sum carries round-half-even(value) in its low mantissa
+  // bits; the 24-bit multiply takes those bits as they are, the constants they drag along are subtracted from the base.
+  const ds_f2 ba = {b, a}, anb = {a, -b};
+  const unsigned long long ba64 = __builtin_bit_cast(unsigned long long, ba), anb64 = __builtin_bit_cast(unsigned long long, anb);
+  const unsigned long long magic64 = 0x4B4000004B400000ull;  // {1.5 * 2^23, 1.5 * 2^23}
+  typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+  // LDS byte address of patch pixel (0, 0) minus what the mantissa bits drag along
+  const uint32_t kall = (uint32_t)(uintptr_t)(lds_u8*)reinterpret_cast<const uint8_t*>(patch) + (uint32_t)(19 * 48 + 19 + pshift) -
+                        (0x400000u * 48u + 0x4B400000u);
+  uint32_t bits = 0;
 #pragma unroll
-  for (int tst = 0; tst < 4; tst++) {
-    const int8_t pp[4] = {(int8_t)(pws[tst] & 0xFF), (int8_t)((pws[tst] >> 8) & 0xFF), (int8_t)((pws[tst] >> 16) & 0xFF),
-                          (int8_t)((pws[tst] >> 24) & 0xFF)};
-    const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
-    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-    const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-    const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = bc[r0 * 48 + q0], t1 = bc[r1 * 48 + q1];
-    nib |= (uint32_t)(t0 < t1) << tst;
+  for (int tst = 0; tst < 16; tst++) {
+    const float4 pt = c_patf.v[tst][l16];
+    // (operands as 64-bit integers: register pairs; a vector-typed asm output comes back with both lanes reading the low register)
+    const unsigned long long xy0 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.x, pt.y}), xy1 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.z, pt.w});
+    unsigned long long T0, T1, Q0, Q1;
+    // packed FP32 with the operand halves chosen by op_sel (the compiler scalarises this form): P = {x b, x a}, Q = {y a, -(y b)},
+    // T = (P + Q) + magic - each instruction rounds on its own, as the separate float operations of the reference do.  The two
+    // points of a test are interleaved so that no instruction reads the result of the one before it.
+    asm("v_pk_mul_f32 %0, %4, %6 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %5, %6 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %2, %4, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %3, %5, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\t"
+        "v_pk_add_f32 %1, %1, %3\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %0, %0, %8\n\t"
+        "v_pk_add_f32 %1, %1, %8\n\t"
+        "s_nop 0"
+        : "=&v"(T0), "=&v"(T1), "=&v"(Q0), "=&v"(Q1)
+        : "v"(xy0), "v"(xy1), "v"(ba64), "v"(anb64), "v"(magic64));
+    const uint32_t i0 = (uint32_t)__mul24((int)(uint32_t)T0, 48) + ((uint32_t)(T0 >> 32) + kall);
+    const uint32_t i1 = (uint32_t)__mul24((int)(uint32_t)T1, 48) + ((uint32_t)(T1 >> 32) + kall);
+    const int t0 = *(lds_u8*)(uintptr_t)i0, t1 = *(lds_u8*)(uintptr_t)i1;
+    bits |= (uint32_t)(t0 < t1) << tst;
   }
-  // assemble 8 lanes (32 bits) into one dword on lanes 0,8,16,...
-  uint32_t word = nib << (4 * (lane & 7));
-  word |= __shfl_xor(word, 1);
-  word |= __shfl_xor(word, 2);
-  word |= __shfl_xor(word, 4);
-  uint32_t* drow = reinterpret_cast<uint32_t*>(out_desc + ((size_t)img * plan.kp_cap + oi) * 32);
-  if ((lane & 7) == 0) drow[lane >> 3] = word;
-  if (lane == 0) {
+  if (!valid) return;
+  reinterpret_cast<uint16_t*>(out_desc + ((size_t)img * plan.kp_cap + oi) * 32)[l16] = (uint16_t)bits;
+  if (l16 == 0) {
     PsKeyPoint kp;
     kp.x = (float)kx;
     kp.y = (float)ky;
@@ -1432,7 +1480,7 @@ extern "C" void psk_orb_launch_blur(const OrbPlan* plan, uint8_t* arena, int nim
 extern "C" int psk_orb_blur_rows() { return BLUR_ROWS; }
 extern "C" void psk_orb_launch_describe(const OrbPlan* plan, uint8_t* arena, void* kps, uint8_t* desc,
                                         int32_t* counts, int nimg, hipStream_t st) {
-  const int bpi = (plan->sel_total + 3) / 4;
+  const int bpi = (plan->sel_total + 15) / 16;      // four waves x four keypoints per workgroup
   hipLaunchKernelGGL(orb_describe, PS_XCD_GRID(bpi, nimg), dim3(256), 0, st, *plan, arena,
                      (PsKeyPoint*)kps, desc, counts, nimg, bpi);
 }
