@@ -1153,19 +1153,20 @@ __global__ __launch_bounds__(256) void orb_blur(OrbPlan plan, uint8_t* arena) {
 constexpr int8_t k_pattern[1024] = {
 #include "orb_pattern.inc"
 };
-// the pattern as floats, [test within the lane's sixteen][lane of the 16-lane group] x (x0, y0, x1, y1): lane l of a group owns
-// tests 16 l .. 16 l + 15 (two descriptor bytes); a load instruction reads 16 consecutive float4
-struct PatF { float4 v[16][16]; };
-constexpr PatF make_patf() {
-  PatF t{};
-  for (int lane = 0; lane < 16; lane++)
+// the pattern for orb_describe's lane layout: lane l of a 16-lane group owns tests 16 l .. 16 l + 15 (two descriptor bytes);
+// word [jj][l][t] = test 16 l + 4 jj + t as four signed bytes (x0, y0, x1, y1).  The workgroup copies it to LDS, where lane l
+// reads four 16-byte rows (consecutive lanes, consecutive rows: no bank conflicts).
+struct PatTab { uint32_t w[4][16][4]; };
+constexpr PatTab make_pattab() {
+  PatTab t{};
+  for (int l = 0; l < 16; l++)
     for (int j = 0; j < 16; j++) {
-      const int8_t* p = k_pattern + 4 * (16 * lane + j);
-      t.v[j][lane].x = (float)p[0]; t.v[j][lane].y = (float)p[1]; t.v[j][lane].z = (float)p[2]; t.v[j][lane].w = (float)p[3];
+      const int8_t* p = k_pattern + 4 * (16 * l + j);
+      t.w[j >> 2][l][j & 3] = (uint32_t)(uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8) | ((uint32_t)(uint8_t)p[2] << 16) | ((uint32_t)(uint8_t)p[3] << 24);
     }
   return t;
 }
-__constant__ PatF c_patf = make_patf();
+__constant__ PatTab c_pattab = make_pattab();
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   // OpenCV 3.4 atan_f32 (mathfuncs_core.simd.hpp), evaluated without FMA contraction
@@ -1222,24 +1223,24 @@ __device__ __forceinline__ void sincos_0_2pi(double x, double& sn, double& cs, c
 }
 
 // IC_Angle item table for a 16-lane group: lane l = 4 r + c takes, in step j, the eight pixels of row v = 4 j + r - 15 at columns
-// u0 .. u0 + 7, u0 = 8 c - 15, of the 31 x 31 patch; x, y = byte masks of the columns inside the disc (|u| <= umax[|v|],
-// ORBextractor.cc:452-468; row 16 and column 16 do not exist: zero), z, w = the same bytes times (u + 15).
-struct IcTab { uint4 v[8][16]; };
+// u0 .. u0 + 7, u0 = 8 c - 15, of the 31 x 31 patch; the entry is the byte mask (0xFF) of the columns inside the disc
+// (|u| <= umax[|v|], ORBextractor.cc:452-468; row 16 and column 16 do not exist: zero).  Copied to LDS by the workgroup.
+struct IcTab { uint2 v[8][16]; };
 constexpr IcTab make_ictab() {
   IcTab tb{};
   const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
   for (int j = 0; j < 8; j++)
     for (int l = 0; l < 16; l++) {
       const int v = 4 * j + (l >> 2) - 15, u0 = 8 * (l & 3) - 15;
-      uint32_t m[2] = {0, 0}, um[2] = {0, 0};
+      uint32_t m[2] = {0, 0};
       if (v <= 15) {
         const int um_row = umax[v < 0 ? -v : v];
         for (int k = 0; k < 8; k++) {
           const int u = u0 + k, au = u < 0 ? -u : u;
-          if (au <= um_row) { m[k >> 2] |= 1u << (8 * (k & 3)); um[k >> 2] |= (uint32_t)(u + 15) << (8 * (k & 3)); }
+          if (au <= um_row) m[k >> 2] |= 0xFFu << (8 * (k & 3));
         }
       }
-      tb.v[j][l].x = m[0]; tb.v[j][l].y = m[1]; tb.v[j][l].z = um[0]; tb.v[j][l].w = um[1];
+      tb.v[j][l].x = m[0]; tb.v[j][l].y = m[1];
     }
   return tb;
 }
@@ -1267,6 +1268,12 @@ typedef float ds_f2 __attribute__((ext_vector_type(2)));
 // slots (orb_host.hip), so a wave's four slots belong to one level and the level geometry stays on the scalar unit.
 __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena, PsKeyPoint* out_kps,
                                                    uint8_t* out_desc, int32_t* out_counts, int nimg, int bpi) {
+  // the two lane-indexed tables go to LDS once per workgroup (from the vector cache they would be two thirds of the bytes a wave loads)
+  __shared__ uint4 s_pat[4][16];
+  __shared__ uint2 s_icm[8][16];
+  reinterpret_cast<uint32_t*>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&c_pattab)[threadIdx.x];
+  reinterpret_cast<uint32_t*>(s_icm)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&c_ictab)[threadIdx.x];
+  __syncthreads();
   int img, lb;
   if (!xcd_image_block(nimg, img, lb)) return;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1332,11 +1339,13 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
     int s0 = 0;
     uint32_t acc = 0;
     const int v0 = r4 - 15;
+    const uint32_t wlo = 0x03020100u + 0x08080808u * (uint32_t)c4, whi = wlo + 0x04040404u;   // u + 15 of the lane's eight columns
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const uint4 mk = c_ictab.v[j][l16];
-      const uint32_t sr = __builtin_amdgcn_udot4(pix[j].y, mk.y, __builtin_amdgcn_udot4(pix[j].x, mk.x, 0u, false), false);
-      acc = __builtin_amdgcn_udot4(pix[j].y, mk.w, __builtin_amdgcn_udot4(pix[j].x, mk.z, acc, false), false);
+      const uint2 mk = s_icm[j][l16];
+      const uint32_t px = pix[j].x & mk.x, py = pix[j].y & mk.y;
+      const uint32_t sr = __builtin_amdgcn_udot4(py, 0x01010101u, __builtin_amdgcn_udot4(px, 0x01010101u, 0u, false), false);
+      acc = __builtin_amdgcn_udot4(py, whi, __builtin_amdgcn_udot4(px, wlo, acc, false), false);
       s0 += (int)sr;
       m01 += (v0 + 4 * j) * (int)sr;
     }
@@ -1372,7 +1381,10 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
   uint32_t bits = 0;
 #pragma unroll
   for (int tst = 0; tst < 16; tst++) {
-    const float4 pt = c_patf.v[tst][l16];
+    const uint4 pw4 = s_pat[tst >> 2][l16];
+    const uint32_t pw = (tst & 3) == 0 ? pw4.x : (tst & 3) == 1 ? pw4.y : (tst & 3) == 2 ? pw4.z : pw4.w;
+    float4 pt;
+    pt.x = (float)(int8_t)(pw & 0xFF); pt.y = (float)(int8_t)((pw >> 8) & 0xFF); pt.z = (float)(int8_t)((pw >> 16) & 0xFF); pt.w = (float)(int8_t)(pw >> 24);
     // (operands as 64-bit integers: register pairs; a vector-typed asm output comes back with both lanes reading the low register)
     const unsigned long long xy0 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.x, pt.y}), xy1 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.z, pt.w});
     unsigned long long T0, T1, Q0, Q1;
