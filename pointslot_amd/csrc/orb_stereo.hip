@@ -1,10 +1,11 @@
 // Stereo matching of the two extractors' outputs on the device — Frame::ComputeStereoMatches
 // (/root/reference/src/Frame.cc:2142-2316), SURVEY.md section 8f-1: it consumes both padded pyramids and both descriptor sets
 // where they already are (HBM) and yields mvuRight / mvDepth.
-//   st_match  : one wave per LEFT keypoint.  Candidate scan over the right keypoints (row-band test of the reference's
-//               vRowIndices table evaluated on the fly, octave +-1, disparity range, Hamming; smallest (distance, index) by a
-//               wave-min), then the 11 x 11 SAD over 11 shifts on the keypoint's pyramid level (integer-exact), parabola
-//               sub-pixel fit and the disparity gates in the reference's float arithmetic
+//   st_match  : FOUR left keypoints per wave, one per 16-lane DPP row.  Candidate scan over the right keypoints (row-band test of
+//               the reference's vRowIndices table evaluated on the fly, octave +-1, disparity range, Hamming; smallest (distance,
+//               index) by a row-min), then the 11 x 11 SAD over 11 shifts on the keypoint's pyramid level (integer-exact: a lane
+//               per patch row, both rows in registers, v_sad_u16 on packed pairs), parabola sub-pixel fit and the disparity
+//               gates in the reference's float arithmetic
 //   st_median : one workgroup per pair.  Rank selection of the median SAD, cut at 1.5f * 1.4f * median
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void st_bucket(OrbPlan plan, const StPair* pai
     const float r = __fmul_rn(2.0f, plan.lv[kr.octave].scale);
     const int maxr = (int)ceilf(__fadd_rn(kr.y, r)), minr = (int)floorf(__fsub_rn(kr.y, r));
     // bands are stored with an offset of 1024 so that rows a little outside the image stay non-negative
-    rinfo[iR] = make_uint2(__float_as_uint(kr.x), (uint32_t)(min(max(minr + 1024, 0), 8191)) | ((uint32_t)(min(max(maxr + 1024, 0), 8191)) << 13) | ((uint32_t)kr.octave << 26));
+    (void)maxr; (void)minr;
     atomicAdd(&cnt[min(max((int)kr.y >> 3, 0), nb - 1)], 1);
   }
   __syncthreads();
@@ -63,22 +64,55 @@ __global__ __launch_bounds__(256) void st_bucket(OrbPlan plan, const StPair* pai
   __syncthreads();
   for (int b = tid; b <= nb; b += 256) boff[b] = cnt[b];
   for (int iR = tid; iR < Nr; iR += 256) {
-    const int b = min(max((int)KR[iR].y >> 3, 0), nb - 1);
-    bidx[cnt[b] + atomicAdd(&fill[b], 1)] = iR;
+    const PsKeyPoint kr = KR[iR];
+    const int b = min(max((int)kr.y >> 3, 0), nb - 1);
+    const int pos = cnt[b] + atomicAdd(&fill[b], 1);
+    const float r = __fmul_rn(2.0f, plan.lv[kr.octave].scale);
+    const int maxr = (int)ceilf(__fadd_rn(kr.y, r)), minr = (int)floorf(__fsub_rn(kr.y, r));
+    bidx[pos] = iR;
+    // the band record sits at the keypoint's position in bucket order (st_match reads both arrays by position); bands are
+    // stored with an offset of 1024 so that rows a little outside the image stay non-negative
+    rinfo[pos] = make_uint2(__float_as_uint(kr.x), (uint32_t)(min(max(minr + 1024, 0), 8191)) | ((uint32_t)(min(max(maxr + 1024, 0), 8191)) << 13) | ((uint32_t)kr.octave << 26));
   }
 }
 
+typedef unsigned short st_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {     // min over the 16 lanes of a DPP row, left in every lane of the row
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+  return v;
+}
+__device__ __forceinline__ int row_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+  return v;
+}
+// bytes (b, b + 1) of the 8-byte pair {hi, lo} as packed u16; a byte index of 0x0c yields zero
+#define ST_PAIR(hi, lo, b0, b1) __builtin_amdgcn_perm(hi, lo, (uint32_t)(b0) | 0x0c000c00u | ((uint32_t)(b1) << 16))
+
 __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pairs, float mb, float mbf) {
-  __shared__ uint8_t rs_all[4][11 * 24];
+  // the level fields a keypoint needs, indexed by its octave (a lane-dependent index into the kernel arguments would go through memory anyway)
+  __shared__ float s_scale[PS_ORB_MAX_LEVELS], s_inv[PS_ORB_MAX_LEVELS];
+  __shared__ int s_w[PS_ORB_MAX_LEVELS], s_stride[PS_ORB_MAX_LEVELS];
+  __shared__ uint32_t s_plane[PS_ORB_MAX_LEVELS];
+#pragma unroll
+  for (int l = 0; l < PS_ORB_MAX_LEVELS; l++)
+    if ((int)threadIdx.x == l) { s_scale[l] = plan.lv[l].scale; s_inv[l] = plan.lv[l].inv_scale; s_w[l] = plan.lv[l].w; s_stride[l] = plan.lv[l].stride; s_plane[l] = plan.lv[l].plane_off; }
+  __syncthreads();
   const StPair S = pairs[blockIdx.y];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int iL = blockIdx.x * 4 + wave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   const int N = *S.cnt_l;
-  if (iL >= N) return;
-  uint8_t* rs = rs_all[wave];
+  const int iL0 = blockIdx.x * 16 + wave * 4;
+  if (iL0 >= N) return;
+  const int iL = iL0 + grp;
+  const bool live = iL < N;
   const PsKeyPoint* KL = reinterpret_cast<const PsKeyPoint*>(S.kps_l);
   const PsKeyPoint* KR = reinterpret_cast<const PsKeyPoint*>(S.kps_r);
-  const PsKeyPoint kpL = KL[iL];
+  const PsKeyPoint kpL = KL[live ? iL : N - 1];
   float out_ur = -1.0f, out_depth = -1.0f;
   int out_sad = -1;
   const float minD = 0.f, maxD = __fdiv_rn(mbf, mb);
@@ -87,7 +121,7 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
   const int rowL = (int)vL;                      // vRowIndices[vL]
   const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
   uint32_t best = 0xFFFFFFFFu;
-  if (!(maxU < 0)) {
+  if (live && !(maxU < 0)) {
     const uint4* dl = reinterpret_cast<const uint4*>(S.desc_l + (size_t)iL * 32);
     const uint4 a0 = dl[0], a1 = dl[1];
     // candidates: the buckets whose keypoints can have a band containing rowL (|y - rowL| <= 2 * scale[top] + 1)
@@ -98,12 +132,14 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
     const float rmax = __fadd_rn(__fmul_rn(2.0f, plan.lv[plan.nlevels - 1].scale), 2.0f);
     const int b0 = min(max((int)floorf((float)rowL - rmax) >> 3, 0), nb - 1), b1 = min(max((int)ceilf((float)rowL + rmax) >> 3, 0), nb - 1);
     const int k_end = boff[b1 + 1];
-    for (int k = boff[b0] + lane; k < k_end; k += 64) {
+    const uint32_t rowk = (uint32_t)(rowL + 1024);
+    for (int k = boff[b0] + l16; k < k_end; k += 16) {
+      const uint2 ri = rinfo[k];
       const int iR = bidx[k];
-      const uint2 ri = rinfo[iR];
-      const int minr = (int)(ri.y & 0x1FFF) - 1024, maxr = (int)((ri.y >> 13) & 0x1FFF) - 1024, oct = (int)(ri.y >> 26);
-      if (rowL < minr || rowL > maxr) continue;
-      if (oct < levelL - 1 || oct > levelL + 1) continue;
+      const uint32_t minr = ri.y & 0x1FFF, maxr = (ri.y >> 13) & 0x1FFF;
+      const int oct = (int)(ri.y >> 26);
+      if (rowk < minr || rowk > maxr) continue;
+      if ((uint32_t)(oct - levelL + 1) > 2u) continue;
       const float rx = __uint_as_float(ri.x);
       if (!(rx >= minU && rx <= maxU)) continue;
       const uint4* dr = reinterpret_cast<const uint4*>(S.desc_r + (size_t)iR * 32);
@@ -111,41 +147,64 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
       if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR);   // bestDist starts at TH_HIGH, strict <, first wins
     }
   }
-  best = wave_min_u32(best);
+  best = row_min_u32(best);
   const int bestDist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
   if (bestDist < 75) {   // thOrbDist = (TH_HIGH + TH_LOW) / 2
     const int bestIdxR = (int)(best & 0xFFFF);
-    const OrbLevel L = plan.lv[levelL];
+    const float Lscale = s_scale[levelL], Linv = s_inv[levelL];
+    const int Lw = s_w[levelL], Lstride = s_stride[levelL];
+    const uint32_t Lplane = s_plane[levelL];
     const float uR0 = KR[bestIdxR].x;
-    const float scaleduL = roundf(__fmul_rn(kpL.x, L.inv_scale));
-    const float scaledvL = roundf(__fmul_rn(kpL.y, L.inv_scale));
-    const float scaleduR0 = roundf(__fmul_rn(uR0, L.inv_scale));
+    const float scaleduL = roundf(__fmul_rn(kpL.x, Linv));
+    const float scaledvL = roundf(__fmul_rn(kpL.y, Linv));
+    const float scaleduR0 = roundf(__fmul_rn(uR0, Linv));
     const float iniu = scaleduR0 + 5 - 5, endu = scaleduR0 + 5 + 5 + 1;
-    if (!(iniu < 0 || endu >= (float)L.w)) {
+    if (!(iniu < 0 || endu >= (float)Lw)) {
       const int cy = (int)scaledvL, cxl = (int)scaleduL, cxr = (int)scaleduR0;
-      const uint8_t* pl = S.arena_l + L.plane_off + (size_t)(PS_EDGE + cy) * L.stride + PS_EDGE + cxl;
-      const uint8_t* pr = S.arena_r + L.plane_off + (size_t)(PS_EDGE + cy) * L.stride + PS_EDGE + cxr;
-      // right strip: rows -5..5, columns -10..10 around (cy, cxr)
-      for (int q = lane; q < 11 * 21; q += 64) {
-        const int i = q / 21, c = q - i * 21;
-        rs[i * 24 + c] = pr[(ptrdiff_t)(i - 5) * L.stride + (c - 10)];
+      // lane i < 11 of the row owns patch row i - 5: its 11 left pixels (columns -5 .. 5) and the 21 right pixels (columns
+      // -10 .. 10) that the 11 shifts slide over, in registers; every lane also reads the centre row for the centre pixels.
+      const int i = min(l16, 10);
+      const uint8_t* pl = S.arena_l + (Lplane + (uint32_t)((PS_EDGE + cy + i - 5) * Lstride + PS_EDGE + cxl - 5));
+      const uint8_t* pr = S.arena_r + (Lplane + (uint32_t)((PS_EDGE + cy + i - 5) * Lstride + PS_EDGE + cxr - 10));
+      const uint8_t* prc = S.arena_r + (Lplane + (uint32_t)((PS_EDGE + cy) * Lstride + PS_EDGE + cxr - 10));
+      uint32_t lw[3], rw[6], cw[6];
+#pragma unroll
+      for (int q = 0; q < 3; q++) lw[q] = reinterpret_cast<const uint32_t*>(pl)[q];
+#pragma unroll
+      for (int q = 0; q < 6; q++) { rw[q] = reinterpret_cast<const uint32_t*>(pr)[q]; cw[q] = reinterpret_cast<const uint32_t*>(prc)[q]; }
+      const uint32_t Lc = S.arena_l[Lplane + (uint32_t)((PS_EDGE + cy) * Lstride + PS_EDGE + cxl)];
+      // |(L - Lc) - (R - Rc)| on packed u16 with both sides offset by 256: a = L + (256 - Lc), b = R + (256 - Rc)
+      const uint32_t biasA = (256u - Lc) * 0x00010001u;
+      uint32_t a[6];
+#pragma unroll
+      for (int q = 0; q < 5; q++) a[q] = ST_PAIR(lw[q >> 1], lw[q >> 1], (2 * q) & 3, (2 * q + 1) & 3) + biasA;   // an even pair shares a dword
+      a[5] = ST_PAIR(0u, lw[2], 2, 0x0c) + (biasA & 0xFFFFu);                        // pixel 10 alone: the other half stays zero on both sides
+      // right row as packed pairs at both alignments: E[k] = (R[2k], R[2k+1]), O[k] = (R[2k+1], R[2k+2])
+      uint32_t E[11], O[10];
+#pragma unroll
+      for (int q = 0; q < 11; q++) {
+        const int b0i = 2 * q, b1i = 2 * q + 1;
+        E[q] = ST_PAIR(rw[b0i >> 2], rw[b0i >> 2], b0i & 3, q == 10 ? 0x0c : (b1i & 3));     // both bytes of an even pair share a dword
       }
-      // this lane's (up to) two patch pixels
-      const int p0 = lane, p1 = lane + 64;
-      const int i0 = p0 / 11, j0 = p0 - i0 * 11, i1 = p1 / 11, j1 = p1 - i1 * 11;
-      const int Lc = pl[0];
-      const int l0 = (int)pl[(ptrdiff_t)(i0 - 5) * L.stride + (j0 - 5)] - Lc;
-      const int l1 = p1 < 121 ? (int)pl[(ptrdiff_t)(i1 - 5) * L.stride + (j1 - 5)] - Lc : 0;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = 0; q < 10; q++) {
+        const int b0i = 2 * q + 1, b1i = 2 * q + 2;
+        O[q] = ST_PAIR(rw[b1i >> 2], rw[b0i >> 2], b0i & 3, (b1i & 3) + ((b1i >> 2) != (b0i >> 2) ? 4 : 0));
+      }
       int dists[11];
 #pragma unroll
-      for (int s = 0; s < 11; s++) {   // incR = s - 5: right patch column j sits at strip column incR + j + 5
-        const int Rc = rs[5 * 24 + s + 5];
-        int acc = abs(l0 - ((int)rs[i0 * 24 + s + j0] - Rc));
-        if (p1 < 121) acc += abs(l1 - ((int)rs[i1 * 24 + s + j1] - Rc));
-        dists[s] = wave_sum_i32(acc);
+      for (int s = 0; s < 11; s++) {   // incR = s - 5: right patch column j sits at strip column s + j
+        const uint32_t Rc = (cw[(s + 5) >> 2] >> (8 * ((s + 5) & 3))) & 0xFFu;
+        const uint32_t biasB = (256u - Rc) * 0x00010001u;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+          const uint32_t r2 = (s & 1) ? O[(s - 1) / 2 + q] : E[s / 2 + q];
+          acc = __builtin_amdgcn_sad_u16(a[q], r2 + biasB, acc);
+        }
+        const uint32_t rl = ((s & 1) ? O[(s - 1) / 2 + 5] : E[s / 2 + 5]) & 0xFFFFu;   // R[s + 10] alone
+        acc = __builtin_amdgcn_sad_u16(a[5], rl + (biasB & 0xFFFFu), acc);
+        dists[s] = row_sum_i32(l16 < 11 ? (int)acc : 0);
       }
       int bestS = 0x7fffffff, bestinc = 0;
 #pragma unroll
@@ -158,7 +217,7 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
           if (s - 5 == bestinc) { d1 = (float)dists[s - 1]; d2 = (float)dists[s]; d3 = (float)dists[s + 1]; }
         const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
         if (!(deltaR < -1 || deltaR > 1)) {
-          float bestuR = __fmul_rn(L.scale, __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+          float bestuR = __fmul_rn(Lscale, __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
           float disparity = __fsub_rn(uL, bestuR);
           if (disparity >= minD && disparity < maxD) {
             if (disparity <= 0) {
@@ -173,7 +232,7 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
       }
     }
   }
-  if (lane == 0) { S.u_right[iL] = out_ur; S.depth[iL] = out_depth; S.sad[iL] = out_sad; }
+  if (l16 == 0 && live) { S.u_right[iL] = out_ur; S.depth[iL] = out_depth; S.sad[iL] = out_sad; }
 }
 
 __global__ __launch_bounds__(1024) void st_median(OrbPlan plan, const StPair* pairs) {
@@ -222,6 +281,6 @@ __global__ __launch_bounds__(1024) void st_median(OrbPlan plan, const StPair* pa
 
 extern "C" void psk_stereo_launch(const OrbPlan* plan, const StPair* d_pairs, int npairs, int max_left, float mb, float mbf, hipStream_t st) {
   hipLaunchKernelGGL(st_bucket, dim3(npairs), dim3(256), 0, st, *plan, d_pairs);
-  hipLaunchKernelGGL(st_match, dim3((max_left + 3) / 4, npairs), dim3(256), 0, st, *plan, d_pairs, mb, mbf);
+  hipLaunchKernelGGL(st_match, dim3((max_left + 15) / 16, npairs), dim3(256), 0, st, *plan, d_pairs, mb, mbf);
   hipLaunchKernelGGL(st_median, dim3(npairs), dim3(1024), 0, st, *plan, d_pairs);
 }
