@@ -200,8 +200,11 @@ typedef unsigned short lv_us2 __attribute__((ext_vector_type(2)));
 #define LVP_MARK()
 #define LVP_PRINT()
 #endif
+#ifndef PS_LV_WAVES
+#define PS_LV_WAVES 7        // 70 VGPRs: seven waves per SIMD (measured best of 4 / 6 / 7 / 8)
+#endif
 template <bool LEVEL0>
-__global__ __launch_bounds__(256) void orb_level_fused(OrbPlan plan, int level, uint8_t* arena, const uint8_t* imgs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LV_WAVES, 8))) void orb_level_fused(OrbPlan plan, int level, uint8_t* arena, const uint8_t* imgs,
                                                       int img_stride, size_t img_pitch, const int4* tabs) {
   __shared__ uint32_t tile[LV_R][64];
   LVP_DECL;
