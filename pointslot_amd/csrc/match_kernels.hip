@@ -248,40 +248,90 @@ __global__ __launch_bounds__(256) void pj_project(PjArrays A) {
   if (!ok) A.qvalid[q] = 0;
 }
 
+// reductions inside a 16-lane DPP row (every lane of the row gets the result)
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+  return v;
+}
+__device__ __forceinline__ int row_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+  return v;
+}
+__device__ __forceinline__ int row_scan_inclusive(int v) {          // Kogge-Stone over the row (row_shr 1, 2, 4, 8; zero fill)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+  return v;
+}
+
 // Candidate keys are  dist << 23 | position << IDXB | train index  with 23 - IDXB position bits: IDXB = 15 is the everyday format
 // (32 767 features per frame, 256 candidates per window); IDXB = 13 (8191 features, 1024 candidates) serves the problems whose
 // windows overflowed the first one, so that a dense window costs a second pass instead of the result.
+//
+// FOUR queries per wave, one per 16-lane DPP row.  A window is a handful of grid columns, each one contiguous range of the
+// cell-sorted feature list; a lane per column reads the range bounds, a row prefix sum numbers the window's candidates in the
+// reference's traversal order (column by column), and then a lane per CANDIDATE finds its column (binary search over the row's
+// prefix sums through ds_bpermute) and filters / measures it: bounds, feature index, feature fields, descriptor - four dependent
+// memory round trips for a whole window, where a wave per query walking column after column paid four per column.
 template <int IDXB>
 __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
   constexpr int CAP = 1 << (23 - IDXB);
-  const PjProb P = A.prob[blockIdx.y];
-  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (qi >= P.nq) return;
-  const int q = P.q_off + qi;
-  if (!A.qvalid[q]) { if (lane == 0) { A.ncand[q] = 0; A.ttop[q] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); } return; }
+  const PjProb& P = A.prob[blockIdx.y];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
+  const int nq = P.nq;
+  const int qi0 = blockIdx.x * 16 + wave * 4;
+  if (qi0 >= nq) return;
+  const int qi = qi0 + grp;
+  const bool live = qi < nq;
+  const int q = P.q_off + (live ? qi : nq - 1);
+  const bool valid = live && A.qvalid[q];
   const float x = A.qu[q], y = A.qv[q], r = A.qrad[q], rer = A.qrer[q], ur = A.qur[q];
   const int minLevel = A.qminl[q], maxLevel = A.qmaxl[q];
   // Frame::GetFeaturesInArea cell range (Frame.cc:1813-1827)
-  const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, P.min_x), r), P.gw_inv)));
-  const int nMaxCellX = min(PS_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, P.min_x), r), P.gw_inv)));
-  const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, P.min_y), r), P.gh_inv)));
-  const int nMaxCellY = min(PS_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, P.min_y), r), P.gh_inv)));
+  const float min_x = P.min_x, min_y = P.min_y, gw_inv = P.gw_inv, gh_inv = P.gh_inv;
+  const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, min_x), r), gw_inv)));
+  const int nMaxCellX = min(PS_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, min_x), r), gw_inv)));
+  const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, min_y), r), gh_inv)));
+  const int nMaxCellY = min(PS_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, min_y), r), gh_inv)));
   int count = 0;
   uint32_t mk[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // this lane's four smallest keys among the trains free at entry
-  if (nMinCellX < PS_GRID_COLS && nMaxCellX >= 0 && nMinCellY < PS_GRID_ROWS && nMaxCellY >= 0) {
+  if (valid && nMinCellX < PS_GRID_COLS && nMaxCellX >= 0 && nMinCellY < PS_GRID_ROWS && nMaxCellY >= 0) {
     const bool check = (minLevel > 0) || (maxLevel >= 0);
     const uint4* qd = reinterpret_cast<const uint4*>(A.qdesc + (size_t)q * 32);
     const uint4 a0 = qd[0], a1 = qd[1];
     const int32_t* coff = A.cell_off + P.grid_off;
-    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-      const int b = coff[ix * PS_GRID_ROWS + nMinCellY], e = coff[ix * PS_GRID_ROWS + nMaxCellY + 1];
-      for (int k0 = b; k0 < e; k0 += 64) {
-        const int k = k0 + lane;
+    const int t_off = P.t_off;
+    const bool use_bbox = P.use_bbox != 0;
+    const int rowbase = (lane & 48) << 2;                       // ds_bpermute byte address of the row's lane 0
+    for (int cx0 = nMinCellX; cx0 <= nMaxCellX; cx0 += 16) {    // 16 columns at a time (a window rarely has more)
+      const int ix = cx0 + l16;
+      int cb = 0, n = 0;
+      if (ix <= nMaxCellX) { cb = coff[ix * PS_GRID_ROWS + nMinCellY]; n = coff[ix * PS_GRID_ROWS + nMaxCellY + 1] - cb; }
+      const int excl = row_scan_inclusive(n) - n;               // candidates in the columns before this one
+      const int T = row_sum_i32(n);
+      for (int m0 = 0; m0 < T; m0 += 16) {
+        const int m = m0 + l16;                                 // traversal position of this lane's candidate
+        // its column: the last one whose prefix is <= m (empty columns share the prefix of their successor and lose to it)
+        int c = 0;
+#pragma unroll
+        for (int step = 8; step >= 1; step >>= 1) {
+          const int cc = c + step;
+          const int pv = __builtin_amdgcn_ds_bpermute(rowbase + 4 * min(cc, 15), excl);
+          if (cc < 16 && pv <= m) c = cc;
+        }
+        const int cexcl = __builtin_amdgcn_ds_bpermute(rowbase + 4 * c, excl), cbase = __builtin_amdgcn_ds_bpermute(rowbase + 4 * c, cb);
         bool pass = false;
         int j = 0, dist = 0;
-        if (k < e) {
-          j = A.cell_idx[P.t_off + k];
-          const int t = P.t_off + j;
+        if (m < T) {
+          j = A.cell_idx[t_off + cbase + (m - cexcl)];
+          const int t = t_off + j;
           const int oc = A.toct[t];
           pass = true;
           if (check) {
@@ -290,7 +340,7 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
           }
           const float dx = __fsub_rn(A.tx[t], x), dy = __fsub_rn(A.ty[t], y);
           if (!(fabsf(dx) < r && fabsf(dy) < r)) pass = false;
-          if (pass && P.use_bbox && !A.tbbox[t]) pass = false;
+          if (pass && use_bbox && !A.tbbox[t]) pass = false;
           if (pass) {
             const float tu = A.tur[t];
             if (tu > 0.f && fabsf(__fsub_rn(ur, tu)) > rer) pass = false;
@@ -300,18 +350,18 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
             dist = hamming256(a0, a1, td[0], td[1]);
           }
         }
-        const unsigned long long m = __ballot(pass);
-        const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t mrow = (uint32_t)(__ballot(pass) >> (lane & 48)) & 0xFFFFu;     // the row's passing lanes
+        const int pos = count + __popc(mrow & ((1u << l16) - 1u));
         if (pass && pos < CAP) {
           const uint32_t key = ((uint32_t)dist << 23) | ((uint32_t)pos << IDXB) | (uint32_t)j;
           A.cand[((size_t)P.c_off + qi) * CAP + pos] = key;
-          if (!A.tocc[P.t_off + j]) {   // sorted insertion
+          if (!A.tocc[t_off + j]) {   // sorted insertion
             uint32_t kk = key;
 #pragma unroll
-            for (int r = 0; r < 4; r++) { const uint32_t lo = min(mk[r], kk); kk = max(mk[r], kk); mk[r] = lo; }
+            for (int rr = 0; rr < 4; rr++) { const uint32_t lo = min(mk[rr], kk); kk = max(mk[rr], kk); mk[rr] = lo; }
           }
         }
-        count += __popcll(m);
+        count += __popc(mrow);
       }
     }
   }
@@ -321,14 +371,14 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
   uint32_t top[4];
   uint32_t prev = 0;
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
+  for (int rr = 0; rr < 4; rr++) {
     uint32_t c = 0xFFFFFFFFu;
 #pragma unroll
-    for (int u = 3; u >= 0; u--) if (r == 0 || mk[u] > prev) c = min(c, mk[u]);
-    top[r] = wave_min_u32(c);
-    prev = top[r];
+    for (int u = 3; u >= 0; u--) if (rr == 0 || mk[u] > prev) c = min(c, mk[u]);
+    top[rr] = row_min_u32(c);
+    prev = top[rr];
   }
-  if (lane == 0) {
+  if (l16 == 0 && live) {
     if (count > CAP) { atomicAdd(&A.overflow[blockIdx.y], 1); count = CAP; }
     A.ncand[q] = count;
     A.ttop[q] = make_uint4(top[0], top[1], top[2], top[3]);
@@ -590,10 +640,10 @@ extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int
   const PjArrays A = *arrays;
   if (any_frame_mode) hipLaunchKernelGGL(pj_project, dim3((max_nq + 255) / 256, nprob), dim3(256), 0, st, A);
   if (wide) {
-    hipLaunchKernelGGL(pj_gather<13>, dim3((max_nq + 3) / 4, nprob), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(pj_gather<13>, dim3((max_nq + 15) / 16, nprob), dim3(256), 0, st, A);
     hipLaunchKernelGGL(pj_resolve<13>, dim3(nprob), dim3(64), 0, st, A);
   } else {
-    hipLaunchKernelGGL(pj_gather<15>, dim3((max_nq + 3) / 4, nprob), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(pj_gather<15>, dim3((max_nq + 15) / 16, nprob), dim3(256), 0, st, A);
     hipLaunchKernelGGL(pj_resolve<15>, dim3(nprob), dim3(64), 0, st, A);
   }
 }
