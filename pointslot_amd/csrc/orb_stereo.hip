@@ -13,9 +13,18 @@
 
 namespace {
 
+// The pointers of a StPair come out of memory, where the compiler cannot see their address space and would use FLAT loads
+// (both memory pipelines, half the issue rate); they all point to device memory.
+#define ST_G(T) const __attribute__((address_space(1))) T
+#define ST_GM(T) __attribute__((address_space(1))) T
+template <typename T> __device__ __forceinline__ ST_G(T)* st_g(const T* p) { return (ST_G(T)*)p; }
+template <typename T> __device__ __forceinline__ ST_GM(T)* st_gm(T* p) { return (ST_GM(T)*)p; }
+
+typedef uint32_t st_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t st_u2 __attribute__((ext_vector_type(2)));
 struct PsKeyPoint { float x, y, size, angle, response; int32_t octave, class_id; };
 
-__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+__device__ __forceinline__ int hamming256(const st_u4 a0, const st_u4 a1, const st_u4 b0, const st_u4 b1) {
   return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
          __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
@@ -105,14 +114,16 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
   __syncthreads();
   const StPair S = pairs[blockIdx.y];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
-  const int N = *S.cnt_l;
+  const int N = *st_g(S.cnt_l);
   const int iL0 = blockIdx.x * 16 + wave * 4;
   if (iL0 >= N) return;
   const int iL = iL0 + grp;
   const bool live = iL < N;
-  const PsKeyPoint* KL = reinterpret_cast<const PsKeyPoint*>(S.kps_l);
-  const PsKeyPoint* KR = reinterpret_cast<const PsKeyPoint*>(S.kps_r);
-  const PsKeyPoint kpL = KL[live ? iL : N - 1];
+  ST_G(PsKeyPoint)* KL = st_g(reinterpret_cast<const PsKeyPoint*>(S.kps_l));
+  ST_G(PsKeyPoint)* KR = st_g(reinterpret_cast<const PsKeyPoint*>(S.kps_r));
+  const int iLc = live ? iL : N - 1;
+  PsKeyPoint kpL;
+  kpL.x = KL[iLc].x; kpL.y = KL[iLc].y; kpL.octave = KL[iLc].octave;
   float out_ur = -1.0f, out_depth = -1.0f;
   int out_sad = -1;
   const float minD = 0.f, maxD = __fdiv_rn(mbf, mb);
@@ -122,19 +133,19 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
   const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
   uint32_t best = 0xFFFFFFFFu;
   if (live && !(maxU < 0)) {
-    const uint4* dl = reinterpret_cast<const uint4*>(S.desc_l + (size_t)iL * 32);
-    const uint4 a0 = dl[0], a1 = dl[1];
+    ST_G(st_u4)* dl = st_g(reinterpret_cast<const st_u4*>(S.desc_l + (size_t)iL * 32));
+    const st_u4 a0 = dl[0], a1 = dl[1];
     // candidates: the buckets whose keypoints can have a band containing rowL (|y - rowL| <= 2 * scale[top] + 1)
-    const int32_t* boff = reinterpret_cast<const int32_t*>(S.scratch);
-    const int32_t* bidx = reinterpret_cast<const int32_t*>(S.scratch + PS_ST_OFF_BYTES);
-    const uint2* rinfo = reinterpret_cast<const uint2*>(S.scratch + PS_ST_OFF_BYTES + PS_ST_CAP * 4);
+    ST_G(int32_t)* boff = st_g(reinterpret_cast<const int32_t*>(S.scratch));
+    ST_G(int32_t)* bidx = st_g(reinterpret_cast<const int32_t*>(S.scratch + PS_ST_OFF_BYTES));
+    ST_G(st_u2)* rinfo = st_g(reinterpret_cast<const st_u2*>(S.scratch + PS_ST_OFF_BYTES + PS_ST_CAP * 4));
     const int nb = min(PS_ST_MAXB, (plan.img_h >> 3) + 1);
     const float rmax = __fadd_rn(__fmul_rn(2.0f, plan.lv[plan.nlevels - 1].scale), 2.0f);
     const int b0 = min(max((int)floorf((float)rowL - rmax) >> 3, 0), nb - 1), b1 = min(max((int)ceilf((float)rowL + rmax) >> 3, 0), nb - 1);
     const int k_end = boff[b1 + 1];
     const uint32_t rowk = (uint32_t)(rowL + 1024);
     for (int k = boff[b0] + l16; k < k_end; k += 16) {
-      const uint2 ri = rinfo[k];
+      const st_u2 ri = rinfo[k];
       const int iR = bidx[k];
       const uint32_t minr = ri.y & 0x1FFF, maxr = (ri.y >> 13) & 0x1FFF;
       const int oct = (int)(ri.y >> 26);
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
       if ((uint32_t)(oct - levelL + 1) > 2u) continue;
       const float rx = __uint_as_float(ri.x);
       if (!(rx >= minU && rx <= maxU)) continue;
-      const uint4* dr = reinterpret_cast<const uint4*>(S.desc_r + (size_t)iR * 32);
+      ST_G(st_u4)* dr = st_g(reinterpret_cast<const st_u4*>(S.desc_r + (size_t)iR * 32));
       const uint32_t d = (uint32_t)hamming256(a0, a1, dr[0], dr[1]);
       if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR);   // bestDist starts at TH_HIGH, strict <, first wins
     }
@@ -164,15 +175,17 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
       // lane i < 11 of the row owns patch row i - 5: its 11 left pixels (columns -5 .. 5) and the 21 right pixels (columns
       // -10 .. 10) that the 11 shifts slide over, in registers; every lane also reads the centre row for the centre pixels.
       const int i = min(l16, 10);
-      const uint8_t* pl = S.arena_l + (Lplane + (uint32_t)((PS_EDGE + cy + i - 5) * Lstride + PS_EDGE + cxl - 5));
-      const uint8_t* pr = S.arena_r + (Lplane + (uint32_t)((PS_EDGE + cy + i - 5) * Lstride + PS_EDGE + cxr - 10));
-      const uint8_t* prc = S.arena_r + (Lplane + (uint32_t)((PS_EDGE + cy) * Lstride + PS_EDGE + cxr - 10));
+      ST_G(uint8_t)* al = st_g(S.arena_l);
+      ST_G(uint8_t)* ar = st_g(S.arena_r);
+      ST_G(uint32_t)* pl = (ST_G(uint32_t)*)(al + (Lplane + (uint32_t)((PS_EDGE + cy + i - 5) * Lstride + PS_EDGE + cxl - 5)));
+      ST_G(uint32_t)* pr = (ST_G(uint32_t)*)(ar + (Lplane + (uint32_t)((PS_EDGE + cy + i - 5) * Lstride + PS_EDGE + cxr - 10)));
+      ST_G(uint32_t)* prc = (ST_G(uint32_t)*)(ar + (Lplane + (uint32_t)((PS_EDGE + cy) * Lstride + PS_EDGE + cxr - 10)));
       uint32_t lw[3], rw[6], cw[6];
 #pragma unroll
-      for (int q = 0; q < 3; q++) lw[q] = reinterpret_cast<const uint32_t*>(pl)[q];
+      for (int q = 0; q < 3; q++) lw[q] = pl[q];
 #pragma unroll
-      for (int q = 0; q < 6; q++) { rw[q] = reinterpret_cast<const uint32_t*>(pr)[q]; cw[q] = reinterpret_cast<const uint32_t*>(prc)[q]; }
-      const uint32_t Lc = S.arena_l[Lplane + (uint32_t)((PS_EDGE + cy) * Lstride + PS_EDGE + cxl)];
+      for (int q = 0; q < 6; q++) { rw[q] = pr[q]; cw[q] = prc[q]; }
+      const uint32_t Lc = al[Lplane + (uint32_t)((PS_EDGE + cy) * Lstride + PS_EDGE + cxl)];
       // |(L - Lc) - (R - Rc)| on packed u16 with both sides offset by 256: a = L + (256 - Lc), b = R + (256 - Rc)
       const uint32_t biasA = (256u - Lc) * 0x00010001u;
       uint32_t a[6];
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
       }
     }
   }
-  if (l16 == 0 && live) { S.u_right[iL] = out_ur; S.depth[iL] = out_depth; S.sad[iL] = out_sad; }
+  if (l16 == 0 && live) { st_gm(S.u_right)[iL] = out_ur; st_gm(S.depth)[iL] = out_depth; st_gm(S.sad)[iL] = out_sad; }
 }
 
 __global__ __launch_bounds__(1024) void st_median(OrbPlan plan, const StPair* pairs) {
