@@ -480,15 +480,16 @@ typedef short fs_s2 __attribute__((ext_vector_type(2)));
 
 // LDS layout of one cell-wave (bytes; every region 16-byte aligned).  TR = window rows of the plan's tallest cell.
 struct FastLds { int smap, bmp, list, cap, total; };
-__host__ __device__ __forceinline__ FastLds fast_lds(int TS, int TR, int SS, int LCAP) {
+__host__ __device__ __forceinline__ FastLds fast_lds(int TS, int TR, int LCAP) {
   FastLds f;
   int o = (TR * TS + 15) & ~15;
-  f.smap = o; o += (SS * (TR - 4) + 15) & ~15;         // score map with a zero ring: (rows + 2) x SS
+  f.smap = o; o += (TS * (TR - 4) + 15) & ~15;         // score map with a zero ring, (rows + 2) x TS: the window's row stride, so that
+                                                       // a list entry (offset of the pixel in the window) addresses both
   f.bmp = o; o += (8 * (TR - 6) + 15) & ~15;           // kept-keypoint bitmap, one u64 per cell row
-  // survivor entries: dark from the front, bright from the back.  Sized for 9/16 of the cell's pixels (a step can add 512);
+  // survivor entries: dark from the front, bright from the back.  Sized for half of the cell's pixels (a step can add 512);
   // a cell that would overflow it is scored in several rounds (exact, slower: see the kernel).  With the 32 x 40 cells of
   // 1242 x 375 a wave takes 5120 bytes: 8 workgroups per CU.
-  f.cap = ((LCAP * 9 / 16 > 640 ? LCAP * 9 / 16 : 640) + 7) & ~7;
+  f.cap = ((LCAP / 2 > 640 ? LCAP / 2 : 640) + 7) & ~7;
   f.list = o; o += 2 * f.cap;
   f.total = o;
   return f;
@@ -500,7 +501,7 @@ __host__ __device__ __forceinline__ FastLds fast_lds(int TS, int TR, int SS, int
 #define PS_FAST_WAVES 8        // waves per SIMD the register allocation aims at (the LDS of the usual cells admits 8 workgroups per CU)
 #endif
 template <int TS, int LG, int MAXROWS>
-__global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_WAVES, 8))) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TR, int SS, int LCAP, int nimg, int bpi,
+__global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_WAVES, 8))) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TR, int LCAP, int nimg, int bpi,
                                                          const uint8_t* masks, int mask_stride, size_t mask_pitch) {
   constexpr int NG = 1 << LG, RPS = 64 >> LG;          // groups per row = loader lanes per row; rows per 64-lane step
   constexpr int NPASS = (MAXROWS + RPS - 1) / RPS;
@@ -510,7 +511,8 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
   if (!xcd_image_block(nimg, img, lb)) return;
   const int cell = lb * 4 + wave;
   if (cell >= plan.n_cells) return;
-  const FastLds F = fast_lds(TS, TR, SS, LCAP);
+  constexpr int SS = TS;                               // score-map row stride = window row stride
+  const FastLds F = fast_lds(TS, TR, LCAP);
   uint8_t* tile = fast_smem + (size_t)wave * F.total;
   uint8_t* smap = tile + F.smap;
   unsigned long long* bmp = reinterpret_cast<unsigned long long*>(tile + F.bmp);
@@ -579,10 +581,10 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
     int nd = 0, nb = 0, y0 = 0;
     bool flushed = false;
     const uint8_t* rp = tile + ry * TS + 4 * g;          // window row of the lane's N points; the centre row is 3 below
-    uint32_t val = (uint32_t)((ry << 7) | (4 * g));      // list entry of the lane's first pixel: y << 7 | x
+    uint32_t val = (uint32_t)(ry * TS + 4 * g);          // list entry of the lane's first pixel: its offset in the window, y * TS + x
     for (;;) {
       bool full = false;
-      for (; y0 < ch; y0 += RPS, rp += RPS * TS, val += RPS << 7) {
+      for (; y0 < ch; y0 += RPS, rp += RPS * TS, val += RPS * TS) {
         // lanes whose row lies below the cell read rows of the window that exist in LDS but mean nothing: masked out (a ballot
         // inside a lane-dependent branch would make every count that follows lane-dependent)
         const int nl = (ch - y0) << LG;
@@ -616,13 +618,16 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           if (DK[i]) {                                   // wave-uniform
-            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(DK[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)DK[i], (uint32_t)nd));
-            if (__builtin_amdgcn_inverse_ballot_w64(DK[i])) list[pos] = (uint16_t)(val | i);
+            // (the running count goes into the scalar base address: as the v_mbcnt accumulator it would cost a move per slot)
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(DK[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)DK[i], 0u));
+            uint16_t* wp = list + nd;
+            if (__builtin_amdgcn_inverse_ballot_w64(DK[i])) wp[pos] = (uint16_t)(val + i);
             nd += __popcll(DK[i]);
           }
           if (BR[i]) {
-            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(BR[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)BR[i], (uint32_t)nb));
-            if (__builtin_amdgcn_inverse_ballot_w64(BR[i])) list[CAP - 1 - (int)pos] = (uint16_t)(val | i);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(BR[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)BR[i], 0u));
+            uint8_t* wp = reinterpret_cast<uint8_t*>(list + (CAP - 1 - nb));
+            if (__builtin_amdgcn_inverse_ballot_w64(BR[i])) *reinterpret_cast<uint16_t*>(wp + __mul24((int)pos, -2)) = (uint16_t)(val + i);
             nb += __popcll(BR[i]);
           }
         }
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
           const bool bright = kk >= nd;
           p[e] = list[bright ? CAP - 1 + nd - kk : kk];
           if (bright) polm |= 0xFFu << (16 * e);
-          q[e] = tile + (p[e] >> 7) * TS + (p[e] & 127u);     // window position of the pixel's 7 x 7 neighbourhood
+          q[e] = tile + p[e];                                  // window position of the pixel's 7 x 7 neighbourhood
         }
         // ring offsets from q (centre at (3, 3)): position 0 is (dx, dy) = (0, +3), then as OpenCV's table
         constexpr int RO[16] = {6 * TS + 3, 6 * TS + 4, 5 * TS + 5, 4 * TS + 6, 3 * TS + 6, 2 * TS + 6, 1 * TS + 5, 0 * TS + 4,
@@ -662,8 +667,8 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
         for (int i = 1; i < 8; i++)
           best = __builtin_elementwise_min(best, __builtin_elementwise_min(__builtin_elementwise_max(S0[i], P1[i]), __builtin_elementwise_max(S1[i], P0[i])));
         const fs_s2 sc = cv - __builtin_bit_cast(fs_s2, best);
-        if ((int)sc.x > th && i0 + lane < ntot) smap[((p[0] >> 7) + 1) * SS + (p[0] & 127u) + 1] = (uint8_t)sc.x;
-        if ((int)sc.y > th && i0 + 64 + lane < ntot) smap[((p[1] >> 7) + 1) * SS + (p[1] & 127u) + 1] = (uint8_t)sc.y;
+        if ((int)sc.x > th && i0 + lane < ntot) smap[p[0] + (SS + 1)] = (uint8_t)sc.x;
+        if ((int)sc.y > th && i0 + 64 + lane < ntot) smap[p[1] + (SS + 1)] = (uint8_t)sc.y;
       }
       if (!full) break;
       wave_sync();
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
         if (k < ntot) {
           const int li = k >= nd ? CAP - 1 + nd - k : k;
           const int pp = list[li];
-          const uint8_t* m = smap + ((pp >> 7) + 1) * SS + (pp & 127) + 1;
+          const uint8_t* m = smap + pp + (SS + 1);
           const int s = m[0];
           lmax = s > m[-1] && s > m[1] && s > m[-SS - 1] && s > m[-SS] && s > m[-SS + 1] && s > m[SS - 1] && s > m[SS] && s > m[SS + 1];
           if (lmax) list[li] = (uint16_t)(pp | 0x8000); // bit 15: survives the NMS (a pixel listed twice is marked twice)
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
       for (int i0 = 0; i0 < ntot; i0 += 64) {
         const int k = i0 + lane;
         const int pv = k < ntot ? list[k >= nd ? CAP - 1 + nd - k : k] : 0;
-        if (pv & 0x8000) atomicOr(&bmp[(pv >> 7) & 127], 1ull << (pv & 127));
+        if (pv & 0x8000) { const int po = pv & 0x7FFF, py = po / TS; atomicOr(&bmp[py], 1ull << (po - py * TS)); }
       }
       wave_sync();
       rowbits = lane < ch ? bmp[lane] : 0ull;
@@ -1463,16 +1468,16 @@ extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nim
     mw = plan->lv[l].w_cell + 6 > mw ? plan->lv[l].w_cell + 6 : mw;
     mh = plan->lv[l].h_cell + 6 > mh ? plan->lv[l].h_cell + 6 : mh;
   }
-  const int TR = mh, SS = (mw - 6 + 2 + 3) & ~3;
+  const int TR = mh;
   const int LCAP = (mw - 6) * (mh - 6);
   const int bpi = (plan->n_cells + 3) / 4;
   if (mw <= 38 && mh <= 48) {      // cells up to 32 px wide (30-px cells of the usual image sizes): 8 groups per row, 8 rows per step
-    const FastLds F = fast_lds(40, TR, SS, LCAP);
-    hipLaunchKernelGGL((orb_fast_cells<40, 3, 48>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, TR, SS, LCAP,
+    const FastLds F = fast_lds(40, TR, LCAP);
+    hipLaunchKernelGGL((orb_fast_cells<40, 3, 48>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, TR, LCAP,
                        nimg, bpi, masks, mask_stride, mask_pitch);
   } else {                         // up to PS_FAST_WIN: 16 groups per row, 4 rows per step
-    const FastLds F = fast_lds(72, TR, SS, LCAP);
-    hipLaunchKernelGGL((orb_fast_cells<72, 4, 68>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, TR, SS, LCAP,
+    const FastLds F = fast_lds(72, TR, LCAP);
+    hipLaunchKernelGGL((orb_fast_cells<72, 4, 68>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, TR, LCAP,
                        nimg, bpi, masks, mask_stride, mask_pitch);
   }
 }
