@@ -233,6 +233,30 @@ def test_full_size_batch_properties():
     m.close(); exb.close(); ex1.close()
 
 
+def test_large_batch_takes_the_split_quadtree_launch(images):
+    """from 256 images on the quadtree runs as two launches (512-thread workgroups for the large levels, 256-thread ones with half
+    the LDS for the small levels): images of such a batch equal their single-image runs, real texture and synthetic"""
+    import torch
+    from pointslot_amd.extractor import ORBextractor
+    k = images["kitti_000212"]
+    hgt, w = images["synth_left"].shape
+    kk = np.zeros((hgt, w), np.uint8)
+    kk[: min(hgt, k.shape[0]), : min(w, k.shape[1])] = k[:hgt, :w]
+    distinct = [images["synth_left"], kk, images["synth_right"], np.ascontiguousarray(kk[:, ::-1])]
+    n = 256
+    batch = np.stack([distinct[i % 4] for i in range(n)])
+    d = torch.from_numpy(batch).cuda()
+    exb = ORBextractor(2000, 1.2, 8, 20, 5, max_batch=n)
+    ex1 = ORBextractor(2000, 1.2, 8, 20, 5)
+    exb.extract_batch_device(d.data_ptr(), n, w, hgt, w, w * hgt)
+    ref = [ex1(im) for im in distinct]
+    for i in (0, 1, 2, 3, 129, 254, 255):
+        kb, db = exb.fetch(i)
+        k1, d1 = ref[i % 4]
+        assert len(kb) == len(k1) and np.array_equal(kb.view(np.uint8), k1.view(np.uint8)) and np.array_equal(db, d1), "image %d of the batch differs" % i
+    exb.close(); ex1.close()
+
+
 def test_stereo_matches_bit_exact(images):
     """Frame::ComputeStereoMatches (SURVEY 8f-1): mvuRight / mvDepth from the device-resident pyramids and descriptors are
     bit-exact against the oracle, through both layouts (two extractor objects; one interleaved batch)."""
