@@ -1278,7 +1278,10 @@ typedef float ds_f2 __attribute__((ext_vector_type(2)));
 // FOUR keypoints per wave, one per 16-lane DPP row: the angle (atan2, double-precision sincos) is the same ~100 instructions
 // whether 16 or 64 lanes share a keypoint, and the reductions stay inside a DPP row.  Levels start at multiples of four
 // slots (orb_host.hip), so a wave's four slots belong to one level and the level geometry stays on the scalar unit.
-__global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena, PsKeyPoint* out_kps,
+#ifndef PS_DESC_WAVES
+#define PS_DESC_WAVES 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_DESC_WAVES, 8))) void orb_describe(OrbPlan plan, uint8_t* arena, PsKeyPoint* out_kps,
                                                    uint8_t* out_desc, int32_t* out_counts, int nimg, int bpi) {
   // the two lane-indexed tables go to LDS once per workgroup (from the vector cache they would be two thirds of the bytes a wave loads)
   __shared__ uint4 s_pat[4][16];
@@ -1321,8 +1324,9 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
 
   // ---- the 39 x 39 neighbourhood of the blurred level that the steered pattern can reach (|coordinate| <= 18.4 before
   // rounding) goes to LDS with row-coalesced loads: the 512 byte gathers of the tests would otherwise touch ~30 cache lines
-  // per load instruction.  Four lanes x 12 bytes per row, four rows per step, ten steps.  Issued first, consumed last. ----
-  __shared__ uint32_t patch_all[16][40 * 12];
+  // per load instruction.  Four lanes x 12 bytes per row, four rows per step, ten steps.  Issued first, consumed last.  The
+  // rows land in LDS shifted to the patch's own first column (40-byte rows: 1560 bytes per keypoint, six workgroups per CU). ----
+  __shared__ uint32_t patch_all[16][39 * 10];
   uint32_t* patch = patch_all[wv * 4 + grp];
   const int pshift = (kx - 19) & 3;
   const int r4 = l16 >> 2, c4 = l16 & 3;
@@ -1348,6 +1352,19 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
     uint2 pix[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) pix[j] = *reinterpret_cast<const uint2*>(base + (coff + (uint32_t)j * s4));
+    // the patch goes to LDS before the moments are computed: its 30 staging registers are free again by then
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+      // the dword after the lane's three comes from the next lane of the quad
+      const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tmp[i][0], 0xF9 /* quad_perm [1,2,3,3] */, 0xF, 0xF, false);
+      const uint32_t o0 = __builtin_amdgcn_alignbyte(tmp[i][1], tmp[i][0], (uint32_t)pshift), o1 = __builtin_amdgcn_alignbyte(tmp[i][2], tmp[i][1], (uint32_t)pshift),
+                     o2 = __builtin_amdgcn_alignbyte(nxt, tmp[i][2], (uint32_t)pshift);
+      uint32_t* d = patch + (4 * i + r4) * 10 + 3 * c4;
+      if (i < 9 || r4 < 3) {                     // row 39 does not exist
+        d[0] = o0;
+        if (c4 < 3) { d[1] = o1; d[2] = o2; }    // ten dwords per row: the fourth lane only has the last one
+      }
+    }
     int s0 = 0;
     uint32_t acc = 0;
     const int v0 = r4 - 15;
@@ -1362,11 +1379,6 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
       m01 += (v0 + 4 * j) * (int)sr;
     }
     m10 = (int)acc - 15 * s0;
-  }
-#pragma unroll
-  for (int i = 0; i < 10; i++) {
-    uint32_t* d = patch + (4 * i + r4) * 12 + 3 * c4;
-    d[0] = tmp[i][0]; d[1] = tmp[i][1]; d[2] = tmp[i][2];
   }
   m10 = row_sum_i32(m10);
   m01 = row_sum_i32(m01);
@@ -1388,13 +1400,16 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
   const unsigned long long magic64 = 0x4B4000004B400000ull;  // {1.5 * 2^23, 1.5 * 2^23}
   typedef __attribute__((address_space(3))) const uint8_t lds_u8;
   // LDS byte address of patch pixel (0, 0) minus what the mantissa bits drag along
-  const uint32_t kall = (uint32_t)(uintptr_t)(lds_u8*)reinterpret_cast<const uint8_t*>(patch) + (uint32_t)(19 * 48 + 19 + pshift) -
-                        (0x400000u * 48u + 0x4B400000u);
+  const uint32_t kall = (uint32_t)(uintptr_t)(lds_u8*)reinterpret_cast<const uint8_t*>(patch) + (uint32_t)(19 * 40 + 19) -
+                        (0x400000u * 40u + 0x4B400000u);
   uint32_t bits = 0;
+#pragma unroll 1
+  for (int t4 = 0; t4 < 4; t4++) {
+  const uint4 pw4 = s_pat[t4][l16];
 #pragma unroll
-  for (int tst = 0; tst < 16; tst++) {
-    const uint4 pw4 = s_pat[tst >> 2][l16];
-    const uint32_t pw = (tst & 3) == 0 ? pw4.x : (tst & 3) == 1 ? pw4.y : (tst & 3) == 2 ? pw4.z : pw4.w;
+  for (int tq = 0; tq < 4; tq++) {
+    const int tst = 4 * t4 + tq;
+    const uint32_t pw = tq == 0 ? pw4.x : tq == 1 ? pw4.y : tq == 2 ? pw4.z : pw4.w;
     float4 pt;
     pt.x = (float)(int8_t)(pw & 0xFF); pt.y = (float)(int8_t)((pw >> 8) & 0xFF); pt.z = (float)(int8_t)((pw >> 16) & 0xFF); pt.w = (float)(int8_t)(pw >> 24);
     // (operands as 64-bit integers: register pairs; a vector-typed asm output comes back with both lanes reading the low register)
@@ -1416,10 +1431,11 @@ __global__ __launch_bounds__(256) void orb_describe(OrbPlan plan, uint8_t* arena
         "s_nop 0"
         : "=&v"(T0), "=&v"(T1), "=&v"(Q0), "=&v"(Q1)
         : "v"(xy0), "v"(xy1), "v"(ba64), "v"(anb64), "v"(magic64));
-    const uint32_t i0 = (uint32_t)__mul24((int)(uint32_t)T0, 48) + ((uint32_t)(T0 >> 32) + kall);
-    const uint32_t i1 = (uint32_t)__mul24((int)(uint32_t)T1, 48) + ((uint32_t)(T1 >> 32) + kall);
+    const uint32_t i0 = (uint32_t)__mul24((int)(uint32_t)T0, 40) + ((uint32_t)(T0 >> 32) + kall);
+    const uint32_t i1 = (uint32_t)__mul24((int)(uint32_t)T1, 40) + ((uint32_t)(T1 >> 32) + kall);
     const int t0 = *(lds_u8*)(uintptr_t)i0, t1 = *(lds_u8*)(uintptr_t)i1;
     bits |= (uint32_t)(t0 < t1) << tst;
+  }
   }
   if (!valid) return;
   reinterpret_cast<uint16_t*>(out_desc + ((size_t)img * plan.kp_cap + oi) * 32)[l16] = (uint16_t)bits;
