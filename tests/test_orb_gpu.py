@@ -137,6 +137,22 @@ def test_noise_images_take_the_multi_round_path(kind):
     ex.close()
 
 
+def test_noise_image_with_wide_cells():
+    """the same overflow path in the kernel instance for FAST cells wider than 32 pixels (16 four-pixel groups per row)"""
+    from pointslot_amd.extractor import ORBextractor
+    rng = np.random.default_rng(5)
+    h, w = 200, 320                                      # level 1 has 34-pixel cells
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[:, 200:] = (img[:, 200:] // 8 + 100).astype(np.uint8)   # a low-contrast part: cells that take the minThFAST pass
+    ex = ORBextractor(600, 1.2, 4, 20, 7)
+    orc = OracleORB(600, 1.2, 4, 20, 7)
+    kg, dg = ex(img)
+    ko, do = orc.run(img)
+    assert len(kg) == len(ko) and len(kg) > 50
+    assert np.array_equal(kg.view(np.uint8), ko.view(np.uint8)) and np.array_equal(dg, do)
+    ex.close()
+
+
 @pytest.mark.parametrize("shape,nfeatures,nlevels,ths,scale", [
     ((480, 640), 1500, 8, (20, 7), 1.2),
     ((300, 800), 500, 8, (20, 5), 1.2),
