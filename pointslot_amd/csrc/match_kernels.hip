@@ -216,7 +216,7 @@ __device__ __forceinline__ float dot3_f(const float* R, float x, float y, float 
 }
 
 __global__ __launch_bounds__(256) void pj_project(PjArrays A) {
-  const PjProb P = A.prob[blockIdx.y];
+  const PjProb& P = A.prob[blockIdx.y];   // by reference: a private copy indexed by the octave (P.scale[oct]) would live in scratch memory
   if (!P.frame_mode) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P.nq) return;
@@ -697,7 +697,7 @@ extern "C" void psk_distinctive_launch(const uint8_t* desc, const int32_t* off, 
 // ================================================================================================
 namespace {
 __global__ __launch_bounds__(256) void fuse_search(FuArrays A) {
-  const FuProb P = A.prob[blockIdx.y];
+  const FuProb& P = A.prob[blockIdx.y];   // by reference (see pj_project)
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (qi >= P.nq) return;
   const int q = P.q_off + qi;
