@@ -879,9 +879,9 @@ __global__ __launch_bounds__(NT) void orb_quadtree(OrbPlan plan, uint8_t* arena,
   }
   // flattened gather: key j lives in cell c with off[c] <= j < off[c+1] (binary search in LDS), so every thread
   // issues independent slot loads instead of walking the cells one dependent global round trip at a time
-  // keys live in LDS when they fit (generic pointers: the same code serves both cases)
-  uint32_t* kxy = n <= KCAP ? s.kxy : gkxy;
-  uint32_t* kns = n <= KCAP ? s.kns : gkxy + L.key_cap;   // node | score << 16
+  // keys live in LDS when they fit, else in the level's global scratch: the passes below are compiled once for either address
+  // space (a generic pointer would make every key access a FLAT instruction, which takes the slow path to LDS)
+  auto passes = [&](auto kxy, auto kns) {
   if (t == 0) coff[ncell] = n;
   __syncthreads();
   for (int j = t; j < n; j += NT) {
@@ -1098,6 +1098,11 @@ __global__ __launch_bounds__(NT) void orb_quadtree(OrbPlan plan, uint8_t* arena,
   }
   if (t == 0) selcnt[level] = min(nn, L.sel_cap);
   QTP_MARK(8);
+  };
+  typedef __attribute__((address_space(3))) uint32_t* lds_keys;
+  typedef __attribute__((address_space(1))) uint32_t* glb_keys;
+  if (n <= KCAP) passes((lds_keys)s.kxy, (lds_keys)s.kns);
+  else passes((glb_keys)gkxy, (glb_keys)(gkxy + L.key_cap));      // node | score << 16
   QTP_PRINT();
 }
 
