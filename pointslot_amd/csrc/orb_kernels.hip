@@ -772,8 +772,13 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
 #endif
 #define QT_INV 0x80000000u
 
+#ifndef QT_KCAP512
+#define QT_KCAP512 2048          // ... of the 512-node configuration
+#endif
+#ifndef QT_KCAP
 #define QT_KCAP 2048              // keys kept in LDS (levels with more candidates use the global scratch); sized so that three
                                   // workgroups share a CU: the kernel is latency-bound and its duration is rounds x workgroup latency
+#endif
 template <int NCAP, int NT, int KCAP>
 struct QtShared {
   uint32_t boxa[2][NCAP];   // x0 | y0 << 16
@@ -1523,7 +1528,7 @@ extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int
   // grid: x = (level - first level) * nimg + image (level-major)
   if (split > 0) {
     const dim3 grid(split * nimg, 1);
-    if (big <= 512) hipLaunchKernelGGL((orb_quadtree<512, QT_T, QT_KCAP>), grid, dim3(QT_T), 0, st, *plan, arena, nimg, 0);
+    if (big <= 512) hipLaunchKernelGGL((orb_quadtree<512, QT_T, QT_KCAP512>), grid, dim3(QT_T), 0, st, *plan, arena, nimg, 0);
     else if (big <= 1024) hipLaunchKernelGGL((orb_quadtree<1024, QT_T, QT_KCAP>), grid, dim3(QT_T), 0, st, *plan, arena, nimg, 0);
     else hipLaunchKernelGGL((orb_quadtree<PS_QT_NCAP, QT_T, QT_KCAP>), grid, dim3(QT_T), 0, st, *plan, arena, nimg, 0);
   }
