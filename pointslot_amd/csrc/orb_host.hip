@@ -68,6 +68,11 @@ struct ps_orb {
   uint8_t* h_frames = nullptr;    // pinned staging of ps_orb_stereo_fetch_frames
   size_t h_frames_bytes = 0;
   hipStream_t stream = nullptr;
+  // host-image batches: the upload of a batch runs on its own stream, behind the level-0 kernel of the batch before it (the only
+  // reader of the staging buffer) and ahead of its own kernels - it overlaps the rest of the previous batch's work
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_input_free = nullptr, ev_uploaded = nullptr;
+  bool input_read_pending = false;
   // stage timing: a ring of event sets so that consecutive batches can be timed without a host
   // synchronisation in between; ps_orb_stage_times() averages over the recorded batches.
   static const int RING = 32;
@@ -318,6 +323,10 @@ int run_batch(ps_orb* h, const uint8_t* d_imgs, int nimg, int stride, size_t pit
       for (int l = 0; l < P->nlevels; l++) psk_orb_launch_pyramid(P, l, arena, imgs, stride, pitch, h->d_tabs, n, st);
       psk_orb_launch_border(P, arena, n, st);
     }
+    if (c == nchunks - 1 && h->ev_input_free && d_imgs == h->d_img) {   // the staging buffer may be overwritten from here on
+      PS_HIP(hipEventRecord(h->ev_input_free, st));
+      h->input_read_pending = true;
+    }
     if (tm) PS_HIP(hipEventRecord(ev[1], st));
     psk_orb_launch_fast(P, arena, n, h->d_mask ? h->d_mask + (size_t)i0 * h->mask_pitch : nullptr, h->mask_stride, h->mask_pitch, st);
     if (tm) PS_HIP(hipEventRecord(ev[2], st));
@@ -358,6 +367,13 @@ int ps_orb_create(const ps_orb_config* cfg, ps_orb** out) {
   for (int r = 0; r < ps_orb::RING; r++)
     for (int c = 0; c < ps_orb::MAXCHUNK; c++)
       for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&h->ev[r][c][i]);
+  if (!(getenv("PS_ORB_COPY_STREAM") && getenv("PS_ORB_COPY_STREAM")[0] == '0')) {
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_input_free, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_uploaded, hipEventDisableTiming) != hipSuccess) {
+      ps_orb_destroy(h);
+      return ps_set_error(PS_ERR_HIP, "copy stream / event creation failed");
+    }
+  }
   if (const char* e = getenv("PS_ORB_CHUNK")) h->chunk = atoi(e);
   if (const char* e = getenv("PS_ORB_FUSED")) h->fused = atoi(e) != 0;
   *out = h;
@@ -368,6 +384,9 @@ void ps_orb_destroy(ps_orb* h) {
   if (!h) return;
   hipSetDevice(h->cfg.device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); h->copy_stream = nullptr; }
+  if (h->ev_input_free) hipEventDestroy(h->ev_input_free);
+  if (h->ev_uploaded) hipEventDestroy(h->ev_uploaded);
   free_device(h);
   if (h->d_img) hipFree(h->d_img);
   if (h->d_mask_buf) hipFree(h->d_mask_buf);
@@ -524,13 +543,20 @@ int ps_orb_extract_batch(ps_orb* h, const uint8_t* const* imgs, int nimg, int w,
     PS_HIP(hipMalloc(&h->d_img, bytes));
     h->d_img_bytes = bytes;
   }
-  // uploads on the handle's stream, asynchronous when the caller's buffers are pinned (ps_pinned_alloc).  Images that follow each
-  // other in host memory go in ONE transfer: a 0.47 MB copy reaches half the PCIe rate of a multi-megabyte one.
+  // uploads asynchronous when the caller's buffers are pinned (ps_pinned_alloc), on the copy stream: behind the last reader of the
+  // staging buffer, ahead of this batch's kernels.  Images that follow each other in host memory go in ONE transfer: a 0.47 MB
+  // copy reaches half the PCIe rate of a multi-megabyte one.
+  hipStream_t cs = h->copy_stream ? h->copy_stream : h->stream;
+  if (h->copy_stream && h->input_read_pending) PS_HIP(hipStreamWaitEvent(cs, h->ev_input_free, 0));
   for (int i = 0; i < nimg;) {
     int j = i + 1;
     while (j < nimg && imgs[j] == imgs[j - 1] + pitch) j++;
-    PS_HIP(hipMemcpyAsync(h->d_img + pitch * i, imgs[i], pitch * (size_t)(j - i), hipMemcpyHostToDevice, h->stream));
+    PS_HIP(hipMemcpyAsync(h->d_img + pitch * i, imgs[i], pitch * (size_t)(j - i), hipMemcpyHostToDevice, cs));
     i = j;
+  }
+  if (h->copy_stream) {
+    PS_HIP(hipEventRecord(h->ev_uploaded, cs));
+    PS_HIP(hipStreamWaitEvent(h->stream, h->ev_uploaded, 0));
   }
   return ps_orb_extract_batch_device(h, h->d_img, nimg, w, hgt, stride, pitch, nullptr);
 }
