@@ -181,14 +181,17 @@ __global__ __launch_bounds__(256) void orb_pyramid_level(OrbPlan plan, int level
 //     weights are pre-shifted by 16) and one add3.  No saturation is needed: a0 + a1 = 2048 bounds the result by 255.
 // ------------------------------------------------------------------------------------------------
 #define LV_RPT 10                 // region rows per thread
-#define LV_R (4 * LV_RPT)         // region rows per workgroup
+#ifndef LV_WAVES
+#define LV_WAVES 4                // waves per workgroup: each takes LV_RPT region rows
+#endif
+#define LV_R (LV_WAVES * LV_RPT)  // region rows per workgroup
 #define LV_OWN_R (LV_R - 6)       // owned rows
 #define LV_OWN_C 248              // owned columns (62 dword groups; lanes 0 and 63 are halo)
 #ifndef LV_HALVES
 #define LV_HALVES 2            // the region rows of a thread are loaded and resized in this many groups
 #endif
 #define LV_HROWS (LV_RPT / LV_HALVES)
-#define LV_BLUR_ROWS 9            // 4 row chunks of <= 9 cover the 34 owned rows
+#define LV_BLUR_ROWS ((LV_OWN_R + LV_WAVES - 1) / LV_WAVES)   // LV_WAVES row chunks cover the owned rows (9 of 34 with 4 waves)
 typedef unsigned short lv_us2 __attribute__((ext_vector_type(2)));
 
 #ifdef PS_LV_PROFILE   // developer build: 100 MHz ticks of one workgroup in the middle of the launch
@@ -204,7 +207,7 @@ typedef unsigned short lv_us2 __attribute__((ext_vector_type(2)));
 #define PS_LV_WAVES 7        // 70 VGPRs: seven waves per SIMD (measured best of 4 / 6 / 7 / 8)
 #endif
 template <bool LEVEL0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LV_WAVES, 8))) void orb_level_fused(OrbPlan plan, int level, uint8_t* arena, const uint8_t* imgs,
+__global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(PS_LV_WAVES, 8))) void orb_level_fused(OrbPlan plan, int level, uint8_t* arena, const uint8_t* imgs,
                                                       int img_stride, size_t img_pitch, const int4* tabs) {
   __shared__ uint32_t tile[LV_R][64];
   LVP_DECL;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LV_WAVES
 
   // ---- phase 2: GaussianBlur 7x7 of the owned in-image pixels from LDS (fixed point, see orb_blur) ----
   const int tid = threadIdx.x;
-  if (tid >= 4 * 62) return;
+  if (tid >= LV_WAVES * 62) return;
   const int c = tid % 62, q = tid / 62;
   const int x0 = P0 + 4 * c + 3 - PS_EDGE;                 // level column of the blur group (multiple of 4)
   if (x0 < 0 || x0 >= L.w) return;
@@ -1484,9 +1487,9 @@ extern "C" void psk_orb_launch_level_fused(const OrbPlan* plan, int level, uint8
   const int PW = L.w + 2 * PS_EDGE, PH = L.h + 2 * PS_EDGE;
   dim3 grd((PW + LV_OWN_C - 1) / LV_OWN_C, (PH + LV_OWN_R - 1) / LV_OWN_R, nimg);
   if (level == 0)
-    hipLaunchKernelGGL(orb_level_fused<true>, grd, dim3(256), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
+    hipLaunchKernelGGL(orb_level_fused<true>, grd, dim3(64 * LV_WAVES), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
   else
-    hipLaunchKernelGGL(orb_level_fused<false>, grd, dim3(256), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
+    hipLaunchKernelGGL(orb_level_fused<false>, grd, dim3(64 * LV_WAVES), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
 }
 extern "C" void psk_orb_launch_border(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   hipLaunchKernelGGL(orb_border, dim3(plan->border_blocks, nimg), dim3(256), 0, st, *plan, arena);
