@@ -199,7 +199,7 @@ extern "C" void psk_hamming_matrix_launch(const uint8_t* q, int nq, const uint8_
 //   (Frame&, nOrder, const vector<MapObjectPoint*>&, th)   :157-248
 // with Frame::GetFeaturesInArea (/root/reference/src/Frame.cc:1808-1861) as the candidate generator.
 //   pj_project  : frame-to-frame variant only — float projection of the last frame's map points
-//   pj_gather   : one wave per query — grid window walk in the reference's order (ix, iy, cell order), static
+//   pj_gather   : four queries per wave — grid window walk in the reference's order (ix, iy, cell order), static
 //                 filters (level, |dx|,|dy| < r, stereo uR gate, bbox), Hamming distance; candidates are
 //                 stored in traversal order as keys  dist << 23 | position << IDXB | train index
 //   pj_resolve  : one wave per problem — the order-dependent part: queries in order, trains blocked by an

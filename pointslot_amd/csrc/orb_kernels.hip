@@ -3,11 +3,11 @@
 // Pipeline per batch of images (all images of a batch in one launch):
 //   orb_level_fused     x nlevels  one launch per level: bilinear level (OpenCV fixed point), its 19-px REFLECT_101 border and
 //                                  its 7x7 sigma-2 blurred plane, the blur taken from LDS
-//   orb_fast_cells      x 1        one wave per 30-px FAST cell: necessary test on packed u16 trees, exact score of the
-//                                  survivors, per-cell NMS, iniThFAST / minThFAST fallback, raster-ordered compaction
-//   orb_quadtree        x 1        one workgroup per (level, image): DistributeOctTree as parallel key passes + node-level
-//                                  list bookkeeping in LDS
-//   orb_describe        x 1        one wave per keypoint: intensity-centroid angle + 256-bit rBRIEF from an LDS-staged patch
+//   orb_fast_cells      x 1        one wave per 30-px FAST cell: compass-point necessary test on packed u16, exact score of the
+//                                  survivors (two per lane), per-cell NMS, iniThFAST / minThFAST fallback, bitmap-ranked emission
+//   orb_quadtree        x 1 or 2   one workgroup per (level, image): DistributeOctTree as parallel key passes + node-level
+//                                  list bookkeeping in LDS (large batches: a second, smaller configuration for the small levels)
+//   orb_describe        x 1        four keypoints per wave: intensity-centroid angle + 256-bit rBRIEF from an LDS-staged patch
 // (orb_pyramid_level / orb_border / orb_blur are the unfused forms of the first stage, kept behind PS_ORB_FUSED=0.)
 //
 // Reference semantics each kernel reproduces are cited at the kernel.  Integer stages are exact;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
       thv[pq].y = (short)(4 * g + 2 * pq + 1 < cw ? th : 0x7FFF);
     }
     // ---- B + C.  B fills the survivor region step by step; C scores what is listed.  One round unless the region
-    // would overflow (more than 60 % of the cell's pixels listed: noise), then C runs on what is there and B goes on. ----
+    // would overflow (more than half of the cell's pixels listed: noise), then C runs on what is there and B goes on. ----
     int nd = 0, nb = 0, y0 = 0;
     bool flushed = false;
     const uint8_t* rp = tile + ry * TS + 4 * g;          // window row of the lane's N points; the centre row is 3 below
