@@ -306,6 +306,16 @@ def optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak):
                           "frac": ach / fp64_peak if fp64_peak else None, "traffic": None, "algorithmic_flop_per_batch": flop,
                           "peak_source": "v_mfma_f64_16x16x4_f64 microbenchmark measured in this run (ps_debug_mfma_f64_peak)",
                           "note": "latency-bound: one object's reduced system is 300 unknowns; see DESIGN.md section 7"}
+    if graphs and world == 1:
+        # where the latency floor ends: the same schedule for 1, 8, 16, 32, 64 independent objects in one batch (seeds 0x51070004 + j)
+        scale = {}
+        many = graphs + [synth.object_ba_problem(0x51070004 + j) for j in range(len(graphs), 64)]
+        for nobj in (16, 32, 64):
+            rr = opt.ObjectLocalBundleAdjustment(many[:nobj])
+            scale[str(nobj)] = {"gpu_ms_per_batch": opt.last_kernel_ms(), "ms_per_iter": opt.last_kernel_ms() / max(max(x["iterations"] for x in rr), 1)}
+        scale["1"] = {"gpu_ms_per_batch": ms1, "ms_per_iter": ms1 / iters1}
+        scale["8"] = {"gpu_ms_per_batch": ms, "ms_per_iter": ms / max(iters, 1)}
+        ba["batch_scaling"] = scale
     out["object_ba"] = ba
     if with_cpu and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
