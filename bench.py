@@ -179,7 +179,7 @@ def cpu_tracking_baseline(seqs, tcw_gpu, budget_s=12.0):
         k += 1
     return {"value": frames / spent, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d frames of %d of the run's sequences through the CPU restatement of the same tracking loop (oracle/*.cpp, -O3 "
-                      "-march=native, one thread: the reference's per-frame call structure); host has %d cores" % (frames, min(k, len(seqs)), os.cpu_count())}, worst, checked
+                      "-march=x86-64-v3, one thread: the reference's per-frame call structure); host has %d cores" % (frames, min(k, len(seqs)), os.cpu_count())}, worst, checked
 
 
 def orb_leg(rank, local_rank, barrier, with_cpu):

@@ -94,6 +94,8 @@ __device__ void empty_problem(PjProb* p, const TrkArrays& A, int s) {
 __device__ void seq_fail(const TrkArrays& A, int s, int step, TrkStat& st) {
   TrkSeq& q = A.seq[s];
   q.state = TRK_LOST; q.have_velocity = 0; q.phase = TRK_PH_IDLE;
+  // the chain's remaining pose_lm launches must see no edges for this sequence (the host loop stops calling the optimiser here)
+  A.po_vert[s] = PoVertex{(int32_t)(s * A.cap), (int32_t)(s * A.cap)};
   st.state = TRK_LOST; st.tracked = 0;
   A.stats[(size_t)step * A.S + s] = st;
   float* tr = A.traj + ((size_t)step * A.S + s) * 16;
@@ -426,7 +428,9 @@ __global__ __launch_bounds__(TRK_T) void trk_after_pose1(TrkArrays A, int step) 
   st.matches = nmatches; st.map_matches = nmap;
   if (!(nmatches > 20)) { if (tid == 0) seq_fail(A, s, step, st); return; }
   if (nmap < 10) {   // mbVO: the frame is kept without TrackLocalMap
-    if (tid == 0) { q.phase = TRK_PH_FINISH; A.stats[(size_t)step * A.S + s] = st; }
+    // (no second PoseOptimization for this frame: an empty problem, or the launch after TrackLocalMap's search would optimise the
+    // frame again from the optimised pose and rewrite its outlier flags - the host loop and the reference do not)
+    if (tid == 0) { q.phase = TRK_PH_FINISH; A.po_vert[s] = PoVertex{(int32_t)b, (int32_t)b}; A.stats[(size_t)step * A.S + s] = st; }
     return;
   }
   for (int i = tid; i < N; i += TRK_T) {
