@@ -127,6 +127,19 @@ int ps_cvorb_detect_and_compute(ps_cvorb* h, const uint8_t* img, const uint8_t* 
  * 4 the level size as int32[2]. */
 int ps_cvorb_debug_read(ps_cvorb* h, int level, int what, void* out, size_t out_bytes, int* n);
 
+/* Batched, device-resident form of ps_cvorb_detect_and_compute - Frame::ExtractObjORB for many frames at once: `nimg` images of one
+ * size in HBM (image i at d_imgs + i * image_pitch) with their object masks (d_masks + i * mask_pitch, non-zero = keep), all
+ * work queued on `stream` (a hipStream_t; NULL = the handle's stream) with nothing returning to the host: the two retainBest steps
+ * run on the device with libstdc++'s own selection algorithms restated (csrc/retain_best.h), so the keypoints of an image are those
+ * of the single-image call, order included.  Work is restricted to the parts of the pyramid a keypoint under the mask can touch.
+ * Limits (reported as PS_ERR_CAPACITY by ps_cvorb_batch_fetch, never truncated silently): 2048 FAST keypoints under the mask per
+ * level, 2048 keypoints per image.  Outputs stay in HBM: keypoints [nimg][capacity], descriptors [nimg][capacity][32], counts. */
+int ps_cvorb_detect_batch_device(ps_cvorb* h, const uint8_t* d_imgs, const uint8_t* d_masks, int nimg, int w, int hgt, int stride,
+                                 size_t image_pitch, int mask_stride, size_t mask_pitch, void* stream);
+int ps_cvorb_batch_device_outputs(const ps_cvorb* h, const ps_keypoint** d_kps, const uint8_t** d_desc, const int32_t** d_counts,
+                                  const int32_t** d_overflow, int32_t* capacity);
+int ps_cvorb_batch_fetch(ps_cvorb* h, int image, ps_keypoint* kps, uint8_t* desc, int cap, int* n);
+
 /* Batched, device-resident form of the same call: `nimg` images of identical size already in HBM
  * (image i at d_imgs + i * image_pitch, rows `stride` bytes apart).  Results stay in HBM inside the
  * handle; the call is asynchronous on `stream` (a hipStream_t, NULL = the handle's own stream). */

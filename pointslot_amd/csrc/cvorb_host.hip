@@ -5,6 +5,7 @@
 // which run here with std::nth_element / std::partition because their output order is whatever those algorithms leave.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -18,6 +19,7 @@ void psk_cv_resize(const CvLevelDev*, const CvLevelDev*, const int4*, const int4
 void psk_cv_detect(const CvLevelDev*, int, int, int, int32_t*, hipStream_t);
 void psk_cv_blur(const CvLevelDev*, const int*, hipStream_t);
 void psk_cv_describe(const CvPlanDev*, const CvSel*, int, void*, uint8_t*, hipStream_t);
+void psk_cvb_run(const CvbPlan*, int, const uint8_t*, int, size_t, const uint8_t*, int, size_t, hipStream_t);
 }
 
 struct ps_cvorb {
@@ -36,6 +38,11 @@ struct ps_cvorb {
   CvSel* d_sel = nullptr; ps_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr;
   int sel_cap = 0;
   int kq[7];
+  // batched, device-resident form (ps_cvorb_detect_batch_device)
+  CvbPlan bplan; bool bplanned = false; int bw = 0, bh = 0, bcap = 0;
+  uint8_t* b_buf = nullptr;            // one arena: planes of every image, tables, worklists, candidates, selections, outputs
+  uint8_t* b_zero = nullptr; size_t b_zero_bytes = 0;   // the part cleared before every batch (occupancy, counters)
+  int b_last_n = 0;
   // last call (for ps_cvorb_debug_read)
   std::vector<std::vector<float>> last_cand;   // per level: rows of 4 floats
   bool last_had_mask = false;
@@ -172,6 +179,7 @@ void ps_cvorb_destroy(ps_cvorb* h) {
   hipSetDevice(h->device);
   if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
   if (h->d_buf) hipFree(h->d_buf);
+  if (h->b_buf) hipFree(h->b_buf);
   delete h;
 }
 
@@ -256,4 +264,139 @@ int ps_cvorb_debug_read(ps_cvorb* h, int level, int what, void* out, size_t out_
   return PS_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// plan of the batched form for `cap` images of w x hgt
+int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
+  if (h->b_buf) { hipFree(h->b_buf); h->b_buf = nullptr; }
+  h->bplanned = false;
+  CvbPlan& P = h->bplan;
+  memset(&P, 0, sizeof(P));
+  P.nlevels = h->nlevels; P.edge = h->edge; P.fast_th = h->fast_th; P.w0 = w; P.h0 = hgt;
+  P.ow = (w + CVB_TILE - 1) / CVB_TILE; P.oh = (hgt + CVB_TILE - 1) / CVB_TILE;
+  if (P.ow > 128) return ps_set_error(PS_ERR_INVALID, "the batched object detector supports images up to 4096 pixels wide");
+  P.occ_words = (P.ow * P.oh + 31) / 32;
+  {
+    const int hp = 15;
+    int v, v0, vmax = cv_floor(hp * sqrtf(2.f) / 2 + 1), vmin = cv_ceil(hp * sqrtf(2.f) / 2);
+    for (v = 0; v <= vmax; ++v) P.umax[v] = cv_round(sqrt((double)hp * hp - v * v));
+    for (v = hp, v0 = 0; v >= vmin; --v) { while (P.umax[v0] == P.umax[v0 + 1]) ++v0; P.umax[v] = v0; ++v0; }
+  }
+  for (int i = 0; i < 4; i++) P.kq[i] = h->kq[i];
+  std::vector<int> quota(h->nlevels, 0);
+  {
+    const float factor = (float)(1.0 / h->scale_factor);
+    float ndesired = h->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)h->nlevels));
+    int sum = 0;
+    for (int l = 0; l < h->nlevels - 1; l++) { quota[l] = cv_round(ndesired); sum += quota[l]; ndesired *= factor; }
+    quota[h->nlevels - 1] = std::max(h->nfeatures - sum, 0);
+  }
+  std::vector<std::vector<int4>> xt(h->nlevels), yt(h->nlevels);
+  size_t img_off = 0;
+  auto take_img = [&](size_t bytes) { size_t r = img_off; img_off += al(bytes + 64); return r; };
+  for (int l = 0; l < h->nlevels; l++) {
+    CvbLevel& L = P.lv[l];
+    L.scale = (float)pow(h->scale_factor, (double)l);
+    const float inv_scale = 1.0f / L.scale;
+    L.w = cv_round(w * inv_scale); L.h = cv_round(hgt * inv_scale);
+    if (L.w <= 2 * h->edge || L.h <= 2 * h->edge || L.w <= 2 * 24 || L.h <= 2 * 24)
+      return ps_set_error(PS_ERR_INVALID, "image %dx%d: level %d is %dx%d, too small for the detector", w, hgt, l, L.w, L.h);
+    L.stride = (int)((L.w + 2 * CV_BORDER + 63) / 64 * 64);
+    L.tw = (L.w + 2 * CV_BORDER + CVB_TILE - 1) / CVB_TILE; L.th = (L.h + 2 * CV_BORDER + CVB_TILE - 1) / CVB_TILE;
+    if (L.tw * L.th > CVB_MAX_TILES / 4) return ps_set_error(PS_ERR_INVALID, "the batched object detector supports levels of up to %d tiles", CVB_MAX_TILES / 4);
+    L.quota = quota[l];
+    L.o_pad = take_img((size_t)L.stride * (L.h + 2 * CV_BORDER)); L.o_blur = take_img((size_t)L.stride * (L.h + 2 * CV_BORDER));
+    L.o_mask = take_img((size_t)L.w * L.h); L.o_score = take_img((size_t)L.w * L.h);
+    if (l > 0) { exact_table(P.lv[l - 1].w, L.w, xt[l]); exact_table(P.lv[l - 1].h, L.h, yt[l]); }
+  }
+  P.arena_pitch = img_off;
+  P.ocap = 2048;
+  int max_tiles = 0;
+  for (int l = 0; l < h->nlevels; l++) max_tiles = std::max(max_tiles, P.lv[l].tw * P.lv[l].th);
+  P.wl_cap = cap * max_tiles;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += al(bytes + 64); return r; };
+  const size_t o_arena = take(P.arena_pitch * (size_t)cap);
+  std::vector<size_t> o_xt(h->nlevels, 0), o_yt(h->nlevels, 0);
+  for (int l = 1; l < h->nlevels; l++) { o_xt[l] = take(xt[l].size() * 16); o_yt[l] = take(yt[l].size() * 16); }
+  const size_t o_wl = take((size_t)h->nlevels * P.wl_cap * 4);
+  const size_t o_cand = take((size_t)cap * h->nlevels * CVB_CAND_CAP * sizeof(float4));
+  const size_t o_sel = take((size_t)cap * h->nlevels * CVB_CAND_CAP * sizeof(CvSel));
+  const size_t o_kps = take((size_t)cap * P.ocap * sizeof(ps_keypoint)), o_desc = take((size_t)cap * P.ocap * 32);
+  // cleared before every batch: occupancy, worklist counters, candidate counters, selection counts, counts, overflow
+  const size_t z0 = off;
+  const size_t o_occ = take((size_t)cap * P.occ_words * 4), o_wlc = take(CV_MAX_LEVELS * 4), o_ncand = take((size_t)cap * h->nlevels * 4);
+  const size_t o_nsel = take((size_t)cap * h->nlevels * 4), o_count = take((size_t)cap * 4), o_ovf = take((size_t)cap * 4);
+  const size_t z1 = off;
+  hipError_t e = hipMalloc(&h->b_buf, off);
+  if (e != hipSuccess) return ps_set_error(PS_ERR_HIP, "hipMalloc(%zu): %s", off, hipGetErrorString(e));
+  uint8_t* D = h->b_buf;
+  if (const char* fill = getenv("PS_DEBUG_FILL")) PS_HIP(hipMemsetAsync(D, atoi(fill), off, h->stream));   // diagnostic: the inactive tiles stay poisoned
+  P.arena = D + o_arena;
+  for (int l = 1; l < h->nlevels; l++) {
+    P.lv[l].xtab = (const int4*)(D + o_xt[l]); P.lv[l].ytab = (const int4*)(D + o_yt[l]);
+    PS_HIP(hipMemcpyAsync(D + o_xt[l], xt[l].data(), xt[l].size() * 16, hipMemcpyHostToDevice, h->stream));
+    PS_HIP(hipMemcpyAsync(D + o_yt[l], yt[l].data(), yt[l].size() * 16, hipMemcpyHostToDevice, h->stream));
+  }
+  P.wl = (uint32_t*)(D + o_wl); P.cand = (float4*)(D + o_cand); P.sel = (CvSel*)(D + o_sel);
+  P.kps = (ps_keypoint_pod*)(D + o_kps); P.desc = D + o_desc;
+  P.occ = (uint32_t*)(D + o_occ); P.wl_count = (int32_t*)(D + o_wlc); P.ncand = (int32_t*)(D + o_ncand); P.nsel = (int32_t*)(D + o_nsel);
+  P.count = (int32_t*)(D + o_count); P.overflow = (int32_t*)(D + o_ovf);
+  h->b_zero = D + z0; h->b_zero_bytes = z1 - z0;
+  PS_HIP(hipStreamSynchronize(h->stream));
+  h->bw = w; h->bh = hgt; h->bcap = cap; h->bplanned = true;
+  return PS_OK;
+}
+}  // namespace
+
+extern "C" {
+// internal (track_host.hip): the handle's stream
+hipStream_t psi_cvorb_stream(ps_cvorb* h) { return h->stream; }
+
+int ps_cvorb_detect_batch_device(ps_cvorb* h, const uint8_t* d_imgs, const uint8_t* d_masks, int nimg, int w, int hgt, int stride, size_t image_pitch,
+                                 int mask_stride, size_t mask_pitch, void* stream) {
+  if (!h || !d_imgs || !d_masks || nimg < 1 || w < 1 || hgt < 1 || stride < w || mask_stride < w)
+    return ps_set_error(PS_ERR_INVALID, "ps_cvorb_detect_batch_device: bad argument");
+  PS_HIP(hipSetDevice(h->device));
+  if (!h->bplanned || h->bw != w || h->bh != hgt || h->bcap < nimg) {
+    int rc = build_batch_plan(h, w, hgt, nimg);
+    if (rc != PS_OK) return rc;
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  PS_HIP(hipMemsetAsync(h->b_zero, 0, h->b_zero_bytes, st));
+  psk_cvb_run(&h->bplan, nimg, d_imgs, stride, image_pitch, d_masks, mask_stride, mask_pitch, st);
+  PS_HIP(hipGetLastError());
+  h->b_last_n = nimg;
+  return PS_OK;
+}
+
+int ps_cvorb_batch_device_outputs(const ps_cvorb* h, const ps_keypoint** d_kps, const uint8_t** d_desc, const int32_t** d_counts,
+                                  const int32_t** d_overflow, int32_t* capacity) {
+  if (!h || !h->bplanned) return ps_set_error(PS_ERR_INVALID, "no batch plan yet");
+  if (d_kps) *d_kps = (const ps_keypoint*)h->bplan.kps;
+  if (d_desc) *d_desc = h->bplan.desc;
+  if (d_counts) *d_counts = h->bplan.count;
+  if (d_overflow) *d_overflow = h->bplan.overflow;
+  if (capacity) *capacity = h->bplan.ocap;
+  return PS_OK;
+}
+
+int ps_cvorb_batch_fetch(ps_cvorb* h, int image, ps_keypoint* kps, uint8_t* desc, int cap, int* n) {
+  if (!h || !h->bplanned || image < 0 || image >= h->b_last_n || !n) return ps_set_error(PS_ERR_INVALID, "ps_cvorb_batch_fetch: bad argument");
+  PS_HIP(hipSetDevice(h->device));
+  PS_HIP(hipDeviceSynchronize());
+  int32_t cnt = 0, ovf = 0;
+  PS_HIP(hipMemcpy(&cnt, h->bplan.count + image, 4, hipMemcpyDeviceToHost));
+  PS_HIP(hipMemcpy(&ovf, h->bplan.overflow + image, 4, hipMemcpyDeviceToHost));
+  if (ovf) return ps_set_error(PS_ERR_CAPACITY, "image %d: more than %d FAST keypoints under the mask on a level, or more than %d keypoints in all", image, CVB_CAND_CAP, h->bplan.ocap);
+  *n = cnt;
+  if (cnt > cap) return ps_set_error(PS_ERR_CAPACITY, "%d keypoints, caller capacity %d", cnt, cap);
+  if (cnt > 0) {
+    if (!kps || !desc) return ps_set_error(PS_ERR_INVALID, "null output buffer");
+    PS_HIP(hipMemcpy(kps, (const ps_keypoint*)h->bplan.kps + (size_t)image * h->bplan.ocap, (size_t)cnt * sizeof(ps_keypoint), hipMemcpyDeviceToHost));
+    PS_HIP(hipMemcpy(desc, h->bplan.desc + (size_t)image * h->bplan.ocap * 32, (size_t)cnt * 32, hipMemcpyDeviceToHost));
+  }
+  return PS_OK;
+}
 }  // extern "C"

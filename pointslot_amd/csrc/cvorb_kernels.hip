@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "cvorb_plan.h"
+#include "retain_best.h"
 
 namespace {
 
@@ -266,6 +267,410 @@ __global__ __launch_bounds__(64) void cv_describe(CvPlanDev plan, const CvSel* s
   }
 }
 
+
+// =====================================================================================================================
+// Batched, device-resident form: nimg images of one size with object masks (non-zero = object), everything on one stream with
+// no host round trip - the ExtractObjORB stage of the device-resident object chain (track_host.hip).  Results are those of
+// cv_* above image by image; what differs is the work: only the 32 x 32 tiles of every level's padded plane that can reach a
+// keypoint under the mask are computed (object masks cover a few percent of a frame), and the two retainBest steps run on
+// the device with the library's own algorithms (retain_best.h) instead of on the host.
+//   cvb_occupancy  level-0 tile occupancy of the mask             cvb_plan    active tiles per level -> worklists
+//   cvb_level0 / cvb_resize   padded planes + mask pyramid        cvb_score / cvb_emit   FAST score, keypoints (+ Harris)
+//   cvb_blur       7 x 7 blur                                     cvb_select  raster order, retainBest x 2
+//   cvb_describe   angle + rBRIEF
+// Exactness of the restriction (a tile left out never feeds a kept result): a keypoint needs the level mask non-zero at its
+// pixel; the level mask is a chain of 2 x 2 interpolations of the level-0 mask, so it can only be non-zero within
+// 6 (R - 1) + 3 level-0 pixels of an occupied level-0 tile (R = the level's scale): those tiles are `kp-possible`.  Around a
+// keypoint the pipeline reads at most 22 pixels of the padded plane (rBRIEF reach 19 + blur 3; FAST + NMS 4, Harris 4, IC
+// angle 15) - less than one tile - so the active set is the kp-possible tiles and their 8 neighbours, plus, level by level
+// downwards, every tile of level l - 1 that holds a source pixel of an active tile of level l.
+// =====================================================================================================================
+__device__ __forceinline__ CvLevelDev cvb_level(const CvbPlan& P, int img, int l) {
+  const CvbLevel& B = P.lv[l];
+  uint8_t* base = P.arena + (size_t)img * P.arena_pitch;
+  CvLevelDev L;
+  L.w = B.w; L.h = B.h; L.stride = B.stride; L.scale = B.scale;
+  L.pad = base + B.o_pad; L.blur = base + B.o_blur; L.mask = base + B.o_mask; L.score = base + B.o_score;
+  L.rowcnt = nullptr; L.rowoff = nullptr; L.cand = nullptr;
+  return L;
+}
+
+// one workgroup per (image, tile row of 32 image rows): which 32 x 32 tiles hold a non-zero mask pixel
+__global__ __launch_bounds__(256) void cvb_occupancy(CvbPlan P, const uint8_t* masks, int mask_stride, size_t mask_pitch) {
+  __shared__ uint32_t bits[4];   // up to 128 tiles per row (4096-px images)
+  const int img = blockIdx.y, ty = blockIdx.x, tid = threadIdx.x;
+  if (tid < 4) bits[tid] = 0;
+  __syncthreads();
+  const uint8_t* M = masks + (size_t)img * mask_pitch;
+  const int y0 = ty * CVB_TILE, y1 = min(y0 + CVB_TILE, P.h0);
+  for (int x = tid; x < P.w0; x += 256) {
+    uint32_t any = 0;
+    for (int y = y0; y < y1; y++) any |= M[(size_t)y * mask_stride + x];
+    if (any) atomicOr(&bits[(x >> 5) >> 5], 1u << ((x >> 5) & 31));
+  }
+  __syncthreads();
+  uint32_t* occ = P.occ + (size_t)img * P.occ_words;
+  // row ty of the bitmap starts at bit ty * ow: written bit by bit by the threads that own a tile
+  for (int tx = tid; tx < P.ow; tx += 256) {
+    const int b = ty * P.ow + tx;
+    if ((bits[tx >> 5] >> (tx & 31)) & 1u) atomicOr(&occ[b >> 5], 1u << (b & 31));
+  }
+}
+
+__device__ __forceinline__ void cvb_reflect_range(int lo, int hi, int len, int& rlo, int& rhi) {
+  // image of [lo, hi] under REFLECT_101 on [0, len): union of the three monotone pieces
+  rlo = 1 << 30; rhi = -1;
+  if (lo < 0) { const int a = -min(hi, 0), b = -lo; rlo = min(rlo, a); rhi = max(rhi, b); }
+  if (hi >= 0 && lo <= len - 1) { rlo = min(rlo, max(lo, 0)); rhi = max(rhi, min(hi, len - 1)); }
+  if (hi > len - 1) { const int a = 2 * (len - 1) - hi, b = 2 * (len - 1) - max(lo, len - 1); rlo = min(rlo, a); rhi = max(rhi, b); }
+  rlo = max(rlo, 0); rhi = min(rhi, len - 1);
+}
+
+// one workgroup per image: active tiles of every level, appended to the per-level worklists
+__global__ __launch_bounds__(256) void cvb_plan(CvbPlan P) {
+  __shared__ uint8_t act[CV_MAX_LEVELS][CVB_MAX_TILES / 4];   // <= 1024 tiles per level (images up to about 1000 x 1000 px per ... see host check)
+  __shared__ uint8_t kp[CVB_MAX_TILES / 4];
+  __shared__ int wbase;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const uint32_t* occ = P.occ + (size_t)img * P.occ_words;
+  for (int l = 0; l < P.nlevels; l++) {
+    const CvbLevel& B = P.lv[l];
+    const int nt = B.tw * B.th;
+    const float Rx = (float)P.w0 / (float)B.w, Ry = (float)P.h0 / (float)B.h;
+    const float mx = 6.f * (Rx - 1.f) + 3.f, my = 6.f * (Ry - 1.f) + 3.f;
+    for (int t = tid; t < nt; t += 256) {
+      const int tx = t % B.tw, ty = t / B.tw;
+      int x0 = CVB_TILE * tx - CV_BORDER, x1 = x0 + CVB_TILE - 1, y0 = CVB_TILE * ty - CV_BORDER, y1 = y0 + CVB_TILE - 1;
+      x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, B.w - 1); y1 = min(y1, B.h - 1);
+      bool any = false;
+      if (x0 <= x1 && y0 <= y1) {
+        int X0 = (int)floorf((float)x0 * Rx - mx), X1 = (int)ceilf((float)(x1 + 1) * Rx + mx);
+        int Y0 = (int)floorf((float)y0 * Ry - my), Y1 = (int)ceilf((float)(y1 + 1) * Ry + my);
+        X0 = max(X0, 0) >> 5; Y0 = max(Y0, 0) >> 5; X1 = min(X1, P.w0 - 1) >> 5; Y1 = min(Y1, P.h0 - 1) >> 5;
+        for (int oy = Y0; oy <= Y1 && !any; oy++)
+          for (int ox = X0; ox <= X1; ox++) {
+            const int b = oy * P.ow + ox;
+            if ((occ[b >> 5] >> (b & 31)) & 1u) { any = true; break; }
+          }
+      }
+      kp[t] = any ? 1 : 0;
+    }
+    __syncthreads();
+    for (int t = tid; t < nt; t += 256) {
+      const int tx = t % B.tw, ty = t / B.tw;
+      bool a = false;
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          const int nx = tx + dx, ny = ty + dy;
+          if (nx >= 0 && nx < B.tw && ny >= 0 && ny < B.th && kp[ny * B.tw + nx]) a = true;
+        }
+      act[l][t] = a ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  // a level's active tiles need their source pixels one level down
+  for (int l = P.nlevels - 1; l >= 1; l--) {
+    const CvbLevel& B = P.lv[l];
+    const CvbLevel& S = P.lv[l - 1];
+    const int nt = B.tw * B.th;
+    const double rx = (double)S.w / (double)B.w, ry = (double)S.h / (double)B.h;
+    for (int t = tid; t < nt; t += 256) {
+      if (!act[l][t]) continue;
+      const int tx = t % B.tw, ty = t / B.tw;
+      int lx0, lx1, ly0, ly1;
+      cvb_reflect_range(CVB_TILE * tx - CV_BORDER, min(CVB_TILE * tx - CV_BORDER + CVB_TILE - 1, B.w + CV_BORDER - 1), B.w, lx0, lx1);
+      cvb_reflect_range(CVB_TILE * ty - CV_BORDER, min(CVB_TILE * ty - CV_BORDER + CVB_TILE - 1, B.h + CV_BORDER - 1), B.h, ly0, ly1);
+      int sx0 = (int)floor(((double)lx0 + 0.5) * rx - 0.5) - 1, sx1 = (int)floor(((double)lx1 + 0.5) * rx - 0.5) + 2;
+      int sy0 = (int)floor(((double)ly0 + 0.5) * ry - 0.5) - 1, sy1 = (int)floor(((double)ly1 + 0.5) * ry - 0.5) + 2;
+      sx0 = max(sx0, 0); sy0 = max(sy0, 0); sx1 = min(sx1, S.w - 1); sy1 = min(sy1, S.h - 1);
+      const int ax0 = (sx0 + CV_BORDER) >> 5, ax1 = (sx1 + CV_BORDER) >> 5, ay0 = (sy0 + CV_BORDER) >> 5, ay1 = (sy1 + CV_BORDER) >> 5;
+      for (int ay = ay0; ay <= ay1; ay++)
+        for (int ax = ax0; ax <= ax1; ax++) act[l - 1][ay * S.tw + ax] = 1;
+    }
+    __syncthreads();
+  }
+  for (int l = 0; l < P.nlevels; l++) {
+    const CvbLevel& B = P.lv[l];
+    const int nt = B.tw * B.th;
+    // ordered compaction is not needed: a worklist is a set
+    for (int t0 = 0; t0 < nt; t0 += 256) {
+      const int t = t0 + tid;
+      const bool a = t < nt && act[l][t];
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(a);
+      const int lane = tid & 63;
+      int base = 0;
+      if (lane == 0 && m) base = atomicAdd(&P.wl_count[l], __popcll(m));
+      base = __shfl(base, 0);
+      if (a) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < P.wl_cap) P.wl[(size_t)l * P.wl_cap + pos] = ((uint32_t)img << 12) | (uint32_t)t;
+      }
+    }
+  }
+  (void)wbase;
+}
+
+// pixel (px, py) of tile t handled by thread tid, four pixels in a row per thread
+#define CVB_TILE_LOOP(P, l)                                                                             \
+  const CvbLevel& B = P.lv[l];                                                                          \
+  const int cnt = min(P.wl_count[l], P.wl_cap);                                                         \
+  for (int it = blockIdx.x; it < cnt; it += gridDim.x)
+
+__global__ __launch_bounds__(256) void cvb_level0(CvbPlan P, const uint8_t* imgs, int stride, size_t pitch, const uint8_t* masks, int mask_stride, size_t mask_pitch) {
+  CVB_TILE_LOOP(P, 0) {
+    const uint32_t e = P.wl[it];
+    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
+    const CvLevelDev L = cvb_level(P, img, 0);
+    const uint8_t* I = imgs + (size_t)img * pitch;
+    const uint8_t* M = masks + (size_t)img * mask_pitch;
+    const int py = CVB_TILE * ty + (threadIdx.x >> 3);
+    if (py >= L.h + 2 * CV_BORDER) continue;
+    const int y = reflect101(py - CV_BORDER, L.h);
+    for (int j = 0; j < 4; j++) {
+      const int px = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j;
+      if (px >= L.w + 2 * CV_BORDER) break;
+      const int x = reflect101(px - CV_BORDER, L.w);
+      L.pad[(size_t)py * L.stride + px] = I[(size_t)y * stride + x];
+      const int ix = px - CV_BORDER, iy = py - CV_BORDER;
+      if (ix >= 0 && ix < L.w && iy >= 0 && iy < L.h) L.mask[(size_t)iy * L.w + ix] = M[(size_t)iy * mask_stride + ix];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cvb_resize(CvbPlan P, int l) {
+  CVB_TILE_LOOP(P, l) {
+    const uint32_t e = P.wl[(size_t)l * P.wl_cap + it];
+    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
+    const CvLevelDev L = cvb_level(P, img, l), S = cvb_level(P, img, l - 1);
+    const int py = CVB_TILE * ty + (threadIdx.x >> 3);
+    if (py >= L.h + 2 * CV_BORDER) continue;
+    const int y = reflect101(py - CV_BORDER, L.h);
+    const int4 tyv = B.ytab[y];
+    const uint8_t* sroi = S.pad + (size_t)CV_BORDER * S.stride + CV_BORDER;
+    for (int j = 0; j < 4; j++) {
+      const int px = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j;
+      if (px >= L.w + 2 * CV_BORDER) break;
+      const int x = reflect101(px - CV_BORDER, L.w);
+      const int4 txv = B.xtab[x];
+      L.pad[(size_t)py * L.stride + px] = cv_interp(sroi, S.stride, S.w, S.h, txv, tyv);
+      const int ix = px - CV_BORDER, iy = py - CV_BORDER;
+      if (ix >= 0 && ix < L.w && iy >= 0 && iy < L.h) {
+        const uint8_t m = cv_interp(S.mask, S.w, S.w, S.h, txv, tyv);
+        L.mask[(size_t)iy * L.w + ix] = m > 254 ? m : 0;
+      }
+    }
+  }
+}
+
+// FAST score of one level pixel (the body of cv_score)
+__device__ __forceinline__ uint8_t cvb_fast_score(const CvLevelDev& L, int x, int y, int th) {
+  if (!(x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3)) return 0;
+  const uint8_t* c = L.pad + (size_t)(CV_BORDER + y) * L.stride + CV_BORDER + x;
+  const int st = L.stride, v = c[0];
+  const int n = c[3 * st], e = c[3], so = c[-3 * st], w = c[-3];
+  const int M = min(min(max(n, e), max(e, so)), min(max(so, w), max(w, n)));
+  const int m = max(max(min(n, e), min(e, so)), max(min(so, w), min(w, n)));
+  if (!(v - M > th || m - v > th)) return 0;
+  const int off[16] = {3 * st, 3 * st + 1, 2 * st + 2, st + 3, 3, -st + 3, -2 * st + 2, -3 * st + 1,
+                       -3 * st, -3 * st - 1, -2 * st - 2, -st - 3, -3, st - 3, 2 * st - 2, 3 * st - 1};
+  int r[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) r[i] = c[off[i]];
+  int best = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int mx = r[k], mn = r[k];
+#pragma unroll
+    for (int j = 1; j < 9; j++) { mx = max(mx, r[(k + j) & 15]); mn = min(mn, r[(k + j) & 15]); }
+    best = max(best, max(v - mx, mn - v));
+  }
+  return best > th ? (uint8_t)best : (uint8_t)0;
+}
+
+// worklists of all levels in one launch: blockIdx.y = level
+__global__ __launch_bounds__(256) void cvb_score(CvbPlan P) {
+  const int l = blockIdx.y;
+  CVB_TILE_LOOP(P, l) {
+    const uint32_t e = P.wl[(size_t)l * P.wl_cap + it];
+    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
+    const CvLevelDev L = cvb_level(P, img, l);
+    const int y = CVB_TILE * ty + (threadIdx.x >> 3) - CV_BORDER;
+    if (y < 0 || y >= L.h) continue;
+    for (int j = 0; j < 4; j++) {
+      const int x = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j - CV_BORDER;
+      if (x < 0 || x >= L.w) continue;
+      L.score[(size_t)y * L.w + x] = cvb_fast_score(L, x, y, P.fast_th);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cvb_emit(CvbPlan P) {
+  const int l = blockIdx.y;
+  CVB_TILE_LOOP(P, l) {
+    const uint32_t e = P.wl[(size_t)l * P.wl_cap + it];
+    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
+    const CvLevelDev L = cvb_level(P, img, l);
+    const int y = CVB_TILE * ty + (threadIdx.x >> 3) - CV_BORDER;
+    if (y < 0 || y >= L.h) continue;
+    for (int j = 0; j < 4; j++) {
+      const int x = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j - CV_BORDER;
+      if (x < 0 || x >= L.w) continue;
+      // the mask first: outside the kp-possible tiles it is zero, and the score plane next to a tile that is not active is undefined
+      if (L.mask[(size_t)y * L.w + x] == 0) continue;
+      if (!cv_is_keypoint(L, x, y, P.edge)) continue;
+      const int slot = img * P.nlevels + l;
+      const int pos = atomicAdd(&P.ncand[slot], 1);
+      if (pos < CVB_CAND_CAP)
+        P.cand[(size_t)slot * CVB_CAND_CAP + pos] = make_float4((float)x, (float)y, (float)((int)L.score[(size_t)y * L.w + x] - 1), cv_harris(L, x, y));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cvb_blur(CvbPlan P) {
+  const int l = blockIdx.y;
+  const int kq[7] = {P.kq[0], P.kq[1], P.kq[2], P.kq[3], P.kq[2], P.kq[1], P.kq[0]};
+  CVB_TILE_LOOP(P, l) {
+    const uint32_t e = P.wl[(size_t)l * P.wl_cap + it];
+    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
+    const CvLevelDev L = cvb_level(P, img, l);
+    const int py = CVB_TILE * ty + (threadIdx.x >> 3);
+    if (py >= L.h + 2 * CV_BORDER) continue;
+    for (int j = 0; j < 4; j++) {
+      const int px = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j;
+      if (px >= L.w + 2 * CV_BORDER) break;
+      const int x = px - CV_BORDER, y = py - CV_BORDER;
+      if (x < 0 || x >= L.w || y < 0 || y >= L.h) { L.blur[(size_t)py * L.stride + px] = L.pad[(size_t)py * L.stride + px]; continue; }
+      uint32_t acc = 0;
+      for (int jj = 0; jj < 7; jj++) {
+        const uint8_t* row = L.pad + (size_t)(py + jj - 3) * L.stride + px - 3;
+        uint32_t hsum = 0;
+        for (int i = 0; i < 7; i++) hsum += (uint32_t)kq[i] * row[i];
+        acc += (uint32_t)kq[jj] * min(hsum, 65535u);
+      }
+      L.blur[(size_t)py * L.stride + px] = (uint8_t)min((acc + 32768u) >> 16, 255u);
+    }
+  }
+}
+
+// one workgroup per (image, level): the level's keypoints in raster order (the emission order is arbitrary: bitonic sort by
+// (y, x)), then computeKeyPoints' two culls - retainBest(2 * quota) by FAST score, retainBest(quota) by Harris response - run by
+// one lane with the library's algorithms (retain_best.h) when a level holds more than its quota
+__global__ __launch_bounds__(256) void cvb_select(CvbPlan P) {
+  __shared__ uint32_t key[CVB_CAND_CAP];
+  __shared__ int32_t idx[CVB_CAND_CAP];
+  __shared__ float resp[CVB_CAND_CAP];
+  __shared__ int32_t pay[CVB_CAND_CAP];
+  __shared__ int nkeep;
+  const int slot = blockIdx.x, l = slot % P.nlevels, img = slot / P.nlevels, tid = threadIdx.x;
+  const int total = P.ncand[slot];
+  const int n = min(total, CVB_CAND_CAP);
+  if (total > CVB_CAND_CAP && tid == 0) atomicAdd(&P.overflow[img], 1);
+  const float4* C = P.cand + (size_t)slot * CVB_CAND_CAP;
+  int npow = 1;
+  while (npow < n) npow <<= 1;
+  for (int i = tid; i < npow; i += 256) {
+    if (i < n) { const float4 c = C[i]; key[i] = ((uint32_t)c.y << 16) | (uint32_t)c.x; idx[i] = i; }
+    else { key[i] = 0xFFFFFFFFu; idx[i] = -1; }
+  }
+  __syncthreads();
+  for (int k = 2; k <= npow; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow; i += 256) {
+        const int p = i ^ j;
+        if (p > i) {
+          const bool up = (i & k) == 0;
+          const uint32_t a = key[i], b = key[p];
+          if ((a > b) == up) { key[i] = b; key[p] = a; const int32_t t = idx[i]; idx[i] = idx[p]; idx[p] = t; }
+        }
+      }
+      __syncthreads();
+    }
+  // list in raster order: response = FAST score, payload = candidate index
+  for (int i = tid; i < n; i += 256) { const int c = idx[i]; resp[i] = C[c].z; pay[i] = c; }
+  __syncthreads();
+  const int quota = P.lv[l].quota;
+  RbList Lst{resp, pay};
+  if (tid == 0) nkeep = rb_retain_best(Lst, n, 2 * quota);
+  __syncthreads();
+  const int m1 = nkeep;
+  for (int i = tid; i < m1; i += 256) resp[i] = C[pay[i]].w;     // HarrisResponses
+  __syncthreads();
+  if (tid == 0) nkeep = rb_retain_best(Lst, m1, quota);
+  __syncthreads();
+  const int m = nkeep;
+  CvSel* S = P.sel + (size_t)slot * CVB_CAND_CAP;
+  for (int i = tid; i < m; i += 256) { const float4 c = C[pay[i]]; S[i] = CvSel{(int32_t)c.x, (int32_t)c.y, l, resp[i]}; }
+  if (tid == 0) P.nsel[slot] = m;
+}
+
+// four keypoints per workgroup (one wave each): ICAngles, pt *= scale, computeOrbDescriptors - the body of cv_describe on the
+// image's own planes; keypoint k of an image is entry k of the concatenation of its levels' selections
+__global__ __launch_bounds__(256) void cvb_describe(CvbPlan P) {
+  const int img = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int l = 0, base = 0, total = 0;
+  {
+    int acc = 0;
+    bool found = false;
+    for (int i = 0; i < P.nlevels; i++) {
+      const int c = P.nsel[img * P.nlevels + i];
+      if (!found && k < acc + c) { l = i; base = acc; found = true; }
+      acc += c;
+    }
+    total = acc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      P.count[img] = min(total, P.ocap);
+      if (total > P.ocap) atomicAdd(&P.overflow[img], 1);
+    }
+    if (!found || k >= P.ocap) return;
+  }
+  const CvSel S = P.sel[(size_t)(img * P.nlevels + l) * CVB_CAND_CAP + (k - base)];
+  const CvLevelDev L = cvb_level(P, img, l);
+  const int x0 = S.x, y0 = S.y;
+  const uint8_t* center = L.pad + (size_t)(CV_BORDER + y0) * L.stride + CV_BORDER + x0;
+  int m10 = 0, m01 = 0;
+  if (lane <= 15) {
+    const int v = lane, d = P.umax[v];
+    if (v == 0) {
+      for (int u = -15; u <= 15; ++u) m10 += u * center[u];
+    } else {
+      int v_sum = 0;
+      for (int u = -d; u <= d; ++u) {
+        const int vp = center[u + v * L.stride], vm = center[u - v * L.stride];
+        v_sum += vp - vm;
+        m10 += u * (vp + vm);
+      }
+      m01 = v * v_sum;
+    }
+  }
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1) { m10 += __shfl_xor(m10, dd); m01 += __shfl_xor(m01, dd); }
+  const float angle_deg = cv_fast_atan2_deg((float)m01, (float)m10);
+  const float px = __fmul_rn((float)x0, L.scale), py = __fmul_rn((float)y0, L.scale);
+  if (lane == 0) {
+    ps_keypoint_pod o;
+    o.x = px; o.y = py; o.size = __fmul_rn(31.f, L.scale); o.angle = angle_deg; o.response = S.response; o.octave = S.level; o.class_id = -1;
+    P.kps[(size_t)img * P.ocap + k] = o;
+  }
+  if (lane < 32) {
+    const float inv = __fdiv_rn(1.f, L.scale);
+    const float angle = __fmul_rn(angle_deg, (float)(3.14159265358979323846 / 180.f));
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const uint8_t* c = L.blur + (size_t)(CV_BORDER + __float2int_rn(__fmul_rn(py, inv))) * L.stride + CV_BORDER + __float2int_rn(__fmul_rn(px, inv));
+    const int8_t* pat = cv_pattern + lane * 32;
+    int val = 0;
+    for (int t = 0; t < 8; t++) {
+      int tv[2];
+      for (int q = 0; q < 2; q++) {
+        const float fx = (float)pat[4 * t + 2 * q], fy = (float)pat[4 * t + 2 * q + 1];
+        const float rx = __fsub_rn(__fmul_rn(fx, a), __fmul_rn(fy, b)), ry = __fadd_rn(__fmul_rn(fx, b), __fmul_rn(fy, a));
+        tv[q] = c[__float2int_rn(ry) * L.stride + __float2int_rn(rx)];
+      }
+      val |= (tv[0] < tv[1]) << t;
+    }
+    P.desc[((size_t)img * P.ocap + k) * 32 + lane] = (uint8_t)val;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -286,5 +691,20 @@ void psk_cv_blur(const CvLevelDev* L, const int* kq, hipStream_t st) {
 }
 void psk_cv_describe(const CvPlanDev* plan, const CvSel* sel, int nsel, void* kps, uint8_t* desc, hipStream_t st) {
   if (nsel > 0) hipLaunchKernelGGL(cv_describe, dim3(nsel), dim3(64), 0, st, *plan, sel, nsel, (ps_keypoint_pod*)kps, desc);
+}
+
+void psk_cvb_run(const CvbPlan* P, int nimg, const uint8_t* imgs, int stride, size_t pitch, const uint8_t* masks, int mask_stride, size_t mask_pitch,
+                 hipStream_t st) {
+  const int NL = P->nlevels;
+  const int grid = 4096;                                       // persistent loops over the worklists
+  hipLaunchKernelGGL(cvb_occupancy, dim3(P->oh, nimg), dim3(256), 0, st, *P, masks, mask_stride, mask_pitch);
+  hipLaunchKernelGGL(cvb_plan, dim3(nimg), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_level0, dim3(grid), dim3(256), 0, st, *P, imgs, stride, pitch, masks, mask_stride, mask_pitch);
+  for (int l = 1; l < NL; l++) hipLaunchKernelGGL(cvb_resize, dim3(grid), dim3(256), 0, st, *P, l);
+  hipLaunchKernelGGL(cvb_score, dim3(grid / 4, NL), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_emit, dim3(grid / 4, NL), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_blur, dim3(grid / 4, NL), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_select, dim3(nimg * NL), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_describe, dim3((P->ocap + 3) / 4, nimg), dim3(256), 0, st, *P);
 }
 }

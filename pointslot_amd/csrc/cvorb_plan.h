@@ -23,3 +23,32 @@ struct CvPlanDev {
 };
 struct CvSel { int32_t x, y, level; float response; };   // a selected keypoint (level coordinates)
 struct ps_keypoint_pod { float x, y, size, angle, response; int32_t octave, class_id; };
+
+// ---- batched, device-resident form (cvb_* kernels): nimg images with object masks, work restricted to the 32 x 32 tiles of every
+// level's padded plane that can influence a keypoint under the mask ----
+#define CVB_TILE 32
+#define CVB_CAND_CAP 2048      // FAST keypoints under the mask per (image, level); more is reported, never truncated silently
+#define CVB_MAX_TILES 4096     // tiles of one level's padded plane (worklist entries carry the tile in 12 bits)
+struct CvbLevel {
+  int32_t w, h, stride;        // level size, padded-plane row stride
+  int32_t tw, th;              // tiles of the padded plane
+  int32_t quota;               // nfeaturesPerLevel
+  float scale;
+  size_t o_pad, o_blur, o_mask, o_score;   // byte offsets inside one image's arena
+  const int4* xtab; const int4* ytab;      // INTER_LINEAR_EXACT tables from level l - 1 (nullptr at level 0)
+};
+struct CvbPlan {
+  CvbLevel lv[CV_MAX_LEVELS];
+  int32_t nlevels, edge, fast_th, w0, h0;
+  int32_t ow, oh;              // level-0 occupancy tiles (32 x 32 image pixels)
+  int32_t umax[17];
+  int32_t kq[4];
+  uint8_t* arena; size_t arena_pitch;      // per image: the planes of all levels
+  uint32_t* occ;               // [nimg][occ_words] bit (ty * ow + tx): the object mask has a non-zero pixel in that tile
+  int32_t occ_words;
+  uint32_t* wl; int32_t* wl_count; int32_t wl_cap;   // per level: entries (image << 12 | tile); wl + l * wl_cap
+  float4* cand; int32_t* ncand;                      // [nimg][nlevels][CVB_CAND_CAP], [nimg][nlevels]
+  CvSel* sel; int32_t* nsel;                         // [nimg][nlevels][CVB_CAND_CAP], [nimg][nlevels]
+  ps_keypoint_pod* kps; uint8_t* desc; int32_t* count; int32_t* overflow;   // [nimg][ocap], [nimg][ocap][32], [nimg], [nimg]
+  int32_t ocap;
+};

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(TRK_T) void trk_after_pose1(TrkArrays A, int step) 
   }
   for (int i = tid; i < N; i += TRK_T) {
     const bool v = A.cur.mp_valid[b + i];
-    if (v && A.cur.mp_id[b + i] >= 0) already[A.cur.mp_id[b + i]] = 1;
+    if (A.cur.mp_id[b + i] >= 0) already[A.cur.mp_id[b + i]] = 1;   // mnLastFrameSeen: matched points and the outliers just discarded (Tracking.cc:3071-3075)
     A.occupied[b + i] = (v && A.cur.mp_observed[b + i]) ? 1 : 0;
   }
   __syncthreads();

@@ -311,7 +311,7 @@ class OdoSequence {
     std::vector<uint8_t> already(n, 0);
     qvalid.assign(n, 0); qobs.assign(n, 1); occupied.assign(Fr.N, 0);
     for (int i = 0; i < Fr.N; i++) {
-      if (Fr.mp_valid[i] && Fr.mp_id[i] >= 0) already[Fr.mp_id[i]] = 1;
+      if (Fr.mp_id[i] >= 0) already[Fr.mp_id[i]] = 1;   // mnLastFrameSeen: matched points and the outliers just discarded (Tracking.cc:3071-3075)
       occupied[i] = (Fr.mp_valid[i] && Fr.mp_observed[i]) ? 1 : 0;
     }
     qu.assign(n, 0.f); qv.assign(n, 0.f); qur.assign(n, 0.f); rad.assign(n, 0.f);

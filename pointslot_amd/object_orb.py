@@ -14,6 +14,9 @@ lib.ps_cvorb_destroy.restype = None
 lib.ps_cvorb_detect_and_compute.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 lib.ps_cvorb_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+lib.ps_cvorb_detect_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+lib.ps_cvorb_batch_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 
 
 class ORB:
@@ -52,6 +55,19 @@ class ORB:
         n = ctypes.c_int(0)
         check(lib.ps_cvorb_detect_and_compute(self._h, image.ctypes.data, mp, w, h, image.strides[0], ms, kps.ctypes.data, desc.ctypes.data,
                                               self.capacity, ctypes.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def detect_batch_device(self, d_imgs, d_masks, nimg, w, h, stride=None, image_pitch=None, mask_stride=None, mask_pitch=None, stream=None):
+        """The batched, device-resident form: `nimg` images and masks in HBM (device pointers); asynchronous."""
+        stride = stride or w; mask_stride = mask_stride or w
+        check(lib.ps_cvorb_detect_batch_device(self._h, d_imgs, d_masks, nimg, w, h, stride, image_pitch or stride * h, mask_stride,
+                                               mask_pitch or mask_stride * h, stream))
+
+    def batch_fetch(self, image):
+        kps = np.zeros(2048, KEYPOINT_DTYPE)
+        desc = np.zeros((2048, 32), np.uint8)
+        n = ctypes.c_int(0)
+        check(lib.ps_cvorb_batch_fetch(self._h, image, kps.ctypes.data, desc.ctypes.data, 2048, ctypes.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
     def level_size(self, level):

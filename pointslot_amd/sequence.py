@@ -112,6 +112,41 @@ def generate(n_frames=20, seed=4, w=1242, h=375, step=0.08, n_boxes=2, K=KITTI_K
     return {"left": left, "right": right, "twc": twc, "boxes": boxes, "seg": seg, "K": (fx, fy, cx, cy), "bf": float(bf)}
 
 
+BOX_DEPTH_M = 0.5      # extent of a generated box along the viewing direction (the label's `w` at rotation_y = 0)
+
+
+def frame_labels(seq, k):
+    """The KITTI-tracking label fields of frame k's boxes: (track, x1, y1, x2, y2, h, w, l, X, Y, Z, ry).  A box is a textured
+    plane at depth zb facing the camera; its cuboid has the plane as front face: l (along x at ry = 0) = the plane's width,
+    h its height, w = BOX_DEPTH_M, bottom centre (X, Y, Z = zb + w / 2)."""
+    fx, fy, cx, cy = seq["K"]
+    out = []
+    for b, (x1, y1, x2, y2, zb, xw) in enumerate(seq["boxes"][k]):
+        if x2 <= 0 or x1 >= seq["left"].shape[2]:
+            continue
+        hm, lm = (y2 - y1) * zb / fy, (x2 - x1) * zb / fx
+        X = (0.5 * (x1 + x2) - cx) * zb / fx; Y = (y2 - cy) * zb / fy
+        out.append((b, float(x1), float(y1), float(x2), float(y2), hm, BOX_DEPTH_M, lm, X, Y, zb + 0.5 * BOX_DEPTH_M, 0.0))
+    return out
+
+
+def frame_detections(seq, k):
+    """Frame k's offline detections as Frame::OfflineDetectObject hands them to the tracker (SLOT.MODE 4)."""
+    from .object_tracker import detection_from_label
+    return [detection_from_label(*lab) for lab in frame_labels(seq, k)]
+
+
+def frame_mask(seq, k):
+    """Frame::ReadKittiSegmentationImage (src/Frame.cc:1004-1043) on frame k's MOTS ids: 0 background, 255 for 10000 (ignored),
+    instance + 1 for ids 1000..1999."""
+    seg = seq["seg"][k]
+    m = np.zeros(seg.shape, np.uint8)
+    m[seg == 10000] = 255
+    car = (seg >= 1000) & (seg < 2000)
+    m[car] = (seg[car] % 1000 + 1).astype(np.uint8)
+    return m
+
+
 def write(seq_dir, seq, dt=0.1, pgm=False):
     """Writes `seq` (from generate()) in the reference's on-disk layout.  pgm=True adds binary PGM copies of the stereo images
     next to the PNGs (examples/stereo_kitti.cpp reads those: the build image has no PNG decoder for C++)."""
@@ -137,12 +172,9 @@ def write(seq_dir, seq, dt=0.1, pgm=False):
     fx, fy, cx, cy = seq["K"]
     with open(os.path.join(seq_dir, "ObjectTracking.txt"), "w") as f:
         # frame track type trunc occl alpha x1 y1 x2 y2 h w l X Y Z ry   (camera-frame X Y Z of the box bottom centre)
-        for k, fb in enumerate(seq["boxes"]):
-            for b, (x1, y1, x2, y2, zb, xw) in enumerate(fb):
-                hm, wm = (y2 - y1) * zb / fy, (x2 - x1) * zb / fx
-                X = (0.5 * (x1 + x2) - cx) * zb / fx; Y = (y2 - cy) * zb / fy
-                f.write("%d %d Car 0 0 0 %.2f %.2f %.2f %.2f %.3f %.3f %.3f %.3f %.3f %.3f 0\n"
-                        % (k, b, x1, y1, x2, y2, hm, wm, 0.5, X, Y, zb))
+        for k in range(n):
+            for lab in frame_labels(seq, k):
+                f.write("%d %d Car 0 0 0 %.2f %.2f %.2f %.2f %.3f %.3f %.3f %.3f %.3f %.3f %.3f\n" % ((k,) + lab))
     with open(os.path.join(seq_dir, "calib.txt"), "w") as f:
         f.write("Camera.fx: %.9g\nCamera.fy: %.9g\nCamera.cx: %.9g\nCamera.cy: %.9g\nCamera.bf: %.9g\nThDepth: 35\n" % (fx, fy, cx, cy, seq["bf"]))
 

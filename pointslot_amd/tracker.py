@@ -31,6 +31,8 @@ class HipBackend:
         self.matcher_mm = ORBmatcher(0.9, True, device=device)     # Tracking.cc:3030
         self.matcher_lm = ORBmatcher(0.8, True, device=device)     # Tracking.cc SearchLocalPoints
         self.optimizer = Optimizer(device=device)
+        self.device = device
+        self.cv_left = self.cv_right = None                        # the object detector pair, created on first use
         self.scale_factors = self.left.GetScaleFactors()
         self.inv_level_sigma2 = self.left.GetInverseScaleSigmaSquares()
 
@@ -50,9 +52,34 @@ class HipBackend:
     def pose_optimization(self, frame):
         return self.optimizer.PoseOptimization([frame])[0]
 
+    # ---- the object half (object_tracker.ObjectTracker) ----
+    def extract_objects(self, left, right, mask_left, mask_right, mb, mbf):
+        """Frame::ExtractObjORB + ComputeObjStereoMatches: cv::ORB(1000, 1.2, 8, 19) under the object masks, then the stereo matcher
+        on those key sets against the pyramids the two ORBextractors hold for the SAME frame (extract_stereo ran before)."""
+        from .extractor import ComputeObjStereoMatches
+        if self.cv_left is None:
+            from .object_orb import ORB
+            self.cv_left, self.cv_right = ORB(1000, 1.2, 8, 19, device=self.device), ORB(1000, 1.2, 8, 19, device=self.device)
+        kl, dl = self.cv_left.detectAndCompute(left, mask_left)
+        kr, dr = self.cv_right.detectAndCompute(right, mask_right)
+        if len(kl) == 0:
+            return kl, dl, np.zeros(0, np.float32), np.zeros(0, np.float32)
+        ur, dp, _ = ComputeObjStereoMatches(self.left, self.right, kl, dl, kr, dr, mb, mbf)
+        return kl, dl, ur, dp
+
+    def search_bruteforce(self, problems):
+        return self.matcher_mm.SearchByBruceMatching(problems)          # ORBmatcher matcher(0.9, true), Tracking.cc:2381
+
+    def search_object_points(self, problems):
+        return self.matcher_lm.SearchByProjection(problems)             # ORBmatcher matcher(0.8), Tracking.cc:2569
+
+    def cfse3(self, objs, K):
+        return self.optimizer.CFSE3ObjStateOptimization([{"objs": objs, "K": K}])[0]
+
     def close(self):
-        for o in (self.left, self.right, self.matcher_mm, self.matcher_lm, self.optimizer):
-            o.close()
+        for o in (self.left, self.right, self.matcher_mm, self.matcher_lm, self.optimizer, self.cv_left, self.cv_right):
+            if o is not None:
+                o.close()
 
 
 class _Frame:
@@ -82,13 +109,20 @@ class StereoOdometry:
         self.local_map = None
         self.track_local_map = track_local_map
         self.state = "NOT_INITIALIZED"
+        self.prev_tcw = None            # mLastFrame.mTcw (None: the frame before had no pose)
+        self.objects = None             # object_tracker.ObjectTracker once a frame came with a mask
         self.trajectory = []            # Tcw per frame (float32 4x4), None when lost
         self.stats = []
 
     # ---- Frame::Frame (stereo) ----
-    def _make_frame(self, left, right):
+    def _make_frame(self, left, right, mask=None):
         F = _Frame()
         F.kps, F.desc, F.u_right, F.depth = self.be.extract_stereo(left, right, self.mb, self.bf)
+        if mask is not None and len(F.kps):
+            # Frame::AssignFeatures (Frame.cc:762-977, after ComputeStereoMatches): only keypoints on background pixels
+            # (mask 0) stay static features; object / ignored pixels leave the static set
+            keep = mask[F.kps["y"].astype(np.int64), F.kps["x"].astype(np.int64)] == 0
+            F.kps, F.desc, F.u_right, F.depth = F.kps[keep], F.desc[keep], F.u_right[keep], F.depth[keep]
         F.N = len(F.kps)
         F.x, F.y = _f32(F.kps["x"]), _f32(F.kps["y"])
         F.octave = np.asarray(F.kps["octave"], np.int32)
@@ -208,7 +242,9 @@ class StereoOdometry:
         M = self.local_map
         n = len(M["xw"])
         already = np.zeros(n, bool)
-        ids = F.mp_id[F.mp_valid & (F.mp_id >= 0)]
+        # mnLastFrameSeen == mCurrentFrame.mnId: the frame's map points, and the ones PoseOptimization just discarded as outliers
+        # (Tracking.cc:3071-3075 stamps them too; their slot keeps the id)
+        ids = F.mp_id[F.mp_id >= 0]
         already[ids] = True
         # Frame::isInFrustum (Frame.cc:1686-1743), float arithmetic, viewingCosLimit 0.5
         Rcw, tcw = F.tcw[:3, :3], F.tcw[:3, 3]
@@ -249,8 +285,24 @@ class StereoOdometry:
         return int(inl.sum()) >= 30, int(inl.sum()), nfound
 
     # ---- Tracking::Track for one stereo frame ----
-    def track(self, left, right):
-        F = self._make_frame(left, right)
+    def track(self, left, right, mask=None, detections=None):
+        """mask / detections (SLOT.MODE 4): the frame's 8-bit instance-id mask (Frame::ReadKittiSegmentationImage: 0 background,
+        255 ignored, id + 1 on object pixels) and its offline detections (object_tracker.detection_from_label); with them the
+        static features are the background keypoints and the object chain runs after the camera chain, as in Tracking::Track."""
+        F = self._make_frame(left, right, mask)
+        was_initialized = self.state != "NOT_INITIALIZED"
+        prev_tcw = self.prev_tcw
+        tcw = self._track_camera(F)
+        self.prev_tcw = None if tcw is None else tcw.copy()
+        if mask is not None:
+            if self.objects is None:
+                from .object_tracker import ObjectTracker
+                self.objects = ObjectTracker(self.be, (self.fx, self.fy, self.cx, self.cy), self.bf, self.w, self.h, self.th_depth, self.grid,
+                                             self.sf, self.be.inv_level_sigma2)
+            self.objects.track(left, right, mask, detections or [], tcw, prev_tcw, was_initialized)
+        return tcw
+
+    def _track_camera(self, F):
         st = {"N": F.N, "stereo": int((F.depth > 0).sum())}
         if self.state == "NOT_INITIALIZED":
             if self._initialize(F):

@@ -28,5 +28,25 @@ class OracleBackend:
         r, tcw, outlier, _ = oracle_lib.pose_optimize(frame)
         return r, tcw, outlier
 
+    # ---- the object half ----
+    def extract_objects(self, left, right, mask_left, mask_right, mb, mbf):
+        if not hasattr(self, "cv"):
+            self.cv = oracle_lib.OracleCvORB(1000, 1.2, 8, 19, 20)
+        kl, dl = self.cv.run(left, mask_left)
+        kr, dr = self.cv.run(right, mask_right)
+        if len(kl) == 0:
+            return kl, dl, np.zeros(0, np.float32), np.zeros(0, np.float32)
+        _, ur, dp = oracle_lib.stereo_match_keys(self.left, self.right, kl, dl, kr, dr, mb, mbf)
+        return kl, dl, ur, dp
+
+    def search_bruteforce(self, problems):
+        return [oracle_lib.search_bruteforce(p, 0.9, True) for p in problems]
+
+    def search_object_points(self, problems):
+        return [oracle_lib.search_projection_points(p, 0.8) for p in problems]
+
+    def cfse3(self, objs, K):
+        return oracle_lib.cfse3_optimize(objs, K)
+
     def close(self):
         pass

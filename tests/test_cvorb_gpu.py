@@ -63,3 +63,58 @@ def test_object_orb_other_parameters_and_empty_mask():
     kps, desc = det.detectAndCompute(left, np.zeros_like(left))
     assert len(kps) == 0
     det.close()
+
+
+def _blob_mask(rng, h, w, nblobs, big=False):
+    m = np.zeros((h, w), np.uint8)
+    for _ in range(nblobs):
+        bw, bh = (int(rng.integers(150, 500)), int(rng.integers(80, 220))) if big else (int(rng.integers(20, 160)), int(rng.integers(15, 90)))
+        x0, y0 = int(rng.integers(-bw // 2, w - bw // 2)), int(rng.integers(-bh // 2, h - bh // 2))
+        yy, xx = np.mgrid[0:h, 0:w]
+        if rng.random() < 0.5:
+            m[max(y0, 0):y0 + bh, max(x0, 0):x0 + bw] = 255
+        else:
+            m[((xx - x0 - bw / 2) / (bw / 2)) ** 2 + ((yy - y0 - bh / 2) / (bh / 2)) ** 2 <= 1] = 255
+    return m
+
+
+def test_batched_device_detector_matches_the_cpu_restatement():
+    """ps_cvorb_detect_batch_device: images + object masks in HBM, tile-restricted work, retainBest on the device - keypoints (order
+    included) and descriptors of every image against cv_orb_run; masks: boxes / ellipses of all sizes, touching the image borders,
+    an empty one, a full one small enough for the per-level limit, and large ones that push levels over their quota (both
+    retainBest steps run, ties included)."""
+    import os
+    import torch
+    from PIL import Image
+    from pointslot_amd.object_orb import ORB
+    kitti = np.ascontiguousarray(np.asarray(Image.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_000212_gray.png"))))
+    h, w = kitti.shape
+    rng = np.random.default_rng(5)
+    seq = sequence.generate(n_frames=3, seed=11, texture=sequence.kitti_texture())
+    imgs, masks = [], []
+    for k in range(3):
+        imgs.append(seq["left"][k]); masks.append(np.where(seq["seg"][k] != 0, 255, 0).astype(np.uint8))
+    for k in range(9):
+        imgs.append(kitti if k % 2 == 0 else np.ascontiguousarray(kitti[:, ::-1]))
+        masks.append(_blob_mask(rng, h, w, 1 + k % 4, big=k >= 5))
+    imgs.append(kitti); masks.append(np.zeros((h, w), np.uint8))
+    edge = np.zeros((h, w), np.uint8); edge[:60, :] = 255; edge[:, :50] = 255; edge[-45:, -300:] = 255
+    imgs.append(kitti); masks.append(edge)
+    n = len(imgs)
+    d_i = torch.from_numpy(np.stack(imgs)).cuda(); d_m = torch.from_numpy(np.stack(masks)).cuda()
+    det = ORB()
+    orc = OracleCvORB()
+    for rep in range(2):                       # the second batch reuses the arena: stale planes of the first must not leak
+        det.detect_batch_device(d_i.data_ptr(), d_m.data_ptr(), n, w, h)
+        culled = 0
+        for i in range(n):
+            kps, desc = det.batch_fetch(i)
+            ko, do = orc.run(imgs[i], masks[i])
+            assert len(kps) == len(ko), (i, len(kps), len(ko))
+            assert np.array_equal(kps.view(np.uint8), ko.view(np.uint8)), "image %d: keypoints (order included)" % i
+            assert np.array_equal(desc, do), "image %d: descriptors" % i
+            culled += len(ko) >= 400
+        assert culled >= 2                     # some masks are large enough for the quota culls
+        d_i = torch.from_numpy(np.stack(imgs[::-1])).cuda(); d_m = torch.from_numpy(np.stack(masks[::-1])).cuda()
+        imgs, masks = imgs[::-1], masks[::-1]
+    det.close()

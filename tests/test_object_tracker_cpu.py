@@ -1,0 +1,99 @@
+"""The object half of the per-frame chain on the CPU checker (pointslot_amd/object_tracker.py over oracle/liboracle.so): host logic
+of the slice - mask handling, detections, RANSAC centroid, box fine tuning, object initialisation, the two
+match-and-optimise rounds - on a generated sequence with two moving boxes (SLOT.MODE 4 inputs: Segmentation ids + KITTI labels)."""
+import os
+import subprocess
+
+import numpy as np
+
+from oracle_backend import OracleBackend
+from pointslot_amd import sequence
+from pointslot_amd.object_tracker import CvRng, detection_from_label, object_masks, right_mask
+from pointslot_amd.tracker import StereoOdometry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _right_mask_raster(mask):
+    """the reference's loop, literally (src/Frame.cc:1217-1290)"""
+    h, w = mask.shape
+    out = np.zeros_like(mask)
+    for i in range(h):
+        for j in range(w):
+            t = mask[i, j]
+            if t == 0:
+                out[i, j] = 0
+            else:
+                out[i, j] = t
+                for k in range(50):
+                    if j - k > 0:
+                        out[i, j - k] = t
+                    if j + k < w:
+                        out[i, j + k] = t
+    return out
+
+
+def test_right_mask_is_the_raster_scan_of_the_reference():
+    rng = np.random.default_rng(0)
+    m = np.zeros((6, 230), np.uint8)
+    m[1, 60:80] = 3; m[2, 0:5] = 255; m[3, 150:229] = 7; m[4, 100] = 2; m[4, 229] = 9; m[5, 0] = 4
+    assert np.array_equal(_right_mask_raster(m), right_mask(m))
+    m2 = ((rng.random((24, 300)) < 0.02) * rng.integers(1, 255, (24, 300))).astype(np.uint8)
+    assert np.array_equal(_right_mask_raster(m2), right_mask(m2))
+    ol, orr = object_masks(m, right_mask(m))
+    assert set(np.unique(ol)) <= {0, 255} and ol[2, 2] == 0 and ol[1, 70] == 255 and orr[1, 30] == 255 and orr[1, 5] == 0
+
+
+def test_cv_rng_and_detection_label():
+    # cv::RNG: state = (uint32)state * 4164903690 + (state >> 32), default state 0xFFFFFFFF (core.hpp: RNG::next)
+    r = CvRng()
+    s = 0xFFFFFFFF
+    for n in (97, 1000, 3, 65536, 7):
+        s = (s & 0xFFFFFFFF) * 4164903690 + (s >> 32)
+        assert r(n) == (s & 0xFFFFFFFF) % n
+    d = detection_from_label(3, 100.7, 50.2, 220.9, 130.6, 1.5, 1.6, 4.0, 2.0, 1.7, 15.0, 0.0)
+    assert d["id"] == 3 and d["bbox"] == (100, 50, 120, 80)                 # cv::Rect of truncated doubles; width = x2 - x1
+    assert d["scale"] == (4.0, 1.5, 1.6)                                      # (length, height, width)
+    assert np.allclose(d["pose7"], [2.0, 1.7 - 0.75, 15.0, 0, 0, 0, 1])     # the label's Y is the bottom of the box
+    d = detection_from_label(3, 0, 0, 10, 10, 1.5, 1.6, 4.0, 0, 0, 10, 0.5)
+    assert np.allclose(d["pose7"][3:], [0, np.sin(0.25), 0, np.cos(0.25)])   # rotation about the camera's y axis
+
+
+def test_retain_best_restatement_equals_the_library():
+    exe = os.path.join(ROOT, "build", "retain_best_check")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "retain_best_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 failures" in out.stdout
+
+
+def test_object_chain_on_a_generated_sequence():
+    n = 7
+    seq = sequence.generate(n_frames=n, seed=4, texture=sequence.kitti_texture())
+    h, w = seq["left"][0].shape
+    vo = StereoOdometry(OracleBackend(), seq["K"], seq["bf"], w, h)
+    fx, fy, cx, cy = seq["K"]
+    for k in range(n):
+        mask = sequence.frame_mask(seq, k)
+        tcw = vo.track(seq["left"][k], seq["right"][k], mask, sequence.frame_detections(seq, k))
+        assert tcw is not None
+        # the static features are the background keypoints
+        st = vo.objects.stats[-1]
+        assert len(st["objects"]) == 2
+        for b, o in enumerate(st["objects"]):
+            assert o["n"] > 60 and o["stereo"] > 40
+            if k == 0:
+                assert not o["tracked"]                  # the frame of StereoInitialization: no object functions
+                continue
+            assert o["tracked"]
+            assert o["new"] == (k == 1)                  # MapObjectInit on the first frame after the camera initialisation
+            if k >= 2:
+                assert o["track_ok"] and o["inliers"] > 40 and o["bf_matches"] > 30, (k, o)
+            # the cuboid centre against the generator: box plane at zb, centre BOX_DEPTH_M / 2 behind it
+            x1, y1, x2, y2, zb, _ = seq["boxes"][k][b]
+            truth = np.array([(0.5 * (x1 + x2) - cx) * zb / fx, (0.5 * (y1 + y2) - cy) * zb / fy, zb + 0.5 * sequence.BOX_DEPTH_M])
+            assert np.abs(o["tco"][:3] - truth).max() < 0.35, (k, b, o["tco"][:3], truth)
+    # camera: the two moving boxes no longer feed the static tracker
+    err = max(float(np.abs(-(t[:3, :3].T @ t[:3, 3]) - seq["twc"][k][:, 3]).max()) for k, t in enumerate(vo.trajectory))
+    assert err < 0.05
