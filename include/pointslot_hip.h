@@ -457,6 +457,7 @@ typedef struct ps_tracker_config {
   int32_t nfeatures; float scale_factor; int32_t nlevels, ini_th_fast, min_th_fast;   /* ORBextractor.*      */
   int32_t max_steps;                 /* frames per sequence the handle keeps results for                       */
   int32_t device;
+  int32_t max_objects;               /* detections per frame (SLOT.MODE 4 object chain; 0 = camera only, <= 8)  */
 } ps_tracker_config;
 /* what Tracking::Track leaves per frame and sequence */
 typedef struct ps_track_stat {
@@ -478,6 +479,44 @@ void ps_tracker_destroy(ps_tracker* t);
  * they come from ps_pinned_alloc).  Both return as soon as the step is queued. */
 int ps_tracker_step_device(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_pitch);
 int ps_tracker_step(ps_tracker* t, const uint8_t* const* left, const uint8_t* const* right, int stride);
+/* SLOT.MODE 4 (offline detections + instance masks), the whole of Tracking::Track's per-frame work: the camera chain above on the
+ * background keypoints (Frame::AssignFeatures, src/Frame.cc:762-977: keypoints on mask != 0 leave the static set) and behind it
+ * the object chain on the device -
+ *   Frame::ExtractObjORB (cv::ORB(1000, 1.2, 8, 19) under the object masks, :2623-2665) and ComputeObjStereoMatches (:2318-2503),
+ *   TrackMapObject (pose prediction, InitializeCurrentObjPose's RANSAC centroid, FineTuningUsing2dBox, MapObjectInit;
+ *   src/Tracking.cc:1533-1930), TrackLastFrameObjectPoint (temporal points, SearchByBruceMatching, CFSE3ObjStateOptimization,
+ *   :2288-2466), TrackObjectLocalMap (isInFrustum(pMP, nOrder), SearchByProjection(F, nOrder, MOPs), CFSE3, :2468-2712), the end of
+ *   Track (MapObjectReInit for an object whose tracking failed, :1443-1478,1932-2031)
+ * - in the localisation-mode slice pointslot_amd/object_tracker.py documents (an object's local map is the object keyframe of its
+ * (re-)initialisation).  d_masks: per sequence the LEFT 8-bit id mask of Frame::ReadKittiSegmentationImage (0 background, 255
+ * ignored, instance + 1), sequence k at d_masks + k * mask_pitch; d_dets: [n_sequences][max_objects] detections of the frame in
+ * label order, unused slots with id < 0 behind the used ones.  Both in HBM; they must stay unchanged until the step has run. */
+typedef struct ps_detection {
+  int32_t id;            /* DetectionObject::mnObjectID (the label's track id); < 0: empty slot                               */
+  int32_t bbox[4];       /* mrectBBox: x, y, width, height (cv::Rect of the label's truncated doubles)                         */
+  int32_t reserved[3];
+  double scale[3];       /* mScale: length, height, width                                                                      */
+  double pose7[7];       /* mTruthPosInCameraFrame.pose (tx, ty, tz, qx, qy, qz, qw): fromMinimalVector(X, Y - h / 2, Z, 0, ry, 0) */
+} ps_detection;
+/* what the object chain leaves per frame, sequence and detection slot */
+typedef struct ps_object_stat {
+  int32_t id;             /* the detection's id, -1 for an empty slot                                                          */
+  int32_t n, stereo;      /* object features of the detection / of which with depth                                            */
+  int32_t tracked;        /* the detection has a MapObject after the frame                                                     */
+  int32_t is_new;         /* MapObjectInit ran in this frame                                                                   */
+  int32_t track_ok;       /* DetectionObject::mbTrackOK at the end of TrackObjectLocalMap                                      */
+  int32_t inliers;        /* mnMatchesInliers                                                                                  */
+  int32_t bf_matches;     /* SearchByBruceMatching's return value                                                              */
+  int32_t lm_candidates;  /* local points that passed isInFrustum                                                              */
+  int32_t lm_matches;     /* SearchByProjection(F, nOrder, MOPs)'s return value                                                */
+  int32_t map_points;     /* the frame's MapObjectPoints with observations when the frame was finished                         */
+  int32_t reinit;         /* MapObjectReInit ran                                                                               */
+  double tco[7];          /* GetCFInFrameObjState(frame).pose when the frame was finished                                      */
+} ps_object_stat;
+int ps_tracker_step_slot_device(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_pitch, const uint8_t* d_masks, int mask_stride,
+                                size_t mask_pitch, const ps_detection* d_dets);
+/* Blocks, then copies the object results of steps [first_step, first_step + nsteps): [nsteps][n_sequences][max_objects]. */
+int ps_tracker_fetch_objects(ps_tracker* t, int first_step, int nsteps, ps_object_stat* out);
 int ps_tracker_sync(ps_tracker* t);
 int ps_tracker_steps(const ps_tracker* t, int* steps);
 /* Blocks, then copies the results of steps [first_step, first_step + nsteps): tcw [nsteps][n_sequences][16] (mTcw row-major,
@@ -487,7 +526,8 @@ int ps_tracker_fetch(ps_tracker* t, int first_step, int nsteps, float* tcw, ps_t
 /* All sequences back to NOT_INITIALIZED, step counter 0. */
 int ps_tracker_reset(ps_tracker* t);
 /* GPU time per stage of a step (HIP events on the tracker's stream, mean over the recorded steps, at most 64):
- * orb_extract, stereo_match, track_glue, search_by_projection, pose_optimization. */
+ * orb_extract, stereo_match, track_glue, search_by_projection, pose_optimization, and with objects: object_features,
+ * object_stereo_match, object_glue, object_bruteforce, object_cfse3, object_search_by_projection. */
 int ps_tracker_enable_stage_timing(ps_tracker* t, int enable);
 int ps_tracker_stage_times(ps_tracker* t, const char** names, float* ms, int cap, int* n);
 /* The extractor the tracker owns (its per-kernel stage times, debug reads). */

@@ -274,9 +274,8 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
   CvbPlan& P = h->bplan;
   memset(&P, 0, sizeof(P));
   P.nlevels = h->nlevels; P.edge = h->edge; P.fast_th = h->fast_th; P.w0 = w; P.h0 = hgt;
-  P.ow = (w + CVB_TILE - 1) / CVB_TILE; P.oh = (hgt + CVB_TILE - 1) / CVB_TILE;
-  if (P.ow > 128) return ps_set_error(PS_ERR_INVALID, "the batched object detector supports images up to 4096 pixels wide");
-  P.occ_words = (P.ow * P.oh + 31) / 32;
+  P.ocw = (w + 7) / 8; P.och = (hgt + 7) / 8;
+  if (P.ocw > 512) return ps_set_error(PS_ERR_INVALID, "the batched object detector supports images up to 4096 pixels wide");
   {
     const int hp = 15;
     int v, v0, vmax = cv_floor(hp * sqrtf(2.f) / 2 + 1), vmin = cv_ceil(hp * sqrtf(2.f) / 2);
@@ -304,10 +303,13 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
       return ps_set_error(PS_ERR_INVALID, "image %dx%d: level %d is %dx%d, too small for the detector", w, hgt, l, L.w, L.h);
     L.stride = (int)((L.w + 2 * CV_BORDER + 63) / 64 * 64);
     L.tw = (L.w + 2 * CV_BORDER + CVB_TILE - 1) / CVB_TILE; L.th = (L.h + 2 * CV_BORDER + CVB_TILE - 1) / CVB_TILE;
-    if (L.tw * L.th > CVB_MAX_TILES / 4) return ps_set_error(PS_ERR_INVALID, "the batched object detector supports levels of up to %d tiles", CVB_MAX_TILES / 4);
+    if (L.tw * L.th > CVB_MAX_TILES) return ps_set_error(PS_ERR_INVALID, "the batched object detector supports levels of up to %d tiles", CVB_MAX_TILES);
+    L.cw = (L.w + 2 * CV_BORDER + 7) / 8; L.ch = (L.h + 2 * CV_BORDER + 7) / 8;
+    L.cw = std::max(L.cw, 4 * L.tw); L.ch = std::max(L.ch, 4 * L.th);   // every tile owns 4 x 4 cells
+    L.cell_off = P.cell_total; P.cell_total += L.cw * L.ch; P.cell_max = std::max(P.cell_max, L.cw * L.ch);
     L.quota = quota[l];
     L.o_pad = take_img((size_t)L.stride * (L.h + 2 * CV_BORDER)); L.o_blur = take_img((size_t)L.stride * (L.h + 2 * CV_BORDER));
-    L.o_mask = take_img((size_t)L.w * L.h); L.o_score = take_img((size_t)L.w * L.h);
+    L.o_mask = take_img((size_t)L.w * L.h); L.o_score = 0;
     if (l > 0) { exact_table(P.lv[l - 1].w, L.w, xt[l]); exact_table(P.lv[l - 1].h, L.h, yt[l]); }
   }
   P.arena_pitch = img_off;
@@ -315,18 +317,20 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
   int max_tiles = 0;
   for (int l = 0; l < h->nlevels; l++) max_tiles = std::max(max_tiles, P.lv[l].tw * P.lv[l].th);
   P.wl_cap = cap * max_tiles;
+  if ((size_t)P.cell_total + 2 * (size_t)P.cell_max > 150 * 1024) return ps_set_error(PS_ERR_INVALID, "image too large for the batched object detector's planning kernel");
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t r = off; off += al(bytes + 64); return r; };
   const size_t o_arena = take(P.arena_pitch * (size_t)cap);
   std::vector<size_t> o_xt(h->nlevels, 0), o_yt(h->nlevels, 0);
   for (int l = 1; l < h->nlevels; l++) { o_xt[l] = take(xt[l].size() * 16); o_yt[l] = take(yt[l].size() * 16); }
-  const size_t o_wl = take((size_t)h->nlevels * P.wl_cap * 4);
+  const size_t o_wl = take((size_t)3 * CV_MAX_LEVELS * P.wl_cap * 4);
+  const size_t o_kpmap = take((size_t)cap * P.cell_total);
   const size_t o_cand = take((size_t)cap * h->nlevels * CVB_CAND_CAP * sizeof(float4));
   const size_t o_sel = take((size_t)cap * h->nlevels * CVB_CAND_CAP * sizeof(CvSel));
   const size_t o_kps = take((size_t)cap * P.ocap * sizeof(ps_keypoint)), o_desc = take((size_t)cap * P.ocap * 32);
   // cleared before every batch: occupancy, worklist counters, candidate counters, selection counts, counts, overflow
   const size_t z0 = off;
-  const size_t o_occ = take((size_t)cap * P.occ_words * 4), o_wlc = take(CV_MAX_LEVELS * 4), o_ncand = take((size_t)cap * h->nlevels * 4);
+  const size_t o_occ = take((size_t)cap * P.ocw * P.och), o_wlc = take(3 * CV_MAX_LEVELS * 4), o_ncand = take((size_t)cap * h->nlevels * 4);
   const size_t o_nsel = take((size_t)cap * h->nlevels * 4), o_count = take((size_t)cap * 4), o_ovf = take((size_t)cap * 4);
   const size_t z1 = off;
   hipError_t e = hipMalloc(&h->b_buf, off);
@@ -341,7 +345,7 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
   }
   P.wl = (uint32_t*)(D + o_wl); P.cand = (float4*)(D + o_cand); P.sel = (CvSel*)(D + o_sel);
   P.kps = (ps_keypoint_pod*)(D + o_kps); P.desc = D + o_desc;
-  P.occ = (uint32_t*)(D + o_occ); P.wl_count = (int32_t*)(D + o_wlc); P.ncand = (int32_t*)(D + o_ncand); P.nsel = (int32_t*)(D + o_nsel);
+  P.occ = D + o_occ; P.kpmap = D + o_kpmap; P.wl_count = (int32_t*)(D + o_wlc); P.ncand = (int32_t*)(D + o_ncand); P.nsel = (int32_t*)(D + o_nsel);
   P.count = (int32_t*)(D + o_count); P.overflow = (int32_t*)(D + o_ovf);
   h->b_zero = D + z0; h->b_zero_bytes = z1 - z0;
   PS_HIP(hipStreamSynchronize(h->stream));

@@ -271,49 +271,51 @@ __global__ __launch_bounds__(64) void cv_describe(CvPlanDev plan, const CvSel* s
 // =====================================================================================================================
 // Batched, device-resident form: nimg images of one size with object masks (non-zero = object), everything on one stream with
 // no host round trip - the ExtractObjORB stage of the device-resident object chain (track_host.hip).  Results are those of
-// cv_* above image by image; what differs is the work: only the 32 x 32 tiles of every level's padded plane that can reach a
+// cv_* above image by image; what differs is the work: only the parts of every level's padded plane that can reach a
 // keypoint under the mask are computed (object masks cover a few percent of a frame), and the two retainBest steps run on
 // the device with the library's own algorithms (retain_best.h) instead of on the host.
-//   cvb_occupancy  level-0 tile occupancy of the mask             cvb_plan    active tiles per level -> worklists
-//   cvb_level0 / cvb_resize   padded planes + mask pyramid        cvb_score / cvb_emit   FAST score, keypoints (+ Harris)
-//   cvb_blur       7 x 7 blur                                     cvb_select  raster order, retainBest x 2
+//   cvb_occupancy  8 x 8 cell occupancy of the mask               cvb_plan    needed cells per level -> tile worklists
+//   cvb_level0 / cvb_resize   padded planes + mask pyramid        cvb_detect  FAST score + NMS + filters (+ Harris) per tile, in LDS
+//   cvb_blur       7 x 7 blur, separable in LDS                   cvb_select  raster order, retainBest x 2
 //   cvb_describe   angle + rBRIEF
-// Exactness of the restriction (a tile left out never feeds a kept result): a keypoint needs the level mask non-zero at its
-// pixel; the level mask is a chain of 2 x 2 interpolations of the level-0 mask, so it can only be non-zero within
-// 6 (R - 1) + 3 level-0 pixels of an occupied level-0 tile (R = the level's scale): those tiles are `kp-possible`.  Around a
-// keypoint the pipeline reads at most 22 pixels of the padded plane (rBRIEF reach 19 + blur 3; FAST + NMS 4, Harris 4, IC
-// angle 15) - less than one tile - so the active set is the kp-possible tiles and their 8 neighbours, plus, level by level
-// downwards, every tile of level l - 1 that holds a source pixel of an active tile of level l.
+// Exactness of the restriction (a pixel left out never feeds a kept result).  Planning is done on 8 x 8 cells of the padded planes:
+// * a keypoint needs the level mask non-zero at its pixel; the level mask is a chain of 2 x 2 interpolations of the level-0 mask, so
+//   it can only be non-zero within 6 (R - 1) + 3 level-0 pixels of an occupied level-0 cell (R = the level's scale): `kp cells`;
+// * around a keypoint the pipeline reads at most 22 pixels of the padded plane (rBRIEF reach 19 + blur 3; FAST + NMS 4, Harris 4,
+//   IC angle 15): the plane is needed on the kp cells dilated by 3 cells, and, level by level downwards, on every cell of level
+//   l - 1 that holds a source pixel of a needed cell of level l; the blur on the kp cells dilated by 3, the FAST score by 1;
+// * kernels run on the 32 x 32 tiles that hold a needed cell.  What a tile computes outside the needed cells may come from
+//   pixels that were never written; it is never read for a result (keypoints are only taken inside kp cells).
 // =====================================================================================================================
 __device__ __forceinline__ CvLevelDev cvb_level(const CvbPlan& P, int img, int l) {
   const CvbLevel& B = P.lv[l];
   uint8_t* base = P.arena + (size_t)img * P.arena_pitch;
   CvLevelDev L;
   L.w = B.w; L.h = B.h; L.stride = B.stride; L.scale = B.scale;
-  L.pad = base + B.o_pad; L.blur = base + B.o_blur; L.mask = base + B.o_mask; L.score = base + B.o_score;
+  L.pad = base + B.o_pad; L.blur = base + B.o_blur; L.mask = base + B.o_mask; L.score = nullptr;
   L.rowcnt = nullptr; L.rowoff = nullptr; L.cand = nullptr;
   return L;
 }
 
-// one workgroup per (image, tile row of 32 image rows): which 32 x 32 tiles hold a non-zero mask pixel
+// one workgroup per (image, band of 32 image rows): which 8 x 8 cells hold a non-zero mask pixel
 __global__ __launch_bounds__(256) void cvb_occupancy(CvbPlan P, const uint8_t* masks, int mask_stride, size_t mask_pitch) {
-  __shared__ uint32_t bits[4];   // up to 128 tiles per row (4096-px images)
-  const int img = blockIdx.y, ty = blockIdx.x, tid = threadIdx.x;
-  if (tid < 4) bits[tid] = 0;
+  __shared__ uint8_t flag[4][512];
+  const int img = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 4 * 512; i += 256) (&flag[0][0])[i] = 0;
   __syncthreads();
   const uint8_t* M = masks + (size_t)img * mask_pitch;
-  const int y0 = ty * CVB_TILE, y1 = min(y0 + CVB_TILE, P.h0);
-  for (int x = tid; x < P.w0; x += 256) {
-    uint32_t any = 0;
-    for (int y = y0; y < y1; y++) any |= M[(size_t)y * mask_stride + x];
-    if (any) atomicOr(&bits[(x >> 5) >> 5], 1u << ((x >> 5) & 31));
-  }
+  for (int x = tid; x < P.w0; x += 256)
+    for (int b = 0; b < 4; b++) {
+      const int y0 = band * 32 + b * 8, y1 = min(y0 + 8, P.h0);
+      uint32_t any = 0;
+      for (int y = y0; y < y1; y++) any |= M[(size_t)y * mask_stride + x];
+      if (any) flag[b][x >> 3] = 1;
+    }
   __syncthreads();
-  uint32_t* occ = P.occ + (size_t)img * P.occ_words;
-  // row ty of the bitmap starts at bit ty * ow: written bit by bit by the threads that own a tile
-  for (int tx = tid; tx < P.ow; tx += 256) {
-    const int b = ty * P.ow + tx;
-    if ((bits[tx >> 5] >> (tx & 31)) & 1u) atomicOr(&occ[b >> 5], 1u << (b & 31));
+  uint8_t* occ = P.occ + (size_t)img * P.ocw * P.och;
+  for (int i = tid; i < 4 * P.ocw; i += 256) {
+    const int b = i / P.ocw, cx = i % P.ocw, cy = band * 4 + b;
+    if (cy < P.och) occ[cy * P.ocw + cx] = flag[b][cx];
   }
 }
 
@@ -326,99 +328,118 @@ __device__ __forceinline__ void cvb_reflect_range(int lo, int hi, int len, int& 
   rlo = max(rlo, 0); rhi = min(rhi, len - 1);
 }
 
-// one workgroup per image: active tiles of every level, appended to the per-level worklists
+// appends the tiles of level l that hold a flagged cell to worklist `which`
+__device__ __forceinline__ void cvb_append_tiles(const CvbPlan& P, int img, int l, int which, const uint8_t* cells, int grow) {
+  const CvbLevel& B = P.lv[l];
+  const int nt = B.tw * B.th, tid = threadIdx.x;
+  uint32_t* wl = P.wl + ((size_t)which * CV_MAX_LEVELS + l) * P.wl_cap;
+  int32_t* cnt = P.wl_count + which * CV_MAX_LEVELS + l;
+  for (int t0 = 0; t0 < nt; t0 += 256) {
+    const int t = t0 + tid;
+    bool a = false;
+    if (t < nt) {
+      const int tx = t % B.tw, ty = t / B.tw;
+      const int cx0 = max(4 * tx - grow, 0), cx1 = min(4 * tx + 3 + grow, B.cw - 1), cy0 = max(4 * ty - grow, 0), cy1 = min(4 * ty + 3 + grow, B.ch - 1);
+      for (int cy = cy0; cy <= cy1; cy++)
+        for (int cx = cx0; cx <= cx1; cx++) a = a || cells[cy * B.cw + cx];
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(a);
+    const int lane = tid & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(cnt, __popcll(m));
+    base = __shfl(base, 0);
+    if (a) {
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < P.wl_cap) wl[pos] = ((uint32_t)img << 12) | (uint32_t)t;
+    }
+  }
+}
+
+// one workgroup per image: kp cells and needed cells of every level (dynamic LDS: a byte per cell of every level + two scratch
+// planes of the largest level), the three tile worklists per level (0 planes, 1 FAST, 2 blur)
 __global__ __launch_bounds__(256) void cvb_plan(CvbPlan P) {
-  __shared__ uint8_t act[CV_MAX_LEVELS][CVB_MAX_TILES / 4];   // <= 1024 tiles per level (images up to about 1000 x 1000 px per ... see host check)
-  __shared__ uint8_t kp[CVB_MAX_TILES / 4];
-  __shared__ int wbase;
+  extern __shared__ uint8_t sm[];
   const int img = blockIdx.x, tid = threadIdx.x;
-  const uint32_t* occ = P.occ + (size_t)img * P.occ_words;
+  uint8_t* kp = sm + P.cell_total;
+  uint8_t* tmp = kp + P.cell_max;
+  const uint8_t* occ = P.occ + (size_t)img * P.ocw * P.och;
+  uint8_t* kpmap = P.kpmap + (size_t)img * P.cell_total;
   for (int l = 0; l < P.nlevels; l++) {
     const CvbLevel& B = P.lv[l];
-    const int nt = B.tw * B.th;
+    const int nc = B.cw * B.ch;
+    uint8_t* need = sm + B.cell_off;
     const float Rx = (float)P.w0 / (float)B.w, Ry = (float)P.h0 / (float)B.h;
     const float mx = 6.f * (Rx - 1.f) + 3.f, my = 6.f * (Ry - 1.f) + 3.f;
-    for (int t = tid; t < nt; t += 256) {
-      const int tx = t % B.tw, ty = t / B.tw;
-      int x0 = CVB_TILE * tx - CV_BORDER, x1 = x0 + CVB_TILE - 1, y0 = CVB_TILE * ty - CV_BORDER, y1 = y0 + CVB_TILE - 1;
+    for (int c = tid; c < nc; c += 256) {
+      const int cx = c % B.cw, cy = c / B.cw;
+      int x0 = 8 * cx - CV_BORDER, x1 = x0 + 7, y0 = 8 * cy - CV_BORDER, y1 = y0 + 7;
       x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, B.w - 1); y1 = min(y1, B.h - 1);
       bool any = false;
       if (x0 <= x1 && y0 <= y1) {
         int X0 = (int)floorf((float)x0 * Rx - mx), X1 = (int)ceilf((float)(x1 + 1) * Rx + mx);
         int Y0 = (int)floorf((float)y0 * Ry - my), Y1 = (int)ceilf((float)(y1 + 1) * Ry + my);
-        X0 = max(X0, 0) >> 5; Y0 = max(Y0, 0) >> 5; X1 = min(X1, P.w0 - 1) >> 5; Y1 = min(Y1, P.h0 - 1) >> 5;
+        X0 = max(X0, 0) >> 3; Y0 = max(Y0, 0) >> 3; X1 = min(X1, P.w0 - 1) >> 3; Y1 = min(Y1, P.h0 - 1) >> 3;
         for (int oy = Y0; oy <= Y1 && !any; oy++)
-          for (int ox = X0; ox <= X1; ox++) {
-            const int b = oy * P.ow + ox;
-            if ((occ[b >> 5] >> (b & 31)) & 1u) { any = true; break; }
-          }
+          for (int ox = X0; ox <= X1; ox++)
+            if (occ[oy * P.ocw + ox]) { any = true; break; }
       }
-      kp[t] = any ? 1 : 0;
+      kp[c] = any ? 1 : 0;
+      kpmap[B.cell_off + c] = any ? 1 : 0;
     }
     __syncthreads();
-    for (int t = tid; t < nt; t += 256) {
-      const int tx = t % B.tw, ty = t / B.tw;
-      bool a = false;
-      for (int dy = -1; dy <= 1; dy++)
-        for (int dx = -1; dx <= 1; dx++) {
-          const int nx = tx + dx, ny = ty + dy;
-          if (nx >= 0 && nx < B.tw && ny >= 0 && ny < B.th && kp[ny * B.tw + nx]) a = true;
-        }
-      act[l][t] = a ? 1 : 0;
+    cvb_append_tiles(P, img, l, 1, kp, 1);                       // FAST + NMS: kp cells and one cell around them
+    for (int c = tid; c < nc; c += 256) {                        // dilation by 3 cells, rows then columns
+      const int cx = c % B.cw, cy = c / B.cw;
+      uint8_t v = 0;
+      for (int d = -3; d <= 3; d++) { const int x = cx + d; if (x >= 0 && x < B.cw) v |= kp[cy * B.cw + x]; }
+      tmp[c] = v;
     }
+    __syncthreads();
+    for (int c = tid; c < nc; c += 256) {
+      const int cx = c % B.cw, cy = c / B.cw;
+      uint8_t v = 0;
+      for (int d = -3; d <= 3; d++) { const int y = cy + d; if (y >= 0 && y < B.ch) v |= tmp[y * B.cw + cx]; }
+      need[c] = v;
+    }
+    __syncthreads();
+    cvb_append_tiles(P, img, l, 2, need, 0);                     // blur
     __syncthreads();
   }
-  // a level's active tiles need their source pixels one level down
+  // a level's needed cells need their source pixels one level down
   for (int l = P.nlevels - 1; l >= 1; l--) {
     const CvbLevel& B = P.lv[l];
     const CvbLevel& S = P.lv[l - 1];
-    const int nt = B.tw * B.th;
+    const uint8_t* need = sm + B.cell_off;
+    uint8_t* down = sm + S.cell_off;
+    const int nc = B.cw * B.ch;
     const double rx = (double)S.w / (double)B.w, ry = (double)S.h / (double)B.h;
-    for (int t = tid; t < nt; t += 256) {
-      if (!act[l][t]) continue;
-      const int tx = t % B.tw, ty = t / B.tw;
+    for (int c = tid; c < nc; c += 256) {
+      if (!need[c]) continue;
+      const int cx = c % B.cw, cy = c / B.cw;
       int lx0, lx1, ly0, ly1;
-      cvb_reflect_range(CVB_TILE * tx - CV_BORDER, min(CVB_TILE * tx - CV_BORDER + CVB_TILE - 1, B.w + CV_BORDER - 1), B.w, lx0, lx1);
-      cvb_reflect_range(CVB_TILE * ty - CV_BORDER, min(CVB_TILE * ty - CV_BORDER + CVB_TILE - 1, B.h + CV_BORDER - 1), B.h, ly0, ly1);
+      cvb_reflect_range(8 * cx - CV_BORDER, min(8 * cx - CV_BORDER + 7, B.w + CV_BORDER - 1), B.w, lx0, lx1);
+      cvb_reflect_range(8 * cy - CV_BORDER, min(8 * cy - CV_BORDER + 7, B.h + CV_BORDER - 1), B.h, ly0, ly1);
       int sx0 = (int)floor(((double)lx0 + 0.5) * rx - 0.5) - 1, sx1 = (int)floor(((double)lx1 + 0.5) * rx - 0.5) + 2;
       int sy0 = (int)floor(((double)ly0 + 0.5) * ry - 0.5) - 1, sy1 = (int)floor(((double)ly1 + 0.5) * ry - 0.5) + 2;
       sx0 = max(sx0, 0); sy0 = max(sy0, 0); sx1 = min(sx1, S.w - 1); sy1 = min(sy1, S.h - 1);
-      const int ax0 = (sx0 + CV_BORDER) >> 5, ax1 = (sx1 + CV_BORDER) >> 5, ay0 = (sy0 + CV_BORDER) >> 5, ay1 = (sy1 + CV_BORDER) >> 5;
+      const int ax0 = (sx0 + CV_BORDER) >> 3, ax1 = (sx1 + CV_BORDER) >> 3, ay0 = (sy0 + CV_BORDER) >> 3, ay1 = (sy1 + CV_BORDER) >> 3;
       for (int ay = ay0; ay <= ay1; ay++)
-        for (int ax = ax0; ax <= ax1; ax++) act[l - 1][ay * S.tw + ax] = 1;
+        for (int ax = ax0; ax <= ax1; ax++) down[ay * S.cw + ax] = 1;
     }
     __syncthreads();
   }
-  for (int l = 0; l < P.nlevels; l++) {
-    const CvbLevel& B = P.lv[l];
-    const int nt = B.tw * B.th;
-    // ordered compaction is not needed: a worklist is a set
-    for (int t0 = 0; t0 < nt; t0 += 256) {
-      const int t = t0 + tid;
-      const bool a = t < nt && act[l][t];
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(a);
-      const int lane = tid & 63;
-      int base = 0;
-      if (lane == 0 && m) base = atomicAdd(&P.wl_count[l], __popcll(m));
-      base = __shfl(base, 0);
-      if (a) {
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < P.wl_cap) P.wl[(size_t)l * P.wl_cap + pos] = ((uint32_t)img << 12) | (uint32_t)t;
-      }
-    }
-  }
-  (void)wbase;
+  for (int l = 0; l < P.nlevels; l++) cvb_append_tiles(P, img, l, 0, sm + P.lv[l].cell_off, 0);
 }
 
-// pixel (px, py) of tile t handled by thread tid, four pixels in a row per thread
-#define CVB_TILE_LOOP(P, l)                                                                             \
+#define CVB_TILE_LOOP(P, which, l)                                                                      \
   const CvbLevel& B = P.lv[l];                                                                          \
-  const int cnt = min(P.wl_count[l], P.wl_cap);                                                         \
+  const uint32_t* wl = P.wl + ((size_t)(which) * CV_MAX_LEVELS + (l)) * P.wl_cap;                       \
+  const int cnt = min(P.wl_count[(which) * CV_MAX_LEVELS + (l)], P.wl_cap);                             \
   for (int it = blockIdx.x; it < cnt; it += gridDim.x)
 
 __global__ __launch_bounds__(256) void cvb_level0(CvbPlan P, const uint8_t* imgs, int stride, size_t pitch, const uint8_t* masks, int mask_stride, size_t mask_pitch) {
-  CVB_TILE_LOOP(P, 0) {
-    const uint32_t e = P.wl[it];
+  CVB_TILE_LOOP(P, 0, 0) {
+    const uint32_t e = wl[it];
     const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, 0);
     const uint8_t* I = imgs + (size_t)img * pitch;
@@ -438,8 +459,8 @@ __global__ __launch_bounds__(256) void cvb_level0(CvbPlan P, const uint8_t* imgs
 }
 
 __global__ __launch_bounds__(256) void cvb_resize(CvbPlan P, int l) {
-  CVB_TILE_LOOP(P, l) {
-    const uint32_t e = P.wl[(size_t)l * P.wl_cap + it];
+  CVB_TILE_LOOP(P, 0, l) {
+    const uint32_t e = wl[it];
     const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l), S = cvb_level(P, img, l - 1);
     const int py = CVB_TILE * ty + (threadIdx.x >> 3);
@@ -462,11 +483,10 @@ __global__ __launch_bounds__(256) void cvb_resize(CvbPlan P, int l) {
   }
 }
 
-// FAST score of one level pixel (the body of cv_score)
-__device__ __forceinline__ uint8_t cvb_fast_score(const CvLevelDev& L, int x, int y, int th) {
-  if (!(x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3)) return 0;
-  const uint8_t* c = L.pad + (size_t)(CV_BORDER + y) * L.stride + CV_BORDER + x;
-  const int st = L.stride, v = c[0];
+// FAST score of one pixel from a tile of the padded plane in LDS (row stride TS, c = the pixel): the body of cv_score
+template <int TS>
+__device__ __forceinline__ uint8_t cvb_fast_score_lds(const uint8_t* c, int th) {
+  const int st = TS, v = c[0];
   const int n = c[3 * st], e = c[3], so = c[-3 * st], w = c[-3];
   const int M = min(min(max(n, e), max(e, so)), min(max(so, w), max(w, n)));
   const int m = max(max(min(n, e), min(e, so)), max(min(so, w), min(w, n)));
@@ -487,67 +507,95 @@ __device__ __forceinline__ uint8_t cvb_fast_score(const CvLevelDev& L, int x, in
   return best > th ? (uint8_t)best : (uint8_t)0;
 }
 
-// worklists of all levels in one launch: blockIdx.y = level
-__global__ __launch_bounds__(256) void cvb_score(CvbPlan P) {
-  const int l = blockIdx.y;
-  CVB_TILE_LOOP(P, l) {
-    const uint32_t e = P.wl[(size_t)l * P.wl_cap + it];
+// worklists of all levels in one launch (blockIdx.y = level).  Per tile: the 40 x 40 neighbourhood of the padded plane into LDS,
+// FAST scores of the tile and one ring around it (34 x 34) into LDS, then per tile pixel inside a kp cell the keypoint
+// predicate of cv_is_keypoint - strict 3 x 3 maximum, mask, border rectangle - and the append with the Harris response
+__global__ __launch_bounds__(256) void cvb_detect(CvbPlan P) {
+  constexpr int TS = 40, SS = 34;
+  __shared__ uint8_t tile[TS * TS];
+  __shared__ uint8_t sc[SS * SS];
+  const int l = blockIdx.y, tid = threadIdx.x;
+  CVB_TILE_LOOP(P, 1, l) {
+    const uint32_t e = wl[it];
     const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l);
-    const int y = CVB_TILE * ty + (threadIdx.x >> 3) - CV_BORDER;
-    if (y < 0 || y >= L.h) continue;
-    for (int j = 0; j < 4; j++) {
-      const int x = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j - CV_BORDER;
-      if (x < 0 || x >= L.w) continue;
-      L.score[(size_t)y * L.w + x] = cvb_fast_score(L, x, y, P.fast_th);
+    const int PW = L.w + 2 * CV_BORDER, PH = L.h + 2 * CV_BORDER;
+    const int bx = CVB_TILE * tx - 4, by = CVB_TILE * ty - 4;           // padded coordinates of tile[0]
+    __syncthreads();
+    for (int i = tid; i < TS * TS; i += 256) {
+      const int px = bx + i % TS, py = by + i / TS;
+      tile[i] = (px >= 0 && px < PW && py >= 0 && py < PH) ? L.pad[(size_t)py * L.stride + px] : 0;
     }
-  }
-}
-
-__global__ __launch_bounds__(256) void cvb_emit(CvbPlan P) {
-  const int l = blockIdx.y;
-  CVB_TILE_LOOP(P, l) {
-    const uint32_t e = P.wl[(size_t)l * P.wl_cap + it];
-    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
-    const CvLevelDev L = cvb_level(P, img, l);
-    const int y = CVB_TILE * ty + (threadIdx.x >> 3) - CV_BORDER;
-    if (y < 0 || y >= L.h) continue;
+    __syncthreads();
+    for (int i = tid; i < SS * SS; i += 256) {
+      const int sx = i % SS, sy = i / SS;                                // score pixel: padded (bx + 3 + sx, by + 3 + sy)
+      const int x = bx + 3 + sx - CV_BORDER, y = by + 3 + sy - CV_BORDER;
+      uint8_t v = 0;
+      if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) v = cvb_fast_score_lds<TS>(tile + (sy + 3) * TS + sx + 3, P.fast_th);
+      sc[i] = v;
+    }
+    __syncthreads();
+    const uint8_t* kpmap = P.kpmap + (size_t)img * P.cell_total + B.cell_off;
     for (int j = 0; j < 4; j++) {
-      const int x = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j - CV_BORDER;
-      if (x < 0 || x >= L.w) continue;
-      // the mask first: outside the kp-possible tiles it is zero, and the score plane next to a tile that is not active is undefined
+      const int lx = (tid & 7) * 4 + j, ly = tid >> 3;
+      const int px = CVB_TILE * tx + lx, py = CVB_TILE * ty + ly;
+      const int x = px - CV_BORDER, y = py - CV_BORDER;
+      if (x < P.edge || x >= L.w - P.edge || y < P.edge || y >= L.h - P.edge) continue;
+      if (!kpmap[(py >> 3) * B.cw + (px >> 3)]) continue;
+      const uint8_t* s = sc + (ly + 1) * SS + lx + 1;
+      const int v = s[0];
+      if (v == 0) continue;
+      if (!(v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] && v > s[SS - 1] && v > s[SS] && v > s[SS + 1])) continue;
       if (L.mask[(size_t)y * L.w + x] == 0) continue;
-      if (!cv_is_keypoint(L, x, y, P.edge)) continue;
       const int slot = img * P.nlevels + l;
       const int pos = atomicAdd(&P.ncand[slot], 1);
-      if (pos < CVB_CAND_CAP)
-        P.cand[(size_t)slot * CVB_CAND_CAP + pos] = make_float4((float)x, (float)y, (float)((int)L.score[(size_t)y * L.w + x] - 1), cv_harris(L, x, y));
+      if (pos < CVB_CAND_CAP) P.cand[(size_t)slot * CVB_CAND_CAP + pos] = make_float4((float)x, (float)y, (float)(v - 1), cv_harris(L, x, y));
     }
   }
 }
 
+// 7 x 7 blur of a tile: 38 x 38 neighbourhood in LDS, horizontal pass into 16-bit sums, vertical pass, one rounding
 __global__ __launch_bounds__(256) void cvb_blur(CvbPlan P) {
-  const int l = blockIdx.y;
-  const int kq[7] = {P.kq[0], P.kq[1], P.kq[2], P.kq[3], P.kq[2], P.kq[1], P.kq[0]};
-  CVB_TILE_LOOP(P, l) {
-    const uint32_t e = P.wl[(size_t)l * P.wl_cap + it];
+  constexpr int TS = 38;
+  __shared__ uint8_t tile[TS * TS];
+  __shared__ uint16_t hs[TS * 32];
+  const int l = blockIdx.y, tid = threadIdx.x;
+  const uint32_t kq[7] = {(uint32_t)P.kq[0], (uint32_t)P.kq[1], (uint32_t)P.kq[2], (uint32_t)P.kq[3], (uint32_t)P.kq[2], (uint32_t)P.kq[1], (uint32_t)P.kq[0]};
+  CVB_TILE_LOOP(P, 2, l) {
+    const uint32_t e = wl[it];
     const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l);
-    const int py = CVB_TILE * ty + (threadIdx.x >> 3);
-    if (py >= L.h + 2 * CV_BORDER) continue;
+    const int PW = L.w + 2 * CV_BORDER, PH = L.h + 2 * CV_BORDER;
+    const int bx = CVB_TILE * tx - 3, by = CVB_TILE * ty - 3;
+    __syncthreads();
+    for (int i = tid; i < TS * TS; i += 256) {
+      const int px = bx + i % TS, py = by + i / TS;
+      tile[i] = (px >= 0 && px < PW && py >= 0 && py < PH) ? L.pad[(size_t)py * L.stride + px] : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < TS * 32; i += 256) {
+      const int r = i >> 5, c = i & 31;
+      const uint8_t* row = tile + r * TS + c;
+      uint32_t hsum = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) hsum += kq[k] * row[k];
+      hs[i] = (uint16_t)min(hsum, 65535u);
+    }
+    __syncthreads();
     for (int j = 0; j < 4; j++) {
-      const int px = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j;
-      if (px >= L.w + 2 * CV_BORDER) break;
+      const int lx = (tid & 7) * 4 + j, ly = tid >> 3;
+      const int px = CVB_TILE * tx + lx, py = CVB_TILE * ty + ly;
+      if (px >= PW || py >= PH) continue;
       const int x = px - CV_BORDER, y = py - CV_BORDER;
-      if (x < 0 || x >= L.w || y < 0 || y >= L.h) { L.blur[(size_t)py * L.stride + px] = L.pad[(size_t)py * L.stride + px]; continue; }
-      uint32_t acc = 0;
-      for (int jj = 0; jj < 7; jj++) {
-        const uint8_t* row = L.pad + (size_t)(py + jj - 3) * L.stride + px - 3;
-        uint32_t hsum = 0;
-        for (int i = 0; i < 7; i++) hsum += (uint32_t)kq[i] * row[i];
-        acc += (uint32_t)kq[jj] * min(hsum, 65535u);
+      uint8_t o;
+      if (x < 0 || x >= L.w || y < 0 || y >= L.h) o = tile[(ly + 3) * TS + lx + 3];
+      else {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += kq[k] * hs[(ly + k) * 32 + lx];
+        o = (uint8_t)min((acc + 32768u) >> 16, 255u);
       }
-      L.blur[(size_t)py * L.stride + px] = (uint8_t)min((acc + 32768u) >> 16, 255u);
+      L.blur[(size_t)py * L.stride + px] = o;
     }
   }
 }
@@ -565,6 +613,7 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P) {
   const int total = P.ncand[slot];
   const int n = min(total, CVB_CAND_CAP);
   if (total > CVB_CAND_CAP && tid == 0) atomicAdd(&P.overflow[img], 1);
+  if (n == 0) { if (tid == 0) P.nsel[slot] = 0; return; }
   const float4* C = P.cand + (size_t)slot * CVB_CAND_CAP;
   int npow = 1;
   while (npow < n) npow <<= 1;
@@ -580,7 +629,7 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P) {
         if (p > i) {
           const bool up = (i & k) == 0;
           const uint32_t a = key[i], b = key[p];
-          if ((a > b) == up) { key[i] = b; key[p] = a; const int32_t t = idx[i]; idx[i] = idx[p]; idx[p] = t; }
+          if ((a > b) == up) { key[i] = b; key[p] = a; const int32_t tt = idx[i]; idx[i] = idx[p]; idx[p] = tt; }
         }
       }
       __syncthreads();
@@ -697,12 +746,13 @@ void psk_cvb_run(const CvbPlan* P, int nimg, const uint8_t* imgs, int stride, si
                  hipStream_t st) {
   const int NL = P->nlevels;
   const int grid = 4096;                                       // persistent loops over the worklists
-  hipLaunchKernelGGL(cvb_occupancy, dim3(P->oh, nimg), dim3(256), 0, st, *P, masks, mask_stride, mask_pitch);
-  hipLaunchKernelGGL(cvb_plan, dim3(nimg), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_occupancy, dim3((P->h0 + 31) / 32, nimg), dim3(256), 0, st, *P, masks, mask_stride, mask_pitch);
+  const size_t plan_lds = (size_t)P->cell_total + 2 * (size_t)P->cell_max;
+  if (plan_lds > 48 * 1024) hipFuncSetAttribute((const void*)cvb_plan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds);
+  hipLaunchKernelGGL(cvb_plan, dim3(nimg), dim3(256), plan_lds, st, *P);
   hipLaunchKernelGGL(cvb_level0, dim3(grid), dim3(256), 0, st, *P, imgs, stride, pitch, masks, mask_stride, mask_pitch);
   for (int l = 1; l < NL; l++) hipLaunchKernelGGL(cvb_resize, dim3(grid), dim3(256), 0, st, *P, l);
-  hipLaunchKernelGGL(cvb_score, dim3(grid / 4, NL), dim3(256), 0, st, *P);
-  hipLaunchKernelGGL(cvb_emit, dim3(grid / 4, NL), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_detect, dim3(grid / 4, NL), dim3(256), 0, st, *P);
   hipLaunchKernelGGL(cvb_blur, dim3(grid / 4, NL), dim3(256), 0, st, *P);
   hipLaunchKernelGGL(cvb_select, dim3(nimg * NL), dim3(256), 0, st, *P);
   hipLaunchKernelGGL(cvb_describe, dim3((P->ocap + 3) / 4, nimg), dim3(256), 0, st, *P);

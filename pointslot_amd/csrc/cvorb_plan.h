@@ -32,6 +32,7 @@ struct ps_keypoint_pod { float x, y, size, angle, response; int32_t octave, clas
 struct CvbLevel {
   int32_t w, h, stride;        // level size, padded-plane row stride
   int32_t tw, th;              // tiles of the padded plane
+  int32_t cw, ch, cell_off;    // 8 x 8 cells of the padded plane; offset of the level in the per-image cell arrays
   int32_t quota;               // nfeaturesPerLevel
   float scale;
   size_t o_pad, o_blur, o_mask, o_score;   // byte offsets inside one image's arena
@@ -40,13 +41,14 @@ struct CvbLevel {
 struct CvbPlan {
   CvbLevel lv[CV_MAX_LEVELS];
   int32_t nlevels, edge, fast_th, w0, h0;
-  int32_t ow, oh;              // level-0 occupancy tiles (32 x 32 image pixels)
+  int32_t ocw, och;            // level-0 occupancy cells (8 x 8 image pixels)
+  int32_t cell_total, cell_max; // cells of all levels / of the largest level
   int32_t umax[17];
   int32_t kq[4];
   uint8_t* arena; size_t arena_pitch;      // per image: the planes of all levels
-  uint32_t* occ;               // [nimg][occ_words] bit (ty * ow + tx): the object mask has a non-zero pixel in that tile
-  int32_t occ_words;
-  uint32_t* wl; int32_t* wl_count; int32_t wl_cap;   // per level: entries (image << 12 | tile); wl + l * wl_cap
+  uint8_t* occ;                // [nimg][och][ocw]: the object mask has a non-zero pixel in that cell
+  uint8_t* kpmap;              // [nimg][cell_total]: cells of every level in which a keypoint is possible
+  uint32_t* wl; int32_t* wl_count; int32_t wl_cap;   // [3 (planes, FAST, blur)][CV_MAX_LEVELS][wl_cap] entries (image << 12 | tile)
   float4* cand; int32_t* ncand;                      // [nimg][nlevels][CVB_CAND_CAP], [nimg][nlevels]
   CvSel* sel; int32_t* nsel;                         // [nimg][nlevels][CVB_CAND_CAP], [nimg][nlevels]
   ps_keypoint_pod* kps; uint8_t* desc; int32_t* count; int32_t* overflow;   // [nimg][ocap], [nimg][ocap][32], [nimg], [nimg]

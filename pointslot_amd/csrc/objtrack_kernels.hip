@@ -1,0 +1,1046 @@
+// Glue kernels of the object half of the device-resident lockstep tracker: the host side of Tracking::Track's object functions
+// between the hot-path calls, moved onto the device so that a frame's object chain
+//   ExtractObjORB (cvb_*) -> ComputeObjStereoMatches (st_*) -> AssignFeatures -> TrackMapObject -> SearchByBruceMatching (bf_*) ->
+//   CFSE3ObjStateOptimization (pose_lm) -> SearchObjectLocalPoints / SearchByProjection(F, nOrder, MOPs) (pj_*) -> CFSE3 -> end of Track
+// is one stream of launches behind the camera chain of the same step, with no host round trip.  The per-call twin
+// pointslot_amd/object_tracker.py documents the slice and the mapping to /root/reference/src/Tracking.cc:1224-1233,1443-1478,
+// 1533-2031,2288-2712 and src/Frame.cc:690-733,762-977,1744-1806; every float / double expression here is written operation by
+// operation as that file evaluates it (this file is compiled with -ffp-contract=off) - tests/test_object_device_gpu.py compares the
+// two drivers bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pointslot_hip.h"
+#include "objtrack_plan.h"
+#include "se3.h"
+
+namespace {
+
+#define OB_T 256
+
+__device__ __forceinline__ int ob_block_sum(int v, int* red) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int w = 0; w < OB_T / 64; w++) t += red[w];
+  return t;
+}
+__device__ __forceinline__ int ob_block_scan_excl(int v, int* red, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  __syncthreads();
+  if (lane == 63) red[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; w++) base += red[w];
+  int t = 0;
+#pragma unroll
+  for (int w = 0; w < OB_T / 64; w++) t += red[w];
+  *total = t;
+  return base + incl - v;
+}
+
+__device__ __forceinline__ Se3 ob_pose(const double* p) {
+  Se3 T;
+  T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q[0] = p[3]; T.q[1] = p[4]; T.q[2] = p[5]; T.q[3] = p[6];
+  return T;
+}
+__device__ __forceinline__ void ob_store_pose(double* p, const Se3& T) {
+  p[0] = T.t[0]; p[1] = T.t[1]; p[2] = T.t[2]; p[3] = T.q[0]; p[4] = T.q[1]; p[5] = T.q[2]; p[6] = T.q[3];
+}
+
+// the camera tracker's view of the frame: was the tracker initialised before it, and the poses of this and the last frame
+__device__ __forceinline__ bool ob_camera_initialized(const ObArrays& A, int s, int step) {
+  return step > 0 && A.cam_stats[((size_t)(step - 1) * A.S + s) * A.cam_stat_words] != 0;   // TrkStat::state after the frame before
+}
+__device__ __forceinline__ const float* ob_cam_pose(const ObArrays& A, int s, int step) {      // nullptr: the frame has no pose
+  if (step < 0) return nullptr;
+  if (A.cam_stats[((size_t)step * A.S + s) * A.cam_stat_words + 1] == 0) return nullptr;       // TrkStat::tracked
+  return A.cam_traj + ((size_t)step * A.S + s) * 16;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LeftObjMask / RightObjMask of Frame::ExtractObjORB (Frame.cc:2632-2643) from the left 8-bit id mask; the right id mask is
+// Frame::ReadKittiSegmentationImage(.., rightseg = true) (Frame.cc:1217-1290): scanning a row from the left, every labelled
+// pixel writes its label 49 pixels to both sides, so a pixel ends up with the label of the RIGHTMOST labelled pixel within
+// (x, x + 49] or else with its own (column 0 is never written from the right).  One workgroup per image row.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OB_T) void ob_masks(ObArrays A, uint8_t* objmask, int W, int H) {
+  extern __shared__ uint8_t row_sm[];
+  int16_t* run = reinterpret_cast<int16_t*>(row_sm + ((W + 63) & ~63));
+  __shared__ int red[OB_T / 64];
+  const int y = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const uint8_t* M = A.idmask + (size_t)s * A.mask_pitch + (size_t)y * A.mask_stride;
+  for (int x = tid; x < W; x += OB_T) row_sm[x] = M[x];
+  __syncthreads();
+  // run[c] = rightmost labelled column <= c (-1: none): per-thread chunks, block-wide prefix maximum of the chunk maxima
+  const int per = (W + OB_T - 1) / OB_T, c0 = tid * per, c1 = min(c0 + per, W);
+  int local = -1;
+  for (int c = c0; c < c1; c++) if (row_sm[c] != 0) local = c;
+  int incl = local;
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    int base = -1;
+    for (int w = 0; w < wave; w++) base = max(base, red[w]);
+    const int prev_lane = __shfl_up(incl, 1);
+    int excl = lane == 0 ? -1 : prev_lane;
+    excl = max(excl, base);
+    int r = excl;
+    for (int c = c0; c < c1; c++) { if (row_sm[c] != 0) r = c; run[c] = (int16_t)r; }
+  }
+  __syncthreads();
+  uint8_t* L = objmask + ((size_t)(2 * s) * H + y) * W;
+  uint8_t* R = objmask + ((size_t)(2 * s + 1) * H + y) * W;
+  for (int x = tid; x < W; x += OB_T) {
+    const uint8_t m = row_sm[x];
+    L[x] = (m != 0 && m != 255) ? 255 : 0;
+    const int r = run[min(x + 49, W - 1)];
+    const uint8_t lab = (r > x && x > 0) ? row_sm[r] : m;
+    R[x] = (lab != 0 && lab != 255) ? 255 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Frame::Frame, object part after ExtractObjORB / ComputeObjStereoMatches: AssignFeatures (Frame.cc:762-977; the temp object
+// keys go to the detection whose id is the mask label - 1), AssignDetObjFeasToGrid (:1863-1888), and the lookup of the
+// detections' MapObjects (AllObjects by mnTruthID, Tracking.cc:1548-1551).  One workgroup per sequence.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OB_T) void ob_begin(ObArrays A, int step) {
+  __shared__ int cnt[OB_NCELL + 1];
+  __shared__ int cursor[OB_NCELL];
+  __shared__ int red[OB_T / 64];
+  __shared__ int s_off[OB_MAXK + 1];
+  const int s = blockIdx.x, tid = threadIdx.x, K = A.K;
+  const ObCam& C = A.cam;
+  const size_t fb = (size_t)s * A.OC;
+  ObFrame& F = A.cur;
+  int ndet = 0;
+  for (int j = 0; j < K; j++) if (A.dets_in[(size_t)s * K + j].id >= 0) ndet = j + 1;
+  if (tid < K) {
+    F.det[(size_t)s * K + tid] = A.dets_in[(size_t)s * K + tid];
+    F.mo[(size_t)s * K + tid] = -1;
+    A.in_last[(size_t)s * K + tid] = -1; A.tracked[(size_t)s * K + tid] = 0; A.need[(size_t)s * K + tid] = 0; A.track_ok[(size_t)s * K + tid] = 0;
+  }
+  if (tid == 0) F.ndet[s] = ndet;
+  const ps_keypoint* kps = (const ps_keypoint*)A.cv_kps + (size_t)(2 * s) * A.cv_cap;
+  const uint8_t* desc = A.cv_desc + (size_t)(2 * s) * A.cv_cap * 32;
+  int N = A.cv_count[2 * s];
+  N = N < A.cv_cap ? N : A.cv_cap;
+  const uint8_t* M = A.idmask + (size_t)s * A.mask_pitch;
+  int8_t* owner = A.owner + (size_t)s * A.cv_cap;
+  for (int i = tid; i < N; i += OB_T) {
+    const ps_keypoint k = kps[i];
+    const int lab = M[(size_t)(int)k.y * A.mask_stride + (int)k.x];
+    int own = -1;
+    if (lab != 0 && lab != 255)
+      for (int j = 0; j < ndet; j++) {
+        const int id = A.dets_in[(size_t)s * K + j].id;
+        if ((id > 255 ? id - 255 : id) == lab - 1) { own = j; break; }
+      }
+    owner[i] = (int8_t)own;
+  }
+  __syncthreads();
+  int run = 0;
+  for (int j = 0; j < K; j++) {
+    if (tid == 0) s_off[j] = run;
+    if (j >= ndet) continue;
+    for (int i0 = 0; i0 < N; i0 += OB_T) {
+      const int i = i0 + tid;
+      const bool mine = i < N && owner[i] == j;
+      int total;
+      const int pos = run + ob_block_scan_excl(mine ? 1 : 0, red, &total);
+      if (mine && pos < A.OC) {
+        const ps_keypoint k = kps[i];
+        const size_t o = fb + pos;
+        F.x[o] = k.x; F.y[o] = k.y; F.angle[o] = k.angle; F.octave[o] = k.octave;
+        F.uright[o] = A.st_uright[fb + i]; F.depth[o] = A.st_depth[fb + i];
+        const uint4* sd = reinterpret_cast<const uint4*>(desc + (size_t)i * 32);
+        uint4* dd = reinterpret_cast<uint4*>(F.desc + o * 32);
+        dd[0] = sd[0]; dd[1] = sd[1];
+        F.mp_valid[o] = 0; F.mp_observed[o] = 0; F.outlier[o] = 0; F.mp_id[o] = -1;
+        F.mp_po[3 * o] = 0.f; F.mp_po[3 * o + 1] = 0.f; F.mp_po[3 * o + 2] = 0.f;
+        A.occupied[o] = 0; A.inbbox[o] = 0;
+      }
+      run += total;
+    }
+  }
+  run = run < A.OC ? run : A.OC;
+  if (tid == 0) { s_off[K] = run; for (int j = ndet; j < K; j++) s_off[j] = run; }
+  __syncthreads();
+  if (tid <= K) F.off[(size_t)s * (K + 1) + tid] = s_off[tid];
+  // ---- mvObjKeysGrid of every detection as CSR (the 64 x 48 grid over the image, Frame::PosInGrid) ----
+  const bool init = ob_camera_initialized(A, s, step);
+  for (int j = 0; j < ndet; j++) {
+    const int b0 = s_off[j], n = s_off[j + 1] - b0;
+    for (int i = tid; i <= OB_NCELL; i += OB_T) cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += OB_T) {
+      const int px = (int)roundf((F.x[fb + b0 + i] - 0.f) * C.gw_inv), py = (int)roundf((F.y[fb + b0 + i] - 0.f) * C.gh_inv);
+      if (px >= 0 && px < PS_GRID_COLS && py >= 0 && py < PS_GRID_ROWS) atomicAdd(&cnt[px * PS_GRID_ROWS + py], 1);
+    }
+    __syncthreads();
+    {
+      const int per = OB_NCELL / OB_T;
+      int local[per];
+      int sum = 0;
+      for (int k = 0; k < per; k++) { local[k] = cnt[tid * per + k]; sum += local[k]; }
+      int total;
+      int base = ob_block_scan_excl(sum, red, &total);
+      for (int k = 0; k < per; k++) { cnt[tid * per + k] = base; cursor[tid * per + k] = base; base += local[k]; }
+      if (tid == 0) cnt[OB_NCELL] = total;
+    }
+    __syncthreads();
+    int32_t* coff = F.cell_off + ((size_t)s * K + j) * (OB_NCELL + 1);
+    int32_t* cidx = F.cell_idx + fb + b0;
+    for (int i = tid; i <= OB_NCELL; i += OB_T) coff[i] = cnt[i];
+    for (int i = tid; i < n; i += OB_T) {
+      const int px = (int)roundf((F.x[fb + b0 + i] - 0.f) * C.gw_inv), py = (int)roundf((F.y[fb + b0 + i] - 0.f) * C.gh_inv);
+      if (px >= 0 && px < PS_GRID_COLS && py >= 0 && py < PS_GRID_ROWS) cidx[atomicAdd(&cursor[px * PS_GRID_ROWS + py], 1)] = i;
+    }
+    __syncthreads();
+    for (int c = tid; c < OB_NCELL; c += OB_T) {   // push_back order: ascending feature index inside a cell
+      const int a = cnt[c], e = cnt[c + 1];
+      for (int i = a + 1; i < e; i++) {
+        const int v = cidx[i];
+        int k = i - 1;
+        while (k >= a && cidx[k] > v) { cidx[k + 1] = cidx[k]; k--; }
+        cidx[k + 1] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- statistics, MapObjects of the detections; first observations reserve a free slot in detection order ----
+  for (int j = 0; j < ndet; j++) {
+    const int b0 = s_off[j], n = s_off[j + 1] - b0;
+    int st = 0;
+    for (int i = tid; i < n; i += OB_T) st += F.depth[fb + b0 + i] > 0 ? 1 : 0;
+    st = ob_block_sum(st, red);
+    if (tid == 0) {
+      ObStat o;
+      for (int i = 0; i < (int)(sizeof(ObStat) / 4); i++) ((int32_t*)&o)[i] = 0;
+      o.id = F.det[(size_t)s * K + j].id; o.n = n; o.stereo = st;
+      A.stats[((size_t)step * A.S + s) * K + j] = o;
+    }
+  }
+  for (int j = ndet + tid; j < K; j += OB_T) {
+    ObStat o;
+    for (int i = 0; i < (int)(sizeof(ObStat) / 4); i++) ((int32_t*)&o)[i] = 0;
+    o.id = -1;
+    A.stats[((size_t)step * A.S + s) * K + j] = o;
+  }
+  if (tid == 0 && init) {
+    ObMapObject* T = A.mobj + (size_t)s * A.M;
+    uint32_t reserved = 0;
+    for (int j = 0; j < ndet; j++) {
+      const int id = F.det[(size_t)s * K + j].id;
+      int slot = -1;
+      for (int m = 0; m < A.M; m++) if (T[m].id == id) { slot = m; break; }
+      if (slot < 0) {
+        int fr = -1;
+        for (int m = 0; m < A.M; m++) if (T[m].id < 0 && !((reserved >> m) & 1u)) { fr = m; break; }
+        if (fr < 0) { A.dropped[s]++; slot = -1; }
+        else { reserved |= 1u << fr; slot = -2 - fr; }     // reserved for MapObjectInit
+      }
+      F.mo[(size_t)s * K + j] = slot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device functions of one detection's workgroup
+// ---------------------------------------------------------------------------------------------------------------------
+struct ObShared {
+  int red[OB_T / 64];
+  unsigned long long red64[OB_T / 64];
+  double mean[3];
+  int ibuf[8];
+};
+
+// the detection's camera-frame points in `order` (feature indices relative to the detection, or nullptr = every feature with depth,
+// ascending): Frame::UnprojectStereodynamic (Frame.cc:2521-2544), float arithmetic, widened to double
+__device__ void ob_cam_points(const ObArrays& A, const ObFrame& F, size_t fo, int n, double* pts, int32_t* pidx, int* l_out, ObShared& sh) {
+  const ObCam& C = A.cam;
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += OB_T) {
+    const int i = i0 + threadIdx.x;
+    const bool has = i < n && F.depth[fo + i] > 0;
+    int total;
+    const int u = base + ob_block_scan_excl(has ? 1 : 0, sh.red, &total);
+    if (has) {
+      const float z = F.depth[fo + i];
+      const float xx = (F.x[fo + i] - C.cx) * z * C.inv_fx, yy = (F.y[fo + i] - C.cy) * z * C.inv_fy;
+      pts[3 * u] = (double)xx; pts[3 * u + 1] = (double)yy; pts[3 * u + 2] = (double)z;
+      pidx[u] = i;
+    }
+    base += total;
+  }
+  __syncthreads();
+  *l_out = base;
+}
+
+// the RANSAC centroid of InitializeCurrentObjPose / MapObjectInit / MapObjectReInit (Tracking.cc:1656-1700): `iterations` draws
+// of cv::RNG (default state), score = points within fmax of the drawn one, the first best draw's inliers (flags, ascending) and
+// their mean summed in that order.  score / draw scratch: scr[0 .. iterations) ints.  Returns the inlier count.
+__device__ int ob_ransac(const double* pts, int l, float fmax, int iterations, int32_t* scr, uint8_t* flag, double* mean, ObShared& sh) {
+  const int tid = threadIdx.x;
+  if (l == 0 || iterations <= 0) { if (tid < 3) mean[tid] = 0; __syncthreads(); return 0; }
+  if (tid == 0) {
+    unsigned long long state = 0xFFFFFFFFull;
+    for (int k = 0; k < iterations; k++) {
+      state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32);
+      scr[k] = (int)((unsigned)state % (unsigned)l);
+    }
+  }
+  __syncthreads();
+  const double fm = (double)fmax;
+  unsigned long long best = 0;   // (score + 1) << 32 | ~k : the largest is the first draw with the best score
+  for (int k = tid; k < iterations; k += OB_T) {
+    const int i1 = scr[k];
+    const double px = pts[3 * i1], py = pts[3 * i1 + 1], pz = pts[3 * i1 + 2];
+    int score = 0;
+    for (int u = 0; u < l; u++) {
+      const double dx = pts[3 * u] - px, dy = pts[3 * u + 1] - py, dz = pts[3 * u + 2] - pz;
+      score += sqrt(dx * dx + dy * dy + dz * dz) < fm ? 1 : 0;
+    }
+    const unsigned long long key = ((unsigned long long)(unsigned)(score + 1) << 32) | (unsigned)(0x7FFFFFFF - k);
+    best = key > best ? key : best;
+  }
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)best, dd), hi = __shfl_xor((unsigned)(best >> 32), dd);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    best = o > best ? o : best;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) sh.red64[tid >> 6] = best;
+  __syncthreads();
+  best = sh.red64[0];
+  for (int w = 1; w < OB_T / 64; w++) best = sh.red64[w] > best ? sh.red64[w] : best;
+  const int kbest = 0x7FFFFFFF - (int)(unsigned)best;
+  const int i1 = scr[kbest];
+  const double px = pts[3 * i1], py = pts[3 * i1 + 1], pz = pts[3 * i1 + 2];
+  int cntl = 0;
+  for (int u = tid; u < l; u += OB_T) {
+    const double dx = pts[3 * u] - px, dy = pts[3 * u + 1] - py, dz = pts[3 * u + 2] - pz;
+    const bool in = sqrt(dx * dx + dy * dy + dz * dz) < fm;
+    flag[u] = in ? 1 : 0;
+    cntl += in ? 1 : 0;
+  }
+  const int ninl = ob_block_sum(cntl, sh.red);
+  __syncthreads();
+  if (tid == 0) {
+    double sx = 0, sy = 0, sz = 0;
+    for (int u = 0; u < l; u++) if (flag[u]) { sx += pts[3 * u]; sy += pts[3 * u + 1]; sz += pts[3 * u + 2]; }
+    const double m = (double)ninl;
+    mean[0] = sx / m; mean[1] = sy / m; mean[2] = sz / m;
+  }
+  __syncthreads();
+  return ninl;
+}
+
+// ObjectState::projectOntoImageRectFromCamera (g2o_Object.cc:156-169, EnObjectCenter = 0) as cv::Rect(x, y, w, h) of truncated
+// doubles; corner k on lane k & 7, extremes over the eight lanes
+__device__ __forceinline__ void ob_project_box(const ObCam& C, const double* R, const double* t, const double* scale, int* box) {
+  const int k = threadIdx.x & 7;
+  const double b0 = (k == 0 || k == 1 || k == 4 || k == 5) ? 1.0 : -1.0;
+  const double b1 = (k == 0 || k == 3 || k == 4 || k == 7) ? 1.0 : -1.0;
+  const double b2 = k < 4 ? -1.0 : 1.0;
+  double c[3];
+  for (int r = 0; r < 3; r++) {
+    const double s0 = R[3 * r] * (scale[0] * 0.5), s1 = R[3 * r + 1] * (scale[1] * 0.5), s2 = R[3 * r + 2] * (scale[2] * 0.5);
+    c[r] = s0 * b0 + s1 * b1 + s2 * b2 + t[r] * 1.0;
+  }
+  const double fx = (double)C.fx, fy = (double)C.fy, cx = (double)C.cx, cy = (double)C.cy;
+  const double p0 = fx * c[0] + 0.0 * c[1] + cx * c[2];
+  const double p1 = 0.0 * c[0] + fy * c[1] + cy * c[2];
+  const double p2 = 0.0 * c[0] + 0.0 * c[1] + 1.0 * c[2];
+  double ulo = p0 / p2, vlo = p1 / p2, uhi = ulo, vhi = vlo;
+#pragma unroll
+  for (int d = 1; d <= 4; d <<= 1) {
+    ulo = fmin(ulo, __shfl_xor(ulo, d)); uhi = fmax(uhi, __shfl_xor(uhi, d));
+    vlo = fmin(vlo, __shfl_xor(vlo, d)); vhi = fmax(vhi, __shfl_xor(vhi, d));
+  }
+  box[0] = (int)ulo; box[1] = (int)vlo; box[2] = (int)(uhi - ulo); box[3] = (int)(vhi - vlo);
+}
+
+// Tracking::FineTuningUsing2dBox (Tracking.cc:1704-1786): executed by every lane of the calling wave (all lanes end with the
+// same translation); t is updated in place
+__device__ void ob_fine_tune(const ObCam& C, const ObDet& det, const double* q, const double* scale, double* t) {
+  double R[9];
+  se3_quat_to_R(q, R);
+  const int bx = det.bbox[0], by = det.bbox[1], bw = det.bbox[2], bh = det.bbox[3];
+  const int rcx = (bx + (bx + bw)) / 2, rcy = (by + (by + bh)) / 2;
+  int pb[4];
+  ob_project_box(C, R, t, scale, pb);
+  int dcx = (pb[0] + pb[0] + pb[2]) / 2 - rcx, dcy = (pb[1] + pb[1] + pb[3]) / 2 - rcy;
+  for (int i = 0; i < 400; i++) {
+    const int direction = dcy < 0 ? -1 : 1;
+    t[1] = t[1] - direction * 0.01;
+    ob_project_box(C, R, t, scale, pb);
+    dcx = (pb[0] + pb[0] + pb[2]) / 2 - rcx; dcy = (pb[1] + pb[1] + pb[3]) / 2 - rcy;
+    if (abs(dcy) < 1) break;
+  }
+  if (t[2] > 8) {
+    int dh = pb[3] - bh;
+    for (int i = 0; i < 400; i++) {
+      const int direction = dh < 0 ? -1 : 1;
+      t[2] = t[2] + direction * 0.05;
+      ob_project_box(C, R, t, scale, pb);
+      dh = pb[3] - bh;
+      if (abs(dh) < 1) break;
+    }
+  }
+  dcx = (pb[0] + pb[0] + pb[2]) / 2 - rcx;
+  for (int i = 0; i < 400; i++) {
+    const int direction = dcx < 0 ? -1 : 1;
+    t[0] = t[0] - direction * 0.01;
+    ob_project_box(C, R, t, scale, pb);
+    dcx = (pb[0] + pb[0] + pb[2]) / 2 - rcx;
+    if (abs(dcx) < 1) break;
+  }
+}
+
+__device__ __forceinline__ float ob_fmax(const double* scale) {   // float fMaxDis = scale.norm()
+  return (float)sqrt(scale[0] * scale[0] + scale[1] * scale[1] + scale[2] * scale[2]);
+}
+
+// The MapObjectPoints of a new ObjectKeyFrame (MapObjectInit / MapObjectReInit tail): for the inliers whose object-frame position
+// lies within fmax, position (float), descriptor of the keypoint, one observation, UpdateNormalAndDepth against the keyframe's
+// camera centre mPoc = -Roc * tco; the keyframe lists its points by feature index (sel[i] = 1 for the features that get a point)
+__device__ void ob_keyframe_points(const ObArrays& A, const ObFrame& F, int s, int slot, size_t fo, int n, const Se3& pose, const double* pts,
+                                   const int32_t* pidx, const uint8_t* flag, int l, float fmax, uint8_t* sel, float* selpo, int step, ObShared& sh) {
+  const ObCam& C = A.cam;
+  const int tid = threadIdx.x;
+  const Se3 inv = se3_inverse(pose);
+  float m[12];
+  {
+    double R[9];
+    se3_quat_to_R(pose.q, R);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) m[4 * r + c] = (float)R[3 * r + c]; m[4 * r + 3] = (float)pose.t[r]; }
+  }
+  float poc[3];
+  for (int r = 0; r < 3; r++) poc[r] = (float)(-((double)m[r] * (double)m[3] + (double)m[4 + r] * (double)m[7] + (double)m[8 + r] * (double)m[11]));
+  for (int i = tid; i < n; i += OB_T) sel[i] = 0;
+  __syncthreads();
+  for (int u = tid; u < l; u += OB_T) {
+    if (!flag[u]) continue;
+    double x3do[3];
+    se3_map(inv, pts + 3 * u, x3do);
+    if (sqrt(x3do[0] * x3do[0] + x3do[1] * x3do[1] + x3do[2] * x3do[2]) > (double)fmax) continue;
+    const int i = pidx[u];
+    sel[i] = 1;
+    selpo[3 * i] = (float)x3do[0]; selpo[3 * i + 1] = (float)x3do[1]; selpo[3 * i + 2] = (float)x3do[2];
+  }
+  __syncthreads();
+  const size_t lb = ((size_t)s * A.M + slot) * A.LC;
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += OB_T) {
+    const int i = i0 + tid;
+    const bool has = i < n && sel[i];
+    int total;
+    const int pid = base + ob_block_scan_excl(has ? 1 : 0, sh.red, &total);
+    if (has && pid < A.LC) {
+      const float po[3] = {selpo[3 * i], selpo[3 * i + 1], selpo[3 * i + 2]};
+      const float v[3] = {po[0] - poc[0], po[1] - poc[1], po[2] - poc[2]};
+      const double nd = sqrt((double)v[0] * (double)v[0] + (double)v[1] * (double)v[1] + (double)v[2] * (double)v[2]);
+      const float dist = (float)nd, inv_n = (float)(1.0 / nd);
+      const float maxd = dist * C.sf[F.octave[fo + i]];
+      for (int c = 0; c < 3; c++) { A.lm_po[3 * (lb + pid) + c] = po[c]; A.lm_normal[3 * (lb + pid) + c] = v[c] * inv_n; }
+      A.lm_maxd[lb + pid] = maxd; A.lm_mind[lb + pid] = maxd / C.sf[C.nlevels - 1];
+      const uint4* sd = reinterpret_cast<const uint4*>(F.desc + (fo + i) * 32);
+      uint4* dd = reinterpret_cast<uint4*>(A.lm_desc + (lb + pid) * 32);
+      dd[0] = sd[0]; dd[1] = sd[1];
+      F.mp_valid[fo + i] = 1; F.mp_observed[fo + i] = 1; F.mp_id[fo + i] = pid; F.outlier[fo + i] = 0;
+      for (int c = 0; c < 3; c++) F.mp_po[3 * (fo + i) + c] = po[c];
+    }
+    base += total;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    ObMapObject& O = A.mobj[(size_t)s * A.M + slot];
+    O.npts = base < A.LC ? base : A.LC;
+    O.kf_frame = step; O.local_valid = 0;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Tracking::TrackMapObject for one detection (pose prediction Tcl * Tco, InitializeCurrentObjPose, FineTuningUsing2dBox, or
+// MapObjectInit), then this detection's part of TrackLastFrameObjectPoint: the temporal points of its last-frame features and
+// the SearchByBruceMatching problem.  One workgroup per (detection, sequence).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OB_T) void ob_track(ObArrays A, int step) {
+  __shared__ ObShared sh;
+  __shared__ Se3 s_pose;
+  __shared__ int s_flag[4];
+  __shared__ unsigned long long s_stop[OB_T / 64];
+  const int j = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, K = A.K;
+  const ObCam& C = A.cam;
+  ObFrame& F = A.cur;
+  BfProb* bp = A.bf_prob + (size_t)s * K + j;
+  if (tid == 0) *bp = BfProb{0, 0, 0, 0};
+  if (j >= F.ndet[s] || !ob_camera_initialized(A, s, step)) return;
+  const size_t fb = (size_t)s * A.OC;
+  const int b0 = F.off[(size_t)s * (K + 1) + j], n = F.off[(size_t)s * (K + 1) + j + 1] - b0;
+  const size_t fo = fb + b0;
+  const ObDet det = F.det[(size_t)s * K + j];
+  const int moslot = F.mo[(size_t)s * K + j];
+  if (moslot == -1) return;                                         // the MapObject table is full: the detection is ignored
+  double* pts = A.cam_pts + 3 * fo;
+  int32_t* pidx = A.inl_flag + fo;                                  // feature index of point u
+  int32_t* scr = A.pj_match + fo;                                   // scratch of this detection's range: draws / per-feature flags
+  uint8_t* flag = reinterpret_cast<uint8_t*>(A.bf_qot + fo);        // inlier flags (bytes) in the range's bf_qot slots
+  ObStat* st = A.stats + ((size_t)step * A.S + s) * K + j;
+  int l;
+  ob_cam_points(A, F, fo, n, pts, pidx, &l, sh);
+  const float fmax_det = ob_fmax(det.scale);
+  if (moslot < 0) {
+    // ---- Tracking::MapObjectInit (Tracking.cc:1787-1930) ----
+    const int slot = -2 - moslot;
+    const int ninl = ob_ransac(pts, l, fmax_det, (int)(0.8 * l), scr, flag, sh.mean, sh);
+    bool ok = ninl >= 3;
+    double c[3] = {sh.mean[0], sh.mean[1], sh.mean[2]};
+    if (ok && c[2] < 8) ok = false;
+    if (!ok) { if (tid == 0) F.mo[(size_t)s * K + j] = -1; return; }
+    c[2] += 0.2 * det.scale[0];
+    c[1] = 0 + det.scale[1] / 2;
+    const Se3 truth = ob_pose(det.pose7);
+    if (tid < 64) {
+      double t[3] = {c[0], c[1], c[2]};
+      ob_fine_tune(C, det, truth.q, det.scale, t);
+      if (tid == 0) {
+        Se3 P = truth;
+        P.t[0] = t[0]; P.t[1] = t[1]; P.t[2] = t[2];
+        s_pose = P;
+        ObMapObject& O = A.mobj[(size_t)s * A.M + slot];
+        O.id = det.id; O.first_frame = step; O.tco_frame = step;
+        for (int k = 0; k < 3; k++) O.scale[k] = det.scale[k];
+        ob_store_pose(O.tco, P);
+        F.mo[(size_t)s * K + j] = slot;
+        st->tracked = 1; st->is_new = 1;
+      }
+    }
+    __syncthreads();
+    const Se3 pose = s_pose;
+    ob_keyframe_points(A, F, s, slot, fo, n, pose, pts, pidx, flag, l, fmax_det, A.occupied + fo, A.po_obs + 3 * fo, step, sh);
+    return;
+  }
+  // ---- an object seen before (Tracking.cc:1553-1622) ----
+  ObMapObject& O = A.mobj[(size_t)s * A.M + moslot];
+  if (tid == 0) {
+    // camera_Tcl = mCurrentFrame.mTcw * mLastFrame.mTwc when both frames have a pose, else the identity
+    const float* Fc = ob_cam_pose(A, s, step);
+    const float* Lc = ob_cam_pose(A, s, step - 1);
+    Se3 tcl;
+    tcl.q[0] = tcl.q[1] = tcl.q[2] = 0; tcl.q[3] = 1; tcl.t[0] = tcl.t[1] = tcl.t[2] = 0;
+    if (Fc && Lc) {
+      float twc[16], M4[16];
+      for (int i = 0; i < 16; i++) twc[i] = (i % 5 == 0) ? 1.f : 0.f;
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) twc[4 * r + c] = Lc[4 * c + r];
+      for (int r = 0; r < 3; r++) {
+        float acc = 0;
+        for (int c = 0; c < 3; c++) acc += Lc[4 * c + r] * Lc[4 * c + 3];
+        twc[4 * r + 3] = -acc;
+      }
+      for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+          float acc = 0;
+          for (int k = 0; k < 4; k++) acc += Fc[4 * r + k] * twc[4 * k + c];
+          M4[4 * r + c] = acc;
+        }
+      tcl = se3_from_mat4f(M4);
+    }
+    s_pose = se3_mul(tcl, ob_pose(O.tco));
+  }
+  __syncthreads();
+  {
+    // InitializeCurrentObjPose (Tracking.cc:1640-1702): the RANSAC centroid of the detection's stereo points replaces the translation
+    const int ninl = ob_ransac(pts, l, fmax_det, (int)(0.8 * l), scr, flag, sh.mean, sh);
+    Se3 pose = s_pose;
+    if (ninl >= 3) {
+      double c[3] = {sh.mean[0], sh.mean[1], sh.mean[2]};
+      if (c[2] > 8) c[2] += 0.2 * det.scale[0];
+      c[1] = 0 + det.scale[1] / 2;
+      pose.t[0] = c[0]; pose.t[1] = c[1]; pose.t[2] = c[2];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double t[3] = {pose.t[0], pose.t[1], pose.t[2]};
+      ob_fine_tune(C, det, pose.q, O.scale, t);
+      if (tid == 0) {
+        pose.t[0] = t[0]; pose.t[1] = t[1]; pose.t[2] = t[2];
+        s_pose = pose;
+        const int latest = O.tco_frame;
+        ob_store_pose(O.tco, pose);
+        O.tco_frame = step;
+        A.tracked[(size_t)s * K + j] = 1;
+        st->tracked = 1;
+        int lj = -1;
+        if (latest == step - 1) {
+          const int nl = A.last.ndet[s];
+          for (int k = 0; k < nl; k++) if (A.last.det[(size_t)s * K + k].id == det.id) { lj = k; break; }
+        }
+        A.in_last[(size_t)s * K + j] = lj;
+        s_flag[0] = lj;
+      }
+    }
+    __syncthreads();
+  }
+  const int lj = s_flag[0];
+  if (lj < 0) return;
+  // ---- TrackLastFrameObjectPoint, first part (Tracking.cc:2296-2366): temporal MapObjectPoints of the last frame's features ----
+  ObFrame& L = A.last;
+  const int lb0 = L.off[(size_t)s * (K + 1) + lj], ln = L.off[(size_t)s * (K + 1) + lj + 1] - lb0;
+  const size_t lo = fb + lb0;
+  if (!(O.kf_frame == step - 1 || O.first_frame == step - 1)) {
+    const Se3 inv = se3_inverse(ob_pose(L.tco + ((size_t)s * K + lj) * 7));
+    const float fmax_mo = ob_fmax(O.scale);
+    const float thr = 2 * C.th_depth;
+    // the reference walks the features by (depth, index) and stops behind the first one beyond 2 * mThDepth that it did not skip
+    // (a feature whose new point would lie farther than fmax from the object centre is skipped with `continue`, past the stop test)
+    unsigned long long stop = ~0ull;
+    for (int i = tid; i < ln; i += OB_T) {
+      const float d = L.depth[lo + i];
+      if (!(d > 0)) continue;
+      bool skipped = false;
+      if (!L.mp_valid[lo + i] || !L.mp_observed[lo + i]) {
+        const float xx = (L.x[lo + i] - C.cx) * d * C.inv_fx, yy = (L.y[lo + i] - C.cy) * d * C.inv_fy;
+        const double pc[3] = {(double)xx, (double)yy, (double)d};
+        double po[3];
+        se3_map(inv, pc, po);
+        const float pf[3] = {(float)po[0], (float)po[1], (float)po[2]};
+        const float nf = sqrtf(pf[0] * pf[0] + pf[1] * pf[1] + pf[2] * pf[2]);
+        skipped = nf > fmax_mo;
+      }
+      if (!skipped && d > thr) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+        stop = key < stop ? key : stop;
+      }
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+      const unsigned lo32 = __shfl_xor((unsigned)stop, dd), hi32 = __shfl_xor((unsigned)(stop >> 32), dd);
+      const unsigned long long o = ((unsigned long long)hi32 << 32) | lo32;
+      stop = o < stop ? o : stop;
+    }
+    if ((tid & 63) == 0) s_stop[tid >> 6] = stop;
+    __syncthreads();
+    stop = s_stop[0];
+    for (int w = 1; w < OB_T / 64; w++) stop = s_stop[w] < stop ? s_stop[w] : stop;
+    for (int i = tid; i < ln; i += OB_T) {
+      const float d = L.depth[lo + i];
+      if (!(d > 0)) continue;
+      const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+      if (key > stop) continue;
+      if (!L.mp_valid[lo + i] || !L.mp_observed[lo + i]) {
+        const float xx = (L.x[lo + i] - C.cx) * d * C.inv_fx, yy = (L.y[lo + i] - C.cy) * d * C.inv_fy;
+        const double pc[3] = {(double)xx, (double)yy, (double)d};
+        double po[3];
+        se3_map(inv, pc, po);
+        const float pf[3] = {(float)po[0], (float)po[1], (float)po[2]};
+        const float nf = sqrtf(pf[0] * pf[0] + pf[1] * pf[1] + pf[2] * pf[2]);
+        if (nf > fmax_mo) continue;
+        L.mp_valid[lo + i] = 1; L.mp_observed[lo + i] = 0; L.mp_id[lo + i] = -1;
+        for (int c = 0; c < 3; c++) L.mp_po[3 * (lo + i) + c] = pf[c];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- the SearchByBruceMatching problem (ORBmatcher.cc:2043-2155): queries = the last frame's features of the object ----
+  for (int i = tid; i < ln; i += OB_T) A.bf_qvalid[lo + i] = (L.mp_valid[lo + i] && !L.outlier[lo + i]) ? 1 : 0;
+  if (tid == 0) *bp = BfProb{(int32_t)lo, ln, (int32_t)fo, n};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// After the brute-force matcher: the matches become the frame's MapObjectPoints (Tracking.cc:2388-2390), and the first
+// CFSE3ObjStateOptimization problem over the detections with at least 10 matches (:2391-2425).  One workgroup per sequence.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ void ob_fill_cfse3(const ObArrays& A, int s, const int32_t* which, int step) {
+  const int tid = threadIdx.x, K = A.K;
+  const ObFrame& F = A.cur;
+  const ObCam& C = A.cam;
+  const size_t fb = (size_t)s * A.OC;
+  const int ntot = F.off[(size_t)s * (K + 1) + K];
+  for (int i = tid; i < ntot; i += OB_T) {
+    A.po_obs[3 * (fb + i)] = F.x[fb + i]; A.po_obs[3 * (fb + i) + 1] = F.y[fb + i]; A.po_obs[3 * (fb + i) + 2] = F.uright[fb + i];
+    A.po_is2[fb + i] = C.inv_sigma2[F.octave[fb + i]];
+  }
+  if (tid == 0) {
+    int nv = 0;
+    const int nd = F.ndet[s];
+    for (int j = 0; j < nd; j++) {
+      if (!which[(size_t)s * K + j]) continue;
+      const int slot = F.mo[(size_t)s * K + j];
+      const int b0 = F.off[(size_t)s * (K + 1) + j], b1 = F.off[(size_t)s * (K + 1) + j + 1];
+      A.po_vert[(size_t)s * K + nv] = PoVertex{(int32_t)(fb + b0), (int32_t)(fb + b1)};
+      const double* p = A.mobj[(size_t)s * A.M + slot].tco;
+      for (int c = 0; c < 7; c++) A.po_pose[((size_t)s * K + nv) * 7 + c] = p[c];
+      A.po_vmap[(size_t)s * K + nv] = j;
+      nv++;
+    }
+    A.po_prob[s] = PoProb{(int32_t)(s * K), nv, 1, C.fx, C.fy, C.cx, C.cy, C.mbf};
+    A.po_result[s] = 0;
+  }
+}
+
+__global__ __launch_bounds__(OB_T) void ob_after_bf(ObArrays A, int step) {
+  const int s = blockIdx.x, tid = threadIdx.x, K = A.K;
+  ObFrame& F = A.cur;
+  const ObFrame& L = A.last;
+  const size_t fb = (size_t)s * A.OC;
+  const int nd = F.ndet[s];
+  for (int j = 0; j < nd; j++) {
+    const int lj = A.in_last[(size_t)s * K + j];
+    if (lj < 0) continue;
+    const int b0 = F.off[(size_t)s * (K + 1) + j], n = F.off[(size_t)s * (K + 1) + j + 1] - b0;
+    const size_t lo = fb + L.off[(size_t)s * (K + 1) + lj];
+    for (int t = tid; t < n; t += OB_T) {
+      const int q = A.bf_qot[fb + b0 + t];
+      const size_t o = fb + b0 + t;
+      F.mp_valid[o] = q >= 0; F.mp_observed[o] = 0; F.mp_id[o] = -1;
+      if (q >= 0) {
+        F.mp_observed[o] = L.mp_observed[lo + q]; F.mp_id[o] = L.mp_id[lo + q];
+        for (int c = 0; c < 3; c++) F.mp_po[3 * o + c] = L.mp_po[3 * (lo + q) + c];
+      }
+    }
+    if (tid == 0) {
+      const int nm = A.bf_nmatch[(size_t)s * K + j];
+      A.stats[((size_t)step * A.S + s) * K + j].bf_matches = nm;
+      A.need[(size_t)s * K + j] = nm >= 10 ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  ob_fill_cfse3(A, s, A.need, step);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// After the first CFSE3: the optimised poses, the outliers discarded (Tracking.cc:2426-2462), then TrackObjectLocalMap's search:
+// UpdateObjectLocalKeyFrames / Points (the keyframe of the object's (re-)initialisation), Frame::isInFrustum(pMP, nOrder, 0.5)
+// (Frame.cc:1744-1790) and the SearchByProjection(F, nOrder, MOPs, th = 1) problem (Tracking.cc:2522-2575).
+// One workgroup per (detection, sequence).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OB_T) void ob_after_cf1(ObArrays A, int step) {
+  __shared__ int red[OB_T / 64];
+  extern __shared__ uint8_t seen[];
+  const int j = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, K = A.K;
+  const ObCam& C = A.cam;
+  ObFrame& F = A.cur;
+  PjProb* pp = A.pj_prob + (size_t)s * K + j;
+  if (tid == 0) {
+    PjProb d;
+    for (int i = 0; i < (int)(sizeof(PjProb) / 4); i++) ((int32_t*)&d)[i] = 0;
+    *pp = d;
+  }
+  if (j >= F.ndet[s] || !A.tracked[(size_t)s * K + j]) return;
+  const size_t fb = (size_t)s * A.OC;
+  const int b0 = F.off[(size_t)s * (K + 1) + j], n = F.off[(size_t)s * (K + 1) + j + 1] - b0;
+  const size_t fo = fb + b0;
+  const int slot = F.mo[(size_t)s * K + j];
+  ObMapObject& O = A.mobj[(size_t)s * A.M + slot];
+  ObStat* st = A.stats + ((size_t)step * A.S + s) * K + j;
+  if (A.need[(size_t)s * K + j]) {
+    if (A.po_result[s] && tid == 0) {
+      const int nv = A.po_prob[s].k;
+      for (int v = 0; v < nv; v++)
+        if (A.po_vmap[(size_t)s * K + v] == j) for (int c = 0; c < 7; c++) O.tco[c] = A.po_pose[((size_t)s * K + v) * 7 + c];
+    }
+    int nmap = 0;
+    for (int i = tid; i < n; i += OB_T) {
+      if (!F.mp_valid[fo + i]) continue;
+      if (F.outlier[fo + i]) { F.mp_valid[fo + i] = 0; F.outlier[fo + i] = 0; continue; }
+      if (F.mp_observed[fo + i]) nmap++;
+    }
+    nmap = ob_block_sum(nmap, red);
+    if (tid == 0) A.track_ok[(size_t)s * K + j] = nmap >= 10 ? 1 : 0;
+  }
+  __syncthreads();
+  // ---- SearchObjectLocalPoints ----
+  int anyobs = 0;
+  for (int i = tid; i < n; i += OB_T) anyobs |= (F.mp_valid[fo + i] && F.mp_observed[fo + i]) ? 1 : 0;
+  anyobs = ob_block_sum(anyobs, red);
+  if (anyobs && tid == 0) O.local_valid = 1;
+  __syncthreads();
+  const int nloc = O.local_valid ? O.npts : 0;
+  for (int i = tid; i < nloc; i += OB_T) seen[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += OB_T) {
+    const int id = F.mp_id[fo + i];
+    if (id >= 0 && id < nloc) seen[id] = 1;        // mnLastFrameSeen: the frame's points and the outliers just discarded
+  }
+  __syncthreads();
+  const ObDet det = F.det[(size_t)s * K + j];
+  const double bx0 = (double)det.bbox[0], by0 = (double)det.bbox[1];
+  const double bx1 = (double)det.bbox[0] + (double)det.bbox[2], by1 = (double)det.bbox[1] + (double)det.bbox[3];
+  const Se3 tco = ob_pose(O.tco);
+  const Se3 inv = se3_inverse(tco);
+  const float poc[3] = {(float)inv.t[0], (float)inv.t[1], (float)inv.t[2]};
+  const size_t lb = ((size_t)s * A.M + slot) * A.LC;
+  int nto = 0;
+  for (int i = tid; i < nloc; i += OB_T) {
+    const size_t q = lb + i;
+    A.pj_qvalid[q] = 0; A.pj_qu[q] = 0.f; A.pj_qv[q] = 0.f; A.pj_qur[q] = 0.f; A.pj_qrad[q] = 5.f; A.pj_qrer[q] = 0.f; A.pj_qminl[q] = 0; A.pj_qmaxl[q] = 0;
+    if (seen[i]) continue;
+    const float* po = A.lm_po + 3 * q;
+    const double pod[3] = {(double)po[0], (double)po[1], (double)po[2]};
+    double pc[3];
+    se3_map(tco, pod, pc);
+    const float X = (float)pc[0], Y = (float)pc[1], Z = (float)pc[2];
+    if (Z < 0) continue;
+    const float invz = 1.0f / Z;
+    const float u = C.fx * X * invz + C.cx, v = C.fy * Y * invz + C.cy;
+    if (!((double)u >= bx0 && (double)u < bx1 && (double)v >= by0 && (double)v < by1)) continue;
+    const float d[3] = {po[0] - poc[0], po[1] - poc[1], po[2] - poc[2]};
+    const float dist = (float)sqrt((double)d[0] * (double)d[0] + (double)d[1] * (double)d[1] + (double)d[2] * (double)d[2]);
+    const float maxd = 1.2f * A.lm_maxd[q], mind = 0.8f * A.lm_mind[q];
+    if (dist < mind || dist > maxd) continue;
+    const float* pn = A.lm_normal + 3 * q;
+    const double dot = (double)d[0] * (double)pn[0] + (double)d[1] * (double)pn[1] + (double)d[2] * (double)pn[2];
+    const float viewCos = (float)(dot / (double)dist);
+    if (viewCos < 0.5f) continue;
+    const float ratio = A.lm_maxd[q] / dist;
+    int level = (int)ceilf((float)log((double)ratio) / C.log_sf);
+    level = level < 0 ? 0 : (level >= C.nlevels ? C.nlevels - 1 : level);
+    const float r = (double)viewCos > 0.998 ? 2.5f : 4.0f;
+    A.pj_qvalid[q] = 1; A.pj_qu[q] = u; A.pj_qv[q] = v; A.pj_qur[q] = u - C.mbf * invz;
+    A.pj_qrer[q] = r * C.sf[level]; A.pj_qminl[q] = level - 1; A.pj_qmaxl[q] = level + 1;
+    nto++;
+  }
+  nto = ob_block_sum(nto, red);
+  if (tid == 0) st->lm_candidates = nto;
+  if (nto > 0) {
+    for (int i = tid; i < n; i += OB_T) {
+      const double x = (double)F.x[fo + i], y = (double)F.y[fo + i];
+      A.inbbox[fo + i] = (x >= bx0 && x < bx1 && y >= by0 && y < by1) ? 1 : 0;
+      A.occupied[fo + i] = (F.mp_valid[fo + i] && F.mp_observed[fo + i]) ? 1 : 0;
+    }
+    if (tid == 0) {
+      PjProb d;
+      for (int i = 0; i < (int)(sizeof(PjProb) / 4); i++) ((int32_t*)&d)[i] = 0;
+      d.t_off = (int32_t)fo; d.nt = n; d.q_off = (int32_t)lb; d.nq = nloc; d.c_off = (int32_t)(((size_t)s * K + j) * A.LC);
+      d.grid_off = (int32_t)(((size_t)s * K + j) * (OB_NCELL + 1));
+      d.min_x = 0.f; d.min_y = 0.f; d.gw_inv = C.gw_inv; d.gh_inv = C.gh_inv;
+      d.th_dist = 130; d.ratio_test = 1; d.nn_ratio = 0.8f; d.check_ori = 0; d.use_bbox = 1; d.frame_mode = 0;
+      d.fx = C.fx; d.fy = C.fy; d.cx = C.cx; d.cy = C.cy; d.mbf = C.mbf; d.mb = C.mb;
+      for (int l = 0; l < 8; l++) d.scale[l] = l < C.nlevels ? C.sf[l] : 1.f;
+      d.th = 1.f;
+      *pp = d;
+    }
+  }
+}
+
+// After the windowed matcher: the local-map matches join the frame's points (ORBmatcher.cc:236-239), then the second CFSE3 problem
+// over every tracked detection (Tracking.cc:2473-2491).  One workgroup per sequence.
+__global__ __launch_bounds__(OB_T) void ob_after_lm(ObArrays A, int step) {
+  const int s = blockIdx.x, tid = threadIdx.x, K = A.K;
+  ObFrame& F = A.cur;
+  const size_t fb = (size_t)s * A.OC;
+  const int nd = F.ndet[s];
+  for (int j = 0; j < nd; j++) {
+    if (!A.tracked[(size_t)s * K + j] || A.pj_prob[(size_t)s * K + j].nq == 0) continue;
+    const int b0 = F.off[(size_t)s * (K + 1) + j], n = F.off[(size_t)s * (K + 1) + j + 1] - b0;
+    const int slot = F.mo[(size_t)s * K + j];
+    const size_t lb = ((size_t)s * A.M + slot) * A.LC;
+    for (int t = tid; t < n; t += OB_T) {
+      const int m = A.pj_match[fb + b0 + t];
+      if (m < 0) continue;
+      const size_t o = fb + b0 + t;
+      F.mp_valid[o] = 1; F.mp_observed[o] = 1; F.mp_id[o] = m;
+      for (int c = 0; c < 3; c++) F.mp_po[3 * o + c] = A.lm_po[3 * (lb + m) + c];
+    }
+    if (tid == 0) A.stats[((size_t)step * A.S + s) * K + j].lm_matches = A.pj_nmatch[(size_t)s * K + j];
+  }
+  __syncthreads();
+  ob_fill_cfse3(A, s, A.tracked, step);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The end of the object chain: the second CFSE3's poses and inliers (Tracking.cc:2492-2520), the end of Track for SLOT mode 4
+// (:1443-1478: matches on temporal points dropped, MapObjectReInit for a detection whose tracking failed, :1932-2031), the
+// frame's statistics, and mLastFrame = Frame(mCurrentFrame).  One workgroup per (detection, sequence).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OB_T) void ob_finish(ObArrays A, int step) {
+  __shared__ ObShared sh;
+  __shared__ Se3 s_pose;
+  __shared__ int s_int[2];
+  const int j = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, K = A.K;
+  const ObCam& C = A.cam;
+  ObFrame& F = A.cur;
+  ObFrame& L = A.last;
+  const size_t fb = (size_t)s * A.OC;
+  const int nd = F.ndet[s];
+  if (j < nd) {
+    const int b0 = F.off[(size_t)s * (K + 1) + j], n = F.off[(size_t)s * (K + 1) + j + 1] - b0;
+    const size_t fo = fb + b0;
+    const int slot = F.mo[(size_t)s * K + j];
+    ObStat* st = A.stats + ((size_t)step * A.S + s) * K + j;
+    if (slot >= 0) {
+      ObMapObject& O = A.mobj[(size_t)s * A.M + slot];
+      if (A.tracked[(size_t)s * K + j]) {
+        if (A.po_result[s] && tid == 0) {
+          const int nv = A.po_prob[s].k;
+          for (int v = 0; v < nv; v++)
+            if (A.po_vmap[(size_t)s * K + v] == j) for (int c = 0; c < 7; c++) O.tco[c] = A.po_pose[((size_t)s * K + v) * 7 + c];
+        }
+        int inl = 0;
+        for (int i = tid; i < n; i += OB_T) {
+          if (!F.mp_valid[fo + i]) continue;
+          if (F.outlier[fo + i]) F.mp_valid[fo + i] = 0;
+          else if (F.mp_observed[fo + i]) inl++;
+        }
+        inl = ob_block_sum(inl, sh.red);
+        if (tid == 0) { st->inliers = inl; A.track_ok[(size_t)s * K + j] = inl > 10 ? 1 : 0; }
+      }
+      __syncthreads();
+      if (O.first_frame != step) {
+        for (int i = tid; i < n; i += OB_T)
+          if (F.mp_valid[fo + i] && !F.mp_observed[fo + i]) { F.mp_valid[fo + i] = 0; F.outlier[fo + i] = 0; }
+        __syncthreads();
+        if (!A.track_ok[(size_t)s * K + j]) {
+          // ---- Tracking::MapObjectReInit ----
+          if (tid == 0) { st->reinit = 1; O.npts = 0; }
+          for (int i = tid; i < n; i += OB_T) { F.mp_valid[fo + i] = 0; F.mp_observed[fo + i] = 0; F.mp_id[fo + i] = -1; F.outlier[fo + i] = 0; }
+          const ObDet det = F.det[(size_t)s * K + j];
+          const float fmax_det = ob_fmax(det.scale);
+          double* pts = A.cam_pts + 3 * fo;
+          int32_t* pidx = A.inl_flag + fo;
+          int32_t* scr = A.pj_match + fo;
+          uint8_t* flag = reinterpret_cast<uint8_t*>(A.bf_qot + fo);
+          // the features with depth in (depth, index) order up to the first one beyond 2 * mThDepth past the 100th
+          const float thr = 2 * C.th_depth;
+          int l = 0;
+          {
+            // rank of every feature among those with depth; the list ends at the smallest rank r with depth > thr and r + 1 > 100
+            int* rank = scr;
+            for (int i = tid; i < n; i += OB_T) {
+              const float d = F.depth[fo + i];
+              int r = -1;
+              if (d > 0) {
+                r = 0;
+                for (int k = 0; k < n; k++) { const float dk = F.depth[fo + k]; r += (dk > 0 && (dk < d || (dk == d && k < i))) ? 1 : 0; }
+              }
+              rank[i] = r;
+            }
+            __syncthreads();
+            int stop = 1 << 30, cntd = 0;
+            for (int i = tid; i < n; i += OB_T) {
+              const int r = rank[i];
+              if (r < 0) continue;
+              cntd++;
+              if (F.depth[fo + i] > thr && r + 1 > 100) stop = min(stop, r);
+            }
+            cntd = ob_block_sum(cntd, sh.red);
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) stop = min(stop, __shfl_xor(stop, dd));
+            __syncthreads();
+            if ((tid & 63) == 0) sh.red[tid >> 6] = stop;
+            __syncthreads();
+            stop = sh.red[0];
+            for (int w = 1; w < OB_T / 64; w++) stop = min(stop, sh.red[w]);
+            l = stop < cntd ? stop + 1 : cntd;
+            __syncthreads();
+            for (int i = tid; i < n; i += OB_T) {
+              const int r = rank[i];
+              if (r < 0 || r >= l) continue;
+              const float z = F.depth[fo + i];
+              const float xx = (F.x[fo + i] - C.cx) * z * C.inv_fx, yy = (F.y[fo + i] - C.cy) * z * C.inv_fy;
+              pts[3 * r] = (double)xx; pts[3 * r + 1] = (double)yy; pts[3 * r + 2] = (double)z;
+              pidx[r] = i;
+            }
+            __syncthreads();
+          }
+          const int ninl = ob_ransac(pts, l, fmax_det, l, scr, flag, sh.mean, sh);
+          bool ok = ninl > 3;
+          double c[3] = {sh.mean[0], sh.mean[1], sh.mean[2]};
+          if (ok && c[2] < 8) ok = false;
+          if (ok) {
+            if (c[2] > 8) c[2] += 0.2 * det.scale[0];
+            c[1] = 0 + det.scale[1] / 2;
+            const Se3 truth = ob_pose(det.pose7);
+            if (tid < 64) {
+              double t[3] = {c[0], c[1], c[2]};
+              ob_fine_tune(C, det, truth.q, det.scale, t);
+              if (tid == 0) {
+                Se3 P = truth;
+                P.t[0] = t[0]; P.t[1] = t[1]; P.t[2] = t[2];
+                s_pose = P;
+                ob_store_pose(O.tco, P);
+                O.tco_frame = step;
+              }
+            }
+            __syncthreads();
+            const Se3 pose = s_pose;
+            ob_keyframe_points(A, F, s, slot, fo, n, pose, pts, pidx, flag, l, fmax_det, A.occupied + fo, A.po_obs + 3 * fo, step, sh);
+          }
+        }
+      }
+      __syncthreads();
+      int mpn = 0;
+      for (int i = tid; i < n; i += OB_T) mpn += (F.mp_valid[fo + i] && F.mp_observed[fo + i]) ? 1 : 0;
+      mpn = ob_block_sum(mpn, sh.red);
+      if (tid == 0) {
+        st->map_points = mpn; st->track_ok = A.track_ok[(size_t)s * K + j];
+        for (int c = 0; c < 7; c++) { st->tco[c] = O.tco[c]; F.tco[((size_t)s * K + j) * 7 + c] = O.tco[c]; }
+      }
+    }
+    __syncthreads();
+    // ---- mLastFrame = Frame(mCurrentFrame): this detection's features ----
+    for (int i = tid; i < n; i += OB_T) {
+      const size_t o = fo + i;
+      L.x[o] = F.x[o]; L.y[o] = F.y[o]; L.angle[o] = F.angle[o]; L.uright[o] = F.uright[o]; L.depth[o] = F.depth[o]; L.octave[o] = F.octave[o];
+      L.mp_valid[o] = F.mp_valid[o]; L.mp_observed[o] = F.mp_observed[o]; L.outlier[o] = F.outlier[o]; L.mp_id[o] = F.mp_id[o];
+      for (int c = 0; c < 3; c++) L.mp_po[3 * o + c] = F.mp_po[3 * o + c];
+    }
+    const uint4* sd = reinterpret_cast<const uint4*>(F.desc + fo * 32);
+    uint4* dd = reinterpret_cast<uint4*>(L.desc + fo * 32);
+    for (int i = tid; i < 2 * n; i += OB_T) dd[i] = sd[i];
+    if (tid == 0) {
+      L.det[(size_t)s * K + j] = F.det[(size_t)s * K + j];
+      L.mo[(size_t)s * K + j] = F.mo[(size_t)s * K + j];
+      for (int c = 0; c < 7; c++) L.tco[((size_t)s * K + j) * 7 + c] = F.tco[((size_t)s * K + j) * 7 + c];
+    }
+  }
+  if (j == 0) {
+    if (tid <= K) L.off[(size_t)s * (K + 1) + tid] = F.off[(size_t)s * (K + 1) + tid];
+    if (tid == 0) L.ndet[s] = nd;
+  }
+  (void)s_int;
+}
+
+// ---- brute-force matcher: the block table of bf_topk derived from the problem table on the device ----
+__global__ __launch_bounds__(64) void ob_bf_blocks(const BfProb* probs, BfBlock* blocks, int nprob, int blocks_per_prob) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= nprob * blocks_per_prob) return;
+  const int p = i / blocks_per_prob, b = i % blocks_per_prob;
+  const BfProb P = probs[p];
+  const int first = b * PS_BF_QPB;
+  const int count = (P.nt > 0 && first < P.nq) ? min(PS_BF_QPB, P.nq - first) : 0;
+  blocks[i] = BfBlock{p, first, count, 0};
+}
+
+}  // namespace
+
+extern "C" {
+void psk_ob_masks(const ObArrays* A, uint8_t* objmask, int W, int H, hipStream_t st) {
+  const size_t lds = ((W + 63) & ~63) + (size_t)W * 2 + 64;
+  hipLaunchKernelGGL(ob_masks, dim3(H, A->S), dim3(OB_T), lds, st, *A, objmask, W, H);
+}
+void psk_ob_begin(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_begin, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
+void psk_ob_track(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_track, dim3(A->K, A->S), dim3(OB_T), 0, st, *A, step); }
+void psk_ob_bf_blocks(const BfProb* probs, BfBlock* blocks, int nprob, int blocks_per_prob, hipStream_t st) {
+  hipLaunchKernelGGL(ob_bf_blocks, dim3((nprob * blocks_per_prob + 63) / 64), dim3(64), 0, st, probs, blocks, nprob, blocks_per_prob);
+}
+void psk_ob_after_bf(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_bf, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
+void psk_ob_after_cf1(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_cf1, dim3(A->K, A->S), dim3(OB_T), (size_t)A->LC, st, *A, step); }
+void psk_ob_after_lm(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_lm, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
+void psk_ob_finish(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_finish, dim3(A->K, A->S), dim3(OB_T), 0, st, *A, step); }
+}

@@ -400,6 +400,7 @@ void ps_orb_destroy(ps_orb* h) {
 // accessors for track_host.hip (the lockstep tracker owns an extractor and queues its own kernels behind it)
 hipStream_t psi_orb_stream(ps_orb* h) { return h->stream; }
 const OrbPlan* psi_orb_plan(ps_orb* h) { return &h->plan; }
+uint8_t* psi_orb_arena(ps_orb* h) { return h->d_arena; }
 int psi_orb_prepare(ps_orb* h, int w, int hgt) {
   PS_HIP(hipSetDevice(h->cfg.device));
   if (!h->planned || h->plan.img_w != w || h->plan.img_h != hgt) return build_plan(h, w, hgt);

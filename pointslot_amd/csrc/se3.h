@@ -76,6 +76,14 @@ PS_HD Se3 se3_mul(const Se3& a, const Se3& b) {
   se3_normalize(r);
   return r;
 }
+// SE3Quat::inverse (se3quat.h:112-117): conjugate rotation, t = q^-1 * (t * -1)
+PS_HD Se3 se3_inverse(const Se3& a) {
+  Se3 r;
+  r.q[0] = -a.q[0]; r.q[1] = -a.q[1]; r.q[2] = -a.q[2]; r.q[3] = a.q[3];
+  const double nt[3] = {a.t[0] * -1., a.t[1] * -1., a.t[2] * -1.};
+  se3_rotate(r.q, nt, r.t);
+  return r;
+}
 PS_HD Se3 se3_from_Rt(const double R[9], const double t[3]) {
   Se3 T;
   se3_quat_from_R(R, T.q);

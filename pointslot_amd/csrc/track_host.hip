@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "../../include/pointslot_hip.h"
+#include "objtrack_plan.h"
 #include "orb_plan.h"
 #include "ps_common.h"
 #include "track_plan.h"
@@ -25,14 +26,25 @@ void psk_trk_after_mm(const TrkArrays*, int, hipStream_t);
 void psk_trk_after_pose1(const TrkArrays*, int, hipStream_t);
 void psk_trk_after_lm(const TrkArrays*, hipStream_t);
 void psk_trk_finish(const TrkArrays*, int, hipStream_t);
+uint8_t* psi_orb_arena(ps_orb*);
+void psk_stereo_launch(const OrbPlan*, const StPair*, int, int, float, float, hipStream_t);
+void psk_bf_launch(const BfBlock*, int, const BfProb*, int, const uint8_t*, const float*, const uint8_t*, const uint8_t*, const float*, uint32_t*, int32_t*, int32_t*,
+                   float, int, hipStream_t);
+void psk_ob_masks(const ObArrays*, uint8_t*, int, int, hipStream_t);
+void psk_ob_begin(const ObArrays*, int, hipStream_t);
+void psk_ob_track(const ObArrays*, int, hipStream_t);
+void psk_ob_bf_blocks(const BfProb*, BfBlock*, int, int, hipStream_t);
+void psk_ob_after_bf(const ObArrays*, int, hipStream_t);
+void psk_ob_after_cf1(const ObArrays*, int, hipStream_t);
+void psk_ob_after_lm(const ObArrays*, int, hipStream_t);
+void psk_ob_finish(const ObArrays*, int, hipStream_t);
 }
 
 namespace {
-enum { TS_ORB = 0, TS_STEREO, TS_GLUE, TS_SEARCH, TS_POSE, TS_COUNT };
-const char* kTrkStage[TS_COUNT] = {"orb_extract", "stereo_match", "track_glue", "search_by_projection", "pose_optimization"};
-// events of one step: boundaries between the launches below, and the stage every interval belongs to
-const int kTrkIntervals = 12;
-const int kTrkIntervalStage[kTrkIntervals] = {TS_ORB, TS_STEREO, TS_GLUE, TS_SEARCH, TS_GLUE, TS_SEARCH, TS_GLUE, TS_POSE, TS_GLUE, TS_SEARCH, TS_GLUE, TS_POSE};
+enum { TS_ORB = 0, TS_STEREO, TS_GLUE, TS_SEARCH, TS_POSE, TS_OBJ_FEATURES, TS_OBJ_STEREO, TS_OBJ_GLUE, TS_OBJ_BRUTEFORCE, TS_OBJ_CFSE3, TS_OBJ_SEARCH, TS_COUNT };
+const char* kTrkStage[TS_COUNT] = {"orb_extract", "stereo_match", "track_glue", "search_by_projection", "pose_optimization",
+                                   "object_features", "object_stereo_match", "object_glue", "object_bruteforce", "object_cfse3", "object_search_by_projection"};
+const int kTrkMaxEvents = 32;   // events of one step: boundaries between the launches of queue_chain
 }  // namespace
 
 struct ps_tracker {
@@ -48,9 +60,20 @@ struct ps_tracker {
   int32_t* d_overflow = nullptr;
   int step = 0;
   float mb = 0, mbf = 0;
+  // the object half (max_objects > 0)
+  ps_cvorb* cvorb = nullptr;
+  uint8_t* d_obj = nullptr; size_t d_obj_bytes = 0;
+  ObArrays OA;
+  uint8_t* d_objmask = nullptr;      // [2 S][h][w] LeftObjMask / RightObjMask
+  StPair* d_obj_pairs = nullptr;
+  BfBlock* d_bf_blocks = nullptr; int bf_blocks_per_prob = 0;
+  PjArrays pj_obj;
+  double* ob_chi2 = nullptr; uint8_t* ob_state = nullptr;
   // stage timing
   static const int RING = 64;
-  hipEvent_t ev[RING][kTrkIntervals + 2] = {};
+  hipEvent_t ev[RING][kTrkMaxEvents] = {};
+  int ev_stage[kTrkMaxEvents] = {};   // stage of the interval that ends at event i (the same for every step)
+  int ev_count = 0;
   bool timing = false;
   int timed = 0;
 };
@@ -115,34 +138,140 @@ size_t carve(ps_tracker* t, uint8_t* base) {
   return c.off;
 }
 
-int queue_chain(ps_tracker* t) {
-  const TrkArrays* A = &t->A;
+// carve the object half's arrays (nullptr base: only measures)
+void carve_obj_frame(Carver& c, ObFrame& f, size_t S, size_t OC, size_t K) {
+  const size_t n = S * OC;
+  f.x = c.take<float>(n); f.y = c.take<float>(n); f.angle = c.take<float>(n); f.uright = c.take<float>(n); f.depth = c.take<float>(n);
+  f.octave = c.take<int32_t>(n); f.desc = c.take<uint8_t>(32 * n);
+  f.mp_valid = c.take<uint8_t>(n); f.mp_observed = c.take<uint8_t>(n); f.outlier = c.take<uint8_t>(n); f.mp_id = c.take<int32_t>(n); f.mp_po = c.take<float>(3 * n);
+  f.off = c.take<int32_t>(S * (K + 1)); f.det = c.take<ObDet>(S * K); f.mo = c.take<int32_t>(S * K); f.tco = c.take<double>(S * K * 7);
+  f.cell_off = c.take<int32_t>(S * K * (OB_NCELL + 1)); f.cell_idx = c.take<int32_t>(n); f.ndet = c.take<int32_t>(S);
+}
+
+size_t carve_obj(ps_tracker* t, uint8_t* base) {
+  Carver c{base};
+  ObArrays& A = t->OA;
+  const size_t S = A.S, K = A.K, M = A.M, OC = A.OC, LC = A.LC, n = S * OC, nl = S * M * LC;
+  carve_obj_frame(c, A.cur, S, OC, K); carve_obj_frame(c, A.last, S, OC, K);
+  A.mobj = c.take<ObMapObject>(S * M);
+  A.lm_po = c.take<float>(3 * nl); A.lm_normal = c.take<float>(3 * nl); A.lm_maxd = c.take<float>(nl); A.lm_mind = c.take<float>(nl); A.lm_desc = c.take<uint8_t>(32 * nl);
+  A.owner = c.take<int8_t>(n);
+  A.in_last = c.take<int32_t>(S * K); A.tracked = c.take<int32_t>(S * K); A.need = c.take<int32_t>(S * K); A.track_ok = c.take<int32_t>(S * K);
+  A.inl_flag = c.take<int32_t>(n); A.cam_pts = c.take<double>(3 * n);
+  A.bf_prob = c.take<BfProb>(S * K); A.bf_topk = c.take<uint32_t>(n * PS_BF_TOPK); A.bf_qvalid = c.take<uint8_t>(n); A.bf_qot = c.take<int32_t>(n);
+  A.bf_nmatch = c.take<int32_t>(S * K);
+  A.pj_prob = c.take<PjProb>(S * K);
+  A.pj_qvalid = c.take<uint8_t>(nl); A.pj_qu = c.take<float>(nl); A.pj_qv = c.take<float>(nl); A.pj_qur = c.take<float>(nl); A.pj_qrad = c.take<float>(nl);
+  A.pj_qrer = c.take<float>(nl); A.pj_qminl = c.take<int32_t>(nl); A.pj_qmaxl = c.take<int32_t>(nl);
+  A.occupied = c.take<uint8_t>(n); A.inbbox = c.take<uint8_t>(n); A.pj_match = c.take<int32_t>(n); A.pj_nmatch = c.take<int32_t>(S * K);
+  A.po_prob = c.take<PoProb>(S); A.po_vert = c.take<PoVertex>(S * K + 1); A.po_obs = c.take<float>(3 * n); A.po_is2 = c.take<float>(n);
+  A.po_pose = c.take<double>(S * K * 7); A.po_result = c.take<int32_t>(S); A.po_vmap = c.take<int32_t>(S * K);
+  A.stats = c.take<ObStat>((size_t)A.max_steps * S * K);
+  A.dropped = c.take<int32_t>(S);
+  t->ob_chi2 = c.take<double>(n); t->ob_state = c.take<uint8_t>(n);
+  t->d_objmask = c.take<uint8_t>(2 * S * (size_t)t->cfg.width * t->cfg.height);
+  t->d_obj_pairs = c.take<StPair>(S);
+  t->bf_blocks_per_prob = (int)((OC + PS_BF_QPB - 1) / PS_BF_QPB);
+  t->d_bf_blocks = c.take<BfBlock>(S * K * t->bf_blocks_per_prob);
+  float* st_ur = c.take<float>(n); float* st_dp = c.take<float>(n); int32_t* st_sad = c.take<int32_t>(n); int32_t* st_kept = c.take<int32_t>(S);
+  uint8_t* st_scratch = c.take<uint8_t>(S * (size_t)PS_ST_SCRATCH);
+  // windowed-matcher work arrays of the object searches
+  uint8_t* ones = c.take<uint8_t>(nl);
+  uint32_t* cand = c.take<uint32_t>(S * K * LC * PS_PJ_CAP);
+  int32_t* ncand = c.take<int32_t>(nl); int32_t* qbest = c.take<int32_t>(nl); uint8_t* qbin = c.take<uint8_t>(nl); uint4* ttop = c.take<uint4>(nl);
+  int32_t* ovf = c.take<int32_t>(S * K);
+  A.st_uright = st_ur; A.st_depth = st_dp;
+  PjArrays P;
+  memset(&P, 0, sizeof(P));
+  P.prob = A.pj_prob;
+  P.tx = A.cur.x; P.ty = A.cur.y; P.toct = A.cur.octave; P.tang = A.cur.angle; P.tur = A.cur.uright; P.tdesc = A.cur.desc;
+  P.tocc = A.occupied; P.tbbox = A.inbbox; P.cell_off = A.cur.cell_off; P.cell_idx = A.cur.cell_idx;
+  P.qvalid = A.pj_qvalid; P.qu = A.pj_qu; P.qv = A.pj_qv; P.qur = A.pj_qur; P.qrad = A.pj_qrad; P.qrer = A.pj_qrer; P.qminl = A.pj_qminl; P.qmaxl = A.pj_qmaxl;
+  P.qdesc = A.lm_desc; P.qobs = ones; P.qang = A.pj_qu; P.qxw = nullptr; P.qoct = nullptr;
+  P.cand = cand; P.ncand = ncand; P.match = A.pj_match; P.nmatch = A.pj_nmatch; P.overflow = ovf; P.qbest = qbest; P.ttop = ttop; P.qbin = qbin;
+  t->pj_obj = P;
+  if (base) {
+    hipMemsetAsync(ones, 1, nl, t->stream);
+    // the stereo matcher's pair table of the object keys: cv::ORB results of images 2s / 2s + 1 against the extractor's pyramids
+    const OrbPlan* plan = psi_orb_plan(t->orb);
+    uint8_t* arena = psi_orb_arena(t->orb);
+    const ps_keypoint* ckps = nullptr; const uint8_t* cdesc = nullptr; const int32_t* ccnt = nullptr; int32_t ccap = 0;
+    ps_cvorb_batch_device_outputs(t->cvorb, &ckps, &cdesc, &ccnt, nullptr, &ccap);
+    std::vector<StPair> pairs(S);
+    for (size_t k = 0; k < S; k++) {
+      StPair& p = pairs[k];
+      const size_t l = 2 * k, r = l + 1;
+      p.arena_l = arena + l * plan->arena_bytes; p.arena_r = arena + r * plan->arena_bytes;
+      p.kps_l = ckps + l * ccap; p.desc_l = cdesc + l * ccap * 32; p.cnt_l = ccnt + l;
+      p.kps_r = ckps + r * ccap; p.desc_r = cdesc + r * ccap * 32; p.cnt_r = ccnt + r;
+      p.u_right = st_ur + k * OC; p.depth = st_dp + k * OC; p.sad = st_sad + k * OC; p.kept = st_kept + k;
+      p.scratch = st_scratch + k * PS_ST_SCRATCH;
+    }
+    hipMemcpy(t->d_obj_pairs, pairs.data(), S * sizeof(StPair), hipMemcpyHostToDevice);
+    A.cv_kps = ckps; A.cv_desc = cdesc; A.cv_count = ccnt; A.cv_cap = ccap;
+  }
+  return c.off;
+}
+
+int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_pitch, const uint8_t* d_masks, int mask_stride, size_t mask_pitch,
+                const ps_detection* d_dets) {
+  TrkArrays* A = &t->A;
   hipStream_t st = t->stream;
   const int S = A->S, cap = A->cap;
   const bool tm = t->timing;
   hipEvent_t* ev = t->ev[t->timed % ps_tracker::RING];
-  int e = 1;   // ev[0] was recorded before the extraction, ev[1] after it comes first here
-  auto mark = [&]() { if (tm) hipEventRecord(ev[e++], st); };
-  mark();                                                       // end of orb
+  int e = 1;   // ev[0] was recorded before the extraction
+  auto mark = [&](int stage) { t->ev_stage[e] = stage; if (tm) hipEventRecord(ev[e], st); e++; };
+  A->idmask = d_masks; A->mask_stride = mask_stride; A->mask_pitch = mask_pitch;
+  mark(TS_ORB);
   int rc = ps_orb_stereo_match_batch(t->orb, S, t->mb, t->mbf);
   if (rc != PS_OK) return rc;
-  mark();                                                       // stereo
-  psk_trk_begin(A, t->step, st); mark();                        // glue
-  psk_pj_launch(&t->pj_mm1, S, cap, 1, 0, st); mark();             // search
-  psk_trk_after_mm1(A, st); mark();                             // glue
-  psk_pj_launch(&t->pj_mm2, S, cap, 1, 0, st); mark();             // search (the 2 * th retry; empty problems where it is not needed)
-  psk_trk_after_mm(A, t->step, st); mark();                     // glue
+  mark(TS_STEREO);
+  psk_trk_begin(A, t->step, st); mark(TS_GLUE);
+  psk_pj_launch(&t->pj_mm1, S, cap, 1, 0, st); mark(TS_SEARCH);
+  psk_trk_after_mm1(A, st); mark(TS_GLUE);
+  psk_pj_launch(&t->pj_mm2, S, cap, 1, 0, st); mark(TS_SEARCH);   // the 2 * th retry; empty problems where it is not needed
+  psk_trk_after_mm(A, t->step, st); mark(TS_GLUE);
   psk_pose_lm_launch(A->po_prob, S, A->po_vert, A->cur.xw, A->po_obs, A->po_is2, A->cur.mp_valid, A->cur.outlier, t->po_chi2, t->po_state,
                      A->po_pose, A->po_result, nullptr, st);
-  mark();                                                       // pose
-  psk_trk_after_pose1(A, t->step, st); mark();                  // glue
-  psk_pj_launch(&t->pj_lm, S, cap, 0, 0, st); mark();              // search
-  psk_trk_after_lm(A, st); mark();                              // glue
+  mark(TS_POSE);
+  psk_trk_after_pose1(A, t->step, st); mark(TS_GLUE);
+  psk_pj_launch(&t->pj_lm, S, cap, 0, 0, st); mark(TS_SEARCH);
+  psk_trk_after_lm(A, st); mark(TS_GLUE);
   psk_pose_lm_launch(A->po_prob, S, A->po_vert, A->cur.xw, A->po_obs, A->po_is2, A->cur.mp_valid, A->cur.outlier, t->po_chi2, t->po_state,
                      A->po_pose, A->po_result, nullptr, st);
-  mark();                                                       // pose
-  psk_trk_finish(A, t->step, st);
-  if (tm) { hipEventRecord(ev[e++], st); t->timed++; }          // glue (the last interval is folded into the previous glue slot below)
+  mark(TS_POSE);
+  psk_trk_finish(A, t->step, st); mark(TS_GLUE);
+  if (d_masks && t->cvorb) {
+    // ---- the object half of Tracking::Track, behind the camera chain of the same frame ----
+    ObArrays* O = &t->OA;
+    O->idmask = d_masks; O->mask_stride = mask_stride; O->mask_pitch = mask_pitch; O->dets_in = (const ObDet*)d_dets;
+    const int K = O->K, W = t->cfg.width, H = t->cfg.height;
+    psk_ob_masks(O, t->d_objmask, W, H, st);
+    rc = ps_cvorb_detect_batch_device(t->cvorb, d_imgs, t->d_objmask, 2 * S, W, H, stride, image_pitch, W, (size_t)W * H, st);
+    if (rc != PS_OK) return rc;
+    mark(TS_OBJ_FEATURES);
+    psk_stereo_launch(psi_orb_plan(t->orb), t->d_obj_pairs, S, O->OC, t->mb, t->mbf, st); mark(TS_OBJ_STEREO);
+    psk_ob_begin(O, t->step, st);
+    psk_ob_track(O, t->step, st);
+    psk_ob_bf_blocks(O->bf_prob, t->d_bf_blocks, S * K, t->bf_blocks_per_prob, st); mark(TS_OBJ_GLUE);
+    psk_bf_launch(t->d_bf_blocks, S * K * t->bf_blocks_per_prob, O->bf_prob, S * K, O->last.desc, O->last.angle, O->bf_qvalid, O->cur.desc, O->cur.angle,
+                  O->bf_topk, O->bf_qot, O->bf_nmatch, 0.9f, 1, st);                       // ORBmatcher matcher(0.9, true), Tracking.cc:2381
+    mark(TS_OBJ_BRUTEFORCE);
+    psk_ob_after_bf(O, t->step, st); mark(TS_OBJ_GLUE);
+    psk_pose_lm_launch(O->po_prob, S, O->po_vert, O->cur.mp_po, O->po_obs, O->po_is2, O->cur.mp_valid, O->cur.outlier, t->ob_chi2, t->ob_state,
+                       O->po_pose, O->po_result, nullptr, st);
+    mark(TS_OBJ_CFSE3);
+    psk_ob_after_cf1(O, t->step, st); mark(TS_OBJ_GLUE);
+    psk_pj_launch(&t->pj_obj, S * K, O->LC, 0, 0, st); mark(TS_OBJ_SEARCH);
+    psk_ob_after_lm(O, t->step, st); mark(TS_OBJ_GLUE);
+    psk_pose_lm_launch(O->po_prob, S, O->po_vert, O->cur.mp_po, O->po_obs, O->po_is2, O->cur.mp_valid, O->cur.outlier, t->ob_chi2, t->ob_state,
+                       O->po_pose, O->po_result, nullptr, st);
+    mark(TS_OBJ_CFSE3);
+    psk_ob_finish(O, t->step, st); mark(TS_OBJ_GLUE);
+  }
+  t->ev_count = e;
+  if (tm) t->timed++;
   PS_HIP(hipGetLastError());
   t->step++;
   return PS_OK;
@@ -194,7 +323,47 @@ int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out) {
   ps_orb_stereo_device_outputs(orb, &d_ur, &d_dp, &d_kept);
   A.orb_kps = d_kps; A.orb_desc = d_desc; A.orb_counts = d_cnt; A.orb_uright = d_ur; A.orb_depth = d_dp;
   for (int r = 0; r < ps_tracker::RING; r++)
-    for (int i = 0; i < kTrkIntervals + 2; i++) hipEventCreate(&t->ev[r][i]);
+    for (int i = 0; i < kTrkMaxEvents; i++) hipEventCreate(&t->ev[r][i]);
+  if (cfg->max_objects > 0) {
+    // the object half: its own cv::ORB detector (Frame.cc:2625: cv::ORB::create(1000, 1.2, 8, 19)) and the arrays of objtrack_plan.h
+    if (cfg->max_objects > OB_MAXK) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_INVALID, "max_objects: at most %d detections per frame", OB_MAXK); }
+    rc = ps_cvorb_create(1000, 1.2f, 8, 19, 20, cfg->device, &t->cvorb);
+    if (rc == PS_OK) {
+      // plan the detector for 2 S images of this size (one untimed batch over zero masks: allocations happen here, not in the first step)
+      uint8_t* z = nullptr;
+      const size_t img_bytes = (size_t)cfg->width * cfg->height;
+      if (hipMalloc(&z, 2 * (size_t)A.S * img_bytes) != hipSuccess) rc = ps_set_error(PS_ERR_HIP, "hipMalloc failed");
+      else {
+        hipMemsetAsync(z, 0, 2 * (size_t)A.S * img_bytes, t->stream);
+        rc = ps_cvorb_detect_batch_device(t->cvorb, z, z, 2 * A.S, cfg->width, cfg->height, cfg->width, img_bytes, cfg->width, img_bytes, t->stream);
+        hipStreamSynchronize(t->stream);
+        hipFree(z);
+      }
+    }
+    if (rc != PS_OK) { ps_tracker_destroy(t); return rc; }
+    ObArrays& O = t->OA;
+    memset(&O, 0, sizeof(O));
+    O.S = A.S; O.K = cfg->max_objects; O.M = OB_MAXM; O.max_steps = cfg->max_steps;
+    int32_t ccap = 0;
+    ps_cvorb_batch_device_outputs(t->cvorb, nullptr, nullptr, nullptr, nullptr, &ccap);
+    O.OC = ccap; O.LC = 1024;
+    ObCam& OC = O.cam;
+    OC.fx = C.fx; OC.fy = C.fy; OC.cx = C.cx; OC.cy = C.cy; OC.mbf = C.mbf; OC.mb = C.mb; OC.th_depth = C.th_depth; OC.gw_inv = C.gw_inv; OC.gh_inv = C.gh_inv;
+    OC.log_sf = C.log_sf; OC.inv_fx = C.inv_fx; OC.inv_fy = C.inv_fy; OC.w = C.w; OC.h = C.h; OC.nlevels = C.nlevels;
+    for (int l = 0; l < 8; l++) { OC.sf[l] = C.sf[l]; OC.inv_sigma2[l] = C.inv_sigma2[l]; }
+    const size_t ob_bytes = carve_obj(t, nullptr);
+    e = hipMalloc(&t->d_obj, ob_bytes);
+    if (e != hipSuccess) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_HIP, "hipMalloc(%zu): %s", ob_bytes, hipGetErrorString(e)); }
+    t->d_obj_bytes = ob_bytes;
+    hipMemsetAsync(t->d_obj, 0, ob_bytes, t->stream);
+    carve_obj(t, t->d_obj);
+    // every MapObject slot free
+    std::vector<ObMapObject> mo((size_t)O.S * O.M);
+    memset(mo.data(), 0, mo.size() * sizeof(ObMapObject));
+    for (ObMapObject& m : mo) m.id = -1;
+    hipMemcpy(O.mobj, mo.data(), mo.size() * sizeof(ObMapObject), hipMemcpyHostToDevice);
+    O.cam_traj = A.traj; O.cam_stats = (const int32_t*)A.stats; O.cam_stat_words = (int32_t)(sizeof(TrkStat) / 4);
+  }
   if (hipStreamSynchronize(t->stream) != hipSuccess) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_HIP, "tracker initialisation failed"); }
   *out = t;
   return PS_OK;
@@ -205,8 +374,10 @@ void ps_tracker_destroy(ps_tracker* t) {
   hipSetDevice(t->cfg.device);
   if (t->stream) hipStreamSynchronize(t->stream);
   for (int r = 0; r < ps_tracker::RING; r++)
-    for (int i = 0; i < kTrkIntervals + 2; i++) if (t->ev[r][i]) hipEventDestroy(t->ev[r][i]);
+    for (int i = 0; i < kTrkMaxEvents; i++) if (t->ev[r][i]) hipEventDestroy(t->ev[r][i]);
   if (t->d_buf) hipFree(t->d_buf);
+  if (t->d_obj) hipFree(t->d_obj);
+  if (t->cvorb) ps_cvorb_destroy(t->cvorb);
   ps_orb_destroy(t->orb);
   delete t;
 }
@@ -224,7 +395,42 @@ int ps_tracker_step_device(ps_tracker* t, const uint8_t* d_imgs, int stride, siz
   if (t->timing) PS_HIP(hipEventRecord(t->ev[t->timed % ps_tracker::RING][0], t->stream));
   int rc = ps_orb_extract_batch_device(t->orb, d_imgs, 2 * t->A.S, t->cfg.width, t->cfg.height, stride, image_pitch, nullptr);
   if (rc != PS_OK) return rc;
-  return queue_chain(t);
+  return queue_chain(t, d_imgs, stride, image_pitch, nullptr, 0, 0, nullptr);
+}
+
+int ps_tracker_step_slot_device(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_pitch, const uint8_t* d_masks, int mask_stride,
+                                size_t mask_pitch, const ps_detection* d_dets) {
+  if (!t || !d_imgs || !d_masks || !d_dets) return ps_set_error(PS_ERR_INVALID, "ps_tracker_step_slot_device: null argument");
+  if (!t->cvorb) return ps_set_error(PS_ERR_INVALID, "the tracker was created without objects (max_objects = 0)");
+  if (mask_stride < t->cfg.width) return ps_set_error(PS_ERR_INVALID, "mask stride < width");
+  if (t->step >= t->A.max_steps) return ps_set_error(PS_ERR_CAPACITY, "the tracker was created for %d steps", t->A.max_steps);
+  PS_HIP(hipSetDevice(t->cfg.device));
+  if (t->timing) PS_HIP(hipEventRecord(t->ev[t->timed % ps_tracker::RING][0], t->stream));
+  int rc = ps_orb_extract_batch_device(t->orb, d_imgs, 2 * t->A.S, t->cfg.width, t->cfg.height, stride, image_pitch, nullptr);
+  if (rc != PS_OK) return rc;
+  return queue_chain(t, d_imgs, stride, image_pitch, d_masks, mask_stride, mask_pitch, d_dets);
+}
+
+int ps_tracker_fetch_objects(ps_tracker* t, int first_step, int nsteps, ps_object_stat* out) {
+  if (!t || !t->cvorb || !out || first_step < 0 || nsteps < 0 || first_step + nsteps > t->step)
+    return ps_set_error(PS_ERR_INVALID, "ps_tracker_fetch_objects: steps [%d, %d) of %d", first_step, first_step + nsteps, t ? t->step : 0);
+  PS_HIP(hipSetDevice(t->cfg.device));
+  PS_HIP(hipStreamSynchronize(t->stream));
+  static_assert(sizeof(ps_object_stat) == sizeof(ObStat), "ps_object_stat layout");
+  static_assert(sizeof(ps_detection) == sizeof(ObDet), "ps_detection layout");
+  const size_t per = (size_t)t->OA.S * t->OA.K;
+  if (nsteps) PS_HIP(hipMemcpy(out, t->OA.stats + (size_t)first_step * per, (size_t)nsteps * per * sizeof(ObStat), hipMemcpyDeviceToHost));
+  // the detector's limits and the MapObject table are part of the result's validity
+  const int32_t* d_ovf = nullptr;
+  ps_cvorb_batch_device_outputs(t->cvorb, nullptr, nullptr, nullptr, &d_ovf, nullptr);
+  std::vector<int32_t> ovf(2 * (size_t)t->OA.S, 0), drop(t->OA.S, 0);
+  PS_HIP(hipMemcpy(ovf.data(), d_ovf, ovf.size() * 4, hipMemcpyDeviceToHost));
+  PS_HIP(hipMemcpy(drop.data(), t->OA.dropped, drop.size() * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < ovf.size(); i++)
+    if (ovf[i]) return ps_set_error(PS_ERR_CAPACITY, "sequence %zu: the object detector exceeded its per-level / per-image keypoint capacity in the last step", i / 2);
+  for (size_t i = 0; i < drop.size(); i++)
+    if (drop[i]) return ps_set_error(PS_ERR_CAPACITY, "sequence %zu: more than %d objects over the sequence (%d detections ignored)", i, OB_MAXM, drop[i]);
+  return PS_OK;
 }
 
 int ps_tracker_step(ps_tracker* t, const uint8_t* const* left, const uint8_t* const* right, int stride) {
@@ -236,7 +442,7 @@ int ps_tracker_step(ps_tracker* t, const uint8_t* const* left, const uint8_t* co
   if (t->timing) PS_HIP(hipEventRecord(t->ev[t->timed % ps_tracker::RING][0], t->stream));
   int rc = ps_orb_extract_batch(t->orb, imgs.data(), 2 * t->A.S, t->cfg.width, t->cfg.height, stride);
   if (rc != PS_OK) return rc;
-  return queue_chain(t);
+  return queue_chain(t, nullptr, 0, 0, nullptr, 0, 0, nullptr);
 }
 
 int ps_tracker_sync(ps_tracker* t) {
@@ -277,6 +483,14 @@ int ps_tracker_reset(ps_tracker* t) {
   PS_HIP(hipStreamSynchronize(t->stream));
   PS_HIP(hipMemsetAsync(t->A.seq, 0, sizeof(TrkSeq) * t->A.S, t->stream));
   PS_HIP(hipMemsetAsync(t->d_overflow, 0, sizeof(int32_t) * t->A.S, t->stream));
+  if (t->cvorb) {
+    std::vector<ObMapObject> mo((size_t)t->OA.S * t->OA.M);
+    memset(mo.data(), 0, mo.size() * sizeof(ObMapObject));
+    for (ObMapObject& m : mo) m.id = -1;
+    PS_HIP(hipMemcpy(t->OA.mobj, mo.data(), mo.size() * sizeof(ObMapObject), hipMemcpyHostToDevice));
+    PS_HIP(hipMemsetAsync(t->OA.last.ndet, 0, sizeof(int32_t) * t->OA.S, t->stream));
+    PS_HIP(hipMemsetAsync(t->OA.dropped, 0, sizeof(int32_t) * t->OA.S, t->stream));
+  }
   t->step = 0;
   return PS_OK;
 }
@@ -294,16 +508,12 @@ int ps_tracker_stage_times(ps_tracker* t, const char** names, float* ms, int cap
   PS_HIP(hipStreamSynchronize(t->stream));
   const int cnt = t->timed < ps_tracker::RING ? t->timed : ps_tracker::RING;
   double acc[TS_COUNT] = {};
-  for (int r = 0; r < cnt; r++) {
-    for (int i = 0; i < kTrkIntervals; i++) {
+  for (int r = 0; r < cnt; r++)
+    for (int i = 1; i < t->ev_count; i++) {
       float v = 0;
-      PS_HIP(hipEventElapsedTime(&v, t->ev[r][i], t->ev[r][i + 1]));
-      acc[kTrkIntervalStage[i]] += v;
+      PS_HIP(hipEventElapsedTime(&v, t->ev[r][i - 1], t->ev[r][i]));
+      acc[t->ev_stage[i]] += v;
     }
-    float v = 0;   // trk_finish
-    PS_HIP(hipEventElapsedTime(&v, t->ev[r][kTrkIntervals], t->ev[r][kTrkIntervals + 1]));
-    acc[TS_GLUE] += v;
-  }
   *n = TS_COUNT;
   for (int i = 0; i < TS_COUNT && i < cap; i++) {
     if (names) names[i] = kTrkStage[i];

@@ -148,21 +148,39 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
   // ---- per-keypoint arrays ----
   for (int i = tid; i <= PS_TRK_NCELL; i += TRK_T) cnt[i] = 0;
   __syncthreads();
-  for (int i = tid; i < N; i += TRK_T) {
-    const ps_keypoint k = kps[i];
-    A.cur.x[b + i] = k.x; A.cur.y[b + i] = k.y; A.cur.angle[b + i] = k.angle; A.cur.octave[b + i] = k.octave;
-    A.cur.uright[b + i] = A.orb_uright[(size_t)s * A.kp_cap + i]; A.cur.depth[b + i] = A.orb_depth[(size_t)s * A.kp_cap + i];
-    A.cur.xw[3 * (b + i)] = 0.f; A.cur.xw[3 * (b + i) + 1] = 0.f; A.cur.xw[3 * (b + i) + 2] = 0.f;
-    A.cur.mp_valid[b + i] = 0; A.cur.mp_observed[b + i] = 0; A.cur.outlier[b + i] = 0; A.cur.mp_id[b + i] = -1;
-    A.occupied[b + i] = 0;
-    // Frame::PosInGrid: posX = round((kp.pt.x - mnMinX) * mfGridElementWidthInv)
-    const int px = (int)roundf((k.x - 0.f) * C.gw_inv), py = (int)roundf((k.y - 0.f) * C.gh_inv);
-    if (px >= 0 && px < PS_GRID_COLS && py >= 0 && py < PS_GRID_ROWS) atomicAdd(&cnt[px * PS_GRID_ROWS + py], 1);
-  }
   {
-    const uint4* sd = reinterpret_cast<const uint4*>(desc);
-    uint4* dd = reinterpret_cast<uint4*>(A.cur.desc + b * 32);
-    for (int i = tid; i < 2 * N; i += TRK_T) dd[i] = sd[i];
+    // with an instance mask (SLOT.MODE 4) Frame::AssignFeatures keeps the keypoints on background pixels, in order (Frame.cc:811-822)
+    const uint8_t* M = A.idmask ? A.idmask + (size_t)s * A.mask_pitch : nullptr;
+    int kept = 0;
+    for (int i0 = 0; i0 < N; i0 += TRK_T) {
+      const int i = i0 + tid;
+      ps_keypoint k;
+      bool keep = i < N;
+      if (keep) {
+        k = kps[i];
+        if (M) keep = M[(size_t)(int)k.y * A.mask_stride + (int)k.x] == 0;
+      }
+      int pos = i;
+      if (M) {
+        int total;
+        pos = kept + block_scan_excl(keep ? 1 : 0, red, &total);
+        kept += total;
+      }
+      if (keep) {
+        A.cur.x[b + pos] = k.x; A.cur.y[b + pos] = k.y; A.cur.angle[b + pos] = k.angle; A.cur.octave[b + pos] = k.octave;
+        A.cur.uright[b + pos] = A.orb_uright[(size_t)s * A.kp_cap + i]; A.cur.depth[b + pos] = A.orb_depth[(size_t)s * A.kp_cap + i];
+        A.cur.xw[3 * (b + pos)] = 0.f; A.cur.xw[3 * (b + pos) + 1] = 0.f; A.cur.xw[3 * (b + pos) + 2] = 0.f;
+        A.cur.mp_valid[b + pos] = 0; A.cur.mp_observed[b + pos] = 0; A.cur.outlier[b + pos] = 0; A.cur.mp_id[b + pos] = -1;
+        A.occupied[b + pos] = 0;
+        const uint4* sd = reinterpret_cast<const uint4*>(desc + (size_t)i * 32);
+        uint4* dd = reinterpret_cast<uint4*>(A.cur.desc + (b + pos) * 32);
+        dd[0] = sd[0]; dd[1] = sd[1];
+        // Frame::PosInGrid: posX = round((kp.pt.x - mnMinX) * mfGridElementWidthInv)
+        const int px = (int)roundf((k.x - 0.f) * C.gw_inv), py = (int)roundf((k.y - 0.f) * C.gh_inv);
+        if (px >= 0 && px < PS_GRID_COLS && py >= 0 && py < PS_GRID_ROWS) atomicAdd(&cnt[px * PS_GRID_ROWS + py], 1);
+      }
+    }
+    if (M) { N = kept; st.n = N; }
   }
   if (tid == 0) A.cur.n[s] = N;
   __syncthreads();

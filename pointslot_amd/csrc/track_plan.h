@@ -56,6 +56,9 @@ struct TrkArrays {
   int32_t S, cap, kp_cap, max_steps;
   // extractor / stereo matcher outputs of the step (pointslot_hip.h: ps_orb_batch_device_outputs, ps_orb_stereo_device_outputs)
   const void* orb_kps; const uint8_t* orb_desc; const int32_t* orb_counts; const float* orb_uright; const float* orb_depth;
+  // SLOT.MODE 4: the left 8-bit instance-id masks of the step (nullptr: none).  Frame::AssignFeatures keeps the keypoints on
+  // background pixels (mask 0) as static features (Frame.cc:811-822)
+  const uint8_t* idmask; int32_t mask_stride; size_t mask_pitch;
   TrkFrame cur, last;
   TrkSeq* seq;
   // the initial keyframe's map points = the local map of this slice

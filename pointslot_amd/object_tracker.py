@@ -347,7 +347,7 @@ class ObjectTracker:
                 m[r, c] = F32(R[r][c])
             m[r, 3] = F32(pose[0][r])
         # ObjectKeyFrame::SetPose: mPoc = -Roc * tco (float)
-        poc = [-(m[0, r] * m[0, 3] + m[1, r] * m[1, 3] + m[2, r] * m[2, 3]) for r in range(3)]
+        poc = [F32(-(float(m[0, r]) * float(m[0, 3]) + float(m[1, r]) * float(m[1, 3]) + float(m[2, r]) * float(m[2, 3]))) for r in range(3)]
         rows = []
         for j in inl:
             x3do = se3_map(inv, pts[j])
@@ -623,11 +623,8 @@ class ObjectTracker:
             self._finish(F, st)
             return st
         if tcw_cur is not None and tcw_last is not None:
-            tl = np.asarray(tcw_last, np.float32)
-            twc = np.eye(4, dtype=np.float32)
-            twc[:3, :3] = tl[:3, :3].T
-            twc[:3, 3] = -(tl[:3, :3].T @ tl[:3, 3])
-            tcl = se3_from_mat4f((np.asarray(tcw_cur, np.float32) @ twc).astype(np.float32))
+            from .tracker import mul4, inverse_rt
+            tcl = se3_from_mat4f(mul4(tcw_cur, inverse_rt(tcw_last)))        # camera_Tcl = mCurrentFrame.mTcw * mLastFrame.mTwc
         else:
             tcl = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0))
         self._track_map_object(F, tcl)

@@ -112,6 +112,139 @@ def generate(n_frames=20, seed=4, w=1242, h=375, step=0.08, n_boxes=2, K=KITTI_K
     return {"left": left, "right": right, "twc": twc, "boxes": boxes, "seg": seg, "K": (fx, fy, cx, cy), "bf": float(bf)}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# A KITTI-like drive: the camera moves FORWARD with a slowly changing yaw through a corridor of exactly ray-cast planes - a ground
+# plane 1.65 m below the camera, two side walls, a ceiling far above, an end wall ahead - textured from a photograph; the right
+# camera sees the same world from one baseline to the right, so depth and disparity are analytic per pixel.  Forward motion makes
+# SearchByProjection(cur, last) take its bForward branch (ORBmatcher.cc:1634-1675), keypoints change octave between frames and
+# local-map points leave the frustum - what the lateral scene of generate() never exercises.  Moving objects are textured
+# rectangles (the front faces of cuboids) with their own world velocity, rendered by the same ray casting in both cameras.
+# ---------------------------------------------------------------------------------------------------------------------
+def _mip_chain(tex, levels=5):
+    out = [np.asarray(tex, np.float64)]
+    for _ in range(levels - 1):
+        t = out[-1]
+        h, w = t.shape[0] // 2 * 2, t.shape[1] // 2 * 2
+        out.append(0.25 * (t[0:h:2, 0:w:2] + t[1:h:2, 0:w:2] + t[0:h:2, 1:w:2] + t[1:h:2, 1:w:2]))
+    return out
+
+
+def _sample(mips, u, v, footprint):
+    """bilinear lookup of the (mirror-tiled) texture at texel coordinates (u, v), mip level by the pixel footprint in texels"""
+    lvl = np.clip(np.floor(np.log2(np.maximum(footprint, 1.0)) + 0.5), 0, len(mips) - 1).astype(np.int64)
+    out = np.zeros(u.shape)
+    for l, t in enumerate(mips):
+        m = lvl == l
+        if not m.any():
+            continue
+        th, tw = t.shape
+        uu, vv = u[m] / (1 << l) - 0.5, v[m] / (1 << l) - 0.5
+        x0 = np.floor(uu).astype(np.int64); y0 = np.floor(vv).astype(np.int64)
+        fx, fy = uu - x0, vv - y0
+
+        def wrap(i, n):            # mirror tiling: ... 2 1 0 | 0 1 2 ... n-1 | n-1 n-2 ...
+            i = np.mod(i, 2 * n)
+            return np.where(i < n, i, 2 * n - 1 - i)
+        xa, xb, ya, yb = wrap(x0, tw), wrap(x0 + 1, tw), wrap(y0, th), wrap(y0 + 1, th)
+        out[m] = (t[ya, xa] * (1 - fx) + t[ya, xb] * fx) * (1 - fy) + (t[yb, xa] * (1 - fx) + t[yb, xb] * fx) * fy
+    return out
+
+
+def _render(cam_pos, yaw, K, w, h, mips, objs, texel_per_m=40.0):
+    """One pinhole view from cam_pos (world, y down) rotated by `yaw` about y.  Returns (image float, depth along the camera's z,
+    object id per pixel (-1: static world)).  objs: list of (centre x, bottom y, z of the face, width, height, texture mips)."""
+    fx, fy, cx, cy = K
+    us, vs = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    dc = np.stack([(us - cx) / fx, (vs - cy) / fy, np.ones_like(us)], -1)           # camera-frame ray, z = 1
+    c, s_ = np.cos(yaw), np.sin(yaw)
+    dw = np.stack([c * dc[..., 0] + s_ * dc[..., 2], dc[..., 1], -s_ * dc[..., 0] + c * dc[..., 2]], -1)   # Rwc = Ry(yaw)
+    best_t = np.full((h, w), np.inf)
+    img = np.zeros((h, w)); oid = np.full((h, w), -1, np.int64)
+    half_w, ground, ceil_y, z_end = 9.0, 1.65, -7.0, 400.0
+
+    def hit(t, ucoord, vcoord, valid, tex, scale, ident):
+        nonlocal best_t, img, oid
+        ok = valid & (t > 0.05) & (t < best_t)
+        if not ok.any():
+            return
+        foot = (t[ok] / fx) * scale                                              # texels per image pixel (isotropic estimate)
+        img[ok] = _sample(tex, ucoord[ok] * scale, vcoord[ok] * scale, foot)
+        best_t = np.where(ok, t, best_t)
+        oid[ok] = ident
+    with np.errstate(divide="ignore", invalid="ignore"):
+        # ground y = ground (texture over x, z), ceiling, walls x = +-half_w (texture over z, y), end wall
+        t = (ground - cam_pos[1]) / dw[..., 1]
+        hit(t, cam_pos[0] + t * dw[..., 0] + 1000.0, cam_pos[2] + t * dw[..., 2], dw[..., 1] > 1e-9, mips, texel_per_m, -1)
+        t = (ceil_y - cam_pos[1]) / dw[..., 1]
+        hit(t, cam_pos[0] + t * dw[..., 0] + 1000.0, cam_pos[2] + t * dw[..., 2] + 517.0, dw[..., 1] < -1e-9, mips, texel_per_m * 0.5, -1)
+        for sign, off in ((1.0, 211.0), (-1.0, 733.0)):
+            t = (sign * half_w - cam_pos[0]) / dw[..., 0]
+            hit(t, cam_pos[2] + t * dw[..., 2] + off, cam_pos[1] + t * dw[..., 1] + 50.0, sign * dw[..., 0] > 1e-9, mips, texel_per_m, -1)
+        t = (z_end - cam_pos[2]) / dw[..., 2]
+        hit(t, cam_pos[0] + t * dw[..., 0] + 300.0, cam_pos[1] + t * dw[..., 1] + 80.0, dw[..., 2] > 1e-9, mips, texel_per_m * 0.25, -1)
+        for k, (ox, oy, oz, ow, oh, otex) in enumerate(objs):
+            t = (oz - cam_pos[2]) / dw[..., 2]
+            px, py = cam_pos[0] + t * dw[..., 0], cam_pos[1] + t * dw[..., 1]
+            inside = (dw[..., 2] > 1e-9) & (px >= ox - ow / 2) & (px < ox + ow / 2) & (py >= oy - oh) & (py < oy)
+            hit(t, px - (ox - ow / 2), py - (oy - oh), inside, otex, 60.0, k)
+    depth = best_t * 1.0                                                          # camera z of the hit: t * dc.z with dc.z = 1
+    return img, depth, oid
+
+
+def generate_drive(n_frames=20, seed=4, w=1242, h=375, speed=0.7, n_objects=2, K=KITTI_K, bf=KITTI_BF, texture=None, yaw_rate_deg=0.6):
+    """A forward drive with yaw: dict like generate() - left / right uint8 [n, h, w], twc [n, 3, 4] (Twc rows, ground truth), seg
+    uint16 [n, h, w] (MOTS ids 1000 + object), boxes per frame, K, bf - plus `labels` (per frame the KITTI label fields)."""
+    rng = Rng(0x51071000 + seed)
+    fx, fy, cx, cy = [float(v) for v in K]
+    b = float(bf) / fx
+    if texture is None:
+        texture = _texture(rng, 1536, 768, 600)
+    mips = _mip_chain(texture)
+    steps = speed * (1.0 + rng.uniform(n_frames, -0.25, 0.25)); steps[0] = 0.0
+    # yaw: a slow sine plus a seeded phase, so that the constant-velocity model is never exact
+    ph = float(rng.uniform(1, 0.0, 6.28)[0])
+    yaw = np.deg2rad(yaw_rate_deg) * 8.0 * (np.sin(np.arange(n_frames) / 8.0 + ph) - np.sin(ph))
+    pos = np.zeros((n_frames, 3))
+    for k in range(1, n_frames):
+        pos[k] = pos[k - 1] + steps[k] * np.array([np.sin(yaw[k - 1]), 0.0, np.cos(yaw[k - 1])])
+    # objects: a vehicle ahead driving on at about the camera's speed, and one standing at the side that the camera passes
+    objs0 = []
+    for o in range(n_objects):
+        ow, oh = float(rng.uniform(1, 1.6, 2.2)[0]), float(rng.uniform(1, 1.3, 1.7)[0])
+        if o % 2 == 0:
+            ox, oz, vz = float(rng.uniform(1, -1.5, 1.5)[0]), float(rng.uniform(1, 11.0, 15.0)[0]), speed * float(rng.uniform(1, 0.85, 1.1)[0])
+        else:
+            ox, oz, vz = float(rng.uniform(1, 3.0, 5.0)[0]) * (1 if o % 4 == 1 else -1), float(rng.uniform(1, 22.0, 30.0)[0]), 0.0
+        otex = _mip_chain(_texture(rng, int(ow * 60) + 2, int(oh * 60) + 2, 14), 3)
+        objs0.append((ox, oz, vz, ow, oh, otex))
+    left = np.zeros((n_frames, h, w), np.uint8); right = np.zeros_like(left)
+    seg = np.zeros((n_frames, h, w), np.uint16)
+    twc = np.zeros((n_frames, 3, 4))
+    boxes, labels = [], []
+    for k in range(n_frames):
+        objs = [(ox, 1.65, oz + vz * k, ow, oh, otex) for (ox, oz, vz, ow, oh, otex) in objs0]
+        c, s_ = np.cos(yaw[k]), np.sin(yaw[k])
+        Rwc = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])
+        L, _, oid = _render(pos[k], yaw[k], (fx, fy, cx, cy), w, h, mips, objs)
+        R, _, _ = _render(pos[k] + Rwc @ np.array([b, 0.0, 0.0]), yaw[k], (fx, fy, cx, cy), w, h, mips, objs)
+        left[k] = np.clip(np.rint(L), 0, 255).astype(np.uint8); right[k] = np.clip(np.rint(R), 0, 255).astype(np.uint8)
+        seg[k][oid >= 0] = (1000 + oid[oid >= 0]).astype(np.uint16)
+        twc[k, :3, :3] = Rwc; twc[k, :, 3] = pos[k]
+        fb, fl = [], []
+        for o, (ox, oy, oz, ow, oh, _) in enumerate(objs):
+            ys, xs = np.nonzero(oid == o)
+            if len(xs) < 200:
+                fb.append(None)
+                continue
+            x1, x2, y1, y2 = float(xs.min()), float(xs.max() + 1), float(ys.min()), float(ys.max() + 1)
+            # the cuboid: front face = the rendered rectangle, BOX_DEPTH_M deep; bottom centre and rotation_y in the camera frame
+            cw = Rwc.T @ (np.array([ox, oy, oz + 0.5 * BOX_DEPTH_M]) - pos[k])
+            fb.append((x1, y1, x2, y2, float(cw[2]), float(cw[0])))
+            fl.append((o, x1, y1, x2, y2, oh, BOX_DEPTH_M, ow, float(cw[0]), float(cw[1]), float(cw[2]), float(-yaw[k])))
+        boxes.append(fb); labels.append(fl)
+    return {"left": left, "right": right, "twc": twc, "boxes": boxes, "labels": labels, "seg": seg, "K": (fx, fy, cx, cy), "bf": float(bf)}
+
+
 BOX_DEPTH_M = 0.5      # extent of a generated box along the viewing direction (the label's `w` at rotation_y = 0)
 
 
@@ -119,6 +252,8 @@ def frame_labels(seq, k):
     """The KITTI-tracking label fields of frame k's boxes: (track, x1, y1, x2, y2, h, w, l, X, Y, Z, ry).  A box is a textured
     plane at depth zb facing the camera; its cuboid has the plane as front face: l (along x at ry = 0) = the plane's width,
     h its height, w = BOX_DEPTH_M, bottom centre (X, Y, Z = zb + w / 2)."""
+    if "labels" in seq:
+        return list(seq["labels"][k])
     fx, fy, cx, cy = seq["K"]
     out = []
     for b, (x1, y1, x2, y2, zb, xw) in enumerate(seq["boxes"][k]):

@@ -90,6 +90,35 @@ def _f32(x):
     return np.asarray(x, np.float32)
 
 
+# float32 4x4 products written out as the device kernels (track_kernels.hip: mul4) and the C++ host class evaluate them - sum over k
+# in order, every product and sum rounded to float32 - so that the three drivers agree bit for bit (a BLAS matmul may fuse or reorder)
+def mul4(a, b):
+    a = _f32(a); b = _f32(b)
+    out = np.zeros((4, 4), np.float32)
+    for r in range(4):
+        for c in range(4):
+            acc = np.float32(0)
+            for k in range(4):
+                acc = np.float32(acc + np.float32(a[r, k] * b[k, c]))
+            out[r, c] = acc
+    return out
+
+
+def inverse_rt(t):
+    """[R | t]^-1 = [R^T | -(R^T t)] as Tracking.cc:1260-1268 builds LastTwc (the sum over the rows in order)"""
+    t = _f32(t)
+    out = np.eye(4, dtype=np.float32)
+    for r in range(3):
+        for c in range(3):
+            out[r, c] = t[c, r]
+    for r in range(3):
+        acc = np.float32(0)
+        for c in range(3):
+            acc = np.float32(acc + np.float32(t[c, r] * t[c, 3]))
+        out[r, 3] = -acc
+    return out
+
+
 class StereoOdometry:
     """State of the tracking thread that the hot path needs: last frame, motion model, the initial keyframe's map points."""
 
@@ -141,10 +170,12 @@ class StereoOdometry:
         z = F.depth[idx]
         x = (F.x[idx] - self.cx) * z * (np.float32(1) / self.fx)
         y = (F.y[idx] - self.cy) * z * (np.float32(1) / self.fy)
-        Xc = np.stack([x, y, z], 1).astype(np.float32)
-        Rwc = F.tcw[:3, :3].T
-        Ow = -(Rwc @ F.tcw[:3, 3])
-        return (Xc @ Rwc.T + Ow).astype(np.float32)
+        T = F.tcw
+        out = np.zeros((len(x), 3), np.float32)
+        for r in range(3):
+            ow = -((T[0, r] * T[0, 3] + T[1, r] * T[1, 3]) + T[2, r] * T[2, 3])          # mOw = -Rcw^T tcw
+            out[:, r] = ((T[0, r] * x + T[1, r] * y) + T[2, r] * z) + ow
+        return out
 
     def _train(self, F):
         return {"x": F.x, "y": F.y, "octave": F.octave, "angle": F.angle, "u_right": F.u_right, "desc": F.desc,
@@ -166,7 +197,7 @@ class StereoOdometry:
         F.mp_id[idx] = np.arange(len(idx))
         # MapPoint::UpdateNormalAndDepth for one observation (MapPoint.cc:470-497)
         PO = F.mp_xw[idx]                              # camera centre of the initial keyframe is the origin
-        dist = np.sqrt((PO.astype(np.float32) ** 2).sum(1, dtype=np.float32)).astype(np.float32)
+        dist = np.sqrt((PO[:, 0] * PO[:, 0] + PO[:, 1] * PO[:, 1]) + PO[:, 2] * PO[:, 2]).astype(np.float32)
         maxd = (dist * self.sf[F.octave[idx]]).astype(np.float32)
         self.local_map = {"xw": F.mp_xw[idx].copy(), "desc": F.desc[idx].copy(), "normal": (PO / dist[:, None]).astype(np.float32),
                           "max_dist": maxd, "min_dist": (maxd / self.sf[-1]).astype(np.float32)}
@@ -199,7 +230,7 @@ class StereoOdometry:
     def _track_motion_model(self, F):
         L = self.last
         self._update_last_frame()
-        F.tcw = (self.velocity @ L.tcw).astype(np.float32)
+        F.tcw = mul4(self.velocity, L.tcw)
         query = {"valid": (L.mp_valid & (L.outlier == 0)).astype(np.uint8), "desc": L.desc,
                  "observed": np.ones(L.N, np.uint8), "angle": L.angle, "xw": L.mp_xw, "octave": L.octave}
         nm = 0
@@ -247,20 +278,23 @@ class StereoOdometry:
         ids = F.mp_id[F.mp_id >= 0]
         already[ids] = True
         # Frame::isInFrustum (Frame.cc:1686-1743), float arithmetic, viewingCosLimit 0.5
-        Rcw, tcw = F.tcw[:3, :3], F.tcw[:3, 3]
-        Pc = (M["xw"] @ Rcw.T + tcw).astype(np.float32)
-        z = Pc[:, 2]
+        T = F.tcw
+        X, Y, Z = M["xw"][:, 0], M["xw"][:, 1], M["xw"][:, 2]
+        Pc = [((T[r, 0] * X + T[r, 1] * Y) + T[r, 2] * Z) + T[r, 3] for r in range(3)]
+        z = Pc[2]
         with np.errstate(divide="ignore", invalid="ignore"):
             invz = (np.float32(1) / z).astype(np.float32)
-            u = (self.fx * Pc[:, 0] * invz + self.cx).astype(np.float32)
-            v = (self.fy * Pc[:, 1] * invz + self.cy).astype(np.float32)
-        Ow = -(Rcw.T @ tcw)
-        PO = (M["xw"] - Ow).astype(np.float32)
-        dist = np.sqrt((PO * PO).sum(1, dtype=np.float32)).astype(np.float32)
+            u = (self.fx * Pc[0] * invz + self.cx).astype(np.float32)
+            v = (self.fy * Pc[1] * invz + self.cy).astype(np.float32)
+        Ow = [-((T[0, r] * T[0, 3] + T[1, r] * T[1, 3]) + T[2, r] * T[2, 3]) for r in range(3)]
+        PO = np.stack([X - Ow[0], Y - Ow[1], Z - Ow[2]], 1).astype(np.float32)
+        dist = np.sqrt((PO[:, 0] * PO[:, 0] + PO[:, 1] * PO[:, 1]) + PO[:, 2] * PO[:, 2]).astype(np.float32)
+        N = M["normal"]
         with np.errstate(divide="ignore", invalid="ignore"):
-            view_cos = ((PO * M["normal"]).sum(1, dtype=np.float32) / dist).astype(np.float32)
+            view_cos = (((PO[:, 0] * N[:, 0] + PO[:, 1] * N[:, 1]) + PO[:, 2] * N[:, 2]) / dist).astype(np.float32)
             ratio = (M["max_dist"] / dist).astype(np.float32)
-            level = np.ceil(np.log(ratio) / self.log_sf)
+            # MapPoint::PredictScale: the float logarithm taken as the rounded double one (as the device kernel does)
+            level = np.ceil(np.log(ratio.astype(np.float64)).astype(np.float32) / self.log_sf)
         ok = ~already & ~(z < 0) & ~(u < 0) & ~(u > self.w) & ~(v < 0) & ~(v > self.h)
         ok &= ~(dist < np.float32(0.8) * M["min_dist"]) & ~(dist > np.float32(1.2) * M["max_dist"]) & ~(view_cos < np.float32(0.5))
         level = np.clip(np.nan_to_num(level, nan=0.0, posinf=7.0, neginf=0.0), 0, len(self.sf) - 1).astype(np.int32)
@@ -329,10 +363,7 @@ class StereoOdometry:
             return None
         # motion model (Tracking.cc:1260-1270)
         L = self.last
-        last_twc = np.eye(4, dtype=np.float32)
-        last_twc[:3, :3] = L.tcw[:3, :3].T
-        last_twc[:3, 3] = -(L.tcw[:3, :3].T @ L.tcw[:3, 3])
-        self.velocity = (F.tcw @ last_twc).astype(np.float32)
+        self.velocity = mul4(F.tcw, inverse_rt(L.tcw))
         # clean VO matches (Tracking.cc:1274-1286): matches to temporal points do not outlive the frame
         tmp = F.mp_valid & ~F.mp_observed
         F.mp_valid[tmp] = False

@@ -90,7 +90,7 @@ def test_batched_device_detector_matches_the_cpu_restatement():
     kitti = np.ascontiguousarray(np.asarray(Image.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_000212_gray.png"))))
     h, w = kitti.shape
     rng = np.random.default_rng(5)
-    seq = sequence.generate(n_frames=3, seed=11, texture=sequence.kitti_texture())
+    seq = sequence.generate(n_frames=3, seed=11, w=w, h=h, texture=sequence.kitti_texture())
     imgs, masks = [], []
     for k in range(3):
         imgs.append(seq["left"][k]); masks.append(np.where(seq["seg"][k] != 0, 255, 0).astype(np.uint8))

@@ -1,0 +1,96 @@
+"""The device-resident object chain of ps_tracker (ps_tracker_step_slot_device: masks + detections in HBM, camera chain on the
+background keypoints, then ExtractObjORB -> ComputeObjStereoMatches -> TrackMapObject -> SearchByBruceMatching -> CFSE3 ->
+SearchByProjection(F, nOrder, MOPs) -> CFSE3 -> end of Track on the device) against its per-call twin
+pointslot_amd/object_tracker.py driven (a) over the per-call C-ABI on the GPU and (b) over the CPU checker."""
+import numpy as np
+import pytest
+
+from oracle_backend import OracleBackend
+from pointslot_amd import sequence
+from pointslot_amd.tracker import HipBackend, StereoOdometry
+
+pytestmark = pytest.mark.gpu
+
+INT_FIELDS = ("id", "n", "stereo", "tracked", "is_new", "track_ok", "inliers", "bf_matches", "lm_candidates", "lm_matches", "map_points")
+
+
+def _run_host(backend, seq, n):
+    h, w = seq["left"][0].shape
+    vo = StereoOdometry(backend, seq["K"], seq["bf"], w, h)
+    for k in range(n):
+        vo.track(seq["left"][k], seq["right"][k], sequence.frame_mask(seq, k), sequence.frame_detections(seq, k))
+    return vo
+
+
+def _run_device(seqs, n, max_objects=4):
+    import torch
+    from pointslot_amd.tracker_device import LockstepTracker, pack_detections
+    h, w = seqs[0]["left"][0].shape
+    S = len(seqs)
+    trk = LockstepTracker(S, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n, max_objects=max_objects)
+    imgs = torch.from_numpy(np.stack([np.stack([q["left"][:n], q["right"][:n]], 1) for q in seqs], 1)).cuda()      # [n, S, 2, h, w]
+    masks = torch.from_numpy(np.stack([np.stack([sequence.frame_mask(q, k) for q in seqs]) for k in range(n)])).cuda()   # [n, S, h, w]
+    keep = []
+    for k in range(n):
+        d = torch.from_numpy(pack_detections([sequence.frame_detections(q, k) for q in seqs], max_objects).view(np.uint8)).cuda()
+        keep.append(d)
+        trk.step_slot_device(imgs[k].data_ptr(), masks[k].data_ptr(), d.data_ptr())
+    tcw, st = trk.fetch()
+    obj = trk.fetch_objects()
+    trk.close()
+    return tcw, st, obj
+
+
+def _check_against(vo, tcw, st, obj, s, n, exact):
+    for k in range(n):
+        a = vo.trajectory[k]
+        if a is None:
+            assert st["tracked"][k, s] == 0
+        elif exact:
+            assert np.array_equal(a, tcw[k, s]), "camera pose of frame %d" % k
+        else:
+            assert np.abs(a - tcw[k, s]).max() < 2e-5, "camera pose of frame %d" % k
+        ho = vo.objects.stats[k]["objects"]
+        for j, o in enumerate(ho):
+            d = obj[k, s, j]
+            got = {f: int(d[f]) for f in INT_FIELDS}
+            want = {"id": o["id"], "n": o["n"], "stereo": o["stereo"], "tracked": int(o["tracked"]), "is_new": int(o["new"]), "track_ok": int(o["track_ok"]),
+                    "inliers": o["inliers"], "bf_matches": o["bf_matches"], "lm_candidates": o["lm_candidates"], "lm_matches": o["lm_matches"],
+                    "map_points": o["map_points"]}
+            assert got == want, (k, j, got, want)
+            if o["tco"] is not None:
+                if exact:
+                    assert np.array_equal(d["tco"], o["tco"]), (k, j, d["tco"], o["tco"])
+                else:
+                    assert np.abs(d["tco"] - o["tco"]).max() < 1e-6, (k, j, d["tco"], o["tco"])
+        for j in range(len(ho), obj.shape[2]):
+            assert obj[k, s, j]["id"] == -1
+
+
+def test_device_object_chain_equals_the_per_call_chain_and_the_cpu_checker():
+    n = 6
+    seqs = [sequence.generate(n_frames=n, seed=4 + 3 * i, texture=sequence.kitti_texture()) for i in range(3)]
+    tcw, st, obj = _run_device(seqs, n)
+    for s, q in enumerate(seqs):
+        be = HipBackend()
+        vo = _run_host(be, q, n)
+        # the per-call chain over the same kernels: integer results identical, poses bit for bit
+        _check_against(vo, tcw, st, obj, s, n, exact=True)
+        be.close()
+    # the CPU restatement of the hot-path calls behind the same host logic: match sets identical, poses within the optimiser's tolerance
+    vo = _run_host(OracleBackend(), seqs[0], n)
+    _check_against(vo, tcw, st, obj, 0, n, exact=False)
+    # and the objects are where the generator put them
+    fx, fy, cx, cy = seqs[0]["K"]
+    # (box 0 of this sequence is half hidden behind box 1: too few features, its tracking fails and MapObjectReInit runs every frame -
+    # on the device exactly as in the per-call chain, which is what the comparison above covers)
+    ok = 0
+    for k in range(2, n):
+        for b in range(2):
+            if not obj[k, 0, b]["track_ok"]:
+                continue
+            x1, y1, x2, y2, zb, _ = seqs[0]["boxes"][k][b]
+            truth = np.array([(0.5 * (x1 + x2) - cx) * zb / fx, (0.5 * (y1 + y2) - cy) * zb / fy, zb + 0.5 * sequence.BOX_DEPTH_M])
+            assert np.abs(obj[k, 0, b]["tco"][:3] - truth).max() < 0.35
+            ok += 1
+    assert ok >= n - 2 and int(obj["reinit"][:, 0].sum()) >= 1
