@@ -79,72 +79,125 @@ def pmc_valu_issue(kernel, nimg):
     return None
 
 
-def make_sequences(rank, n_frames, n_distinct, texture):
+def _make_one(job):
+    scene, n_frames, seed, k, texture = job
     from pointslot_amd import sequence
     tex = sequence.kitti_texture() if texture == "kitti" else None
-    return [sequence.generate(n_frames=n_frames, seed=40 + 16 * rank + k, step=0.05 + 0.01 * k, texture=tex) for k in range(n_distinct)]
+    if scene == "drive":
+        q = sequence.generate_drive(n_frames=n_frames, seed=seed, speed=0.55 + 0.02 * (k % 16), yaw_rate_deg=0.3 + 0.05 * (k % 9), texture=tex)
+    else:
+        q = sequence.generate(n_frames=n_frames, seed=seed, step=0.05 + 0.01 * (k % 4), texture=tex)
+    q["masks"] = np.stack([sequence.frame_mask(q, i) for i in range(n_frames)])
+    q["dets"] = [sequence.frame_detections(q, i) for i in range(n_frames)]
+    del q["seg"]
+    return q
 
 
-def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barrier):
-    """The headline loop: `n_seq` sequences per GPU in `n_groups` lockstep groups (one ps_tracker and one stream each, so that one
-    group's latency-bound kernels overlap another's), images of all frames resident in HBM.  Returns the timing, the per-stage
-    HIP-event times of group 0 and the checks on what was tracked."""
+def make_sequences(rank, n_frames, n_distinct, texture, scene="drive"):
+    """n_distinct generated stereo sequences (seeds differ per rank), rendered by a pool of fresh processes (the ray-cast drive scene
+    costs about 0.3 s of numpy per frame)."""
+    jobs = [(scene, n_frames, 40 + 64 * rank + k, k, texture) for k in range(n_distinct)]
+    if n_distinct <= 2:
+        return [_make_one(j) for j in jobs]
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(max_workers=min(n_distinct, max(1, (os.cpu_count() or 8) - 2), 48), mp_context=mp.get_context("spawn")) as pool:
+        return list(pool.map(_make_one, jobs))
+
+
+MAX_OBJECTS = 4
+
+
+def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barrier, scene="drive", n_distinct=32, objects=True, seqs=None):
+    """The headline loop: `n_seq` sequences per GPU in `n_groups` lockstep groups (one ps_tracker and one stream each), images - and
+    with `objects` the instance masks and the detections (SLOT.MODE 4 inputs) - of all frames resident in HBM.  Every step is one
+    frame of every sequence through the camera chain and, with `objects`, the object chain behind it.  Returns the timing, the
+    per-stage HIP-event times of group 0 and the checks on what was tracked."""
     import torch
-    from pointslot_amd.tracker_device import LockstepTracker
+    from pointslot_amd.tracker_device import LockstepTracker, pack_detections
     n_frames = warmup + steps
-    n_distinct = min(4, n_seq)
-    seqs = make_sequences(rank, n_frames, n_distinct, texture)
+    n_distinct = min(n_distinct, n_seq)
+    if seqs is None:
+        seqs = make_sequences(rank, n_frames, n_distinct, texture, scene)
     h, w = seqs[0]["left"][0].shape
     per_group = n_seq // n_groups
-    base = torch.from_numpy(np.stack([np.stack([q["left"], q["right"]], 1) for q in seqs], 1)).cuda()   # [n, nd, 2, h, w]
+    base = torch.from_numpy(np.stack([np.stack([q["left"][:n_frames], q["right"][:n_frames]], 1) for q in seqs], 1)).cuda()   # [n, nd, 2, h, w]
     # sequence j of group g shows generated sequence (g * per_group + j) % n_distinct
-    imgs = []
+    imgs, masks, dets = [], [], []
+    if objects:
+        mbase = torch.from_numpy(np.stack([q["masks"][:n_frames] for q in seqs], 1)).cuda()                                  # [n, nd, h, w]
+        dbase = np.stack([pack_detections([q["dets"][i] for q in seqs], MAX_OBJECTS) for i in range(n_frames)])               # [n, nd, K]
     for g in range(n_groups):
         idx = (torch.arange(per_group, device="cuda") + g * per_group) % n_distinct
         imgs.append(base[:, idx].contiguous())                                                         # [n, per_group, 2, h, w]
+        if objects:
+            masks.append(mbase[:, idx].contiguous())
+            dets.append(torch.from_numpy(np.ascontiguousarray(dbase[:, idx.cpu().numpy()]).view(np.uint8)).cuda())
     del base
-    trks = [LockstepTracker(per_group, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n_frames, device=local_rank) for _ in range(n_groups)]
+    if objects:
+        del mbase
+    trks = [LockstepTracker(per_group, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n_frames, device=local_rank, max_objects=MAX_OBJECTS if objects else 0)
+            for _ in range(n_groups)]
+
+    def step(i):
+        for g, t in enumerate(trks):
+            if objects:
+                t.step_slot_device(imgs[g][i].data_ptr(), masks[g][i].data_ptr(), dets[g][i].data_ptr())
+            else:
+                t.step_device(imgs[g][i].data_ptr())
 
     def sync():
         for t in trks:
             t.sync()
 
     for i in range(warmup):
-        for g, t in enumerate(trks):
-            t.step_device(imgs[g][i].data_ptr())
+        step(i)
     sync()
     barrier()
     for t in trks:
         t.enable_stage_timing(True)      # HIP events on the stream the kernels run on
     t0 = time.perf_counter()
     for i in range(warmup, n_frames):
-        for g, t in enumerate(trks):
-            t.step_device(imgs[g][i].data_ptr())
+        step(i)
     sync()
     barrier()
     dt = time.perf_counter() - t0
     stage = trks[0].stage_times()
     out = {"dt": dt, "stage_ms_group0": stage, "frames_per_step_per_gpu": per_group * n_groups, "images_per_launch": 2 * per_group,
-           "h": h, "w": w}
+           "h": h, "w": w, "n_distinct": n_distinct}
     # every trajectory against the ground truth of the generator, every frame's tracked flag
-    err, untracked = 0.0, 0
+    err, untracked, tracked_timed = 0.0, 0, 0
     tcw0 = st0 = None
+    ob = {"detections": 0, "with_object": 0, "track_ok": 0, "max_abs_centre_error_m": 0.0, "reinit": 0}
     for g, t in enumerate(trks):
         tcw, st = t.fetch()
         untracked += int((st["tracked"] == 0).sum())
+        tracked_timed += int((st["tracked"][warmup:] != 0).sum())
         if g == 0:
             tcw0, st0 = tcw, st
         R = tcw[:, :, :3, :3]
         twc = -np.einsum("nsji,nsj->nsi", R, tcw[:, :, :3, 3])
         for j in range(per_group):
-            truth = seqs[(g * per_group + j) % n_distinct]["twc"][:, :, 3]
+            truth = seqs[(g * per_group + j) % n_distinct]["twc"][:n_frames, :, 3]
             ok = st["tracked"][:, j] != 0
             if ok.any():
                 err = max(err, float(np.abs(twc[ok, j] - truth[ok]).max()))
-    out.update(max_abs_position_error_m=err, untracked_frames=untracked, seqs=seqs, tcw_group0=tcw0, stats_group0=st0)
+        if objects:
+            o = t.fetch_objects()
+            live = o["id"] >= 0
+            ob["detections"] += int(live[2:].sum()); ob["with_object"] += int((o["tracked"][2:] != 0).sum())
+            ob["track_ok"] += int((o["track_ok"][2:] != 0).sum()); ob["reinit"] += int(o["reinit"].sum())
+            for j in range(min(per_group, n_distinct)):                  # the distinct sequences once: cuboid centres against the labels
+                q = seqs[(g * per_group + j) % n_distinct]
+                for i in range(2, n_frames):
+                    for k, d in enumerate(q["dets"][i]):
+                        if o[i, j, k]["track_ok"]:
+                            ob["max_abs_centre_error_m"] = max(ob["max_abs_centre_error_m"], float(np.abs(o[i, j, k]["tco"][:3] - d["pose7"][:3]).max()))
+    out.update(max_abs_position_error_m=err, untracked_frames=untracked, tracked_frames_timed=tracked_timed, seqs=seqs, tcw_group0=tcw0, stats_group0=st0,
+               objects=ob if objects else None)
     for t in trks:
         t.close()
-    del imgs
+    del imgs, masks, dets
     torch.cuda.empty_cache()
     return out
 
@@ -483,6 +536,9 @@ def main():
     ap.add_argument("--sequences", type=int, default=512, help="independent stereo sequences tracked in lockstep per GPU")
     ap.add_argument("--groups", type=int, default=1, help="lockstep groups per GPU (one tracker handle and stream each)")
     ap.add_argument("--texture", choices=["kitti", "synthetic"], default="kitti", help="texture of the generated sequences of the headline run")
+    ap.add_argument("--scene", choices=["drive", "lateral"], default="drive", help="generator of the headline sequences: forward drive with yaw / lateral translation")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct generated sequences per GPU (the tracked ones cycle through them)")
+    ap.add_argument("--no-objects", action="store_true", help="headline without the object chain (camera chain only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the headline loop")
     args = ap.parse_args()
@@ -536,7 +592,8 @@ def main():
 
     from pointslot_amd import parallel
     with_cpu = not args.no_cpu and rank == 0 and world == 1
-    head = tracking_leg(rank, local_rank, args.texture, args.steps, args.warmup, args.sequences, args.groups, barrier)
+    head = tracking_leg(rank, local_rank, args.texture, args.steps, args.warmup, args.sequences, args.groups, barrier, scene=args.scene,
+                        n_distinct=args.distinct, objects=not args.no_objects)
     dt = parallel.max_over_ranks(dist, head["dt"], RED_DEV)
     untracked = int(parallel.max_over_ranks(dist, head["untracked_frames"], RED_DEV))
     err = parallel.max_over_ranks(dist, head["max_abs_position_error_m"], RED_DEV)
@@ -548,7 +605,7 @@ def main():
         osteps = min(args.steps, 10)
 
         def other_texture():
-            o = tracking_leg(rank, local_rank, other, osteps, max(args.warmup, 2), args.sequences, args.groups, barrier)
+            o = tracking_leg(rank, local_rank, other, osteps, max(args.warmup, 2), args.sequences, args.groups, barrier, scene="lateral", n_distinct=4, objects=False)
             odt = parallel.max_over_ranks(dist, o["dt"], RED_DEV)
             return {"workload": "the headline loop on the generator's %s texture" % ("value-noise + rectangles" if other == "synthetic" else "KITTI-frame"),
                     "tracked_frames_per_s": world * o["frames_per_step_per_gpu"] * osteps / odt, "ms_per_step": odt / osteps * 1e3,
@@ -607,8 +664,10 @@ def main():
                                    % head["frames_per_step_per_gpu"],
                        "sequences_per_gpu": head["frames_per_step_per_gpu"], "lockstep_groups_per_gpu": args.groups, "images_per_step_per_gpu": 2 * head["frames_per_step_per_gpu"],
                        "parallelism": "sequences sharded over %d GPU(s), no collective in the data path" % world},
-            "tracking_checks": {"untracked_frames": untracked, "max_abs_position_error_m": err,
-                                "checked": "every frame of every sequence: tracked flag, position against the generator's ground truth"},
+            "tracking_checks": {"untracked_frames": untracked, "max_abs_position_error_m": err, "distinct_sequences_per_gpu": head["n_distinct"],
+                                "objects": head["objects"],
+                                "checked": "every frame of every sequence: tracked flag, position against the generator's ground truth; objects: "
+                                           "detections with a MapObject / with mbTrackOK, cuboid centres of the distinct sequences against the labels"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms, "images_per_launch": nimg,

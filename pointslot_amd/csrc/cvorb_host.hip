@@ -19,7 +19,7 @@ void psk_cv_resize(const CvLevelDev*, const CvLevelDev*, const int4*, const int4
 void psk_cv_detect(const CvLevelDev*, int, int, int, int32_t*, hipStream_t);
 void psk_cv_blur(const CvLevelDev*, const int*, hipStream_t);
 void psk_cv_describe(const CvPlanDev*, const CvSel*, int, void*, uint8_t*, hipStream_t);
-void psk_cvb_run(const CvbPlan*, int, const uint8_t*, int, size_t, const uint8_t*, int, size_t, hipStream_t);
+void psk_cvb_run(const CvbPlan*, int, const uint8_t*, int, size_t, const uint8_t*, int, size_t, int, hipStream_t);
 }
 
 struct ps_cvorb {
@@ -305,19 +305,26 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
     L.tw = (L.w + 2 * CV_BORDER + CVB_TILE - 1) / CVB_TILE; L.th = (L.h + 2 * CV_BORDER + CVB_TILE - 1) / CVB_TILE;
     if (L.tw * L.th > CVB_MAX_TILES) return ps_set_error(PS_ERR_INVALID, "the batched object detector supports levels of up to %d tiles", CVB_MAX_TILES);
     L.cw = (L.w + 2 * CV_BORDER + 7) / 8; L.ch = (L.h + 2 * CV_BORDER + 7) / 8;
-    L.cw = std::max(L.cw, 4 * L.tw); L.ch = std::max(L.ch, 4 * L.th);   // every tile owns 4 x 4 cells
+    L.cw = std::max(L.cw, 4 * L.tw); L.ch = std::max(L.ch, 4 * L.th);   // every tile owns 4 x 4 cells (cw is a multiple of 4: a tile's cell row is one aligned dword)
+    L.cw = (L.cw + 3) & ~3;
     L.cell_off = P.cell_total; P.cell_total += L.cw * L.ch; P.cell_max = std::max(P.cell_max, L.cw * L.ch);
+    L.tile_off = P.tile_total; P.tile_total += L.tw * L.th;
     L.quota = quota[l];
     L.o_pad = take_img((size_t)L.stride * (L.h + 2 * CV_BORDER)); L.o_blur = take_img((size_t)L.stride * (L.h + 2 * CV_BORDER));
     L.o_mask = take_img((size_t)L.w * L.h); L.o_score = 0;
-    if (l > 0) { exact_table(P.lv[l - 1].w, L.w, xt[l]); exact_table(P.lv[l - 1].h, L.h, yt[l]); }
+    if (l > 0) {
+      exact_table(P.lv[l - 1].w, L.w, xt[l]); exact_table(P.lv[l - 1].h, L.h, yt[l]);
+      // cvb_resize stages the source patch of a 32 x 32 tile in a 48 x 48 LDS array
+      if ((double)P.lv[l - 1].w / L.w * 32 + 6 > 48 || (double)P.lv[l - 1].h / L.h * 32 + 6 > 48)
+        return ps_set_error(PS_ERR_INVALID, "the batched object detector supports scale factors up to 1.3");
+    }
   }
   P.arena_pitch = img_off;
   P.ocap = 2048;
   int max_tiles = 0;
   for (int l = 0; l < h->nlevels; l++) max_tiles = std::max(max_tiles, P.lv[l].tw * P.lv[l].th);
   P.wl_cap = cap * max_tiles;
-  if ((size_t)P.cell_total + 2 * (size_t)P.cell_max > 150 * 1024) return ps_set_error(PS_ERR_INVALID, "image too large for the batched object detector's planning kernel");
+  if (2 * (size_t)P.cell_total + 2 * (size_t)P.cell_max + 2 * (size_t)(P.ocw + 1) * (P.och + 1) + P.tile_total + 64 > 150 * 1024 || P.tile_total > 8 * 512) return ps_set_error(PS_ERR_INVALID, "image too large for the batched object detector's planning kernel");
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t r = off; off += al(bytes + 64); return r; };
   const size_t o_arena = take(P.arena_pitch * (size_t)cap);
@@ -358,21 +365,36 @@ extern "C" {
 // internal (track_host.hip): the handle's stream
 hipStream_t psi_cvorb_stream(ps_cvorb* h) { return h->stream; }
 
+// internal (track_host.hip): the batch in two halves, so that a caller that already walks the masks (the tracker's ob_masks kernel)
+// can fill the 8 x 8 cell occupancy itself between them: begin = plan + clearing the per-batch counters, run = the kernels
+int psi_cvorb_batch_begin(ps_cvorb* h, int nimg, int w, int hgt, hipStream_t st, uint8_t** occ, int* ocw, int* och) {
+  if (!h->bplanned || h->bw != w || h->bh != hgt || h->bcap < nimg) {
+    int rc = build_batch_plan(h, w, hgt, nimg);
+    if (rc != PS_OK) return rc;
+  }
+  PS_HIP(hipMemsetAsync(h->b_zero, 0, h->b_zero_bytes, st));
+  if (occ) *occ = h->bplan.occ;
+  if (ocw) *ocw = h->bplan.ocw;
+  if (och) *och = h->bplan.och;
+  return PS_OK;
+}
+int psi_cvorb_batch_run(ps_cvorb* h, const uint8_t* d_imgs, const uint8_t* d_masks, int nimg, int stride, size_t image_pitch, int mask_stride,
+                        size_t mask_pitch, int occupancy_given, hipStream_t st) {
+  psk_cvb_run(&h->bplan, nimg, d_imgs, stride, image_pitch, d_masks, mask_stride, mask_pitch, occupancy_given, st);
+  PS_HIP(hipGetLastError());
+  h->b_last_n = nimg;
+  return PS_OK;
+}
+
 int ps_cvorb_detect_batch_device(ps_cvorb* h, const uint8_t* d_imgs, const uint8_t* d_masks, int nimg, int w, int hgt, int stride, size_t image_pitch,
                                  int mask_stride, size_t mask_pitch, void* stream) {
   if (!h || !d_imgs || !d_masks || nimg < 1 || w < 1 || hgt < 1 || stride < w || mask_stride < w)
     return ps_set_error(PS_ERR_INVALID, "ps_cvorb_detect_batch_device: bad argument");
   PS_HIP(hipSetDevice(h->device));
-  if (!h->bplanned || h->bw != w || h->bh != hgt || h->bcap < nimg) {
-    int rc = build_batch_plan(h, w, hgt, nimg);
-    if (rc != PS_OK) return rc;
-  }
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-  PS_HIP(hipMemsetAsync(h->b_zero, 0, h->b_zero_bytes, st));
-  psk_cvb_run(&h->bplan, nimg, d_imgs, stride, image_pitch, d_masks, mask_stride, mask_pitch, st);
-  PS_HIP(hipGetLastError());
-  h->b_last_n = nimg;
-  return PS_OK;
+  int rc = psi_cvorb_batch_begin(h, nimg, w, hgt, st, nullptr, nullptr, nullptr);
+  if (rc != PS_OK) return rc;
+  return psi_cvorb_batch_run(h, d_imgs, d_masks, nimg, stride, image_pitch, mask_stride, mask_pitch, 0, st);
 }
 
 int ps_cvorb_batch_device_outputs(const ps_cvorb* h, const ps_keypoint** d_kps, const uint8_t** d_desc, const int32_t** d_counts,

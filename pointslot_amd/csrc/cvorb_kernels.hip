@@ -328,107 +328,162 @@ __device__ __forceinline__ void cvb_reflect_range(int lo, int hi, int len, int& 
   rlo = max(rlo, 0); rhi = min(rhi, len - 1);
 }
 
-// appends the tiles of level l that hold a flagged cell to worklist `which`
-__device__ __forceinline__ void cvb_append_tiles(const CvbPlan& P, int img, int l, int which, const uint8_t* cells, int grow) {
+#define CVB_PLAN_T 512
+// marks the tiles of level l that hold a flagged cell in the workgroup's tile-flag array (bit `which`; bit 3: the tile also holds a cell of `cells2`)
+__device__ __forceinline__ void cvb_flag_tiles(const CvbPlan& P, int l, int which, const uint8_t* cells, int grow, const uint8_t* cells2, uint8_t* tflag) {
   const CvbLevel& B = P.lv[l];
-  const int nt = B.tw * B.th, tid = threadIdx.x;
-  uint32_t* wl = P.wl + ((size_t)which * CV_MAX_LEVELS + l) * P.wl_cap;
-  int32_t* cnt = P.wl_count + which * CV_MAX_LEVELS + l;
-  for (int t0 = 0; t0 < nt; t0 += 256) {
-    const int t = t0 + tid;
-    bool a = false;
-    if (t < nt) {
-      const int tx = t % B.tw, ty = t / B.tw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int ty = wave; ty < B.th; ty += CVB_PLAN_T / 64)
+    for (int tx = lane; tx < B.tw; tx += 64) {
+      bool a = false, m = false;
       const int cx0 = max(4 * tx - grow, 0), cx1 = min(4 * tx + 3 + grow, B.cw - 1), cy0 = max(4 * ty - grow, 0), cy1 = min(4 * ty + 3 + grow, B.ch - 1);
       for (int cy = cy0; cy <= cy1; cy++)
-        for (int cx = cx0; cx <= cx1; cx++) a = a || cells[cy * B.cw + cx];
+        for (int cx = cx0; cx <= cx1; cx++) { a = a || cells[cy * B.cw + cx]; if (cells2) m = m || cells2[cy * B.cw + cx]; }
+      a = a || m;
+      uint8_t& f = tflag[B.tile_off + ty * B.tw + tx];               // one thread per tile: a plain read-modify-write
+      if (a) f |= (uint8_t)(1u << which);
+      if (m) f |= 8u;
     }
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(a);
-    const int lane = tid & 63;
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(cnt, __popcll(m));
-    base = __shfl(base, 0);
-    if (a) {
-      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < P.wl_cap) wl[pos] = ((uint32_t)img << 12) | (uint32_t)t;
-    }
-  }
 }
 
-// one workgroup per image: kp cells and needed cells of every level (dynamic LDS: a byte per cell of every level + two scratch
-// planes of the largest level), the three tile worklists per level (0 planes, 1 FAST, 2 blur)
-__global__ __launch_bounds__(256) void cvb_plan(CvbPlan P) {
-  extern __shared__ uint8_t sm[];
-  const int img = blockIdx.x, tid = threadIdx.x;
-  uint8_t* kp = sm + P.cell_total;
-  uint8_t* tmp = kp + P.cell_max;
+// one workgroup per image: kp cells and needed cells of every level (dynamic LDS: per level a byte per cell for the plane need and
+// one for the mask need, two scratch planes of the largest level, the summed-area table of the occupancy), the three tile
+// worklists per level (0 planes, 1 FAST, 2 blur).  An entry of worklist 0 carries bit 31 when the tile also holds cells of the
+// mask chain (kp cells and, downwards, the cells that hold their source pixels).  Loops run rows by waves, columns by lanes.
+__global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
+  extern __shared__ uint8_t sm[];          // per cell of every level: bit 0 = the plane is needed, bit 1 = the mask is needed (4-byte aligned per level)
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = CVB_PLAN_T / 64;
+  const int cmax4 = (P.cell_max + 3) & ~3;
+  uint8_t* kp = sm + ((P.cell_total + 3) & ~3);
+  uint8_t* tmp = kp + cmax4;
+  uint16_t* sat = reinterpret_cast<uint16_t*>(tmp + cmax4);   // (och + 1) x (ocw + 1), first row / column zero; at an even offset
+  uint8_t* tflag = reinterpret_cast<uint8_t*>(sat + (P.ocw + 1) * (P.och + 1));   // per tile of every level: bits 0..2 = the three worklists, bit 3 = mask chain
+  __shared__ int s_cnt[3 * CV_MAX_LEVELS], s_base[3 * CV_MAX_LEVELS];
+  for (int i = tid; i < P.tile_total; i += CVB_PLAN_T) tflag[i] = 0;
+  if (tid < 3 * CV_MAX_LEVELS) s_cnt[tid] = 0;
   const uint8_t* occ = P.occ + (size_t)img * P.ocw * P.och;
   uint8_t* kpmap = P.kpmap + (size_t)img * P.cell_total;
+  const int SW = P.ocw + 1;
+  for (int y = wave; y <= P.och; y += NW)
+    for (int x = lane; x < SW; x += 64) sat[y * SW + x] = (y > 0 && x > 0) ? occ[(y - 1) * P.ocw + x - 1] : 0;
+  __syncthreads();
+  for (int y = 1 + tid; y <= P.och; y += CVB_PLAN_T) { uint16_t acc = 0; for (int x = 1; x <= P.ocw; x++) { acc += sat[y * SW + x]; sat[y * SW + x] = acc; } }
+  __syncthreads();
+  for (int x = 1 + tid; x <= P.ocw; x += CVB_PLAN_T) { uint16_t acc = 0; for (int y = 1; y <= P.och; y++) { acc += sat[y * SW + x]; sat[y * SW + x] = acc; } }
+  __syncthreads();
   for (int l = 0; l < P.nlevels; l++) {
     const CvbLevel& B = P.lv[l];
-    const int nc = B.cw * B.ch;
     uint8_t* need = sm + B.cell_off;
     const float Rx = (float)P.w0 / (float)B.w, Ry = (float)P.h0 / (float)B.h;
     const float mx = 6.f * (Rx - 1.f) + 3.f, my = 6.f * (Ry - 1.f) + 3.f;
-    for (int c = tid; c < nc; c += 256) {
-      const int cx = c % B.cw, cy = c / B.cw;
-      int x0 = 8 * cx - CV_BORDER, x1 = x0 + 7, y0 = 8 * cy - CV_BORDER, y1 = y0 + 7;
-      x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, B.w - 1); y1 = min(y1, B.h - 1);
-      bool any = false;
-      if (x0 <= x1 && y0 <= y1) {
-        int X0 = (int)floorf((float)x0 * Rx - mx), X1 = (int)ceilf((float)(x1 + 1) * Rx + mx);
-        int Y0 = (int)floorf((float)y0 * Ry - my), Y1 = (int)ceilf((float)(y1 + 1) * Ry + my);
-        X0 = max(X0, 0) >> 3; Y0 = max(Y0, 0) >> 3; X1 = min(X1, P.w0 - 1) >> 3; Y1 = min(Y1, P.h0 - 1) >> 3;
-        for (int oy = Y0; oy <= Y1 && !any; oy++)
-          for (int ox = X0; ox <= X1; ox++)
-            if (occ[oy * P.ocw + ox]) { any = true; break; }
+    for (int cy = wave; cy < B.ch; cy += NW) {
+      const int y0 = max(8 * cy - CV_BORDER, 0), y1 = min(8 * cy - CV_BORDER + 7, B.h - 1);
+      const int Y0 = max((int)floorf((float)y0 * Ry - my), 0) >> 3, Y1 = min((int)ceilf((float)(y1 + 1) * Ry + my), P.h0 - 1) >> 3;
+      for (int cx = lane; cx < B.cw; cx += 64) {
+        const int x0 = max(8 * cx - CV_BORDER, 0), x1 = min(8 * cx - CV_BORDER + 7, B.w - 1);
+        bool any = false;
+        if (x0 <= x1 && y0 <= y1) {
+          const int X0 = max((int)floorf((float)x0 * Rx - mx), 0) >> 3, X1 = min((int)ceilf((float)(x1 + 1) * Rx + mx), P.w0 - 1) >> 3;
+          const int cnt = (int)sat[(Y1 + 1) * SW + X1 + 1] - (int)sat[Y0 * SW + X1 + 1] - (int)sat[(Y1 + 1) * SW + X0] + (int)sat[Y0 * SW + X0];
+          any = cnt > 0;
+        }
+        const int c = cy * B.cw + cx;
+        kp[c] = any ? 1 : 0;
+        need[c] = any ? 2 : 0;
+        kpmap[B.cell_off + c] = any ? 1 : 0;
       }
-      kp[c] = any ? 1 : 0;
-      kpmap[B.cell_off + c] = any ? 1 : 0;
     }
     __syncthreads();
-    cvb_append_tiles(P, img, l, 1, kp, 1);                       // FAST + NMS: kp cells and one cell around them
-    for (int c = tid; c < nc; c += 256) {                        // dilation by 3 cells, rows then columns
-      const int cx = c % B.cw, cy = c / B.cw;
-      uint8_t v = 0;
-      for (int d = -3; d <= 3; d++) { const int x = cx + d; if (x >= 0 && x < B.cw) v |= kp[cy * B.cw + x]; }
-      tmp[c] = v;
-    }
+    cvb_flag_tiles(P, l, 1, kp, 1, nullptr, tflag);               // FAST + NMS: kp cells and one cell around them
+    for (int cy = wave; cy < B.ch; cy += NW)                      // dilation by 3 cells, rows then columns
+      for (int cx = lane; cx < B.cw; cx += 64) {
+        uint8_t v = 0;
+        for (int d = -3; d <= 3; d++) { const int x = cx + d; if (x >= 0 && x < B.cw) v |= kp[cy * B.cw + x]; }
+        tmp[cy * B.cw + cx] = v;
+      }
     __syncthreads();
-    for (int c = tid; c < nc; c += 256) {
-      const int cx = c % B.cw, cy = c / B.cw;
-      uint8_t v = 0;
-      for (int d = -3; d <= 3; d++) { const int y = cy + d; if (y >= 0 && y < B.ch) v |= tmp[y * B.cw + cx]; }
-      need[c] = v;
-    }
+    for (int cy = wave; cy < B.ch; cy += NW)
+      for (int cx = lane; cx < B.cw; cx += 64) {
+        uint8_t v = 0;
+        for (int d = -3; d <= 3; d++) { const int y = cy + d; if (y >= 0 && y < B.ch) v |= tmp[y * B.cw + cx]; }
+        kp[cy * B.cw + cx] = v;                                    // (kp now holds the dilated set; its cells' owners also set bit 0 of need)
+        need[cy * B.cw + cx] |= v;
+      }
     __syncthreads();
-    cvb_append_tiles(P, img, l, 2, need, 0);                     // blur
+    cvb_flag_tiles(P, l, 2, kp, 0, nullptr, tflag);               // blur
+    __syncthreads();
+    if (l == 0) cvb_flag_tiles(P, 0, 0, kp, 0, nullptr, tflag);   // level 0's padded plane is only read around its own keypoints (level 1 reads the image)
     __syncthreads();
   }
-  // a level's needed cells need their source pixels one level down
-  for (int l = P.nlevels - 1; l >= 1; l--) {
+  // a level's needed cells need their source pixels one level down (level 1's come from the image itself)
+  for (int l = P.nlevels - 1; l >= 2; l--) {
     const CvbLevel& B = P.lv[l];
     const CvbLevel& S = P.lv[l - 1];
-    const uint8_t* need = sm + B.cell_off;
-    uint8_t* down = sm + S.cell_off;
-    const int nc = B.cw * B.ch;
-    const double rx = (double)S.w / (double)B.w, ry = (double)S.h / (double)B.h;
-    for (int c = tid; c < nc; c += 256) {
-      if (!need[c]) continue;
-      const int cx = c % B.cw, cy = c / B.cw;
-      int lx0, lx1, ly0, ly1;
-      cvb_reflect_range(8 * cx - CV_BORDER, min(8 * cx - CV_BORDER + 7, B.w + CV_BORDER - 1), B.w, lx0, lx1);
+    uint32_t* down = reinterpret_cast<uint32_t*>(sm + S.cell_off);
+    const float rx = (float)S.w / (float)B.w, ry = (float)S.h / (float)B.h;
+    for (int cy = wave; cy < B.ch; cy += NW) {
+      int ly0, ly1;
       cvb_reflect_range(8 * cy - CV_BORDER, min(8 * cy - CV_BORDER + 7, B.h + CV_BORDER - 1), B.h, ly0, ly1);
-      int sx0 = (int)floor(((double)lx0 + 0.5) * rx - 0.5) - 1, sx1 = (int)floor(((double)lx1 + 0.5) * rx - 0.5) + 2;
-      int sy0 = (int)floor(((double)ly0 + 0.5) * ry - 0.5) - 1, sy1 = (int)floor(((double)ly1 + 0.5) * ry - 0.5) + 2;
-      sx0 = max(sx0, 0); sy0 = max(sy0, 0); sx1 = min(sx1, S.w - 1); sy1 = min(sy1, S.h - 1);
-      const int ax0 = (sx0 + CV_BORDER) >> 3, ax1 = (sx1 + CV_BORDER) >> 3, ay0 = (sy0 + CV_BORDER) >> 3, ay1 = (sy1 + CV_BORDER) >> 3;
-      for (int ay = ay0; ay <= ay1; ay++)
-        for (int ax = ax0; ax <= ax1; ax++) down[ay * S.cw + ax] = 1;
+      const int sy0 = max((int)floorf(((float)ly0 + 0.5f) * ry - 0.5f) - 1, 0), sy1 = min((int)floorf(((float)ly1 + 0.5f) * ry - 0.5f) + 2, S.h - 1);
+      const int ay0 = (sy0 + CV_BORDER) >> 3, ay1 = (sy1 + CV_BORDER) >> 3;
+      for (int cx = lane; cx < B.cw; cx += 64) {
+        const uint32_t bits = sm[B.cell_off + cy * B.cw + cx];
+        if (!bits) continue;
+        int lx0, lx1;
+        cvb_reflect_range(8 * cx - CV_BORDER, min(8 * cx - CV_BORDER + 7, B.w + CV_BORDER - 1), B.w, lx0, lx1);
+        const int sx0 = max((int)floorf(((float)lx0 + 0.5f) * rx - 0.5f) - 1, 0), sx1 = min((int)floorf(((float)lx1 + 0.5f) * rx - 0.5f) + 2, S.w - 1);
+        const int ax0 = (sx0 + CV_BORDER) >> 3, ax1 = (sx1 + CV_BORDER) >> 3;
+        for (int ay = ay0; ay <= ay1; ay++)
+          for (int ax = ax0; ax <= ax1; ax++) {
+            const int i = ay * S.cw + ax;
+            atomicOr(&down[i >> 2], bits << (8 * (i & 3)));
+          }
+      }
     }
     __syncthreads();
   }
-  for (int l = 0; l < P.nlevels; l++) cvb_append_tiles(P, img, l, 0, sm + P.lv[l].cell_off, 0);
+  for (int l = 1; l < P.nlevels; l++) {
+    // worklist 0 of the levels above 0: the tiles with a needed cell; bit 3 when one of them is of the mask chain
+    const CvbLevel& B = P.lv[l];
+    const uint8_t* need = sm + B.cell_off;
+    for (int ty = wave; ty < B.th; ty += NW)
+      for (int tx = lane; tx < B.tw; tx += 64) {
+        uint32_t acc = 0;
+        for (int cy = 4 * ty; cy < 4 * ty + 4; cy++) acc |= *reinterpret_cast<const uint32_t*>(need + cy * B.cw + 4 * tx);
+        uint8_t f = 0;
+        if (acc & 0x03030303u) f |= 1;
+        if (acc & 0x02020202u) f |= 8;
+        tflag[B.tile_off + ty * B.tw + tx] |= f;
+      }
+  }
+  __syncthreads();
+  // worklist entries: positions inside the workgroup by LDS counters, then ONE global atomic per list and level
+  constexpr int PER = 8;                                           // tiles per thread (host check: tile_total <= PER * CVB_PLAN_T)
+  int lpos[PER][3];
+  for (int k = 0; k < PER; k++) {
+    const int i = tid + k * CVB_PLAN_T;
+    lpos[k][0] = lpos[k][1] = lpos[k][2] = -1;
+    if (i >= P.tile_total) continue;
+    int l = 0;
+    for (int q = 1; q < P.nlevels; q++) if (i >= P.lv[q].tile_off) l = q;
+    const uint8_t f = tflag[i];
+    for (int w = 0; w < 3; w++) if ((f >> w) & 1) lpos[k][w] = atomicAdd(&s_cnt[w * CV_MAX_LEVELS + l], 1);
+  }
+  __syncthreads();
+  if (tid < 3 * CV_MAX_LEVELS) s_base[tid] = s_cnt[tid] > 0 ? atomicAdd(&P.wl_count[tid], s_cnt[tid]) : 0;
+  __syncthreads();
+  for (int k = 0; k < PER; k++) {
+    const int i = tid + k * CVB_PLAN_T;
+    if (i >= P.tile_total) continue;
+    int l = 0;
+    for (int q = 1; q < P.nlevels; q++) if (i >= P.lv[q].tile_off) l = q;
+    const uint8_t f = tflag[i];
+    for (int w = 0; w < 3; w++)
+      if (lpos[k][w] >= 0) {
+        const int pos = s_base[w * CV_MAX_LEVELS + l] + lpos[k][w];
+        if (pos < P.wl_cap) P.wl[((size_t)w * CV_MAX_LEVELS + l) * P.wl_cap + pos] = ((uint32_t)img << 12) | (uint32_t)(i - P.lv[l].tile_off) | ((w == 0 && (f & 8)) ? 0x80000000u : 0u);
+      }
+  }
 }
 
 #define CVB_TILE_LOOP(P, which, l)                                                                      \
@@ -437,165 +492,336 @@ __global__ __launch_bounds__(256) void cvb_plan(CvbPlan P) {
   const int cnt = min(P.wl_count[(which) * CV_MAX_LEVELS + (l)], P.wl_cap);                             \
   for (int it = blockIdx.x; it < cnt; it += gridDim.x)
 
-__global__ __launch_bounds__(256) void cvb_level0(CvbPlan P, const uint8_t* imgs, int stride, size_t pitch, const uint8_t* masks, int mask_stride, size_t mask_pitch) {
+// The tile kernels run ONE WAVE per tile (64-thread workgroups): they are chains of dependent memory round trips (worklist entry ->
+// tables -> source patch -> result), so what counts is how many tiles are in flight - 32 per CU instead of 8.
+#define CVB_TT 64
+
+// level 0: copyMakeBorder(image, REFLECT_101) on the tiles around the level's own keypoints (the mask of level 0 is the input)
+__global__ __launch_bounds__(CVB_TT) void cvb_level0(CvbPlan P) {
+  const int tid = threadIdx.x;
   CVB_TILE_LOOP(P, 0, 0) {
     const uint32_t e = wl[it];
-    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
+    const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, 0);
-    const uint8_t* I = imgs + (size_t)img * pitch;
-    const uint8_t* M = masks + (size_t)img * mask_pitch;
-    const int py = CVB_TILE * ty + (threadIdx.x >> 3);
-    if (py >= L.h + 2 * CV_BORDER) continue;
-    const int y = reflect101(py - CV_BORDER, L.h);
-    for (int j = 0; j < 4; j++) {
-      const int px = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j;
-      if (px >= L.w + 2 * CV_BORDER) break;
-      const int x = reflect101(px - CV_BORDER, L.w);
-      L.pad[(size_t)py * L.stride + px] = I[(size_t)y * stride + x];
-      const int ix = px - CV_BORDER, iy = py - CV_BORDER;
-      if (ix >= 0 && ix < L.w && iy >= 0 && iy < L.h) L.mask[(size_t)iy * L.w + ix] = M[(size_t)iy * mask_stride + ix];
+    const uint8_t* I = P.imgs + (size_t)img * P.img_pitch;
+    const int px0 = CVB_TILE * tx + (tid & 7) * 4;
+    int xs[4];
+    for (int j = 0; j < 4; j++) xs[j] = reflect101(min(px0 + j, L.w + 2 * CV_BORDER - 1) - CV_BORDER, L.w);
+    for (int r = 0; r < 4; r++) {
+      const int py = CVB_TILE * ty + (tid >> 3) + 8 * r;
+      if (py >= L.h + 2 * CV_BORDER) continue;
+      const uint8_t* row = I + (size_t)reflect101(py - CV_BORDER, L.h) * P.img_stride;
+      const uint32_t v = (uint32_t)row[xs[0]] | ((uint32_t)row[xs[1]] << 8) | ((uint32_t)row[xs[2]] << 16) | ((uint32_t)row[xs[3]] << 24);
+      if (px0 < L.stride) *reinterpret_cast<uint32_t*>(L.pad + (size_t)py * L.stride + px0) = v;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void cvb_resize(CvbPlan P, int l) {
+// level l >= 1 from level l - 1 (level 1 from the image): the tile's table rows and its source patch are staged in LDS, every thread
+// interpolates four consecutive pixels of four rows and stores each quad as one dword; the mask likewise on the tiles of the mask chain
+__global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
+  constexpr int PS = 48;                          // source patch edge: 32 * 1.2 + taps + rounding
+  __shared__ uint8_t patch[PS * PS];
+  __shared__ uint8_t mpatch[PS * PS];
+  __shared__ int4 xt[CVB_TILE], yt[CVB_TILE];     // table entries of the tile's columns / rows, source offsets resolved
+  const int tid = threadIdx.x;
+  const CvbLevel& Sb = P.lv[l - 1];
   CVB_TILE_LOOP(P, 0, l) {
     const uint32_t e = wl[it];
-    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
-    const CvLevelDev L = cvb_level(P, img, l), S = cvb_level(P, img, l - 1);
-    const int py = CVB_TILE * ty + (threadIdx.x >> 3);
-    if (py >= L.h + 2 * CV_BORDER) continue;
-    const int y = reflect101(py - CV_BORDER, L.h);
-    const int4 tyv = B.ytab[y];
-    const uint8_t* sroi = S.pad + (size_t)CV_BORDER * S.stride + CV_BORDER;
-    for (int j = 0; j < 4; j++) {
-      const int px = CVB_TILE * tx + (threadIdx.x & 7) * 4 + j;
-      if (px >= L.w + 2 * CV_BORDER) break;
-      const int x = reflect101(px - CV_BORDER, L.w);
-      const int4 txv = B.xtab[x];
-      L.pad[(size_t)py * L.stride + px] = cv_interp(sroi, S.stride, S.w, S.h, txv, tyv);
-      const int ix = px - CV_BORDER, iy = py - CV_BORDER;
-      if (ix >= 0 && ix < L.w && iy >= 0 && iy < L.h) {
-        const uint8_t m = cv_interp(S.mask, S.w, S.w, S.h, txv, tyv);
-        L.mask[(size_t)iy * L.w + ix] = m > 254 ? m : 0;
+    const bool with_mask = (e >> 31) != 0;
+    const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
+    const CvLevelDev L = cvb_level(P, img, l);
+    const uint8_t* src; int sstride;
+    const uint8_t* msrc; int mstride;
+    if (l == 1) { src = P.imgs + (size_t)img * P.img_pitch; sstride = P.img_stride; msrc = P.masks + (size_t)img * P.mask_pitch; mstride = P.mask_stride; }
+    else {
+      const CvLevelDev S = cvb_level(P, img, l - 1);
+      src = S.pad + (size_t)CV_BORDER * S.stride + CV_BORDER; sstride = S.stride; msrc = S.mask; mstride = S.w;
+    }
+    __syncthreads();
+    {
+      // lanes 0..31: the columns' table entries, lanes 32..63: the rows'; .x = the first source index of the entry
+      const int k = tid & 31;
+      const bool isx = tid < 32;
+      const int len = isx ? L.w : L.h, slen = isx ? Sb.w : Sb.h;
+      const int p = min(CVB_TILE * (isx ? tx : ty) + k, len + 2 * CV_BORDER - 1);
+      int4 v = (isx ? B.xtab : B.ytab)[reflect101(p - CV_BORDER, len)];
+      v.x = v.w == 1 ? 0 : (v.w == 2 ? slen - 1 : v.x);
+      (isx ? xt : yt)[k] = v;
+    }
+    __syncthreads();
+    // source rectangle: the extreme source indices over the tile's columns / rows (+ 1 for the second tap)
+    int ox, oy, nx, ny;
+    {
+      const int4 v = tid < 32 ? xt[tid & 31] : yt[tid & 31];
+      int mn = v.x, mxv = v.w == 0 ? v.x + 1 : v.x;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) { mn = min(mn, __shfl_xor(mn, d)); mxv = max(mxv, __shfl_xor(mxv, d)); }
+      ox = __shfl(mn, 0); oy = __shfl(mn, 32);
+      nx = min(__shfl(mxv, 0), Sb.w - 1) - ox + 1; ny = min(__shfl(mxv, 32), Sb.h - 1) - oy + 1;
+    }
+    {
+      // 16 lanes per source row, three bytes each, four rows per pass: every load is issued before the first LDS store
+      uint8_t v[PS / 4][3], mv[PS / 4][3];
+#pragma unroll
+      for (int ry = 0; ry < PS / 4; ry++)
+#pragma unroll
+        for (int rx = 0; rx < 3; rx++) {
+          const int yy = (tid >> 4) + 4 * ry, xx = (tid & 15) + 16 * rx;
+          const bool in = yy < ny && xx < nx;
+          v[ry][rx] = in ? src[(size_t)(oy + yy) * sstride + ox + xx] : (uint8_t)0;
+          mv[ry][rx] = (in && with_mask) ? msrc[(size_t)(oy + yy) * mstride + ox + xx] : (uint8_t)0;
+        }
+#pragma unroll
+      for (int ry = 0; ry < PS / 4; ry++)
+#pragma unroll
+        for (int rx = 0; rx < 3; rx++) {
+          const int yy = (tid >> 4) + 4 * ry, xx = (tid & 15) + 16 * rx;
+          patch[yy * PS + xx] = v[ry][rx];
+          if (with_mask) mpatch[yy * PS + xx] = mv[ry][rx];
+        }
+    }
+    __syncthreads();
+    const int c4 = (tid & 7) * 4, px0 = CVB_TILE * tx + c4;
+    int4 txv[4];
+    for (int j = 0; j < 4; j++) txv[j] = xt[c4 + j];
+    for (int r = 0; r < 4; r++) {
+      const int ry = (tid >> 3) + 8 * r, py = CVB_TILE * ty + ry;
+      if (py >= L.h + 2 * CV_BORDER) continue;
+      const int4 tyv = yt[ry];
+      const int r0 = tyv.x - oy;
+      uint32_t out = 0;
+      for (int which = 0; which < (with_mask ? 2 : 1); which++) {
+        const uint8_t* Pp = which == 0 ? patch : mpatch;
+        for (int j = 0; j < 4; j++) {
+          const uint8_t* row0 = Pp + r0 * PS + (txv[j].x - ox);
+          // cv_interp on the patch: horizontal pass in 8.8 per source row, vertical in 16.16, one rounding
+          const uint32_t h0 = txv[j].w != 0 ? (uint32_t)row0[0] << 8 : (uint32_t)txv[j].y * row0[0] + (uint32_t)txv[j].z * row0[1];
+          uint32_t v;
+          if (tyv.w != 0) v = min((h0 + 128u) >> 8, 255u);
+          else {
+            const uint8_t* row1 = row0 + PS;
+            const uint32_t h1 = txv[j].w != 0 ? (uint32_t)row1[0] << 8 : (uint32_t)txv[j].y * row1[0] + (uint32_t)txv[j].z * row1[1];
+            const unsigned long long acc = (unsigned long long)h0 * (uint32_t)tyv.y + (unsigned long long)h1 * (uint32_t)tyv.z;
+            v = (uint32_t)min((acc + 32768ull) >> 16, 255ull);
+          }
+          if (which == 0) out |= v << (8 * j);
+          else {
+            const int ix = px0 + j - CV_BORDER, iy = py - CV_BORDER;
+            if (ix >= 0 && ix < L.w && iy >= 0 && iy < L.h) L.mask[(size_t)iy * L.w + ix] = v > 254 ? (uint8_t)v : (uint8_t)0;
+          }
+        }
       }
+      if (px0 < L.stride) *reinterpret_cast<uint32_t*>(L.pad + (size_t)py * L.stride + px0) = out;
     }
   }
 }
 
-// FAST score of one pixel from a tile of the padded plane in LDS (row stride TS, c = the pixel): the body of cv_score
+// FAST score of one pixel from a tile of the padded plane in LDS (row stride TS, c = the pixel): the largest margin by which 9
+// contiguous ring pixels are all darker or all brighter than the centre.  min / max over every window of 9 consecutive ring
+// pixels by doubling (windows of 2, 4, 8, then one more): 4 x 16 operations per polarity instead of 8 x 16.
 template <int TS>
-__device__ __forceinline__ uint8_t cvb_fast_score_lds(const uint8_t* c, int th) {
+__device__ __forceinline__ int cvb_fast_score_full(const uint8_t* c) {
   const int st = TS, v = c[0];
-  const int n = c[3 * st], e = c[3], so = c[-3 * st], w = c[-3];
-  const int M = min(min(max(n, e), max(e, so)), min(max(so, w), max(w, n)));
-  const int m = max(max(min(n, e), min(e, so)), max(min(so, w), min(w, n)));
-  if (!(v - M > th || m - v > th)) return 0;
   const int off[16] = {3 * st, 3 * st + 1, 2 * st + 2, st + 3, 3, -st + 3, -2 * st + 2, -3 * st + 1,
                        -3 * st, -3 * st - 1, -2 * st - 2, -st - 3, -3, st - 3, 2 * st - 2, 3 * st - 1};
-  int r[16];
+  int r[16], lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) r[i] = c[off[i]];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { lo2[i] = min(r[i], r[(i + 1) & 15]); hi2[i] = max(r[i], r[(i + 1) & 15]); }
+#pragma unroll
+  for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
   int best = 0;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    int mx = r[k], mn = r[k];
-#pragma unroll
-    for (int j = 1; j < 9; j++) { mx = max(mx, r[(k + j) & 15]); mn = min(mn, r[(k + j) & 15]); }
-    best = max(best, max(v - mx, mn - v));
+  for (int i = 0; i < 16; i++) {
+    const int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), r[(i + 8) & 15]);
+    const int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), r[(i + 8) & 15]);
+    best = max(best, max(v - hi9, lo9 - v));
   }
-  return best > th ? (uint8_t)best : (uint8_t)0;
+  return best;
 }
 
-// worklists of all levels in one launch (blockIdx.y = level).  Per tile: the 40 x 40 neighbourhood of the padded plane into LDS,
-// FAST scores of the tile and one ring around it (34 x 34) into LDS, then per tile pixel inside a kp cell the keypoint
-// predicate of cv_is_keypoint - strict 3 x 3 maximum, mask, border rectangle - and the append with the Harris response
-__global__ __launch_bounds__(256) void cvb_detect(CvbPlan P) {
+// HarrisResponses (cv_harris) on a tile of the padded plane in LDS: c = the keypoint's pixel, row stride TS
+template <int TS>
+__device__ __forceinline__ float cvb_harris_lds(const uint8_t* c) {
+  const uint8_t* ptr0 = c - 3 * TS - 3;
+  int a = 0, b = 0, cc = 0;
+  for (int i = 0; i < 7; i++)
+    for (int j = 0; j < 7; j++) {
+      const uint8_t* ptr = ptr0 + i * TS + j;
+      const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-TS + 1] - ptr[-TS - 1]) + (ptr[TS + 1] - ptr[TS - 1]);
+      const int Iy = (ptr[TS] - ptr[-TS]) * 2 + (ptr[TS - 1] - ptr[-TS - 1]) + (ptr[TS + 1] - ptr[-TS + 1]);
+      a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
+    }
+  const float scale = __fdiv_rn(1.f, __fmul_rn((float)(4 * 7), 255.f));
+  const float scale_sq_sq = __fmul_rn(__fmul_rn(__fmul_rn(scale, scale), scale), scale);
+  const float fa = (float)a, fb = (float)b, fc = (float)cc;
+  const float sum = __fadd_rn(fa, fb);
+  return __fmul_rn(__fsub_rn(__fsub_rn(__fmul_rn(fa, fb), __fmul_rn(fc, fc)), __fmul_rn(__fmul_rn(0.04f, sum), sum)), scale_sq_sq);
+}
+
+// worklists of all levels in one launch (blockIdx.y = level).  Per tile: the 40 x 40 neighbourhood of the padded plane into LDS;
+// the compass test (two adjacent compass points both darker / brighter: necessary for a 9-arc) over the tile and one ring around
+// it (34 x 34) leaves a list of survivors; their exact scores go into the LDS score map; then per tile pixel inside a kp cell the
+// keypoint predicate of cv_is_keypoint - strict 3 x 3 maximum, mask, border rectangle - and the append with the Harris response
+__global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
   constexpr int TS = 40, SS = 34;
-  __shared__ uint8_t tile[TS * TS];
-  __shared__ uint8_t sc[SS * SS];
-  const int l = blockIdx.y, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[TS * TS];
+  __shared__ uint8_t sc[SS * SS + 4];
+  __shared__ uint16_t surv[SS * SS];
+  __shared__ int nsurv;
+  const int l = blockIdx.y, tid = threadIdx.x, th = P.fast_th;
   CVB_TILE_LOOP(P, 1, l) {
     const uint32_t e = wl[it];
-    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
+    const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l);
     const int PW = L.w + 2 * CV_BORDER, PH = L.h + 2 * CV_BORDER;
-    const int bx = CVB_TILE * tx - 4, by = CVB_TILE * ty - 4;           // padded coordinates of tile[0]
+    const int bx = CVB_TILE * tx - 4, by = CVB_TILE * ty - 4;           // padded coordinates of tile[0]; bx is a multiple of 4
     __syncthreads();
-    for (int i = tid; i < TS * TS; i += 256) {
-      const int px = bx + i % TS, py = by + i / TS;
-      tile[i] = (px >= 0 && px < PW && py >= 0 && py < PH) ? L.pad[(size_t)py * L.stride + px] : 0;
+    if (tid == 0) nsurv = 0;
+    // 40 rows of 10 aligned dwords (the plane's row stride is a multiple of 64 and wider than the padded width)
+    {
+      constexpr int NIT = (TS * (TS / 4) + CVB_TT - 1) / CVB_TT;
+      uint32_t v[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; k++) {            // every load is issued before the first LDS store
+        const int i = tid + k * CVB_TT, yy = i / (TS / 4), q = i % (TS / 4);
+        const int px = bx + 4 * q, py = by + yy;
+        v[k] = (i < TS * (TS / 4) && px >= 0 && px < L.stride && py >= 0 && py < PH) ? *reinterpret_cast<const uint32_t*>(L.pad + (size_t)py * L.stride + px) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; k++) {
+        const int i = tid + k * CVB_TT;
+        if (i < TS * (TS / 4)) *reinterpret_cast<uint32_t*>(tile + (i / (TS / 4)) * TS + 4 * (i % (TS / 4))) = v[k];
+      }
     }
     __syncthreads();
-    for (int i = tid; i < SS * SS; i += 256) {
+    for (int i = tid; i < SS * SS; i += CVB_TT) {
       const int sx = i % SS, sy = i / SS;                                // score pixel: padded (bx + 3 + sx, by + 3 + sy)
       const int x = bx + 3 + sx - CV_BORDER, y = by + 3 + sy - CV_BORDER;
-      uint8_t v = 0;
-      if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) v = cvb_fast_score_lds<TS>(tile + (sy + 3) * TS + sx + 3, P.fast_th);
-      sc[i] = v;
+      bool cand = false;
+      if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
+        const uint8_t* c = tile + (sy + 3) * TS + sx + 3;
+        const int v = c[0], n = c[3 * TS], ea = c[3], so = c[-3 * TS], w = c[-3];
+        const int M = min(min(max(n, ea), max(ea, so)), min(max(so, w), max(w, n)));
+        const int m = max(max(min(n, ea), min(ea, so)), max(min(so, w), min(w, n)));
+        cand = v - M > th || m - v > th;
+      }
+      sc[i] = 0;
+      if (cand) surv[atomicAdd(&nsurv, 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int ns = nsurv;
+    for (int k = tid; k < ns; k += CVB_TT) {
+      const int i = surv[k], sx = i % SS, sy = i / SS;
+      const int best = cvb_fast_score_full<TS>(tile + (sy + 3) * TS + sx + 3);
+      if (best > th) sc[i] = (uint8_t)best;
     }
     __syncthreads();
     const uint8_t* kpmap = P.kpmap + (size_t)img * P.cell_total + B.cell_off;
-    for (int j = 0; j < 4; j++) {
-      const int lx = (tid & 7) * 4 + j, ly = tid >> 3;
-      const int px = CVB_TILE * tx + lx, py = CVB_TILE * ty + ly;
-      const int x = px - CV_BORDER, y = py - CV_BORDER;
-      if (x < P.edge || x >= L.w - P.edge || y < P.edge || y >= L.h - P.edge) continue;
-      if (!kpmap[(py >> 3) * B.cw + (px >> 3)]) continue;
-      const uint8_t* s = sc + (ly + 1) * SS + lx + 1;
-      const int v = s[0];
-      if (v == 0) continue;
-      if (!(v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] && v > s[SS - 1] && v > s[SS] && v > s[SS + 1])) continue;
-      if (L.mask[(size_t)y * L.w + x] == 0) continue;
-      const int slot = img * P.nlevels + l;
-      const int pos = atomicAdd(&P.ncand[slot], 1);
-      if (pos < CVB_CAND_CAP) P.cand[(size_t)slot * CVB_CAND_CAP + pos] = make_float4((float)x, (float)y, (float)(v - 1), cv_harris(L, x, y));
-    }
+    const uint8_t* mk = l == 0 ? P.masks + (size_t)img * P.mask_pitch : L.mask;
+    const int mks = l == 0 ? P.mask_stride : L.w;
+    for (int r = 0; r < 4; r++)
+      for (int j = 0; j < 4; j++) {
+        const int lx = (tid & 7) * 4 + j, ly = (tid >> 3) + 8 * r;
+        const int px = CVB_TILE * tx + lx, py = CVB_TILE * ty + ly;
+        const int x = px - CV_BORDER, y = py - CV_BORDER;
+        if (x < P.edge || x >= L.w - P.edge || y < P.edge || y >= L.h - P.edge) continue;
+        const uint8_t* s = sc + (ly + 1) * SS + lx + 1;
+        const int v = s[0];
+        if (v == 0) continue;
+        if (!(v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] && v > s[SS - 1] && v > s[SS] && v > s[SS + 1])) continue;
+        if (!kpmap[(py >> 3) * B.cw + (px >> 3)]) continue;
+        if (mk[(size_t)y * mks + x] == 0) continue;
+        const int slot = img * P.nlevels + l;
+        const int pos = atomicAdd(&P.ncand[slot], 1);
+        if (pos < CVB_CAND_CAP) P.cand[(size_t)slot * CVB_CAND_CAP + pos] = make_float4((float)x, (float)y, (float)(v - 1), cvb_harris_lds<TS>(tile + (ly + 4) * TS + lx + 4));
+      }
   }
 }
 
-// 7 x 7 blur of a tile: 38 x 38 neighbourhood in LDS, horizontal pass into 16-bit sums, vertical pass, one rounding
-__global__ __launch_bounds__(256) void cvb_blur(CvbPlan P) {
-  constexpr int TS = 38;
-  __shared__ uint8_t tile[TS * TS];
-  __shared__ uint16_t hs[TS * 32];
+// 7 x 7 blur of a tile: 38 x 38 neighbourhood in LDS (40-byte rows), horizontal pass into 16-bit sums, vertical pass, one rounding
+__global__ __launch_bounds__(CVB_TT) void cvb_blur(CvbPlan P) {
+  constexpr int TS = 40, TR = 38;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[TS * TR];
+  __shared__ __attribute__((aligned(16))) uint16_t hs[TR * 32 + 64];
   const int l = blockIdx.y, tid = threadIdx.x;
   const uint32_t kq[7] = {(uint32_t)P.kq[0], (uint32_t)P.kq[1], (uint32_t)P.kq[2], (uint32_t)P.kq[3], (uint32_t)P.kq[2], (uint32_t)P.kq[1], (uint32_t)P.kq[0]};
   CVB_TILE_LOOP(P, 2, l) {
     const uint32_t e = wl[it];
-    const int img = (int)(e >> 12), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
+    const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l);
     const int PW = L.w + 2 * CV_BORDER, PH = L.h + 2 * CV_BORDER;
-    const int bx = CVB_TILE * tx - 3, by = CVB_TILE * ty - 3;
+    const int bx = CVB_TILE * tx - 4, by = CVB_TILE * ty - 3;           // tile[0] = padded (bx, by); bx is a multiple of 4, the window starts at bx + 1
     __syncthreads();
-    for (int i = tid; i < TS * TS; i += 256) {
-      const int px = bx + i % TS, py = by + i / TS;
-      tile[i] = (px >= 0 && px < PW && py >= 0 && py < PH) ? L.pad[(size_t)py * L.stride + px] : 0;
-    }
-    __syncthreads();
-    for (int i = tid; i < TS * 32; i += 256) {
-      const int r = i >> 5, c = i & 31;
-      const uint8_t* row = tile + r * TS + c;
-      uint32_t hsum = 0;
+    {
+      constexpr int NIT = (TR * (TS / 4) + CVB_TT - 1) / CVB_TT;
+      uint32_t v[NIT];
 #pragma unroll
-      for (int k = 0; k < 7; k++) hsum += kq[k] * row[k];
-      hs[i] = (uint16_t)min(hsum, 65535u);
-    }
-    __syncthreads();
-    for (int j = 0; j < 4; j++) {
-      const int lx = (tid & 7) * 4 + j, ly = tid >> 3;
-      const int px = CVB_TILE * tx + lx, py = CVB_TILE * ty + ly;
-      if (px >= PW || py >= PH) continue;
-      const int x = px - CV_BORDER, y = py - CV_BORDER;
-      uint8_t o;
-      if (x < 0 || x >= L.w || y < 0 || y >= L.h) o = tile[(ly + 3) * TS + lx + 3];
-      else {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) acc += kq[k] * hs[(ly + k) * 32 + lx];
-        o = (uint8_t)min((acc + 32768u) >> 16, 255u);
+      for (int k = 0; k < NIT; k++) {            // every load is issued before the first LDS store
+        const int i = tid + k * CVB_TT, yy = i / (TS / 4), q = i % (TS / 4);
+        const int px = bx + 4 * q, py = by + yy;
+        v[k] = (i < TR * (TS / 4) && px >= 0 && px < L.stride && py >= 0 && py < PH) ? *reinterpret_cast<const uint32_t*>(L.pad + (size_t)py * L.stride + px) : 0u;
       }
-      L.blur[(size_t)py * L.stride + px] = o;
+#pragma unroll
+      for (int k = 0; k < NIT; k++) {
+        const int i = tid + k * CVB_TT;
+        if (i < TR * (TS / 4)) *reinterpret_cast<uint32_t*>(tile + (i / (TS / 4)) * TS + 4 * (i % (TS / 4))) = v[k];
+      }
+    }
+    __syncthreads();
+    // horizontal pass: four adjacent outputs per item from three aligned dwords of the row (bytes 4 q + 1 .. 4 q + 10)
+    for (int i = tid; i < TR * 8; i += CVB_TT) {
+      const int r = i >> 3, q = i & 7;
+      const uint32_t* rw = reinterpret_cast<const uint32_t*>(tile + r * TS + 4 * q);
+      const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
+      uint32_t bb[10];
+      bb[0] = (d0 >> 8) & 255u; bb[1] = (d0 >> 16) & 255u; bb[2] = d0 >> 24;
+      bb[3] = d1 & 255u; bb[4] = (d1 >> 8) & 255u; bb[5] = (d1 >> 16) & 255u; bb[6] = d1 >> 24;
+      bb[7] = d2 & 255u; bb[8] = (d2 >> 8) & 255u; bb[9] = (d2 >> 16) & 255u;
+      uint32_t h[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t hsum = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) hsum += kq[k] * bb[j + k];
+        h[j] = min(hsum, 65535u);
+      }
+      *reinterpret_cast<uint2*>(hs + r * 32 + 4 * q) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    }
+    __syncthreads();
+    // vertical pass: a 4 x 4 block of outputs per thread from ten rows of four sums
+    {
+      const int lx0 = (tid & 7) * 4, ly0 = (tid >> 3) * 4;
+      const int px0 = CVB_TILE * tx + lx0;
+      uint32_t col[10][4];
+#pragma unroll
+      for (int r = 0; r < 10; r++) {
+        const uint2 v = *reinterpret_cast<const uint2*>(hs + (ly0 + r) * 32 + lx0);
+        col[r][0] = v.x & 0xFFFFu; col[r][1] = v.x >> 16; col[r][2] = v.y & 0xFFFFu; col[r][3] = v.y >> 16;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ly = ly0 + r, py = CVB_TILE * ty + ly;
+        if (py >= PH) continue;
+        const int y = py - CV_BORDER;
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int x = px0 + j - CV_BORDER;
+          uint32_t o;
+          if (x < 0 || x >= L.w || y < 0 || y >= L.h) o = tile[(ly + 3) * TS + lx0 + j + 4];
+          else {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) acc += kq[k] * col[r + k][j];
+            o = min((acc + 32768u) >> 16, 255u);
+          }
+          out |= o << (8 * j);
+        }
+        if (px0 < L.stride) *reinterpret_cast<uint32_t*>(L.blur + (size_t)py * L.stride + px0) = out;
+      }
     }
   }
 }
@@ -652,71 +878,78 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P) {
   if (tid == 0) P.nsel[slot] = m;
 }
 
-// four keypoints per workgroup (one wave each): ICAngles, pt *= scale, computeOrbDescriptors - the body of cv_describe on the
+// four keypoints per WAVE, one per 16-lane row: ICAngles, pt *= scale, computeOrbDescriptors - the arithmetic of cv_describe on the
 // image's own planes; keypoint k of an image is entry k of the concatenation of its levels' selections
 __global__ __launch_bounds__(256) void cvb_describe(CvbPlan P) {
-  const int img = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  int l = 0, base = 0, total = 0;
-  {
-    int acc = 0;
-    bool found = false;
-    for (int i = 0; i < P.nlevels; i++) {
-      const int c = P.nsel[img * P.nlevels + i];
-      if (!found && k < acc + c) { l = i; base = acc; found = true; }
-      acc += c;
-    }
-    total = acc;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      P.count[img] = min(total, P.ocap);
-      if (total > P.ocap) atomicAdd(&P.overflow[img], 1);
-    }
-    if (!found || k >= P.ocap) return;
+  const int img = blockIdx.y, lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
+  int nsel[CV_MAX_LEVELS];
+  int total = 0;
+  for (int i = 0; i < P.nlevels; i++) { nsel[i] = P.nsel[img * P.nlevels + i]; total += nsel[i]; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    P.count[img] = min(total, P.ocap);
+    if (total > P.ocap) atomicAdd(&P.overflow[img], 1);
   }
-  const CvSel S = P.sel[(size_t)(img * P.nlevels + l) * CVB_CAND_CAP + (k - base)];
-  const CvLevelDev L = cvb_level(P, img, l);
-  const int x0 = S.x, y0 = S.y;
-  const uint8_t* center = L.pad + (size_t)(CV_BORDER + y0) * L.stride + CV_BORDER + x0;
-  int m10 = 0, m01 = 0;
-  if (lane <= 15) {
-    const int v = lane, d = P.umax[v];
-    if (v == 0) {
-      for (int u = -15; u <= 15; ++u) m10 += u * center[u];
-    } else {
+  total = min(total, P.ocap);
+  for (int k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; k0 < total; k0 += gridDim.x * 16) {
+    const bool live = k0 + grp < total;
+    const int k = live ? k0 + grp : total - 1;
+    int l = 0, base = 0;
+    {
+      int acc = 0;
+      for (int i = 0; i < P.nlevels; i++) {
+        if (k >= acc && k < acc + nsel[i]) { l = i; base = acc; }
+        acc += nsel[i];
+      }
+    }
+    const CvSel S = P.sel[(size_t)(img * P.nlevels + l) * CVB_CAND_CAP + (k - base)];
+    const CvLevelDev L = cvb_level(P, img, l);
+    const int x0 = S.x, y0 = S.y;
+    const uint8_t* center = L.pad + (size_t)(CV_BORDER + y0) * L.stride + CV_BORDER + x0;
+    int m10 = 0, m01 = 0;
+    {
+      // row +v and row -v of the disc on lane v of the keypoint's 16 lanes (lane 0: the centre row, counted once); every load of
+      // the 31-column span is issued (the padded plane holds it all), the disc mask picks the ones that count
+      const int v = l16, d = P.umax[v];
+      const uint8_t* rp = center + v * L.stride;
+      const uint8_t* rm = center - v * L.stride;
       int v_sum = 0;
-      for (int u = -d; u <= d; ++u) {
-        const int vp = center[u + v * L.stride], vm = center[u - v * L.stride];
-        v_sum += vp - vm;
-        m10 += u * (vp + vm);
+#pragma unroll
+      for (int u = -15; u <= 15; ++u) {
+        const int vp = rp[u], vm = rm[u];
+        const int in = (u >= -d && u <= d) ? 1 : 0;
+        v_sum += in * (vp - vm);
+        m10 += in * u * (v == 0 ? vp : vp + vm);
       }
       m01 = v * v_sum;
     }
-  }
 #pragma unroll
-  for (int dd = 32; dd >= 1; dd >>= 1) { m10 += __shfl_xor(m10, dd); m01 += __shfl_xor(m01, dd); }
-  const float angle_deg = cv_fast_atan2_deg((float)m01, (float)m10);
-  const float px = __fmul_rn((float)x0, L.scale), py = __fmul_rn((float)y0, L.scale);
-  if (lane == 0) {
-    ps_keypoint_pod o;
-    o.x = px; o.y = py; o.size = __fmul_rn(31.f, L.scale); o.angle = angle_deg; o.response = S.response; o.octave = S.level; o.class_id = -1;
-    P.kps[(size_t)img * P.ocap + k] = o;
-  }
-  if (lane < 32) {
+    for (int dd = 8; dd >= 1; dd >>= 1) { m10 += __shfl_xor(m10, dd); m01 += __shfl_xor(m01, dd); }
+    const float angle_deg = cv_fast_atan2_deg((float)m01, (float)m10);
+    const float px = __fmul_rn((float)x0, L.scale), py = __fmul_rn((float)y0, L.scale);
+    if (live && l16 == 0) {
+      ps_keypoint_pod o;
+      o.x = px; o.y = py; o.size = __fmul_rn(31.f, L.scale); o.angle = angle_deg; o.response = S.response; o.octave = S.level; o.class_id = -1;
+      P.kps[(size_t)img * P.ocap + k] = o;
+    }
     const float inv = __fdiv_rn(1.f, L.scale);
     const float angle = __fmul_rn(angle_deg, (float)(3.14159265358979323846 / 180.f));
     const float a = (float)cos((double)angle), b = (float)sin((double)angle);
     const uint8_t* c = L.blur + (size_t)(CV_BORDER + __float2int_rn(__fmul_rn(py, inv))) * L.stride + CV_BORDER + __float2int_rn(__fmul_rn(px, inv));
-    const int8_t* pat = cv_pattern + lane * 32;
-    int val = 0;
-    for (int t = 0; t < 8; t++) {
-      int tv[2];
-      for (int q = 0; q < 2; q++) {
-        const float fx = (float)pat[4 * t + 2 * q], fy = (float)pat[4 * t + 2 * q + 1];
+    for (int half = 0; half < 2; half++) {
+      const int byte = l16 + 16 * half;
+      const int8_t* pat = cv_pattern + byte * 32;
+      int tv[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {             // all sixteen taps of the byte in flight together
+        const float fx = (float)pat[2 * i], fy = (float)pat[2 * i + 1];
         const float rx = __fsub_rn(__fmul_rn(fx, a), __fmul_rn(fy, b)), ry = __fadd_rn(__fmul_rn(fx, b), __fmul_rn(fy, a));
-        tv[q] = c[__float2int_rn(ry) * L.stride + __float2int_rn(rx)];
+        tv[i] = c[__float2int_rn(ry) * L.stride + __float2int_rn(rx)];
       }
-      val |= (tv[0] < tv[1]) << t;
+      int val = 0;
+#pragma unroll
+      for (int tt = 0; tt < 8; tt++) val |= (tv[2 * tt] < tv[2 * tt + 1]) << tt;
+      if (live) P.desc[((size_t)img * P.ocap + k) * 32 + byte] = (uint8_t)val;
     }
-    P.desc[((size_t)img * P.ocap + k) * 32 + lane] = (uint8_t)val;
   }
 }
 
@@ -742,19 +975,22 @@ void psk_cv_describe(const CvPlanDev* plan, const CvSel* sel, int nsel, void* kp
   if (nsel > 0) hipLaunchKernelGGL(cv_describe, dim3(nsel), dim3(64), 0, st, *plan, sel, nsel, (ps_keypoint_pod*)kps, desc);
 }
 
-void psk_cvb_run(const CvbPlan* P, int nimg, const uint8_t* imgs, int stride, size_t pitch, const uint8_t* masks, int mask_stride, size_t mask_pitch,
-                 hipStream_t st) {
+void psk_cvb_run(const CvbPlan* Pin, int nimg, const uint8_t* imgs, int stride, size_t pitch, const uint8_t* masks, int mask_stride, size_t mask_pitch,
+                 int occupancy_given, hipStream_t st) {
+  CvbPlan Q = *Pin;
+  Q.imgs = imgs; Q.img_stride = stride; Q.img_pitch = pitch; Q.masks = masks; Q.mask_stride = mask_stride; Q.mask_pitch = mask_pitch;
+  const CvbPlan* P = &Q;
   const int NL = P->nlevels;
-  const int grid = 4096;                                       // persistent loops over the worklists
-  hipLaunchKernelGGL(cvb_occupancy, dim3((P->h0 + 31) / 32, nimg), dim3(256), 0, st, *P, masks, mask_stride, mask_pitch);
-  const size_t plan_lds = (size_t)P->cell_total + 2 * (size_t)P->cell_max;
+  const int grid = 16384;                                      // persistent loops over the worklists, one wave per tile
+  if (!occupancy_given) hipLaunchKernelGGL(cvb_occupancy, dim3((P->h0 + 31) / 32, nimg), dim3(256), 0, st, *P, masks, mask_stride, mask_pitch);
+  const size_t plan_lds = (size_t)((P->cell_total + 3) & ~3) + 2 * (size_t)((P->cell_max + 3) & ~3) + 2 * (size_t)(P->ocw + 1) * (P->och + 1) + (size_t)P->tile_total + 16;
   if (plan_lds > 48 * 1024) hipFuncSetAttribute((const void*)cvb_plan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds);
-  hipLaunchKernelGGL(cvb_plan, dim3(nimg), dim3(256), plan_lds, st, *P);
-  hipLaunchKernelGGL(cvb_level0, dim3(grid), dim3(256), 0, st, *P, imgs, stride, pitch, masks, mask_stride, mask_pitch);
-  for (int l = 1; l < NL; l++) hipLaunchKernelGGL(cvb_resize, dim3(grid), dim3(256), 0, st, *P, l);
-  hipLaunchKernelGGL(cvb_detect, dim3(grid / 4, NL), dim3(256), 0, st, *P);
-  hipLaunchKernelGGL(cvb_blur, dim3(grid / 4, NL), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_plan, dim3(nimg), dim3(CVB_PLAN_T), plan_lds, st, *P);
+  hipLaunchKernelGGL(cvb_level0, dim3(grid), dim3(CVB_TT), 0, st, *P);
+  for (int l = 1; l < NL; l++) hipLaunchKernelGGL(cvb_resize, dim3(grid), dim3(CVB_TT), 0, st, *P, l);
+  hipLaunchKernelGGL(cvb_detect, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
+  hipLaunchKernelGGL(cvb_blur, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
   hipLaunchKernelGGL(cvb_select, dim3(nimg * NL), dim3(256), 0, st, *P);
-  hipLaunchKernelGGL(cvb_describe, dim3((P->ocap + 3) / 4, nimg), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_describe, dim3(8, nimg), dim3(256), 0, st, *P);
 }
 }

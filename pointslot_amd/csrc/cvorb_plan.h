@@ -31,7 +31,7 @@ struct ps_keypoint_pod { float x, y, size, angle, response; int32_t octave, clas
 #define CVB_MAX_TILES 4096     // tiles of one level's padded plane (worklist entries carry the tile in 12 bits)
 struct CvbLevel {
   int32_t w, h, stride;        // level size, padded-plane row stride
-  int32_t tw, th;              // tiles of the padded plane
+  int32_t tw, th, tile_off;    // tiles of the padded plane; offset of the level in the per-image tile arrays
   int32_t cw, ch, cell_off;    // 8 x 8 cells of the padded plane; offset of the level in the per-image cell arrays
   int32_t quota;               // nfeaturesPerLevel
   float scale;
@@ -43,9 +43,12 @@ struct CvbPlan {
   int32_t nlevels, edge, fast_th, w0, h0;
   int32_t ocw, och;            // level-0 occupancy cells (8 x 8 image pixels)
   int32_t cell_total, cell_max; // cells of all levels / of the largest level
+  int32_t tile_total;
   int32_t umax[17];
   int32_t kq[4];
   uint8_t* arena; size_t arena_pitch;      // per image: the planes of all levels
+  const uint8_t* imgs; int32_t img_stride; size_t img_pitch;       // the call's inputs (level 0's source, level 0's mask)
+  const uint8_t* masks; int32_t mask_stride; size_t mask_pitch;
   uint8_t* occ;                // [nimg][och][ocw]: the object mask has a non-zero pixel in that cell
   uint8_t* kpmap;              // [nimg][cell_total]: cells of every level in which a keypoint is possible
   uint32_t* wl; int32_t* wl_count; int32_t wl_cap;   // [3 (planes, FAST, blur)][CV_MAX_LEVELS][wl_cap] entries (image << 12 | tile)

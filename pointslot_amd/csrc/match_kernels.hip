@@ -32,10 +32,14 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #define TOPK_T 256
 // keys[w][j] = dist << 16 | j for the wave's current query (LDS), then 8 rounds of "smallest key greater
 // than the previous one".
+// `count` (nullable): the number of entries of `blocks` when the table was built on the device (the lockstep tracker); the grid then
+// loops over it.  Host-built tables are launched with one workgroup per entry.
 __global__ __launch_bounds__(TOPK_T) void bf_topk(const BfBlock* blocks, const BfProb* probs, const uint8_t* qdesc,
-                                                   const uint8_t* tdesc, uint32_t* topk) {
+                                                   const uint8_t* tdesc, uint32_t* topk, const int32_t* count) {
   __shared__ uint32_t keys[TOPK_T / 64][PS_BF_MAX_TRAIN];
-  const BfBlock blk = blocks[blockIdx.x];
+  const int nb = count ? *count : (int)gridDim.x;
+  for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
+  const BfBlock blk = blocks[bi];
   const BfProb P = probs[blk.prob];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint4* td = reinterpret_cast<const uint4*>(tdesc + (size_t)P.t_off * 32);
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(TOPK_T) void bf_topk(const BfBlock* blocks, const B
       first = false;
     }
     if (lane < PS_BF_TOPK) topk[(size_t)(P.q_off + qi) * PS_BF_TOPK + lane] = mine;
+  }
   }
 }
 
@@ -184,7 +189,15 @@ extern "C" void psk_bf_launch(const BfBlock* blocks, int nblocks, const BfProb* 
                               const float* qang, const uint8_t* qvalid, const uint8_t* tdesc, const float* tang,
                               uint32_t* topk, int32_t* out, int32_t* nmatch, float nn_ratio, int check_ori,
                               hipStream_t st) {
-  if (nblocks > 0) hipLaunchKernelGGL(bf_topk, dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk);
+  if (nblocks > 0) hipLaunchKernelGGL(bf_topk, dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(bf_resolve, dim3(nprob), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
+                     nmatch, nn_ratio, check_ori);
+}
+// the same with a block table that was built on the device: `d_count` entries, `grid` workgroups loop over them
+extern "C" void psk_bf_launch_dev(const BfBlock* blocks, const int32_t* d_count, int grid, const BfProb* probs, int nprob, const uint8_t* qdesc,
+                                  const float* qang, const uint8_t* qvalid, const uint8_t* tdesc, const float* tang, uint32_t* topk, int32_t* out,
+                                  int32_t* nmatch, float nn_ratio, int check_ori, hipStream_t st) {
+  hipLaunchKernelGGL(bf_topk, dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
   hipLaunchKernelGGL(bf_resolve, dim3(nprob), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
                      nmatch, nn_ratio, check_ori);
 }

@@ -70,43 +70,68 @@ __device__ __forceinline__ const float* ob_cam_pose(const ObArrays& A, int s, in
 // pixel writes its label 49 pixels to both sides, so a pixel ends up with the label of the RIGHTMOST labelled pixel within
 // (x, x + 49] or else with its own (column 0 is never written from the right).  One workgroup per image row.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(OB_T) void ob_masks(ObArrays A, uint8_t* objmask, int W, int H) {
+#define OB_MASK_ROWS 8
+// (eight rows per workgroup = one row of the detector's 8 x 8 occupancy cells, which this kernel fills on the way: occ[image][cell])
+__global__ __launch_bounds__(OB_T) void ob_masks(ObArrays A, uint8_t* objmask, int W, int H, int ostride, uint8_t* occ, int ocw, int och) {
   extern __shared__ uint8_t row_sm[];
-  int16_t* run = reinterpret_cast<int16_t*>(row_sm + ((W + 63) & ~63));
+  const int WP = (W + 63) & ~63;
+  int16_t* run = reinterpret_cast<int16_t*>(row_sm + WP);
+  uint8_t* occL = reinterpret_cast<uint8_t*>(run + WP);
+  uint8_t* occR = occL + ((ocw + 3) & ~3);
   __shared__ int red[OB_T / 64];
-  const int y = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-  const uint8_t* M = A.idmask + (size_t)s * A.mask_pitch + (size_t)y * A.mask_stride;
-  for (int x = tid; x < W; x += OB_T) row_sm[x] = M[x];
-  __syncthreads();
-  // run[c] = rightmost labelled column <= c (-1: none): per-thread chunks, block-wide prefix maximum of the chunk maxima
-  const int per = (W + OB_T - 1) / OB_T, c0 = tid * per, c1 = min(c0 + per, W);
-  int local = -1;
-  for (int c = c0; c < c1; c++) if (row_sm[c] != 0) local = c;
-  int incl = local;
-  {
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
-    if (lane == 63) red[wave] = incl;
+  const int s = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < ocw; i += OB_T) { occL[i] = 0; occR[i] = 0; }
+  for (int y = blockIdx.x * OB_MASK_ROWS; y < min((int)(blockIdx.x + 1) * OB_MASK_ROWS, H); y++) {
+    const uint8_t* M = A.idmask + (size_t)s * A.mask_pitch + (size_t)y * A.mask_stride;
     __syncthreads();
-    int base = -1;
-    for (int w = 0; w < wave; w++) base = max(base, red[w]);
-    const int prev_lane = __shfl_up(incl, 1);
-    int excl = lane == 0 ? -1 : prev_lane;
-    excl = max(excl, base);
-    int r = excl;
-    for (int c = c0; c < c1; c++) { if (row_sm[c] != 0) r = c; run[c] = (int16_t)r; }
+    for (int x = tid; x < WP; x += OB_T) row_sm[x] = x < W ? M[x] : (uint8_t)0;
+    __syncthreads();
+    // run[c] = rightmost labelled column <= c (-1: none): per-thread chunks, block-wide prefix maximum of the chunk maxima
+    const int per = (W + OB_T - 1) / OB_T, c0 = tid * per, c1 = min(c0 + per, W);
+    int local = -1;
+    for (int c = c0; c < c1; c++) if (row_sm[c] != 0) local = c;
+    int incl = local;
+    {
+      const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
+      if (lane == 63) red[wave] = incl;
+      __syncthreads();
+      int base = -1;
+      for (int w = 0; w < wave; w++) base = max(base, red[w]);
+      const int prev_lane = __shfl_up(incl, 1);
+      int excl = lane == 0 ? -1 : prev_lane;
+      excl = max(excl, base);
+      int r = excl;
+      for (int c = c0; c < c1; c++) { if (row_sm[c] != 0) r = c; run[c] = (int16_t)r; }
+    }
+    __syncthreads();
+    uint8_t* L = objmask + ((size_t)(2 * s) * H + y) * ostride;
+    uint8_t* R = objmask + ((size_t)(2 * s + 1) * H + y) * ostride;
+    for (int x4 = tid * 4; x4 < ostride; x4 += OB_T * 4) {   // four pixels per thread, one aligned dword per mask (columns beyond W: 0)
+      uint32_t lv = 0, rv = 0;
+      for (int j = 0; j < 4; j++) {
+        const int x = x4 + j;
+        if (x >= W) break;
+        const uint8_t m = row_sm[x];
+        const uint32_t lb = (m != 0 && m != 255) ? 255u : 0u;
+        const int r = run[min(x + 49, W - 1)];
+        const uint8_t lab = (r > x && x > 0) ? row_sm[r] : m;
+        const uint32_t rb = (lab != 0 && lab != 255) ? 255u : 0u;
+        lv |= lb << (8 * j); rv |= rb << (8 * j);
+      }
+      *reinterpret_cast<uint32_t*>(L + x4) = lv;
+      *reinterpret_cast<uint32_t*>(R + x4) = rv;
+      if (lv) occL[x4 >> 3] = 1;
+      if (rv) occR[x4 >> 3] = 1;
+    }
   }
   __syncthreads();
-  uint8_t* L = objmask + ((size_t)(2 * s) * H + y) * W;
-  uint8_t* R = objmask + ((size_t)(2 * s + 1) * H + y) * W;
-  for (int x = tid; x < W; x += OB_T) {
-    const uint8_t m = row_sm[x];
-    L[x] = (m != 0 && m != 255) ? 255 : 0;
-    const int r = run[min(x + 49, W - 1)];
-    const uint8_t lab = (r > x && x > 0) ? row_sm[r] : m;
-    R[x] = (lab != 0 && lab != 255) ? 255 : 0;
-  }
+  if ((int)blockIdx.x < och)
+    for (int i = tid; i < ocw; i += OB_T) {
+      occ[((size_t)(2 * s) * och + blockIdx.x) * ocw + i] = occL[i];
+      occ[((size_t)(2 * s + 1) * och + blockIdx.x) * ocw + i] = occR[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1017,27 +1042,30 @@ __global__ __launch_bounds__(OB_T) void ob_finish(ObArrays A, int step) {
 }
 
 // ---- brute-force matcher: the block table of bf_topk derived from the problem table on the device ----
-__global__ __launch_bounds__(64) void ob_bf_blocks(const BfProb* probs, BfBlock* blocks, int nprob, int blocks_per_prob) {
+// (compact: only the blocks that hold queries, appended in any order; *count is cleared by the host side before the launch)
+__global__ __launch_bounds__(64) void ob_bf_blocks(const BfProb* probs, BfBlock* blocks, int32_t* count, int nprob, int blocks_per_prob) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= nprob * blocks_per_prob) return;
   const int p = i / blocks_per_prob, b = i % blocks_per_prob;
   const BfProb P = probs[p];
   const int first = b * PS_BF_QPB;
-  const int count = (P.nt > 0 && first < P.nq) ? min(PS_BF_QPB, P.nq - first) : 0;
-  blocks[i] = BfBlock{p, first, count, 0};
+  if (!(P.nt > 0 && first < P.nq)) return;
+  blocks[atomicAdd(count, 1)] = BfBlock{p, first, min(PS_BF_QPB, P.nq - first), 0};
 }
 
 }  // namespace
 
 extern "C" {
-void psk_ob_masks(const ObArrays* A, uint8_t* objmask, int W, int H, hipStream_t st) {
-  const size_t lds = ((W + 63) & ~63) + (size_t)W * 2 + 64;
-  hipLaunchKernelGGL(ob_masks, dim3(H, A->S), dim3(OB_T), lds, st, *A, objmask, W, H);
+void psk_ob_masks(const ObArrays* A, uint8_t* objmask, int W, int H, int ostride, uint8_t* occ, int ocw, int och, hipStream_t st) {
+  const size_t WP = (W + 63) & ~63;
+  const size_t lds = WP + WP * 2 + 2 * (size_t)((ocw + 3) & ~3) + 64;
+  hipLaunchKernelGGL(ob_masks, dim3((H + OB_MASK_ROWS - 1) / OB_MASK_ROWS, A->S), dim3(OB_T), lds, st, *A, objmask, W, H, ostride, occ, ocw, och);
 }
 void psk_ob_begin(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_begin, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
 void psk_ob_track(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_track, dim3(A->K, A->S), dim3(OB_T), 0, st, *A, step); }
-void psk_ob_bf_blocks(const BfProb* probs, BfBlock* blocks, int nprob, int blocks_per_prob, hipStream_t st) {
-  hipLaunchKernelGGL(ob_bf_blocks, dim3((nprob * blocks_per_prob + 63) / 64), dim3(64), 0, st, probs, blocks, nprob, blocks_per_prob);
+void psk_ob_bf_blocks(const BfProb* probs, BfBlock* blocks, int32_t* count, int nprob, int blocks_per_prob, hipStream_t st) {
+  hipMemsetAsync(count, 0, 4, st);
+  hipLaunchKernelGGL(ob_bf_blocks, dim3((nprob * blocks_per_prob + 63) / 64), dim3(64), 0, st, probs, blocks, count, nprob, blocks_per_prob);
 }
 void psk_ob_after_bf(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_bf, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
 void psk_ob_after_cf1(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_cf1, dim3(A->K, A->S), dim3(OB_T), (size_t)A->LC, st, *A, step); }

@@ -5,6 +5,8 @@
 // until ps_tracker_fetch.  Same results as pointslot_amd/host/StereoOdometry.h driving the per-call C-ABI.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "../../include/pointslot_hip.h"
@@ -30,10 +32,14 @@ uint8_t* psi_orb_arena(ps_orb*);
 void psk_stereo_launch(const OrbPlan*, const StPair*, int, int, float, float, hipStream_t);
 void psk_bf_launch(const BfBlock*, int, const BfProb*, int, const uint8_t*, const float*, const uint8_t*, const uint8_t*, const float*, uint32_t*, int32_t*, int32_t*,
                    float, int, hipStream_t);
-void psk_ob_masks(const ObArrays*, uint8_t*, int, int, hipStream_t);
+void psk_ob_masks(const ObArrays*, uint8_t*, int, int, int, uint8_t*, int, int, hipStream_t);
+int psi_cvorb_batch_begin(ps_cvorb*, int, int, int, hipStream_t, uint8_t**, int*, int*);
+int psi_cvorb_batch_run(ps_cvorb*, const uint8_t*, const uint8_t*, int, int, size_t, int, size_t, int, hipStream_t);
 void psk_ob_begin(const ObArrays*, int, hipStream_t);
 void psk_ob_track(const ObArrays*, int, hipStream_t);
-void psk_ob_bf_blocks(const BfProb*, BfBlock*, int, int, hipStream_t);
+void psk_ob_bf_blocks(const BfProb*, BfBlock*, int32_t*, int, int, hipStream_t);
+void psk_bf_launch_dev(const BfBlock*, const int32_t*, int, const BfProb*, int, const uint8_t*, const float*, const uint8_t*, const uint8_t*, const float*, uint32_t*,
+                       int32_t*, int32_t*, float, int, hipStream_t);
 void psk_ob_after_bf(const ObArrays*, int, hipStream_t);
 void psk_ob_after_cf1(const ObArrays*, int, hipStream_t);
 void psk_ob_after_lm(const ObArrays*, int, hipStream_t);
@@ -66,7 +72,7 @@ struct ps_tracker {
   ObArrays OA;
   uint8_t* d_objmask = nullptr;      // [2 S][h][w] LeftObjMask / RightObjMask
   StPair* d_obj_pairs = nullptr;
-  BfBlock* d_bf_blocks = nullptr; int bf_blocks_per_prob = 0;
+  BfBlock* d_bf_blocks = nullptr; int32_t* d_bf_count = nullptr; int bf_blocks_per_prob = 0;
   PjArrays pj_obj;
   double* ob_chi2 = nullptr; uint8_t* ob_state = nullptr;
   // stage timing
@@ -169,10 +175,11 @@ size_t carve_obj(ps_tracker* t, uint8_t* base) {
   A.stats = c.take<ObStat>((size_t)A.max_steps * S * K);
   A.dropped = c.take<int32_t>(S);
   t->ob_chi2 = c.take<double>(n); t->ob_state = c.take<uint8_t>(n);
-  t->d_objmask = c.take<uint8_t>(2 * S * (size_t)t->cfg.width * t->cfg.height);
+  t->d_objmask = c.take<uint8_t>(2 * S * (size_t)((t->cfg.width + 15) & ~15) * t->cfg.height);
   t->d_obj_pairs = c.take<StPair>(S);
   t->bf_blocks_per_prob = (int)((OC + PS_BF_QPB - 1) / PS_BF_QPB);
   t->d_bf_blocks = c.take<BfBlock>(S * K * t->bf_blocks_per_prob);
+  t->d_bf_count = c.take<int32_t>(16);
   float* st_ur = c.take<float>(n); float* st_dp = c.take<float>(n); int32_t* st_sad = c.take<int32_t>(n); int32_t* st_kept = c.take<int32_t>(S);
   uint8_t* st_scratch = c.take<uint8_t>(S * (size_t)PS_ST_SCRATCH);
   // windowed-matcher work arrays of the object searches
@@ -221,7 +228,13 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
   const bool tm = t->timing;
   hipEvent_t* ev = t->ev[t->timed % ps_tracker::RING];
   int e = 1;   // ev[0] was recorded before the extraction
-  auto mark = [&](int stage) { t->ev_stage[e] = stage; if (tm) hipEventRecord(ev[e], st); e++; };
+  static const bool dbg = getenv("PS_TRK_DEBUG_SYNC") != nullptr;   // diagnostic: wait after every launch group and say which one it was
+  auto mark = [&](int stage) {
+    t->ev_stage[e] = stage;
+    if (tm) hipEventRecord(ev[e], st);
+    if (dbg) { const hipError_t r = hipStreamSynchronize(st); fprintf(stderr, "[ps_tracker] step %d: launch group %d (%s) done: %s\n", t->step, e, kTrkStage[stage], hipGetErrorString(r)); }
+    e++;
+  };
   A->idmask = d_masks; A->mask_stride = mask_stride; A->mask_pitch = mask_pitch;
   mark(TS_ORB);
   int rc = ps_orb_stereo_match_batch(t->orb, S, t->mb, t->mbf);
@@ -247,16 +260,20 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
     ObArrays* O = &t->OA;
     O->idmask = d_masks; O->mask_stride = mask_stride; O->mask_pitch = mask_pitch; O->dets_in = (const ObDet*)d_dets;
     const int K = O->K, W = t->cfg.width, H = t->cfg.height;
-    psk_ob_masks(O, t->d_objmask, W, H, st);
-    rc = ps_cvorb_detect_batch_device(t->cvorb, d_imgs, t->d_objmask, 2 * S, W, H, stride, image_pitch, W, (size_t)W * H, st);
+    uint8_t* occ = nullptr; int ocw = 0, och = 0;
+    rc = psi_cvorb_batch_begin(t->cvorb, 2 * S, W, H, st, &occ, &ocw, &och);
+    if (rc != PS_OK) return rc;
+    const int ostride = (W + 15) & ~15;                          // rows of the object masks start on 16-byte boundaries
+    psk_ob_masks(O, t->d_objmask, W, H, ostride, occ, ocw, och, st);   // ... and fills the detector's cell occupancy on the way
+    rc = psi_cvorb_batch_run(t->cvorb, d_imgs, t->d_objmask, 2 * S, stride, image_pitch, ostride, (size_t)ostride * H, 1, st);
     if (rc != PS_OK) return rc;
     mark(TS_OBJ_FEATURES);
     psk_stereo_launch(psi_orb_plan(t->orb), t->d_obj_pairs, S, O->OC, t->mb, t->mbf, st); mark(TS_OBJ_STEREO);
     psk_ob_begin(O, t->step, st);
     psk_ob_track(O, t->step, st);
-    psk_ob_bf_blocks(O->bf_prob, t->d_bf_blocks, S * K, t->bf_blocks_per_prob, st); mark(TS_OBJ_GLUE);
-    psk_bf_launch(t->d_bf_blocks, S * K * t->bf_blocks_per_prob, O->bf_prob, S * K, O->last.desc, O->last.angle, O->bf_qvalid, O->cur.desc, O->cur.angle,
-                  O->bf_topk, O->bf_qot, O->bf_nmatch, 0.9f, 1, st);                       // ORBmatcher matcher(0.9, true), Tracking.cc:2381
+    psk_ob_bf_blocks(O->bf_prob, t->d_bf_blocks, t->d_bf_count, S * K, t->bf_blocks_per_prob, st); mark(TS_OBJ_GLUE);
+    psk_bf_launch_dev(t->d_bf_blocks, t->d_bf_count, 1024, O->bf_prob, S * K, O->last.desc, O->last.angle, O->bf_qvalid, O->cur.desc, O->cur.angle,
+                      O->bf_topk, O->bf_qot, O->bf_nmatch, 0.9f, 1, st);                   // ORBmatcher matcher(0.9, true), Tracking.cc:2381
     mark(TS_OBJ_BRUTEFORCE);
     psk_ob_after_bf(O, t->step, st); mark(TS_OBJ_GLUE);
     psk_pose_lm_launch(O->po_prob, S, O->po_vert, O->cur.mp_po, O->po_obs, O->po_is2, O->cur.mp_valid, O->cur.outlier, t->ob_chi2, t->ob_state,
@@ -356,6 +373,7 @@ int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out) {
     if (e != hipSuccess) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_HIP, "hipMalloc(%zu): %s", ob_bytes, hipGetErrorString(e)); }
     t->d_obj_bytes = ob_bytes;
     hipMemsetAsync(t->d_obj, 0, ob_bytes, t->stream);
+    hipStreamSynchronize(t->stream);   // the tables below are written with synchronous copies: not before the clear has run
     carve_obj(t, t->d_obj);
     // every MapObject slot free
     std::vector<ObMapObject> mo((size_t)O.S * O.M);

@@ -18,8 +18,9 @@ def main():
         per.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     rows = []
     for name, d in per.items():
-        if len(d) % (steps + warmup) != 0:      # not a per-step kernel of the timed loop (set-up work): left out
+        if len(d) < steps + warmup:             # not a per-step kernel of the timed loop (set-up work): left out
             continue
+        d = d[len(d) % (steps + warmup):]       # launches before the loop (handle creation runs some kernels once)
         per_step = len(d) // (steps + warmup)
         t = d[warmup * per_step:]
         mean = sum(t) / len(t)
