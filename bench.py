@@ -39,7 +39,7 @@ ALGO_BYTES_PER_FRAME_POSE_ITER = 2000 * 29 + 224      # pose-opt, 
 ALGO_FLOP_PER_OBJECT_BA_ITER = 103e6                  # object BA, per LM iteration per object (P=50, L=300, E=15000)
 RED_DEV = "cuda"              # device of the tensors used for cross-rank reductions
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def _profile_json(name):
@@ -167,7 +167,7 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
            "h": h, "w": w, "n_distinct": n_distinct}
     # every trajectory against the ground truth of the generator, every frame's tracked flag
     err, untracked, tracked_timed = 0.0, 0, 0
-    tcw0 = st0 = None
+    tcw0 = st0 = obj0 = None
     ob = {"detections": 0, "with_object": 0, "track_ok": 0, "max_abs_centre_error_m": 0.0, "reinit": 0}
     for g, t in enumerate(trks):
         tcw, st = t.fetch()
@@ -184,6 +184,8 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
                 err = max(err, float(np.abs(twc[ok, j] - truth[ok]).max()))
         if objects:
             o = t.fetch_objects()
+            if g == 0:
+                obj0 = o
             live = o["id"] >= 0
             ob["detections"] += int(live[2:].sum()); ob["with_object"] += int((o["tracked"][2:] != 0).sum())
             ob["track_ok"] += int((o["track_ok"][2:] != 0).sum()); ob["reinit"] += int(o["reinit"].sum())
@@ -193,7 +195,7 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
                     for k, d in enumerate(q["dets"][i]):
                         if o[i, j, k]["track_ok"]:
                             ob["max_abs_centre_error_m"] = max(ob["max_abs_centre_error_m"], float(np.abs(o[i, j, k]["tco"][:3] - d["pose7"][:3]).max()))
-    out.update(max_abs_position_error_m=err, untracked_frames=untracked, tracked_frames_timed=tracked_timed, seqs=seqs, tcw_group0=tcw0, stats_group0=st0,
+    out.update(max_abs_position_error_m=err, untracked_frames=untracked, tracked_frames_timed=tracked_timed, seqs=seqs, tcw_group0=tcw0, stats_group0=st0, obj_group0=obj0,
                objects=ob if objects else None)
     for t in trks:
         t.close()
@@ -202,37 +204,132 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
     return out
 
 
-def cpu_tracking_baseline(seqs, tcw_gpu, budget_s=12.0):
-    """The CPU restatement of the same tracking loop (tests/oracle_backend.py over oracle/liboracle.so, one core, the
-    reference's per-frame call structure) on the sequences the GPU just tracked: timed as the CPU baseline, and its poses are
-    the parity spot check of the timed run (sequence j of group 0 shows generated sequence j)."""
+class _ThreadedOracle:
+    """The CPU checker behind the chain with the reference's thread model (src/Frame.cc:709-714,2648-2651): the two ORBextractor
+    calls on two threads, the two cv::ORB detectors of ExtractObjORB on two threads (the oracle calls release the GIL)."""
+
+    def __init__(self):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        from oracle_backend import OracleBackend
+        self.o = OracleBackend()
+        self.lib = oracle_lib
+        self.cv2 = oracle_lib.OracleCvORB(1000, 1.2, 8, 19, 20)
+        self.scale_factors, self.inv_level_sigma2 = self.o.scale_factors, self.o.inv_level_sigma2
+
+    def extract_stereo(self, left, right, mb, mbf):
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as pool:
+            a = pool.submit(self.o.left.run, left); b = pool.submit(self.o.right.run, right)
+            kps, desc = a.result(); b.result()
+        _, ur, dp = self.lib.stereo_match(self.o.left, self.o.right, mb, mbf)
+        return kps, desc, ur, dp
+
+    def extract_objects(self, left, right, ml, mr, mb, mbf):
+        from concurrent.futures import ThreadPoolExecutor
+        if not hasattr(self.o, "cv"):
+            self.o.cv = self.lib.OracleCvORB(1000, 1.2, 8, 19, 20)
+        with ThreadPoolExecutor(2) as pool:
+            a = pool.submit(self.o.cv.run, left, ml); b = pool.submit(self.cv2.run, right, mr)
+            (kl, dl), (kr, dr) = a.result(), b.result()
+        if len(kl) == 0:
+            return kl, dl, np.zeros(0, np.float32), np.zeros(0, np.float32)
+        _, ur, dp = self.lib.stereo_match_keys(self.o.left, self.o.right, kl, dl, kr, dr, mb, mbf)
+        return kl, dl, ur, dp
+
+    def __getattr__(self, name):
+        return getattr(self.o, name)
+
+
+def _cpu_chain(q, n, backend, objects=True):
+    """n frames of sequence q through the CPU restatement of the chain; returns (StereoOdometry, seconds)"""
+    from pointslot_amd.tracker import StereoOdometry
+    h, w = q["left"][0].shape
+    vo = StereoOdometry(backend, q["K"], q["bf"], w, h)
+    t0 = time.perf_counter()
+    for i in range(n):
+        if objects:
+            vo.track(q["left"][i], q["right"][i], q["masks"][i], q["dets"][i])
+        else:
+            vo.track(q["left"][i], q["right"][i])
+    return vo, time.perf_counter() - t0
+
+
+def _cpu_worker(job):
+    """one process of the all-cores baseline: a slice of a sequence from the shared file, through the chain, single-threaded"""
+    path, k, n, objects = job
+    import pickle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_backend import OracleBackend
-    from pointslot_amd.tracker import StereoOdometry
-    h, w = seqs[0]["left"][0].shape
-    frames, spent, worst, checked = 0, 0.0, 0.0, 0
+    with open(path, "rb") as f:
+        seqs = pickle.load(f)
+    _, dt = _cpu_chain(seqs[k % len(seqs)], n, OracleBackend(), objects)
+    return n, dt
+
+
+def cpu_tracking_baseline(seqs, tcw_gpu, obj_gpu, objects, budget_s=10.0):
+    """The CPU restatement of the same loop (tests/oracle_backend.py over oracle/liboracle.so) on the sequences the GPU just tracked:
+    (a) one core, the reference's per-frame call structure - the `cpu_baseline` and the parity spot check of the timed run (sequence j of
+    group 0 shows generated sequence j); (b) the reference's thread model (two extraction threads + two object-detector threads);
+    (c) all host cores, one independent sequence slice per process."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleBackend
+    frames, spent, worst, checked, obj_checked, obj_bad = 0, 0.0, 0.0, 0, 0, 0
     k = 0
-    while spent < budget_s and k < 4 * len(seqs):
-        q = seqs[k % len(seqs)]
-        vo = StereoOdometry(OracleBackend(), q["K"], q["bf"], w, h)
-        n = len(q["left"])
-        t0 = time.perf_counter()
-        for i in range(len(q["left"])):
-            vo.track(q["left"][i], q["right"][i])
-            if spent + time.perf_counter() - t0 > 2.5 * budget_s:
-                n = i + 1
-                break
-        spent += time.perf_counter() - t0
-        frames += n
-        if k < len(seqs) and k < tcw_gpu.shape[1]:
-            for i in range(min(n, 30)):          # the first frames: later the chained estimates of two runs random-walk apart (DESIGN.md section 2)
+    n_per = min(len(seqs[0]["left"]), 8)
+    while spent < budget_s and k < len(seqs):
+        q = seqs[k]
+        vo, dt = _cpu_chain(q, n_per, OracleBackend(), objects)
+        spent += dt; frames += n_per
+        if k < tcw_gpu.shape[1]:
+            for i in range(n_per):
                 a, b = vo.trajectory[i], tcw_gpu[i, k]
                 worst = max(worst, float(np.abs(b).max()) if a is None else float(np.abs(a - b).max()))   # no pose: the GPU row is zeros
                 checked += 1
+                if objects and obj_gpu is not None:
+                    for j, o in enumerate(vo.objects.stats[i]["objects"]):
+                        d = obj_gpu[i, k, j]
+                        same = (int(d["n"]) == o["n"] and int(d["tracked"]) == int(o["tracked"]) and int(d["bf_matches"]) == o["bf_matches"]
+                                and int(d["lm_matches"]) == o["lm_matches"] and int(d["inliers"]) == o["inliers"])
+                        obj_checked += 1; obj_bad += 0 if same else 1
         k += 1
-    return {"value": frames / spent, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of %d of the run's sequences through the CPU restatement of the same tracking loop (oracle/*.cpp, -O3 "
-                      "-march=x86-64-v3, one thread: the reference's per-frame call structure); host has %d cores" % (frames, min(k, len(seqs)), os.cpu_count())}, worst, checked
+    one = {"value": frames / spent, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames (the first %d of %d of the run's sequences) through the CPU restatement of the same per-frame chain%s (oracle/*.cpp, -O3 "
+                     "-march=x86-64-v3, one thread); host has %d cores" % (frames, n_per, k, " incl. the object chain" if objects else "", os.cpu_count())}
+    # (b) the reference's thread model
+    t_frames, t_spent = 0, 0.0
+    kk = 0
+    while t_spent < 0.5 * budget_s and kk < len(seqs):
+        _, dt = _cpu_chain(seqs[kk], n_per, _ThreadedOracle(), objects)
+        t_spent += dt; t_frames += n_per; kk += 1
+    threaded = {"value": t_frames / t_spent, "unit": "frames/s", "cores": 2, "kind": "port",
+                "sample": "%d frames, the reference's thread model: ExtractORB left / right on two threads, the two cv::ORB detectors of ExtractObjORB on two "
+                          "threads, everything else on the tracking thread (src/Frame.cc:709-714,2648-2651)" % t_frames}
+    # (c) all cores: independent sequence slices, one single-threaded process each
+    allc = None
+    try:
+        import multiprocessing as mp
+        import pickle
+        import tempfile
+        from concurrent.futures import ProcessPoolExecutor
+        ncpu = os.cpu_count() or 1
+        nproc = max(1, min(ncpu, 192))
+        n_all = 5
+        slim = [{kk2: (q[kk2][:n_all] if kk2 in ("left", "right", "masks", "dets") else q[kk2]) for kk2 in ("left", "right", "masks", "dets", "K", "bf")} for q in seqs[:8]]
+        fd, path = tempfile.mkstemp(suffix=".pkl", dir="/tmp")
+        with os.fdopen(fd, "wb") as f:
+            pickle.dump(slim, f, protocol=4)
+        with ProcessPoolExecutor(max_workers=nproc, mp_context=mp.get_context("spawn")) as pool:
+            list(pool.map(_cpu_worker, [(path, i, 1, objects) for i in range(nproc)]))          # start the workers (imports, library load)
+            t0 = time.perf_counter()
+            res = list(pool.map(_cpu_worker, [(path, i, n_all, objects) for i in range(nproc)]))
+            wall = time.perf_counter() - t0
+        os.unlink(path)
+        allc = {"value": sum(r[0] for r in res) / wall, "unit": "frames/s", "cores": nproc, "kind": "port", "nproc_host": ncpu,
+                "sample": "%d processes x %d frames, one independent sequence slice each (single-threaded chains side by side)" % (nproc, n_all)}
+    except Exception as e:   # noqa: BLE001
+        allc = {"error": "%s: %s" % (type(e).__name__, e)}
+    return one, threaded, allc, worst, checked, obj_checked, obj_bad
 
 
 def orb_leg(rank, local_rank, barrier, with_cpu):
@@ -382,6 +479,105 @@ def optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak):
         dt = time.perf_counter() - t0
         out["object_ba"]["cpu_port_ms_per_iter_1core_1object"] = dt * 1e3 / max(len(tr), 1)
     opt.close()
+    return out
+
+
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9      # 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md chip table): one 32-bit lane-op per lane and cycle
+
+
+def object_legs(local_rank, fp64_peak):
+    """The hot-path kernels of the object half on their own, rank 0, kernel times from HIP
+    events on the handles' streams (host buffers: the PCIe-inclusive wall time is reported beside them)."""
+    import torch
+    from pointslot_amd import sequence, synth
+    from pointslot_amd.matcher import ORBmatcher, build_grid
+    from pointslot_amd.object_orb import ORB
+    from pointslot_amd.object_tracker import object_masks, right_mask
+    from pointslot_amd.optimizer import Optimizer
+    out = {}
+    # ---- a10 SearchByBruceMatching: k objects x (1000 last-frame features against 1000 current ones) ----
+    m = ORBmatcher(0.9, True, device=local_rank)
+    for k in (1, 8, 64):
+        probs = [synth.bruteforce_problem(900 + i, nq=1000, nt=1000) for i in range(k)]
+        m.SearchByBruceMatching(probs)
+        t0 = time.perf_counter()
+        m.SearchByBruceMatching(probs)
+        wall = time.perf_counter() - t0
+        ms = m.last_kernel_ms()
+        pairs = sum(len(p["q_desc"]) * len(p["t_desc"]) for p in probs)
+        ops = pairs * 16                                            # 8 x (v_xor_b32 + v_bcnt_u32_b32) per pair (SURVEY.md 8d: Nq Nt 8 xor + popc32)
+        out["bruteforce_%dx1000x1000" % k] = {
+            "workload": "a10: SearchByBruceMatching, %d object(s) x 1000 x 1000 descriptors, nn ratio 0.9, rotation check" % k,
+            "kernel_ms": ms, "wall_ms_incl_pcie": wall * 1e3, "pairs_per_s": pairs / (ms * 1e-3),
+            "roofline": {"bound": "int-alu", "kernel": "bf_topk + bf_resolve", "achieved": ops / (ms * 1e-3) / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
+                         "unit": "T lane-op/s", "frac": ops / (ms * 1e-3) / VALU_LANE_OPS_PER_S, "traffic": None,
+                         "note": "integer ALU / latency bound as SURVEY 8d states: %d KB of descriptors per object stay in LDS / L2; bf_resolve is the "
+                                 "order-dependent serial part" % (2000 * 32 // 1024)}}
+    # ---- a13 SearchByProjection(F, nOrder, MOPs): k objects x (300 local points into 400 features) ----
+    prs = []
+    for i in range(32):
+        sc = synth.projection_scene(700 + i, n=400, m=300)
+        T = sc["train"]
+        T["cell_off"], T["cell_idx"] = build_grid(T["x"], T["y"], *T["grid"])
+        prs.append({"mode": "points", "object": True, "train": T, "query": sc["points_query"], "scale_factors": sc["scale_factors"], "th": 1.0})
+    m8 = ORBmatcher(0.8, True, device=local_rank)
+    m8.SearchByProjection(prs)
+    t0 = time.perf_counter()
+    m8.SearchByProjection(prs)
+    wall = time.perf_counter() - t0
+    out["object_search_by_projection"] = {"workload": "a13: SearchByProjection(F, nOrder, MOPs, th = 1), 32 objects x (300 local points, 400 features, radius 5 px, bbox test)",
+                                          "kernel_ms": m8.last_kernel_ms(), "wall_ms_incl_pcie": wall * 1e3,
+                                          "roofline": {"bound": "latency", "kernel": "pj_gather<15> + pj_resolve<15>", "achieved": None, "peak": None, "unit": None,
+                                                       "frac": None, "traffic": None, "note": "a window holds a handful of candidates: dependent grid look-ups, no throughput figure in SURVEY 8d"}}
+    m.close(); m8.close()
+    # ---- a15 CFSE3ObjStateOptimization: frames with k objects x ~150 points, two calls per frame ----
+    opt = Optimizer(device=local_rank)
+    rng = np.random.default_rng(3)
+
+    def cf_frame(seed, k):
+        objs = []
+        for o in range(k):
+            pp = synth.pose_problem(seed * 100 + o, n=150, outlier_frac=0.15, mono_frac=0.2, valid_frac=0.8)
+            Tp = pp["tcw_true"].copy(); Tp[:3, 3] += rng.uniform(-0.2, 0.2, 3)
+            from pointslot_amd.optimizer import se3_from_mat4f
+            objs.append({"xo": pp["xw"], "obs": pp["obs"], "inv_sigma2": pp["inv_sigma2"], "valid": pp["valid"], "pose7": se3_from_mat4f(Tp.astype(np.float32))})
+        return {"objs": objs, "K": pp["K"]}
+    for k in (1, 4, 10):
+        frames = [cf_frame(50 + i, k) for i in range(64)]
+        opt.CFSE3ObjStateOptimization(frames[:2])
+        t0 = time.perf_counter()
+        opt.CFSE3ObjStateOptimization(frames)
+        wall = time.perf_counter() - t0
+        ms = opt.last_kernel_ms()
+        edges = sum(int(np.asarray(o["valid"]).sum()) for f in frames for o in f["objs"])
+        out["cfse3_%d_objects" % k] = {"workload": "a15: CFSE3ObjStateOptimization, 64 frames x %d object(s) x 150 points (one graph per frame, 4 x 10 LM)" % k,
+                                       "kernel_ms_per_64_calls": ms, "wall_ms_incl_pcie": wall * 1e3, "edges": edges,
+                                       "roofline": {"bound": "latency", "kernel": "pose_lm (mode 1)", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                                                    "note": "one workgroup per frame, %d x 6 unknowns: the serial LM control flow dominates" % k}}
+    opt.close()
+    # ---- 8f-2 the object detector: 64 stereo pairs with their object masks, device resident ----
+    seq = sequence.generate_drive(n_frames=2, seed=7, texture=sequence.kitti_texture())
+    mk = sequence.frame_mask(seq, 1)
+    ol, orr = object_masks(mk, right_mask(mk))
+    nimg = 128
+    d_i = torch.from_numpy(np.stack([seq["left"][1], seq["right"][1]] * (nimg // 2))).cuda()
+    d_m = torch.from_numpy(np.stack([ol, orr] * (nimg // 2))).cuda()
+    h, w = ol.shape
+    det = ORB(device=local_rank)
+    det.detect_batch_device(d_i.data_ptr(), d_m.data_ptr(), nimg, w, h)
+    kps, _ = det.batch_fetch(0)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        det.detect_batch_device(d_i.data_ptr(), d_m.data_ptr(), nimg, w, h)
+    det.batch_fetch(0)
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    algo = nimg * 2 * w * h
+    out["object_detector"] = {"workload": "8f-2: cv::ORB(1000, 1.2, 8, 19) under the object masks, %d images of %dx%d in HBM (mask coverage %.3f), %d keypoints in image 0" % (nimg, w, h, float((ol != 0).mean()), len(kps)),
+                              "ms_per_batch": ms, "images_per_s": nimg / (ms * 1e-3),
+                              "roofline": {"bound": "hbm", "kernel": "cvb_* (13 launches)", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_batch": algo,
+                                           "note": "algorithmic bytes = image + mask read once; the work is the part of the pyramid a masked keypoint can reach: latency-bound tile kernels"}}
+    det.close()
     return out
 
 
@@ -550,7 +746,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         from pointslot_amd import parallel
-        sys.exit(parallel.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        sys.exit(parallel.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=1800))   # a rank that dies inside a leg must not leave the others waiting for ever
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -592,30 +788,45 @@ def main():
 
     from pointslot_amd import parallel
     with_cpu = not args.no_cpu and rank == 0 and world == 1
+    objects = not args.no_objects
     head = tracking_leg(rank, local_rank, args.texture, args.steps, args.warmup, args.sequences, args.groups, barrier, scene=args.scene,
-                        n_distinct=args.distinct, objects=not args.no_objects)
+                        n_distinct=args.distinct, objects=objects)
     dt = parallel.max_over_ranks(dist, head["dt"], RED_DEV)
     untracked = int(parallel.max_over_ranks(dist, head["untracked_frames"], RED_DEV))
     err = parallel.max_over_ranks(dist, head["max_abs_position_error_m"], RED_DEV)
+    tracked_timed = parallel.sum_over_ranks(dist, head["tracked_frames_timed"], RED_DEV)
 
     secondary = None
     if not args.no_secondary:
         secondary = {}
-        other = "synthetic" if args.texture == "kitti" else "kitti"
         osteps = min(args.steps, 10)
 
-        def other_texture():
-            o = tracking_leg(rank, local_rank, other, osteps, max(args.warmup, 2), args.sequences, args.groups, barrier, scene="lateral", n_distinct=4, objects=False)
+        def camera_only():
+            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, barrier, scene=args.scene,
+                             n_distinct=args.distinct, objects=False, seqs=head["seqs"])
             odt = parallel.max_over_ranks(dist, o["dt"], RED_DEV)
-            return {"workload": "the headline loop on the generator's %s texture" % ("value-noise + rectangles" if other == "synthetic" else "KITTI-frame"),
+            return {"workload": "the headline loop without masks / detections: the camera chain alone on all keypoints (r02's headline definition)",
                     "tracked_frames_per_s": world * o["frames_per_step_per_gpu"] * osteps / odt, "ms_per_step": odt / osteps * 1e3,
                     "untracked_frames": o["untracked_frames"], "max_abs_position_error_m": o["max_abs_position_error_m"],
                     "stage_ms_group0": {k: round(v, 5) for k, v in o["stage_ms_group0"].items()}}
 
-        # a failure of a secondary leg must not take the bench line down (every rank runs every leg: they hold barriers)
-        for name, fn in (("tracking_%s_texture" % other, other_texture),
+        def lateral_scene():
+            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, barrier, scene="lateral",
+                             n_distinct=4, objects=objects)
+            odt = parallel.max_over_ranks(dist, o["dt"], RED_DEV)
+            return {"workload": "the headline loop on r02's scene: lateral translation over a ruled surface, two moving boxes, 4 distinct sequences",
+                    "tracked_frames_per_s": world * o["frames_per_step_per_gpu"] * osteps / odt, "ms_per_step": odt / osteps * 1e3,
+                    "untracked_frames": o["untracked_frames"], "max_abs_position_error_m": o["max_abs_position_error_m"], "objects": o["objects"],
+                    "stage_ms_group0": {k: round(v, 5) for k, v in o["stage_ms_group0"].items()}}
+
+        # a failure of a secondary leg must not take the bench line down; every rank runs every leg (they hold barriers), and a leg
+        # that failed on one rank is skipped... by all of them at the next barrier only if it fails before its first collective: the
+        # launcher's timeout (parallel.launch_ranks) bounds the rest
+        fp64_peak = fp64_mfma_peak(local_rank)
+        for name, fn in (("camera_chain_only", camera_only),
+                         ("lateral_scene", lateral_scene),
                          ("orb_extraction", lambda: orb_leg(rank, local_rank, barrier, with_cpu)),
-                         ("optimizers", lambda: optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_mfma_peak(local_rank))),
+                         ("optimizers", lambda: optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak)),
                          ("lockstep_tracking_host_images", lambda: pcie_leg(rank, world, local_rank, dist, head["seqs"], args.sequences, args.groups, barrier)),
                          ("sequence_tracking", lambda: config5_leg(rank, world, local_rank, dist))):
             try:
@@ -627,26 +838,51 @@ def main():
             except Exception as e:   # noqa: BLE001
                 secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
-            try:
-                secondary["next_rows"] = next_rows_leg(local_rank)
-            except Exception as e:   # noqa: BLE001
-                secondary["next_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            for name, fn in (("object_kernels", lambda: object_legs(local_rank, fp64_peak)), ("next_rows", lambda: next_rows_leg(local_rank))):
+                try:
+                    secondary[name] = fn()
+                except Exception as e:   # noqa: BLE001
+                    secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         frames_per_step = head["frames_per_step_per_gpu"] * world
         stage = head["stage_ms_group0"]
         nimg = head["images_per_launch"]
-        # dominant KERNEL of the loop: one launch per step and group for each of these; the level stage is 8 dependent launches and
-        # the chain stages are several kernels each, so they are reported as stages, not priced as one launch
-        single = {k[4:]: v for k, v in stage.items() if k.startswith("orb/") and ALGO_BYTES_PER_IMAGE.get(k[4:], 0) > 0 and k[4:] != "orb_level_fused"}
-        dom = max(single, key=lambda k: single[k])
-        dom_ms = single[dom]
-        algo = ALGO_BYTES_PER_IMAGE[dom] * nimg
-        achieved = algo / (dom_ms * 1e-3) / 1e9
-        traffic, traffic_source = pmc_traffic(dom, nimg)
+        S = head["frames_per_step_per_gpu"]
+        # ---- one roofline entry per stage / kernel of the timed step (HIP events on the stream the kernels run on) ----
+        rl = []
+
+        def hbm(name, ms, algo, note):
+            a = algo / (ms * 1e-3) / 1e9 if ms > 0 else None
+            traffic, src = pmc_traffic(name.split("/")[-1], nimg)
+            rl.append({"stage": name, "bound": "hbm", "ms_per_step": round(ms, 5), "algorithmic_bytes_per_step": algo, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": a / HBM_PEAK_GBS if a else None, "traffic": traffic, "traffic_source": src, "note": note})
+
+        def other(name, ms, bound, note):
+            rl.append({"stage": name, "bound": bound, "ms_per_step": round(ms, 5), "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "note": note})
+        for k in ("orb_level_fused", "orb_fast_cells", "orb_describe"):
+            if "orb/" + k in stage:
+                hbm("orb/" + k, stage["orb/" + k], ALGO_BYTES_PER_IMAGE[k] * nimg, "SURVEY 8d bytes per image x %d images; bound by instruction issue (profiles/)" % nimg)
+        if "orb/orb_quadtree" in stage:
+            other("orb/orb_quadtree", stage["orb/orb_quadtree"], "latency", "serial list semantics of DistributeOctTree; candidate lists only, no pixel bytes")
+        other("stereo_match", stage.get("stereo_match", 0.0), "latency", "8f-1 ComputeStereoMatches: row-bucket scan + 11 x 11 SAD slide per left keypoint")
+        other("search_by_projection", stage.get("search_by_projection", 0.0), "latency", "a11 + a12: three windowed searches per frame (th 7, its 2 th retry, the local map)")
+        other("pose_optimization", stage.get("pose_optimization", 0.0), "latency", "a14: two PoseOptimization calls per frame, one persistent workgroup per frame; streaming-model roofline in secondary_metrics.pose_optimization")
+        other("track_glue", stage.get("track_glue", 0.0), "latency", "the host side of Tracking::Track between the kernels, on the device")
+        if objects:
+            hbm("object_features", stage.get("object_features", 0.0), 2 * 465750 * nimg + 465750 * S,
+                "8f-2 + masks: image + object mask of %d images and %d id masks read once; the work is the part of the pyramid a masked keypoint can reach (tile kernels, latency-bound)" % (nimg, S))
+            other("object_stereo_match", stage.get("object_stereo_match", 0.0), "latency", "8f-1 ComputeObjStereoMatches on the object keys")
+            ob = head["objects"] or {}
+            other("object_bruteforce", stage.get("object_bruteforce", 0.0), "int-alu", "a10: one problem per tracked detection (last-frame x current features of the object); pairs / s in secondary_metrics.object_kernels")
+            other("object_cfse3", stage.get("object_cfse3", 0.0), "latency", "a15: two CFSE3ObjStateOptimization calls per frame (after the brute-force matches, after the local-map search)")
+            other("object_search_by_projection", stage.get("object_search_by_projection", 0.0), "latency", "a13: SearchByProjection(F, nOrder, MOPs) per tracked detection")
+            other("object_glue", stage.get("object_glue", 0.0), "latency", "AssignFeatures, TrackMapObject (RANSAC centroid, box fine tuning, MapObjectInit / ReInit), bookkeeping: %s" % json.dumps(ob))
+        dom = max((r for r in rl if r["bound"] == "hbm"), key=lambda r: r["ms_per_step"])
+        value = tracked_timed / dt
         out = {
             "metric": "tracked frames/sec KITTI stereo 1242x375",
-            "value": frames_per_step * args.steps / dt,
+            "value": value,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -656,36 +892,45 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic (generated stereo sequences with exact geometry; texture = %s)" % (
+            "data": "synthetic (generated stereo sequences with exact ray-cast geometry: %s; texture = %s)" % (
+                "forward drive with yaw through a corridor of planes, two moving objects with instance masks and KITTI labels" if args.scene == "drive"
+                else "lateral translation over a ruled surface, two moving boxes",
                 "the repository's one real KITTI frame, tests/golden/kitti_000212_gray.png" if args.texture == "kitti" else "seeded value noise + rectangles"),
-            "config": {"workload": "BASELINE metric 'tracked frames/sec KITTI stereo 1242x375': %d independent 1242x375 stereo sequences per GPU tracked in lockstep, "
-                                   "one stereo frame of each per step through the whole chain (BASELINE configs[1] per image: 8-level ORB, 2000 keypoints + rBRIEF; "
-                                   "ComputeStereoMatches; configs[2] per frame: SearchByProjection + PoseOptimization twice), images resident in HBM"
-                                   % head["frames_per_step_per_gpu"],
-                       "sequences_per_gpu": head["frames_per_step_per_gpu"], "lockstep_groups_per_gpu": args.groups, "images_per_step_per_gpu": 2 * head["frames_per_step_per_gpu"],
+            "config": {"workload": "BASELINE metric 'tracked frames/sec KITTI stereo 1242x375' in SLOT.MODE 4: %d independent 1242x375 stereo sequences per GPU tracked in lockstep (%d distinct "
+                                   "generated drives), one stereo frame of each per step through the whole of Tracking::Track's per-frame work on the device - camera chain (BASELINE configs[1] per "
+                                   "image: 8-level ORB, 2000 keypoints + rBRIEF; ComputeStereoMatches; configs[2] per frame: SearchByProjection + PoseOptimization twice)%s - images, instance masks "
+                                   "and detections resident in HBM; value counts the frames that came out tracked"
+                                   % (S, head["n_distinct"], " and object chain (cv::ORB object features, object stereo, SearchByBruceMatching, CFSE3 x 2, object SearchByProjection)" if objects else ""),
+                       "sequences_per_gpu": S, "lockstep_groups_per_gpu": args.groups, "images_per_step_per_gpu": 2 * S, "object_chain": objects, "scene": args.scene,
                        "parallelism": "sequences sharded over %d GPU(s), no collective in the data path" % world},
             "tracking_checks": {"untracked_frames": untracked, "max_abs_position_error_m": err, "distinct_sequences_per_gpu": head["n_distinct"],
                                 "objects": head["objects"],
                                 "checked": "every frame of every sequence: tracked flag, position against the generator's ground truth; objects: "
                                            "detections with a MapObject / with mbTrackOK, cuboid centres of the distinct sequences against the labels"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms, "images_per_launch": nimg,
-                         "issue": pmc_valu_issue(dom, nimg)},
+            "roofline": {"bound": "hbm", "kernel": dom["stage"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                         "traffic": dom["traffic"], "traffic_source": dom.get("traffic_source"), "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_step"],
+                         "avg_launch_ms": dom["ms_per_step"], "images_per_launch": nimg, "issue": pmc_valu_issue(dom["stage"].split("/")[-1], nimg),
+                         "note": "the stage with the largest time among those SURVEY 8d prices in bytes; every stage is in `rooflines`"},
+            "rooflines": rl,
             "stage_ms": {k: round(v, 5) for k, v in stage.items()},
             "stage_ms_note": "HIP events on group 0's stream over the timed steps; with %d groups the stages of different groups overlap in time" % args.groups,
         }
         if with_cpu:
-            cpu, worst, checked = cpu_tracking_baseline(head["seqs"], head["tcw_group0"])
-            out["cpu_baseline"] = cpu
-            out["parity_spot"] = "green" if (checked > 0 and worst < 1e-4) else "red"
-            out["parity_spot_detail"] = ("%d frames of the timed run (the first <= 30 of %d sequences): Tcw vs the CPU restatement of the same loop, max |diff| %.3g "
-                                         "(bar 1e-4: float32 poses of an FP64 LM chained over the frames; tests/test_tracker_gpu.py holds 8 frames to 2e-5)" % (checked, min(len(head["seqs"]), head["tcw_group0"].shape[1]), worst))
+            one, threaded, allc, worst, checked, oc, ob_bad = cpu_tracking_baseline(head["seqs"], head["tcw_group0"], head.get("obj_group0"), objects)
+            out["cpu_baseline"] = one
+            out["cpu_baseline_reference_thread_model"] = threaded
+            out["cpu_baseline_all_cores"] = allc
+            out["parity_spot"] = "green" if (checked > 0 and worst < 1e-4 and ob_bad == 0) else "red"
+            out["parity_spot_detail"] = ("%d frames of the timed run: Tcw vs the CPU restatement of the same loop, max |diff| %.3g (bar 1e-4: float32 poses of an FP64 LM chained over the "
+                                         "frames); %d object records (features, MapObject, brute-force / projection match counts, inliers) compared, %d differ" % (checked, worst, oc, ob_bad))
         if secondary is not None:
             out["secondary_metrics"] = secondary
             if "ms_per_iter" in secondary.get("object_ba", {}):
-                out["metric_ba"] = {"metric": "ms/iter 50-KF object BA (8 objects)", "value": secondary["object_ba"]["ms_per_iter"],
-                                    "unit": "ms", "higher_is_better": False, "roofline": secondary["object_ba"].get("roofline")}
+                ba = secondary["object_ba"]
+                out["metric_ba"] = {"metric": "ms/iter 50-KF object BA (8 objects)", "value": ba["ms_per_iter"], "unit": "ms", "higher_is_better": False,
+                                    "roofline": ba.get("roofline"),
+                                    "cpu_baseline": {"value": ba.get("cpu_port_ms_per_iter_1core_1object"), "unit": "ms/iter (one object)", "cores": 1, "kind": "port",
+                                                     "sample": "one object's 5 + 10 iteration schedule through the CPU restatement (oracle/opt_oracle.cpp)"}}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

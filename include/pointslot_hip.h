@@ -211,6 +211,8 @@ int ps_orb_enable_stage_timing(ps_orb* h, int enable);
 typedef struct ps_matcher ps_matcher;
 int ps_matcher_create(int device, ps_matcher** out);
 void ps_matcher_destroy(ps_matcher* m);
+/* GPU time of the kernels of the last ps_match_bruteforce / ps_search_by_projection call (HIP events on the handle's stream). */
+int ps_matcher_last_kernel_ms(const ps_matcher* m, float* ms);
 
 /* Bulk form of ORBmatcher::DescriptorDistance (ORBmatcher.cc:2704-2720): out[i * nt + j] = Hamming
  * distance between 32-byte descriptors q[i] and t[j] (0..256). */

@@ -30,6 +30,8 @@ struct ps_matcher {
   size_t h_bytes = 0;
   uint8_t* d_wide = nullptr;  // second arena, only for the wide re-run of search problems whose windows overflowed the candidate store
   size_t d_wide_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the kernels of the last brute-force / projection call (ps_matcher_last_kernel_ms)
+  float last_kernel_ms = 0;
 };
 
 namespace {
@@ -67,13 +69,22 @@ int ps_matcher_create(int device, ps_matcher** out) {
   m->device = device;
   hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete m; return ps_set_error(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  hipEventCreate(&m->ev0); hipEventCreate(&m->ev1);
   *out = m;
+  return PS_OK;
+}
+
+int ps_matcher_last_kernel_ms(const ps_matcher* m, float* ms) {
+  if (!m || !ms) return ps_set_error(PS_ERR_INVALID, "null argument");
+  *ms = m->last_kernel_ms;
   return PS_OK;
 }
 
 void ps_matcher_destroy(ps_matcher* m) {
   if (!m) return;
   hipSetDevice(m->device);
+  if (m->ev0) hipEventDestroy(m->ev0);
+  if (m->ev1) hipEventDestroy(m->ev1);
   if (m->stream) { hipStreamSynchronize(m->stream); hipStreamDestroy(m->stream); }
   if (m->d_buf) hipFree(m->d_buf);
   if (m->d_wide) hipFree(m->d_wide);
@@ -151,12 +162,15 @@ int ps_match_bruteforce(ps_matcher* m, ps_bf_problem* probs, int nprob, float nn
   }
   uint8_t* D = m->d_buf;
   PS_HIP(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, m->stream));
+  hipEventRecord(m->ev0, m->stream);
   psk_bf_launch((const BfBlock*)(D + o_blk), (int)blocks.size(), (const BfProb*)(D + o_prob), nprob, D + o_qd,
                 (const float*)(D + o_qa), D + o_qv, D + o_td, (const float*)(D + o_ta), (uint32_t*)(D + o_topk),
                 (int32_t*)(D + o_out), (int32_t*)(D + o_nm), nn_ratio, check_orientation, m->stream);
+  hipEventRecord(m->ev1, m->stream);
   PS_HIP(hipGetLastError());
   PS_HIP(hipMemcpyAsync(H + o_out, D + o_out, out_bytes, hipMemcpyDeviceToHost, m->stream));
   PS_HIP(hipStreamSynchronize(m->stream));
+  hipEventElapsedTime(&m->last_kernel_ms, m->ev0, m->ev1);
   for (int p = 0; p < nprob; p++) {
     ps_bf_problem& P = probs[p];
     if (P.nt > 0) memcpy(P.query_of_train, H + o_out + (size_t)dp[p].t_off * 4, (size_t)P.nt * 4);
@@ -275,12 +289,15 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   A.cand = (uint32_t*)(D + o_cand); A.ncand = (int32_t*)(D + o_ncand); A.match = (int32_t*)(D + o_match);
   A.nmatch = (int32_t*)(D + o_nm); A.overflow = (int32_t*)(D + o_ovf); A.qbest = (int32_t*)(D + o_qbest); A.qbin = D + o_qbin;
   A.ttop = (uint4*)(D + o_tt);
+  hipEventRecord(m->ev0, m->stream);
   psk_pj_launch(&A, nprob, max_nq > 0 ? max_nq : 1, any_frame, 0, m->stream);
+  hipEventRecord(m->ev1, m->stream);
   PS_HIP(hipGetLastError());
   if (prof) PS_HIP(hipStreamSynchronize(m->stream));
   const auto tp3 = std::chrono::steady_clock::now();
   PS_HIP(hipMemcpyAsync(H + o_match, D + o_match, out_end - o_match, hipMemcpyDeviceToHost, m->stream));
   PS_HIP(hipStreamSynchronize(m->stream));
+  hipEventElapsedTime(&m->last_kernel_ms, m->ev0, m->ev1);
   const auto tp4 = std::chrono::steady_clock::now();
   if (prof) {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -23,6 +23,7 @@ lib.ps_match_bruteforce.argtypes = [ctypes.c_void_p, ctypes.POINTER(_BfProblem),
                                     ctypes.c_int]
 
 
+lib.ps_matcher_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
 lib.ps_distinctive_descriptors.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 
 
@@ -49,6 +50,11 @@ class ORBmatcher:
             self.close()
         except Exception:
             pass
+
+    def last_kernel_ms(self):
+        v = ctypes.c_float(0)
+        check(lib.ps_matcher_last_kernel_ms(self._h, ctypes.byref(v)))
+        return v.value
 
     def DescriptorDistanceMatrix(self, q, t):
         """bulk ORBmatcher::DescriptorDistance: uint16 [nq, nt]"""

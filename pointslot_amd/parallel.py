@@ -54,6 +54,15 @@ def max_over_ranks(dist, value, device="cpu"):
     return float(t.item())
 
 
+def sum_over_ranks(dist, value, device="cpu"):
+    import torch
+    if dist is None:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def gather_trajectories(dist, local, device="cpu"):
     """local: float32 array [n_local_frames, 12] (rows of Tcw as System::SaveTrajectoryKITTI writes them,
     /root/reference/src/System.cc:400-402).  Ranks may hold different frame counts.  Returns the list of per-rank

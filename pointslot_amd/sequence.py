@@ -201,6 +201,12 @@ def generate_drive(n_frames=20, seed=4, w=1242, h=375, speed=0.7, n_objects=2, K
         texture = _texture(rng, 1536, 768, 600)
     mips = _mip_chain(texture)
     steps = speed * (1.0 + rng.uniform(n_frames, -0.25, 0.25)); steps[0] = 0.0
+    # the vehicle pulls away: the frame after the initialisation is tracked from an identity velocity (no ORBvoc.bin, tracker.py), which
+    # only reaches a short first step
+    if n_frames > 1:
+        steps[1] *= 0.3
+    if n_frames > 2:
+        steps[2] *= 0.65
     # yaw: a slow sine plus a seeded phase, so that the constant-velocity model is never exact
     ph = float(rng.uniform(1, 0.0, 6.28)[0])
     yaw = np.deg2rad(yaw_rate_deg) * 8.0 * (np.sin(np.arange(n_frames) / 8.0 + ph) - np.sin(ph))
