@@ -472,7 +472,10 @@ typedef struct ps_track_stat {
   int32_t map_matches;    /* ... of which on map points with observations                                      */
   int32_t lm_candidates;  /* local-map points that passed Frame::isInFrustum                                   */
   int32_t lm_inliers;     /* mnMatchesInliers of TrackLocalMap                                                 */
-  int32_t reserved[3];
+  int32_t overflowed;     /* search windows of this frame that held more than 256 candidates: the matcher's candidate store is
+                             bounded here (the reference's GetFeaturesInArea is not), candidates beyond it were not considered and
+                             the frame's result may differ from the reference's; the other sequences are unaffected            */
+  int32_t reserved[2];
 } ps_track_stat;
 int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out);
 void ps_tracker_destroy(ps_tracker* t);
@@ -522,9 +525,11 @@ int ps_tracker_fetch_objects(ps_tracker* t, int first_step, int nsteps, ps_objec
 int ps_tracker_sync(ps_tracker* t);
 int ps_tracker_steps(const ps_tracker* t, int* steps);
 /* Blocks, then copies the results of steps [first_step, first_step + nsteps): tcw [nsteps][n_sequences][16] (mTcw row-major,
- * all zero for a frame without a pose) and stats [nsteps][n_sequences]; either pointer may be NULL.  PS_ERR_CAPACITY if a
- * search window overflowed the candidate store since the last reset (the results are then not the reference's). */
+ * all zero for a frame without a pose) and stats [nsteps][n_sequences]; either pointer may be NULL.  A frame whose search windows
+ * overflowed the candidate store says so in its own ps_track_stat::overflowed; the call itself succeeds. */
 int ps_tracker_fetch(ps_tracker* t, int first_step, int nsteps, float* tcw, ps_track_stat* stats);
+/* Test hook: the next queued step reports `count` overflowed windows for sequence `seq`. */
+int ps_tracker_debug_set_overflow(ps_tracker* t, int seq, int count);
 /* All sequences back to NOT_INITIALIZED, step counter 0. */
 int ps_tracker_reset(ps_tracker* t);
 /* GPU time per stage of a step (HIP events on the tracker's stream, mean over the recorded steps, at most 64):

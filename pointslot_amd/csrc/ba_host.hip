@@ -163,13 +163,18 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   A.W = (double*)(D + L.W); A.S = (double*)(D + L.S); A.part = (double*)(D + L.part); A.trace = (double*)(D + L.trace);
   A.ndone = (int32_t*)(D + L.ndone);
 
-  hipEvent_t e0, e1;
-  PS_HIP(hipEventCreate(&e0));
-  PS_HIP(hipEventCreate(&e1));
+  struct EventPair {   // every early return below goes through PS_HIP: the events must not outlive the call
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+  } ev;
+  PS_HIP(hipEventCreate(&ev.a));
+  PS_HIP(hipEventCreate(&ev.b));
+  hipEvent_t e0 = ev.a, e1 = ev.b;
   PS_HIP(hipEventRecord(e0, st));
   int32_t* h_done = (int32_t*)(H + L.ndone);
   int steps = 0;
-  const int max_steps = 15 * 10 + 8;   // 15 iterations x 10 trials + stage transitions
+  static const char* dbg_steps = getenv("PS_BA_DEBUG_MAX_STEPS");   // test knob: provoke the "did not terminate" error return
+  const int max_steps = dbg_steps ? atoi(dbg_steps) : 15 * 10 + 8;   // 15 iterations x 10 trials + stage transitions
   // Several global steps are enqueued per host readback: finished problems make their kernels exit immediately, so the
   // only cost of over-enqueueing is a few empty launches at the very end, while every avoided readback saves a
   // stream drain + PCIe round trip.
@@ -181,15 +186,13 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
     PS_HIP(hipStreamSynchronize(st));
     steps += steps_per_sync;
     if (*h_done >= nprob) break;
-    if (steps > max_steps) { hipEventDestroy(e0); hipEventDestroy(e1); return ps_set_error(PS_ERR_HIP, "object BA did not terminate after %d global steps", steps); }
+    if (steps > max_steps) return ps_set_error(PS_ERR_HIP, "object BA did not terminate after %d global steps", steps);
   }
   PS_HIP(hipEventRecord(e1, st));
   PS_HIP(hipMemcpyAsync(H, D, L.host_end, hipMemcpyDeviceToHost, st));
   PS_HIP(hipStreamSynchronize(st));
   float ms = 0;
   PS_HIP(hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
   psi_optimizer_set_ms(m, ms);
   pb = lb = eb = 0;
   for (int p = 0; p < nprob; p++) {

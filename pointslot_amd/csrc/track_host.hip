@@ -28,6 +28,7 @@ void psk_trk_after_mm(const TrkArrays*, int, hipStream_t);
 void psk_trk_after_pose1(const TrkArrays*, int, hipStream_t);
 void psk_trk_after_lm(const TrkArrays*, hipStream_t);
 void psk_trk_finish(const TrkArrays*, int, hipStream_t);
+void psk_trk_stamp_overflow(const TrkArrays*, int32_t*, int, hipStream_t);
 uint8_t* psi_orb_arena(ps_orb*);
 void psk_stereo_launch(const OrbPlan*, const StPair*, int, int, float, float, hipStream_t);
 void psk_bf_launch(const BfBlock*, int, const BfProb*, int, const uint8_t*, const float*, const uint8_t*, const uint8_t*, const float*, uint32_t*, int32_t*, int32_t*,
@@ -254,7 +255,8 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
   psk_pose_lm_launch(A->po_prob, S, A->po_vert, A->cur.xw, A->po_obs, A->po_is2, A->cur.mp_valid, A->cur.outlier, t->po_chi2, t->po_state,
                      A->po_pose, A->po_result, nullptr, st);
   mark(TS_POSE);
-  psk_trk_finish(A, t->step, st); mark(TS_GLUE);
+  psk_trk_finish(A, t->step, st);
+  psk_trk_stamp_overflow(A, t->d_overflow, t->step, st); mark(TS_GLUE);
   if (d_masks && t->cvorb) {
     // ---- the object half of Tracking::Track, behind the camera chain of the same frame ----
     ObArrays* O = &t->OA;
@@ -484,14 +486,15 @@ int ps_tracker_fetch(ps_tracker* t, int first_step, int nsteps, float* tcw, ps_t
   const size_t S = t->A.S;
   if (tcw && nsteps) PS_HIP(hipMemcpy(tcw, t->A.traj + (size_t)first_step * S * 16, (size_t)nsteps * S * 64, hipMemcpyDeviceToHost));
   if (stats && nsteps) PS_HIP(hipMemcpy(stats, t->A.stats + (size_t)first_step * S, (size_t)nsteps * S * sizeof(TrkStat), hipMemcpyDeviceToHost));
-  std::vector<int32_t> ovf(S, 0);
-  PS_HIP(hipMemcpy(ovf.data(), t->d_overflow, S * 4, hipMemcpyDeviceToHost));
-  long total = 0;
-  int first = -1;
-  for (size_t k = 0; k < S; k++) { total += ovf[k]; if (ovf[k] && first < 0) first = (int)k; }
-  if (total > 0)
-    return ps_set_error(PS_ERR_CAPACITY, "%ld search window(s) held more than %d candidates (first in sequence %d): use the per-call matcher, which re-runs such "
-                        "problems with the wide candidate store", total, PS_PJ_CAP, first);
+  return PS_OK;
+}
+
+// test hook: pretends that `count` search windows of sequence `seq` overflowed in the step that is queued next
+int ps_tracker_debug_set_overflow(ps_tracker* t, int seq, int count) {
+  if (!t || seq < 0 || seq >= t->A.S) return ps_set_error(PS_ERR_INVALID, "bad argument");
+  PS_HIP(hipSetDevice(t->cfg.device));
+  PS_HIP(hipStreamSynchronize(t->stream));
+  PS_HIP(hipMemcpy(t->d_overflow + seq, &count, 4, hipMemcpyHostToDevice));
   return PS_OK;
 }
 

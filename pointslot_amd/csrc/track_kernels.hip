@@ -577,9 +577,21 @@ __global__ __launch_bounds__(TRK_T) void trk_finish(TrkArrays A, int step) {
   }
 }
 
+// the search windows of this step that held more candidates than the matcher stores (PS_PJ_CAP), per sequence: stamped into the
+// step's statistics, counter cleared for the next step
+__global__ __launch_bounds__(256) void trk_stamp_overflow(TrkArrays A, int32_t* overflow, int step) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= A.S) return;
+  A.stats[(size_t)step * A.S + s].pad[0] = overflow[s];
+  overflow[s] = 0;
+}
+
 }  // namespace
 
 extern "C" {
+void psk_trk_stamp_overflow(const TrkArrays* A, int32_t* overflow, int step, hipStream_t st) {
+  hipLaunchKernelGGL(trk_stamp_overflow, dim3((A->S + 255) / 256), dim3(256), 0, st, *A, overflow, step);
+}
 void psk_trk_begin(const TrkArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(trk_begin, dim3(A->S), dim3(TRK_T), 0, st, *A, step); }
 void psk_trk_after_mm1(const TrkArrays* A, hipStream_t st) { hipLaunchKernelGGL(trk_after_mm1, dim3(A->S), dim3(TRK_T), 0, st, *A); }
 void psk_trk_after_mm(const TrkArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(trk_after_mm, dim3(A->S), dim3(TRK_T), 0, st, *A, step); }

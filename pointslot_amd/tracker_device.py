@@ -19,7 +19,7 @@ class _Config(ctypes.Structure):
 
 
 STAT_DTYPE = np.dtype([("state", "<i4"), ("tracked", "<i4"), ("n", "<i4"), ("mm_matches", "<i4"), ("retried", "<i4"), ("matches", "<i4"),
-                       ("map_matches", "<i4"), ("lm_candidates", "<i4"), ("lm_inliers", "<i4"), ("reserved", "<i4", 3)])
+                       ("map_matches", "<i4"), ("lm_candidates", "<i4"), ("lm_inliers", "<i4"), ("overflowed", "<i4"), ("reserved", "<i4", 2)])
 assert STAT_DTYPE.itemsize == 48
 # ps_detection / ps_object_stat (include/pointslot_hip.h)
 DETECTION_DTYPE = np.dtype([("id", "<i4"), ("bbox", "<i4", 4), ("reserved", "<i4", 3), ("scale", "<f8", 3), ("pose7", "<f8", 7)])
@@ -50,6 +50,7 @@ lib.ps_tracker_sync.argtypes = [ctypes.c_void_p]
 lib.ps_tracker_steps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
 lib.ps_tracker_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 lib.ps_tracker_reset.argtypes = [ctypes.c_void_p]
+lib.ps_tracker_debug_set_overflow.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 lib.ps_tracker_enable_stage_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.ps_tracker_stage_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 lib.ps_tracker_orb.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
@@ -103,6 +104,11 @@ class LockstepTracker:
     def step(self, left, right):
         """left / right: lists of n_sequences contiguous uint8 [h, w] arrays (host memory; pinned buffers upload asynchronously)."""
         assert len(left) == self.n_sequences and len(right) == self.n_sequences
+        for a in list(left) + list(right):
+            if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.shape == (self.height, self.width) and a.flags["C_CONTIGUOUS"]):
+                raise ValueError("step(): every image must be a C-contiguous uint8 array of shape (%d, %d)" % (self.height, self.width))
+        # pinned buffers are uploaded asynchronously: the arrays must stay alive and unchanged until the step has run
+        self._in_flight = (list(left), list(right))
         pl = (ctypes.c_void_p * self.n_sequences)(*[a.ctypes.data for a in left])
         pr = (ctypes.c_void_p * self.n_sequences)(*[a.ctypes.data for a in right])
         check(lib.ps_tracker_step(self._h, pl, pr, self.width))

@@ -94,3 +94,43 @@ def test_device_object_chain_equals_the_per_call_chain_and_the_cpu_checker():
             assert np.abs(obj[k, 0, b]["tco"][:3] - truth).max() < 0.35
             ok += 1
     assert ok >= n - 2 and int(obj["reinit"][:, 0].sum()) >= 1
+
+
+def test_forward_drive_with_yaw_device_chain_host_chain_and_cpu_checker():
+    """The KITTI-like scene (sequence.generate_drive: forward motion with yaw, exact ray-cast planes): SearchByProjection(cur, last)
+    takes its forward branch, keypoints change octave, local-map points leave the frustum.  Device chain = per-call chain bit for
+    bit, = the CPU checker's match sets with poses within the optimiser's tolerance; the trajectory follows the ground truth."""
+    n = 7
+    seqs = [sequence.generate_drive(n_frames=n, seed=60 + i, speed=0.6 + 0.1 * i, yaw_rate_deg=0.4 + 0.2 * i, texture=sequence.kitti_texture()) for i in range(2)]
+    tcw, st, obj = _run_device(seqs, n)
+    for s, q in enumerate(seqs):
+        be = HipBackend()
+        vo = _run_host(be, q, n)
+        _check_against(vo, tcw, st, obj, s, n, exact=True)
+        be.close()
+        for k in range(n):
+            assert st["tracked"][k, s] == 1
+            twc = -(tcw[k, s, :3, :3].T @ tcw[k, s, :3, 3])
+            assert np.abs(twc - q["twc"][k][:, 3]).max() < 0.06, (s, k, twc, q["twc"][k][:, 3])
+        assert twc[2] > 2.5                                   # the camera really drove forward
+    vo = _run_host(OracleBackend(), seqs[0], n)
+    _check_against(vo, tcw, st, obj, 0, n, exact=False)
+    assert int((obj["track_ok"][2:, 0, 0] != 0).sum()) == n - 2        # the vehicle ahead; the far one at the side has too few features at first
+
+
+def test_overflow_is_reported_per_sequence_and_step_not_by_a_failing_fetch():
+    import torch
+    from pointslot_amd._lib import lib, check
+    from pointslot_amd.tracker_device import LockstepTracker
+    seqs = [sequence.generate(n_frames=3, seed=70 + i) for i in range(3)]
+    h, w = seqs[0]["left"][0].shape
+    trk = LockstepTracker(3, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=3)
+    imgs = torch.from_numpy(np.stack([np.stack([q["left"], q["right"]], 1) for q in seqs], 1)).cuda()
+    trk.step_device(imgs[0].data_ptr())
+    check(lib.ps_tracker_debug_set_overflow(trk._h, 1, 5))     # as if five windows of sequence 1 overflowed in the next step
+    trk.step_device(imgs[1].data_ptr())
+    trk.step_device(imgs[2].data_ptr())
+    tcw, st = trk.fetch()                                       # succeeds: the other sequences' results are not withheld
+    assert st["overflowed"].tolist() == [[0, 0, 0], [0, 5, 0], [0, 0, 0]]
+    assert (st["tracked"] == 1).all()
+    trk.close()

@@ -266,3 +266,36 @@ def test_capacity_limits_are_reported_not_hidden(opt):
     kps, desc = ex.fetch(0)                                                           # extraction results are intact
     assert len(kps) > 2000
     ex.close()
+
+
+def test_object_ba_error_return_leaves_the_handle_usable():
+    """PS_BA_DEBUG_MAX_STEPS makes ps_object_ba_batch give up early (its only error return inside the solve loop): the call reports
+    PS_ERR_HIP, frees what it created (scope guard on its events), and the same handle solves the next batch."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from pointslot_amd import synth\n"
+        "from pointslot_amd._lib import PointslotError\n"
+        "from pointslot_amd.optimizer import Optimizer\n"
+        "import os\n"
+        "opt = Optimizer()\n"
+        "g = synth.object_ba_problem(0x51070004, n_kf=10, n_pts=60)\n"
+        "try:\n"
+        "    opt.ObjectLocalBundleAdjustment([g]); print('NOERROR')\n"
+        "except PointslotError as e:\n"
+        "    print('ERROR', 'did not terminate' in str(e))\n"
+        "r = opt.PoseOptimization([synth.pose_problem(0x51070003)])\n"      # the same handle serves the next call
+        "print('HANDLE_OK', r[0][0] > 1000)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PS_BA_DEBUG_MAX_STEPS="2")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert "ERROR True" in out.stdout and "HANDLE_OK True" in out.stdout, out.stdout + out.stderr
+    # and in this process (no knob) the full schedule runs
+    from pointslot_amd.optimizer import Optimizer
+    opt = Optimizer()
+    r, = opt.ObjectLocalBundleAdjustment([synth.object_ba_problem(0x51070004, n_kf=10, n_pts=60)])
+    assert r["iterations"] > 0
+    opt.close()
