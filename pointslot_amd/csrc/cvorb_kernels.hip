@@ -521,8 +521,10 @@ __global__ __launch_bounds__(CVB_TT) void cvb_level0(CvbPlan P) {
 // interpolates four consecutive pixels of four rows and stores each quad as one dword; the mask likewise on the tiles of the mask chain
 __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
   constexpr int PS = 48;                          // source patch edge: 32 * 1.2 + taps + rounding
-  __shared__ uint8_t patch[PS * PS];
-  __shared__ uint8_t mpatch[PS * PS];
+  constexpr int PW = 52;                          // LDS row pitch: 13 aligned dwords cover 48 bytes at any byte offset
+  __shared__ __attribute__((aligned(16))) uint8_t patch[PS * PW];
+  __shared__ __attribute__((aligned(16))) uint8_t mpatch[PS * PW];
+  __shared__ uint8_t shf[PS], mshf[PS];           // byte offset of a row's first source pixel inside its first dword
   __shared__ int4 xt[CVB_TILE], yt[CVB_TILE];     // table entries of the tile's columns / rows, source offsets resolved
   const int tid = threadIdx.x;
   const CvbLevel& Sb = P.lv[l - 1];
@@ -561,25 +563,37 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
       nx = min(__shfl(mxv, 0), Sb.w - 1) - ox + 1; ny = min(__shfl(mxv, 32), Sb.h - 1) - oy + 1;
     }
     {
-      // 16 lanes per source row, three bytes each, four rows per pass: every load is issued before the first LDS store
-      uint8_t v[PS / 4][3], mv[PS / 4][3];
+      // 16 lanes per source row (13 aligned dwords), four rows per pass: every load is issued before the first LDS store.  A row's
+      // first pixel sits `shift` bytes into its first dword (rows of the image / the tight mask planes start at any byte address).
+      uint32_t v[PS / 4], mv[PS / 4];
+      const int q = tid & 15;
 #pragma unroll
-      for (int ry = 0; ry < PS / 4; ry++)
-#pragma unroll
-        for (int rx = 0; rx < 3; rx++) {
-          const int yy = (tid >> 4) + 4 * ry, xx = (tid & 15) + 16 * rx;
-          const bool in = yy < ny && xx < nx;
-          v[ry][rx] = in ? src[(size_t)(oy + yy) * sstride + ox + xx] : (uint8_t)0;
-          mv[ry][rx] = (in && with_mask) ? msrc[(size_t)(oy + yy) * mstride + ox + xx] : (uint8_t)0;
+      for (int ry = 0; ry < PS / 4; ry++) {
+        const int yy = (tid >> 4) + 4 * ry;
+        v[ry] = 0; mv[ry] = 0;
+        if (yy < ny && q < 13) {
+          const uint8_t* a = src + (size_t)(oy + yy) * sstride + ox;
+          const uintptr_t al = reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3;
+          if (al + 4 * q < reinterpret_cast<uintptr_t>(a) + nx) v[ry] = *reinterpret_cast<const uint32_t*>(al + 4 * q);
+          if (with_mask) {
+            const uint8_t* ma = msrc + (size_t)(oy + yy) * mstride + ox;
+            const uintptr_t mal = reinterpret_cast<uintptr_t>(ma) & ~(uintptr_t)3;
+            if (mal + 4 * q < reinterpret_cast<uintptr_t>(ma) + nx) mv[ry] = *reinterpret_cast<const uint32_t*>(mal + 4 * q);
+          }
         }
+      }
 #pragma unroll
-      for (int ry = 0; ry < PS / 4; ry++)
-#pragma unroll
-        for (int rx = 0; rx < 3; rx++) {
-          const int yy = (tid >> 4) + 4 * ry, xx = (tid & 15) + 16 * rx;
-          patch[yy * PS + xx] = v[ry][rx];
-          if (with_mask) mpatch[yy * PS + xx] = mv[ry][rx];
+      for (int ry = 0; ry < PS / 4; ry++) {
+        const int yy = (tid >> 4) + 4 * ry;
+        if (yy < ny && q < 13) {
+          *reinterpret_cast<uint32_t*>(patch + yy * PW + 4 * q) = v[ry];
+          if (with_mask) *reinterpret_cast<uint32_t*>(mpatch + yy * PW + 4 * q) = mv[ry];
+          if (q == 0) {
+            shf[yy] = (uint8_t)(reinterpret_cast<uintptr_t>(src + (size_t)(oy + yy) * sstride + ox) & 3);
+            if (with_mask) mshf[yy] = (uint8_t)(reinterpret_cast<uintptr_t>(msrc + (size_t)(oy + yy) * mstride + ox) & 3);
+          }
         }
+      }
     }
     __syncthreads();
     const int c4 = (tid & 7) * 4, px0 = CVB_TILE * tx + c4;
@@ -589,19 +603,21 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
       const int ry = (tid >> 3) + 8 * r, py = CVB_TILE * ty + ry;
       if (py >= L.h + 2 * CV_BORDER) continue;
       const int4 tyv = yt[ry];
-      const int r0 = tyv.x - oy;
+      const int r0 = tyv.x - oy, r1 = tyv.w == 0 ? r0 + 1 : r0;
       uint32_t out = 0;
       for (int which = 0; which < (with_mask ? 2 : 1); which++) {
         const uint8_t* Pp = which == 0 ? patch : mpatch;
+        const uint8_t* sh = which == 0 ? shf : mshf;
+        const uint8_t* rowa = Pp + r0 * PW + sh[r0];
+        const uint8_t* rowb = Pp + r1 * PW + sh[r1];
         for (int j = 0; j < 4; j++) {
-          const uint8_t* row0 = Pp + r0 * PS + (txv[j].x - ox);
+          const int c0 = txv[j].x - ox;
           // cv_interp on the patch: horizontal pass in 8.8 per source row, vertical in 16.16, one rounding
-          const uint32_t h0 = txv[j].w != 0 ? (uint32_t)row0[0] << 8 : (uint32_t)txv[j].y * row0[0] + (uint32_t)txv[j].z * row0[1];
+          const uint32_t h0 = txv[j].w != 0 ? (uint32_t)rowa[c0] << 8 : (uint32_t)txv[j].y * rowa[c0] + (uint32_t)txv[j].z * rowa[c0 + 1];
           uint32_t v;
           if (tyv.w != 0) v = min((h0 + 128u) >> 8, 255u);
           else {
-            const uint8_t* row1 = row0 + PS;
-            const uint32_t h1 = txv[j].w != 0 ? (uint32_t)row1[0] << 8 : (uint32_t)txv[j].y * row1[0] + (uint32_t)txv[j].z * row1[1];
+            const uint32_t h1 = txv[j].w != 0 ? (uint32_t)rowb[c0] << 8 : (uint32_t)txv[j].y * rowb[c0] + (uint32_t)txv[j].z * rowb[c0 + 1];
             const unsigned long long acc = (unsigned long long)h0 * (uint32_t)tyv.y + (unsigned long long)h1 * (uint32_t)tyv.z;
             v = (uint32_t)min((acc + 32768ull) >> 16, 255ull);
           }
@@ -642,18 +658,19 @@ __device__ __forceinline__ int cvb_fast_score_full(const uint8_t* c) {
   return best;
 }
 
-// HarrisResponses (cv_harris) on a tile of the padded plane in LDS: c = the keypoint's pixel, row stride TS
+// HarrisResponses (cv_harris) on a tile of the padded plane in LDS by one wave: c = the keypoint's pixel, row stride TS.  Lanes
+// 0..48 take one position of the 7 x 7 block each; the three integer sums (exact, so their order does not matter) by butterfly
 template <int TS>
-__device__ __forceinline__ float cvb_harris_lds(const uint8_t* c) {
-  const uint8_t* ptr0 = c - 3 * TS - 3;
+__device__ __forceinline__ float cvb_harris_wave(const uint8_t* c, int lane) {
   int a = 0, b = 0, cc = 0;
-  for (int i = 0; i < 7; i++)
-    for (int j = 0; j < 7; j++) {
-      const uint8_t* ptr = ptr0 + i * TS + j;
-      const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-TS + 1] - ptr[-TS - 1]) + (ptr[TS + 1] - ptr[TS - 1]);
-      const int Iy = (ptr[TS] - ptr[-TS]) * 2 + (ptr[TS - 1] - ptr[-TS - 1]) + (ptr[TS + 1] - ptr[-TS + 1]);
-      a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
-    }
+  if (lane < 49) {
+    const uint8_t* ptr = c + (lane / 7 - 3) * TS + (lane % 7 - 3);
+    const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-TS + 1] - ptr[-TS - 1]) + (ptr[TS + 1] - ptr[TS - 1]);
+    const int Iy = (ptr[TS] - ptr[-TS]) * 2 + (ptr[TS - 1] - ptr[-TS - 1]) + (ptr[TS + 1] - ptr[-TS + 1]);
+    a = Ix * Ix; b = Iy * Iy; cc = Ix * Iy;
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); cc += __shfl_xor(cc, d); }
   const float scale = __fdiv_rn(1.f, __fmul_rn((float)(4 * 7), 255.f));
   const float scale_sq_sq = __fmul_rn(__fmul_rn(__fmul_rn(scale, scale), scale), scale);
   const float fa = (float)a, fb = (float)b, fc = (float)cc;
@@ -722,6 +739,10 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
     const uint8_t* kpmap = P.kpmap + (size_t)img * P.cell_total + B.cell_off;
     const uint8_t* mk = l == 0 ? P.masks + (size_t)img * P.mask_pitch : L.mask;
     const int mks = l == 0 ? P.mask_stride : L.w;
+    // keypoints of the tile into an LDS list (NMS leaves at most one per 2 x 2 block: 256), then the whole wave on each one's
+    // Harris response, then one reservation in the (image, level) candidate list for the tile
+    if (tid == 0) nsurv = 0;                     // every lane is past the survivor loop (barrier above)
+    __syncthreads();
     for (int r = 0; r < 4; r++)
       for (int j = 0; j < 4; j++) {
         const int lx = (tid & 7) * 4 + j, ly = (tid >> 3) + 8 * r;
@@ -734,10 +755,31 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
         if (!(v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] && v > s[SS - 1] && v > s[SS] && v > s[SS + 1])) continue;
         if (!kpmap[(py >> 3) * B.cw + (px >> 3)]) continue;
         if (mk[(size_t)y * mks + x] == 0) continue;
-        const int slot = img * P.nlevels + l;
-        const int pos = atomicAdd(&P.ncand[slot], 1);
-        if (pos < CVB_CAND_CAP) P.cand[(size_t)slot * CVB_CAND_CAP + pos] = make_float4((float)x, (float)y, (float)(v - 1), cvb_harris_lds<TS>(tile + (ly + 4) * TS + lx + 4));
+        surv[atomicAdd(&nsurv, 1)] = (uint16_t)(ly * CVB_TILE + lx);
       }
+    __syncthreads();
+    const int nk = nsurv;
+    if (nk > 0) {
+      const int slot = img * P.nlevels + l;
+      int base = 0;
+      if (tid == 0) base = atomicAdd(&P.ncand[slot], nk);
+      base = __shfl(base, 0);
+      for (int k0 = 0; k0 < nk; k0 += CVB_TT) {
+        float mine = 0.f;
+        const int kn = min(CVB_TT, nk - k0);
+        for (int k = 0; k < kn; k++) {
+          const int q = surv[k0 + k];
+          const float hr = cvb_harris_wave<TS>(tile + ((q >> 5) + 4) * TS + (q & 31) + 4, tid);
+          if (tid == k) mine = hr;
+        }
+        if (tid < kn && base + k0 + tid < CVB_CAND_CAP) {
+          const int q = surv[k0 + tid], lx = q & 31, ly = q >> 5;
+          const int v = sc[(ly + 1) * SS + lx + 1];
+          P.cand[(size_t)slot * CVB_CAND_CAP + base + k0 + tid] =
+              make_float4((float)(CVB_TILE * tx + lx - CV_BORDER), (float)(CVB_TILE * ty + ly - CV_BORDER), (float)(v - 1), mine);
+        }
+      }
+    }
   }
 }
 
@@ -991,6 +1033,6 @@ void psk_cvb_run(const CvbPlan* Pin, int nimg, const uint8_t* imgs, int stride, 
   hipLaunchKernelGGL(cvb_detect, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
   hipLaunchKernelGGL(cvb_blur, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
   hipLaunchKernelGGL(cvb_select, dim3(nimg * NL), dim3(256), 0, st, *P);
-  hipLaunchKernelGGL(cvb_describe, dim3(8, nimg), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_describe, dim3(32, nimg), dim3(256), 0, st, *P);
 }
 }
