@@ -54,7 +54,7 @@ def pmc_traffic(kernel, nimg):
     --pmc WRITE_SIZE in separate passes, same launch shape).  FETCH_SIZE is corrected as MI355X_MICROARCH.md prescribes for the
     kernel's access width; None when no measurement for this launch shape is on file.  PMC counters
     need rocprofv3 around the process, so this figure is read from profiles/, not measured in this run: `traffic_source`."""
-    for name in (PROFILE_ROUND + "_traffic.json", "r01_traffic.json"):
+    for name in (PROFILE_ROUND + "_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         t = _profile_json(name)
         if not t or t.get("images_per_launch") != nimg:
             continue
@@ -68,7 +68,7 @@ def pmc_valu_issue(kernel, nimg):
     """Share of the launch that VALU issue alone accounts for (waves x VALU instructions x 4 cycles / 1024 SIMDs / clock), from the
     committed PMC pass (tools/pmc_issue.sh: SQ_INSTS_VALU, SQ_WAVES, own run).  Explains a low HBM fraction: the kernel is bound by
     instruction issue, not by memory.  None when no measurement for this launch shape is on file."""
-    for name in (PROFILE_ROUND + "_valu_issue.json", "r01_valu_issue.json"):
+    for name in (PROFILE_ROUND + "_valu_issue.json", "r02_valu_issue.json", "r01_valu_issue.json"):
         t = _profile_json(name)
         if not t or t.get("images_per_launch") != nimg:
             continue
@@ -878,7 +878,8 @@ def main():
             other("object_cfse3", stage.get("object_cfse3", 0.0), "latency", "a15: two CFSE3ObjStateOptimization calls per frame (after the brute-force matches, after the local-map search)")
             other("object_search_by_projection", stage.get("object_search_by_projection", 0.0), "latency", "a13: SearchByProjection(F, nOrder, MOPs) per tracked detection")
             other("object_glue", stage.get("object_glue", 0.0), "latency", "AssignFeatures, TrackMapObject (RANSAC centroid, box fine tuning, MapObjectInit / ReInit), bookkeeping: %s" % json.dumps(ob))
-        dom = max((r for r in rl if r["bound"] == "hbm"), key=lambda r: r["ms_per_step"])
+        # the headline roofline is a single KERNEL's (the stages that are several kernels stay in `rooflines`)
+        dom = max((r for r in rl if r["bound"] == "hbm" and r["stage"].startswith("orb/")), key=lambda r: r["ms_per_step"])
         value = tracked_timed / dt
         out = {
             "metric": "tracked frames/sec KITTI stereo 1242x375",

@@ -197,7 +197,7 @@ typedef unsigned short lv_us2 __attribute__((ext_vector_type(2)));
 #ifdef PS_LV_PROFILE   // developer build: 100 MHz ticks of one workgroup in the middle of the launch
 #define LVP_DECL long long lv_t[8]; int lv_n = 0; lv_t[lv_n++] = wall_clock64()
 #define LVP_MARK() (lv_t[lv_n++] = wall_clock64())
-#define LVP_PRINT() do { if (threadIdx.x == 0 && blockIdx.x == 2 && blockIdx.y == 5 && blockIdx.z == 64) printf("level %d ticks: setup %lld half0 %lld half1 %lld barrier %lld blur %lld\n", level, lv_t[1] - lv_t[0], lv_t[2] - lv_t[1], lv_t[3] - lv_t[2], lv_t[4] - lv_t[3], wall_clock64() - lv_t[4]); } while (0)
+#define LVP_PRINT() do { if (threadIdx.x == 0 && bx == 2 && by == 5 && img == 64) printf("level %d ticks: setup %lld half0 %lld half1 %lld barrier %lld blur %lld\n", level, lv_t[1] - lv_t[0], lv_t[2] - lv_t[1], lv_t[3] - lv_t[2], lv_t[4] - lv_t[3], wall_clock64() - lv_t[4]); } while (0)
 #else
 #define LVP_DECL
 #define LVP_MARK()
@@ -208,17 +208,20 @@ typedef unsigned short lv_us2 __attribute__((ext_vector_type(2)));
 #endif
 template <bool LEVEL0>
 __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(PS_LV_WAVES, 8))) void orb_level_fused(OrbPlan plan, int level, uint8_t* arena, const uint8_t* imgs,
-                                                      int img_stride, size_t img_pitch, const int4* tabs) {
+                                                      int img_stride, size_t img_pitch, const int4* tabs, int nimg, int tiles_x) {
   __shared__ uint32_t tile[LV_R][64];
   LVP_DECL;
   const OrbLevel L = plan.lv[level];
-  const int img = blockIdx.z;
+  // one image per XCD at a time, its tiles in row-major order: tiles that share halo rows and 128-byte lines meet in one L2
+  int img, lb;
+  if (!xcd_image_block(nimg, img, lb)) return;
+  const int bx = lb % tiles_x, by = lb / tiles_x;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
   const int lane = threadIdx.x & 63;
   const int tyq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int PW = L.w + 2 * PS_EDGE, PH = L.h + 2 * PS_EDGE;
-  const int P0 = blockIdx.x * LV_OWN_C - 4;      // padded column of region column 0 (multiple of 4)
-  const int Q0 = blockIdx.y * LV_OWN_R - 3;      // padded row of region row 0
+  const int P0 = bx * LV_OWN_C - 4;      // padded column of region column 0 (multiple of 4)
+  const int Q0 = by * LV_OWN_R - 3;      // padded row of region row 0
 
   // ---- phase 1: resize (or copy) the region into LDS, store the owned part of the padded plane ----
   int s0[4], s1[4];
@@ -1485,11 +1488,12 @@ extern "C" void psk_orb_launch_level_fused(const OrbPlan* plan, int level, uint8
                                            int img_stride, size_t img_pitch, const int4* tabs, int nimg, hipStream_t st) {
   const OrbLevel& L = plan->lv[level];
   const int PW = L.w + 2 * PS_EDGE, PH = L.h + 2 * PS_EDGE;
-  dim3 grd((PW + LV_OWN_C - 1) / LV_OWN_C, (PH + LV_OWN_R - 1) / LV_OWN_R, nimg);
+  const int tiles_x = (PW + LV_OWN_C - 1) / LV_OWN_C, tiles_y = (PH + LV_OWN_R - 1) / LV_OWN_R;
+  const dim3 grd = PS_XCD_GRID(tiles_x * tiles_y, nimg);
   if (level == 0)
-    hipLaunchKernelGGL(orb_level_fused<true>, grd, dim3(64 * LV_WAVES), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
+    hipLaunchKernelGGL(orb_level_fused<true>, grd, dim3(64 * LV_WAVES), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs, nimg, tiles_x);
   else
-    hipLaunchKernelGGL(orb_level_fused<false>, grd, dim3(64 * LV_WAVES), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs);
+    hipLaunchKernelGGL(orb_level_fused<false>, grd, dim3(64 * LV_WAVES), 0, st, *plan, level, arena, imgs, img_stride, img_pitch, tabs, nimg, tiles_x);
 }
 extern "C" void psk_orb_launch_border(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   hipLaunchKernelGGL(orb_border, dim3(plan->border_blocks, nimg), dim3(256), 0, st, *plan, arena);

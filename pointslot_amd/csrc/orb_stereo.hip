@@ -103,7 +103,7 @@ __device__ __forceinline__ int row_sum_i32(int v) {
 // bytes (b, b + 1) of the 8-byte pair {hi, lo} as packed u16; a byte index of 0x0c yields zero
 #define ST_PAIR(hi, lo, b0, b1) __builtin_amdgcn_perm(hi, lo, (uint32_t)(b0) | 0x0c000c00u | ((uint32_t)(b1) << 16))
 
-__global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pairs, float mb, float mbf) {
+__global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pairs, float mb, float mbf, int npairs) {
   // the level fields a keypoint needs, indexed by its octave (a lane-dependent index into the kernel arguments would go through memory anyway)
   __shared__ float s_scale[PS_ORB_MAX_LEVELS], s_inv[PS_ORB_MAX_LEVELS];
   __shared__ int s_w[PS_ORB_MAX_LEVELS], s_stride[PS_ORB_MAX_LEVELS];
@@ -112,10 +112,14 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
   for (int l = 0; l < PS_ORB_MAX_LEVELS; l++)
     if ((int)threadIdx.x == l) { s_scale[l] = plan.lv[l].scale; s_inv[l] = plan.lv[l].inv_scale; s_w[l] = plan.lv[l].w; s_stride[l] = plan.lv[l].stride; s_plane[l] = plan.lv[l].plane_off; }
   __syncthreads();
-  const StPair S = pairs[blockIdx.y];
+  // one pair per XCD at a time (workgroup b runs on XCD b % 8; the grid is 8 * blocks wide): the candidate lists, the right image's
+  // descriptors and the planes of a pair are then fetched into one L2 instead of eight
+  const int pair = (int)blockIdx.y * 8 + ((int)blockIdx.x & 7);
+  if (pair >= npairs) return;
+  const StPair S = pairs[pair];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   const int N = *st_g(S.cnt_l);
-  const int iL0 = blockIdx.x * 16 + wave * 4;
+  const int iL0 = ((int)blockIdx.x >> 3) * 16 + wave * 4;
   if (iL0 >= N) return;
   const int iL = iL0 + grp;
   const bool live = iL < N;
@@ -310,6 +314,6 @@ __global__ __launch_bounds__(1024) void st_median(OrbPlan plan, const StPair* pa
 
 extern "C" void psk_stereo_launch(const OrbPlan* plan, const StPair* d_pairs, int npairs, int max_left, float mb, float mbf, hipStream_t st) {
   hipLaunchKernelGGL(st_bucket, dim3(npairs), dim3(256), 0, st, *plan, d_pairs);
-  hipLaunchKernelGGL(st_match, dim3((max_left + 15) / 16, npairs), dim3(256), 0, st, *plan, d_pairs, mb, mbf);
+  hipLaunchKernelGGL(st_match, dim3(((max_left + 15) / 16) * 8, (npairs + 7) / 8), dim3(256), 0, st, *plan, d_pairs, mb, mbf, npairs);
   hipLaunchKernelGGL(st_median, dim3(npairs), dim3(1024), 0, st, *plan, d_pairs);
 }

@@ -48,9 +48,10 @@ void psk_ob_finish(const ObArrays*, int, hipStream_t);
 }
 
 namespace {
-enum { TS_ORB = 0, TS_STEREO, TS_GLUE, TS_SEARCH, TS_POSE, TS_OBJ_FEATURES, TS_OBJ_STEREO, TS_OBJ_GLUE, TS_OBJ_BRUTEFORCE, TS_OBJ_CFSE3, TS_OBJ_SEARCH, TS_COUNT };
+enum { TS_ORB = 0, TS_STEREO, TS_GLUE, TS_SEARCH, TS_POSE, TS_OBJ_FEATURES, TS_OBJ_STEREO, TS_OBJ_GLUE, TS_OBJ_BRUTEFORCE, TS_OBJ_CFSE3, TS_OBJ_SEARCH, TS_OBJ_WAIT, TS_COUNT };
 const char* kTrkStage[TS_COUNT] = {"orb_extract", "stereo_match", "track_glue", "search_by_projection", "pose_optimization",
-                                   "object_features", "object_stereo_match", "object_glue", "object_bruteforce", "object_cfse3", "object_search_by_projection"};
+                                   "object_features", "object_stereo_match", "object_glue", "object_bruteforce", "object_cfse3", "object_search_by_projection",
+                                   "object_features_wait"};
 const int kTrkMaxEvents = 32;   // events of one step: boundaries between the launches of queue_chain
 }  // namespace
 
@@ -76,6 +77,12 @@ struct ps_tracker {
   BfBlock* d_bf_blocks = nullptr; int32_t* d_bf_count = nullptr; int bf_blocks_per_prob = 0;
   PjArrays pj_obj;
   double* ob_chi2 = nullptr; uint8_t* ob_state = nullptr;
+  // ExtractObjORB does not depend on the camera chain of its frame: it runs on a second stream beside the latency-bound part of that
+  // chain (stereo matching, the searches, PoseOptimization) and joins before ComputeObjStereoMatches.  PS_TRK_SERIAL=1: one stream.
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_obj[64][2] = {};     // timing of the object features on stream2 (ring as below)
+  bool overlap = false;
   // stage timing
   static const int RING = 64;
   hipEvent_t ev[RING][kTrkMaxEvents] = {};
@@ -238,7 +245,30 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
   };
   A->idmask = d_masks; A->mask_stride = mask_stride; A->mask_pitch = mask_pitch;
   mark(TS_ORB);
-  int rc = ps_orb_stereo_match_batch(t->orb, S, t->mb, t->mbf);
+  int rc = PS_OK;
+  const bool objects = d_masks && t->cvorb;
+  // ExtractObjORB (Frame.cc:711, 2623-2665) with its masks (Frame.cc:2318-2503): on the second stream from here, or in line below
+  auto object_features = [&](hipStream_t so) -> int {
+    ObArrays* O = &t->OA;
+    O->idmask = d_masks; O->mask_stride = mask_stride; O->mask_pitch = mask_pitch; O->dets_in = (const ObDet*)d_dets;
+    const int W = t->cfg.width, H = t->cfg.height;
+    uint8_t* occ = nullptr; int ocw = 0, och = 0;
+    int r = psi_cvorb_batch_begin(t->cvorb, 2 * S, W, H, so, &occ, &ocw, &och);
+    if (r != PS_OK) return r;
+    const int ostride = (W + 15) & ~15;                          // rows of the object masks start on 16-byte boundaries
+    psk_ob_masks(O, t->d_objmask, W, H, ostride, occ, ocw, och, so);   // ... and fills the detector's cell occupancy on the way
+    return psi_cvorb_batch_run(t->cvorb, d_imgs, t->d_objmask, 2 * S, stride, image_pitch, ostride, (size_t)ostride * H, 1, so);
+  };
+  if (objects && t->overlap) {
+    PS_HIP(hipEventRecord(t->ev_fork, st));
+    PS_HIP(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+    if (tm) hipEventRecord(t->ev_obj[t->timed % ps_tracker::RING][0], t->stream2);
+    rc = object_features(t->stream2);
+    if (rc != PS_OK) return rc;
+    if (tm) hipEventRecord(t->ev_obj[t->timed % ps_tracker::RING][1], t->stream2);
+    PS_HIP(hipEventRecord(t->ev_join, t->stream2));
+  }
+  rc = ps_orb_stereo_match_batch(t->orb, S, t->mb, t->mbf);
   if (rc != PS_OK) return rc;
   mark(TS_STEREO);
   psk_trk_begin(A, t->step, st); mark(TS_GLUE);
@@ -257,19 +287,16 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
   mark(TS_POSE);
   psk_trk_finish(A, t->step, st);
   psk_trk_stamp_overflow(A, t->d_overflow, t->step, st); mark(TS_GLUE);
-  if (d_masks && t->cvorb) {
+  if (objects) {
     // ---- the object half of Tracking::Track, behind the camera chain of the same frame ----
     ObArrays* O = &t->OA;
-    O->idmask = d_masks; O->mask_stride = mask_stride; O->mask_pitch = mask_pitch; O->dets_in = (const ObDet*)d_dets;
-    const int K = O->K, W = t->cfg.width, H = t->cfg.height;
-    uint8_t* occ = nullptr; int ocw = 0, och = 0;
-    rc = psi_cvorb_batch_begin(t->cvorb, 2 * S, W, H, st, &occ, &ocw, &och);
-    if (rc != PS_OK) return rc;
-    const int ostride = (W + 15) & ~15;                          // rows of the object masks start on 16-byte boundaries
-    psk_ob_masks(O, t->d_objmask, W, H, ostride, occ, ocw, och, st);   // ... and fills the detector's cell occupancy on the way
-    rc = psi_cvorb_batch_run(t->cvorb, d_imgs, t->d_objmask, 2 * S, stride, image_pitch, ostride, (size_t)ostride * H, 1, st);
-    if (rc != PS_OK) return rc;
-    mark(TS_OBJ_FEATURES);
+    const int K = O->K;
+    if (t->overlap) { PS_HIP(hipStreamWaitEvent(st, t->ev_join, 0)); mark(TS_OBJ_WAIT); }
+    else {
+      rc = object_features(st);
+      if (rc != PS_OK) return rc;
+      mark(TS_OBJ_FEATURES);
+    }
     psk_stereo_launch(psi_orb_plan(t->orb), t->d_obj_pairs, S, O->OC, t->mb, t->mbf, st); mark(TS_OBJ_STEREO);
     psk_ob_begin(O, t->step, st);
     psk_ob_track(O, t->step, st);
@@ -383,6 +410,12 @@ int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out) {
     for (ObMapObject& m : mo) m.id = -1;
     hipMemcpy(O.mobj, mo.data(), mo.size() * sizeof(ObMapObject), hipMemcpyHostToDevice);
     O.cam_traj = A.traj; O.cam_stats = (const int32_t*)A.stats; O.cam_stat_words = (int32_t)(sizeof(TrkStat) / 4);
+    t->overlap = getenv("PS_TRK_SERIAL") == nullptr;
+    if (t->overlap) {
+      if (hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) != hipSuccess) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_HIP, "ps_tracker_create: second stream"); }
+      for (int r = 0; r < ps_tracker::RING; r++) { hipEventCreate(&t->ev_obj[r][0]); hipEventCreate(&t->ev_obj[r][1]); }
+    }
   }
   if (hipStreamSynchronize(t->stream) != hipSuccess) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_HIP, "tracker initialisation failed"); }
   *out = t;
@@ -395,6 +428,10 @@ void ps_tracker_destroy(ps_tracker* t) {
   if (t->stream) hipStreamSynchronize(t->stream);
   for (int r = 0; r < ps_tracker::RING; r++)
     for (int i = 0; i < kTrkMaxEvents; i++) if (t->ev[r][i]) hipEventDestroy(t->ev[r][i]);
+  if (t->stream2) { hipStreamSynchronize(t->stream2); hipStreamDestroy(t->stream2); }
+  if (t->ev_fork) hipEventDestroy(t->ev_fork);
+  if (t->ev_join) hipEventDestroy(t->ev_join);
+  for (int r = 0; r < ps_tracker::RING; r++) for (int i = 0; i < 2; i++) if (t->ev_obj[r][i]) hipEventDestroy(t->ev_obj[r][i]);
   if (t->d_buf) hipFree(t->d_buf);
   if (t->d_obj) hipFree(t->d_obj);
   if (t->cvorb) ps_cvorb_destroy(t->cvorb);
@@ -534,6 +571,11 @@ int ps_tracker_stage_times(ps_tracker* t, const char** names, float* ms, int cap
       float v = 0;
       PS_HIP(hipEventElapsedTime(&v, t->ev[r][i - 1], t->ev[r][i]));
       acc[t->ev_stage[i]] += v;
+    }
+  if (t->overlap && t->cvorb)
+    for (int r = 0; r < cnt; r++) {
+      float v = 0;
+      if (hipEventElapsedTime(&v, t->ev_obj[r][0], t->ev_obj[r][1]) == hipSuccess) acc[TS_OBJ_FEATURES] += v;   // on the second stream, beside the camera chain
     }
   *n = TS_COUNT;
   for (int i = 0; i < TS_COUNT && i < cap; i++) {
