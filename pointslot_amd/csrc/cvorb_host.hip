@@ -55,7 +55,7 @@ inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
 inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 // interpolationLinear<ufixedpoint16>::getCoeffs (resize.cpp): source offset and 8.8 weights per destination index
-void exact_table(int ssize, int dsize, std::vector<int4>& tab) {
+void exact_table(int ssize, int dsize, std::vector<int4>& tab, double* scale_out = nullptr, int* dmin_out = nullptr, int* dmax_out = nullptr) {
   const double inv_scale = (double)dsize / ssize, scale = 1.0 / inv_scale;
   tab.assign(dsize, int4{0, 0, 0, 0});
   int dmin = 0, dmax = dsize;
@@ -70,6 +70,9 @@ void exact_table(int ssize, int dsize, std::vector<int4>& tab) {
     } else dmin = std::max(dmin, val + 1);
   }
   for (int val = 0; val < dsize; val++) tab[val].w = val < dmin ? 1 : (val >= dmax ? 2 : 0);
+  if (scale_out) *scale_out = scale;
+  if (dmin_out) *dmin_out = dmin;
+  if (dmax_out) *dmax_out = dmax;
 }
 
 void retain_best(std::vector<CvSel>& kp, int n_points) {   // KeyPointsFilter::retainBest (features2d/src/keypoint.cpp)
@@ -313,7 +316,7 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
     L.o_pad = take_img((size_t)L.stride * (L.h + 2 * CV_BORDER)); L.o_blur = take_img((size_t)L.stride * (L.h + 2 * CV_BORDER));
     L.o_mask = take_img((size_t)L.w * L.h); L.o_score = 0;
     if (l > 0) {
-      exact_table(P.lv[l - 1].w, L.w, xt[l]); exact_table(P.lv[l - 1].h, L.h, yt[l]);
+      exact_table(P.lv[l - 1].w, L.w, xt[l], &L.sx, &L.dminx, &L.dmaxx); exact_table(P.lv[l - 1].h, L.h, yt[l], &L.sy, &L.dminy, &L.dmaxy);
       // cvb_resize stages the source patch of a 32 x 32 tile in a 48 x 48 LDS array
       if ((double)P.lv[l - 1].w / L.w * 32 + 6 > 48 || (double)P.lv[l - 1].h / L.h * 32 + 6 > 48)
         return ps_set_error(PS_ERR_INVALID, "the batched object detector supports scale factors up to 1.3");

@@ -486,12 +486,17 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
   }
 }
 
+// the next worklist entry is requested while the current tile is worked on (a tile is a chain of dependent round trips: every one
+// taken off the chain counts)
 #define CVB_TILE_LOOP(P, which, l)                                                                      \
   const CvbLevel& B = P.lv[l];                                                                          \
   const uint32_t* wl = P.wl + ((size_t)(which) * CV_MAX_LEVELS + (l)) * P.wl_cap;                       \
   const int cnt = min(P.wl_count[(which) * CV_MAX_LEVELS + (l)], P.wl_cap);                             \
   const int xchunk = (cnt + 7) >> 3, xend = min(cnt, ((int)(blockIdx.x & 7) + 1) * xchunk);             \
-  for (int it = (int)(blockIdx.x & 7) * xchunk + (int)(blockIdx.x >> 3); it < xend; it += (int)(gridDim.x >> 3))
+  const int xstep = (int)(gridDim.x >> 3);                                                              \
+  int it = (int)(blockIdx.x & 7) * xchunk + (int)(blockIdx.x >> 3);                                     \
+  uint32_t e_next = it < xend ? wl[it] : 0u;                                                            \
+  for (uint32_t e = e_next; it < xend && ((e = e_next), (e_next = it + xstep < xend ? wl[it + xstep] : 0u), true); it += xstep)
 
 // XCD-aware order: workgroup b runs on XCD b % 8, each XCD has its own L2, and a worklist keeps the tiles of one image together.
 // XCD k therefore takes the k-th eighth of the list front to back: neighbouring tiles - which share the 128-byte lines of their
@@ -500,12 +505,29 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
 // tables -> source patch -> result), so what counts is how many tiles are in flight - 32 per CU instead of 8.
 #define CVB_TT 64
 typedef unsigned short cvb_us2 __attribute__((ext_vector_type(2)));
+// A workgroup of these kernels is ONE wave: its LDS instructions execute in program order, so lanes exchange data through LDS
+// without s_barrier and - what matters - without the vmcnt(0) wait a workgroup barrier brings (the prefetched worklist entry and
+// the stores of the previous tile stay in flight).  What is needed is that the compiler keeps the order.
+__device__ __forceinline__ void cvb_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// one entry of interpolationLinear<ufixedpoint16>::getCoeffs (resize.cpp; the host's exact_table): source index and 8.8 weights of
+// destination index val, the same IEEE double operations in the same order; outside [dmin, dmax) the edge sample with weight 256
+__device__ __forceinline__ int4 cvb_tab_entry(int val, double scale, int ssize, int dmin, int dmax) {
+  if (val < dmin) return make_int4(0, 256, 0, 1);
+  if (val >= dmax) return make_int4(ssize - 1, 256, 0, 2);
+  const double fval = __dsub_rn(__dmul_rn(scale, __dadd_rn((double)val, 0.5)), 0.5);
+  const int ival = (int)floor(fval);
+  const int c1 = __double2int_rn(__dmul_rn(__dsub_rn(fval, (double)ival), 256.0));
+  return make_int4(ival, 256 - c1, c1, 0);
+}
 
 // level 0: copyMakeBorder(image, REFLECT_101) on the tiles around the level's own keypoints (the mask of level 0 is the input)
 __global__ __launch_bounds__(CVB_TT) void cvb_level0(CvbPlan P) {
   const int tid = threadIdx.x;
   CVB_TILE_LOOP(P, 0, 0) {
-    const uint32_t e = wl[it];
     const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, 0);
     const uint8_t* I = P.imgs + (size_t)img * P.img_pitch;
@@ -534,7 +556,6 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
   const int tid = threadIdx.x;
   const CvbLevel& Sb = P.lv[l - 1];
   CVB_TILE_LOOP(P, 0, l) {
-    const uint32_t e = wl[it];
     const bool with_mask = (e >> 31) != 0;
     const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l);
@@ -545,19 +566,17 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
       const CvLevelDev S = cvb_level(P, img, l - 1);
       src = S.pad + (size_t)CV_BORDER * S.stride + CV_BORDER; sstride = S.stride; msrc = S.mask; mstride = S.w;
     }
-    __syncthreads();
+    cvb_wave_sync();
     {
       // lanes 0..31: the columns' table entries, lanes 32..63: the rows'; .x = the first source index of the entry
       const int k = tid & 31;
       const bool isx = tid < 32;
       const int len = isx ? L.w : L.h, slen = isx ? Sb.w : Sb.h;
       const int p = min(CVB_TILE * (isx ? tx : ty) + k, len + 2 * CV_BORDER - 1);
-      int4 v = (isx ? B.xtab : B.ytab)[reflect101(p - CV_BORDER, len)];
-      v.x = v.w == 1 ? 0 : (v.w == 2 ? slen - 1 : v.x);
-      if (v.w != 0) { v.y = 256; v.z = 0; }          // outside the interpolated range: the edge sample with weight 1
+      const int4 v = cvb_tab_entry(reflect101(p - CV_BORDER, len), isx ? B.sx : B.sy, slen, isx ? B.dminx : B.dminy, isx ? B.dmaxx : B.dmaxy);
       (isx ? xt : yt)[k] = v;
     }
-    __syncthreads();
+    cvb_wave_sync();
     // source rectangle: the extreme source indices over the tile's columns / rows (+ 1 for the second tap)
     int ox, oy, nx, ny;
     {
@@ -605,7 +624,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
         }
       }
     }
-    __syncthreads();
+    cvb_wave_sync();
     // cv_interp on the patch.  Both passes carry 8.8 weights that add up to 256 (an edge sample has weight 256, its neighbour 0),
     // so the horizontal sums are at most 255 * 256 (16 bits), the 16.16 total fits 32 bits and never exceeds 255 after the one
     // rounding.  Each pass is one v_dot2_u32_u16 on a packed pair (32-bit integer multiplies run at a quarter of that rate).
@@ -704,12 +723,15 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
   __shared__ int nsurv;
   const int l = blockIdx.y, tid = threadIdx.x, th = P.fast_th;
   CVB_TILE_LOOP(P, 1, l) {
-    const uint32_t e = wl[it];
     const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l);
     const int PW = L.w + 2 * CV_BORDER, PH = L.h + 2 * CV_BORDER;
     const int bx = CVB_TILE * tx - 4, by = CVB_TILE * ty - 4;           // padded coordinates of tile[0]; bx is a multiple of 4
-    __syncthreads();
+    const uint8_t* kpmap = P.kpmap + (size_t)img * P.cell_total + B.cell_off;
+    const uint8_t* mk = l == 0 ? P.masks + (size_t)img * P.mask_pitch : L.mask;
+    const int mks = l == 0 ? P.mask_stride : L.w;
+    uint32_t kpm[4], mrow[4];
+    cvb_wave_sync();
     if (tid == 0) nsurv = 0;
     // 40 rows of 10 aligned dwords (the plane's row stride is a multiple of 64 and wider than the padded width)
     {
@@ -721,13 +743,29 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
         const int px = bx + 4 * q, py = by + yy;
         v[k] = (i < TS * (TS / 4) && px >= 0 && px < L.stride && py >= 0 && py < PH) ? *reinterpret_cast<const uint32_t*>(L.pad + (size_t)py * L.stride + px) : 0u;
       }
+      // ... and with them what the keypoint predicate reads at this lane's 4 x 4 pixels (four in a row, rows 8 apart): the cell
+      // flags of the keypoint map and the mask bytes - a second round trip otherwise, for the few pixels that survive the NMS
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int px = CVB_TILE * tx + (tid & 7) * 4, py = CVB_TILE * ty + (tid >> 3) + 8 * r;
+        const int x = px - CV_BORDER, y = py - CV_BORDER;
+        kpm[r] = kpmap[__umul24((uint32_t)(py >> 3), (uint32_t)B.cw) + (uint32_t)(px >> 3)];
+        uint32_t m = 0;
+        if (y >= 0 && y < L.h) {
+          const uint8_t* mp = mk + (__umul24((uint32_t)y, (uint32_t)mks) + x);
+          if (x >= 0 && x + 3 < L.w) __builtin_memcpy(&m, mp, 4);
+          else
+            for (int j = 0; j < 4; j++) if (x + j >= 0 && x + j < L.w) m |= (uint32_t)mp[j] << (8 * j);
+        }
+        mrow[r] = m;
+      }
 #pragma unroll
       for (int k = 0; k < NIT; k++) {
         const int i = tid + k * CVB_TT;
         if (i < TS * (TS / 4)) *reinterpret_cast<uint32_t*>(tile + (i / (TS / 4)) * TS + 4 * (i % (TS / 4))) = v[k];
       }
     }
-    __syncthreads();
+    cvb_wave_sync();
     for (int i = tid; i < SS * SS; i += CVB_TT) {
       const int sx = i % SS, sy = i / SS;                                // score pixel: padded (bx + 3 + sx, by + 3 + sy)
       const int x = bx + 3 + sx - CV_BORDER, y = by + 3 + sy - CV_BORDER;
@@ -742,21 +780,18 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
       sc[i] = 0;
       if (cand) surv[atomicAdd(&nsurv, 1)] = (uint16_t)i;
     }
-    __syncthreads();
+    cvb_wave_sync();
     const int ns = nsurv;
     for (int k = tid; k < ns; k += CVB_TT) {
       const int i = surv[k], sx = i % SS, sy = i / SS;
       const int best = cvb_fast_score_full<TS>(tile + (sy + 3) * TS + sx + 3);
       if (best > th) sc[i] = (uint8_t)best;
     }
-    __syncthreads();
-    const uint8_t* kpmap = P.kpmap + (size_t)img * P.cell_total + B.cell_off;
-    const uint8_t* mk = l == 0 ? P.masks + (size_t)img * P.mask_pitch : L.mask;
-    const int mks = l == 0 ? P.mask_stride : L.w;
+    cvb_wave_sync();
     // keypoints of the tile into an LDS list (NMS leaves at most one per 2 x 2 block: 256), then the whole wave on each one's
     // Harris response, then one reservation in the (image, level) candidate list for the tile
     if (tid == 0) nsurv = 0;                     // every lane is past the survivor loop (barrier above)
-    __syncthreads();
+    cvb_wave_sync();
     for (int r = 0; r < 4; r++)
       for (int j = 0; j < 4; j++) {
         const int lx = (tid & 7) * 4 + j, ly = (tid >> 3) + 8 * r;
@@ -767,17 +802,16 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
         const int v = s[0];
         if (v == 0) continue;
         if (!(v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] && v > s[SS - 1] && v > s[SS] && v > s[SS + 1])) continue;
-        if (!kpmap[(py >> 3) * B.cw + (px >> 3)]) continue;
-        if (mk[(size_t)y * mks + x] == 0) continue;
+        if (!kpm[r]) continue;
+        if (((mrow[r] >> (8 * j)) & 0xFFu) == 0) continue;
         surv[atomicAdd(&nsurv, 1)] = (uint16_t)(ly * CVB_TILE + lx);
       }
-    __syncthreads();
+    cvb_wave_sync();
     const int nk = nsurv;
     if (nk > 0) {
       const int slot = img * P.nlevels + l;
-      int base = 0;
-      if (tid == 0) base = atomicAdd(&P.ncand[slot], nk);
-      base = __shfl(base, 0);
+      int base0 = 0;
+      if (tid == 0) base0 = atomicAdd(&P.ncand[slot], nk);      // in flight under the Harris responses
       for (int k0 = 0; k0 < nk; k0 += CVB_TT) {
         float mine = 0.f;
         const int kn = min(CVB_TT, nk - k0);
@@ -786,6 +820,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
           const float hr = cvb_harris_wave<TS>(tile + ((q >> 5) + 4) * TS + (q & 31) + 4, tid);
           if (tid == k) mine = hr;
         }
+        const int base = __shfl(base0, 0);
         if (tid < kn && base + k0 + tid < CVB_CAND_CAP) {
           const int q = surv[k0 + tid], lx = q & 31, ly = q >> 5;
           const int v = sc[(ly + 1) * SS + lx + 1];
@@ -805,12 +840,11 @@ __global__ __launch_bounds__(CVB_TT) void cvb_blur(CvbPlan P) {
   const int l = blockIdx.y, tid = threadIdx.x;
   const uint32_t kq[7] = {(uint32_t)P.kq[0], (uint32_t)P.kq[1], (uint32_t)P.kq[2], (uint32_t)P.kq[3], (uint32_t)P.kq[2], (uint32_t)P.kq[1], (uint32_t)P.kq[0]};
   CVB_TILE_LOOP(P, 2, l) {
-    const uint32_t e = wl[it];
     const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l);
     const int PW = L.w + 2 * CV_BORDER, PH = L.h + 2 * CV_BORDER;
     const int bx = CVB_TILE * tx - 4, by = CVB_TILE * ty - 3;           // tile[0] = padded (bx, by); bx is a multiple of 4, the window starts at bx + 1
-    __syncthreads();
+    cvb_wave_sync();
     {
       constexpr int NIT = (TR * (TS / 4) + CVB_TT - 1) / CVB_TT;
       uint32_t v[NIT];
@@ -826,7 +860,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_blur(CvbPlan P) {
         if (i < TR * (TS / 4)) *reinterpret_cast<uint32_t*>(tile + (i / (TS / 4)) * TS + 4 * (i % (TS / 4))) = v[k];
       }
     }
-    __syncthreads();
+    cvb_wave_sync();
     // horizontal pass: four adjacent outputs per item from three aligned dwords of the row (bytes 4 q + 1 .. 4 q + 10)
     for (int i = tid; i < TR * 8; i += CVB_TT) {
       const int r = i >> 3, q = i & 7;
@@ -846,7 +880,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_blur(CvbPlan P) {
       }
       *reinterpret_cast<uint2*>(hs + r * 32 + 4 * q) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     }
-    __syncthreads();
+    cvb_wave_sync();
     // vertical pass: a 4 x 4 block of outputs per thread from ten rows of four sums
     {
       const int lx0 = (tid & 7) * 4, ly0 = (tid >> 3) * 4;
@@ -937,6 +971,7 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P) {
 // four keypoints per WAVE, one per 16-lane row: ICAngles, pt *= scale, computeOrbDescriptors - the arithmetic of cv_describe on the
 // image's own planes; keypoint k of an image is entry k of the concatenation of its levels' selections
 __global__ __launch_bounds__(256) void cvb_describe(CvbPlan P) {
+  __shared__ __attribute__((aligned(16))) uint8_t patch_all[16][40 * 48];
   const int img = blockIdx.y, lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   int nsel[CV_MAX_LEVELS];
   int total = 0;
@@ -990,16 +1025,41 @@ __global__ __launch_bounds__(256) void cvb_describe(CvbPlan P) {
     const float inv = __fdiv_rn(1.f, L.scale);
     const float angle = __fmul_rn(angle_deg, (float)(3.14159265358979323846 / 180.f));
     const float a = (float)cos((double)angle), b = (float)sin((double)angle);
-    const uint8_t* c = L.blur + (size_t)(CV_BORDER + __float2int_rn(__fmul_rn(py, inv))) * L.stride + CV_BORDER + __float2int_rn(__fmul_rn(px, inv));
+    // the taps of the steered pattern stay within 19 pixels of the keypoint: that 39 x 39 neighbourhood of the blurred plane goes to
+    // LDS with row-coalesced loads (4 lanes x 12 bytes per row, aligned down: the rows' common byte shift is added at the reads) -
+    // the 32 byte gathers per lane would otherwise touch some 60 cache lines per load instruction
+    uint8_t* patch = patch_all[(threadIdx.x >> 6) * 4 + grp];
+    uint32_t pshift;
+    {
+      const uint8_t* cb = L.blur + (size_t)(CV_BORDER + __float2int_rn(__fmul_rn(py, inv)) - 19) * L.stride + CV_BORDER + __float2int_rn(__fmul_rn(px, inv)) - 19;
+      pshift = (uint32_t)(reinterpret_cast<uintptr_t>(cb) & 3);
+      const int r4 = l16 >> 2, c4 = l16 & 3;
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(cb - pshift) + 3 * c4;
+      const uint32_t sd = (uint32_t)L.stride >> 2;     // row stride in dwords (the planes' strides are multiples of 64)
+      uint32_t tmp[10][3];
+#pragma unroll
+      for (int i = 0; i < 10; i++) {
+        const uint32_t* r = q + (uint32_t)(4 * i + r4) * sd;
+        tmp[i][0] = r[0]; tmp[i][1] = r[1]; tmp[i][2] = r[2];
+      }
+      cvb_wave_sync();                                 // the previous round's taps are read
+#pragma unroll
+      for (int i = 0; i < 10; i++) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(patch + (4 * i + r4) * 48) + 3 * c4;
+        d[0] = tmp[i][0]; d[1] = tmp[i][1]; d[2] = tmp[i][2];
+      }
+      cvb_wave_sync();
+    }
+    const uint8_t* c = patch + 19 * 48 + 19 + pshift;
     for (int half = 0; half < 2; half++) {
       const int byte = l16 + 16 * half;
       const int8_t* pat = cv_pattern + byte * 32;
       int tv[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {             // all sixteen taps of the byte in flight together
+      for (int i = 0; i < 16; i++) {
         const float fx = (float)pat[2 * i], fy = (float)pat[2 * i + 1];
         const float rx = __fsub_rn(__fmul_rn(fx, a), __fmul_rn(fy, b)), ry = __fadd_rn(__fmul_rn(fx, b), __fmul_rn(fy, a));
-        tv[i] = c[__float2int_rn(ry) * L.stride + __float2int_rn(rx)];
+        tv[i] = c[__float2int_rn(ry) * 48 + __float2int_rn(rx)];
       }
       int val = 0;
 #pragma unroll

@@ -37,6 +37,8 @@ struct CvbLevel {
   float scale;
   size_t o_pad, o_blur, o_mask, o_score;   // byte offsets inside one image's arena
   const int4* xtab; const int4* ytab;      // INTER_LINEAR_EXACT tables from level l - 1 (nullptr at level 0)
+  double sx, sy;               // the tables' source step per destination pixel (1 / ((double)dsize / ssize)): cvb_resize evaluates the entries itself
+  int32_t dminx, dmaxx, dminy, dmaxy;      // destination indices below dmin take source 0, from dmax on source ssize - 1 (weight 1)
 };
 struct CvbPlan {
   CvbLevel lv[CV_MAX_LEVELS];
