@@ -71,52 +71,63 @@ __device__ __forceinline__ const float* ob_cam_pose(const ObArrays& A, int s, in
 // (x, x + 49] or else with its own (column 0 is never written from the right).  One workgroup per image row.
 // ---------------------------------------------------------------------------------------------------------------------
 #define OB_MASK_ROWS 8
-// (eight rows per workgroup = one row of the detector's 8 x 8 occupancy cells, which this kernel fills on the way: occ[image][cell])
-__global__ __launch_bounds__(OB_T) void ob_masks(ObArrays A, uint8_t* objmask, int W, int H, int ostride, uint8_t* occ, int ocw, int och) {
-  extern __shared__ uint8_t row_sm[];
-  const int WP = (W + 63) & ~63;
+// (eight rows per workgroup = one row of the detector's 8 x 8 occupancy cells, which this kernel fills on the way: occ[image][cell]).
+// ONE WAVE PER ROW: the row and its `run` table live in the wave's own LDS slice, the prefix maximum is a wave scan - no workgroup
+// barrier between the load and the stores of a row; the eight rows of a workgroup only meet for the occupancy flags.
+#define OB_MASK_T (64 * OB_MASK_ROWS)
+__global__ __launch_bounds__(OB_MASK_T) void ob_masks(ObArrays A, uint8_t* objmask, int W, int H, int ostride, uint8_t* occ, int ocw, int och) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t row_all[];
+  const int WP = (W + 255) & ~255, per = WP >> 6;             // pixels per lane: a multiple of 4
+  const int s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint8_t* row_sm = row_all + (size_t)wave * 3 * WP;
   int16_t* run = reinterpret_cast<int16_t*>(row_sm + WP);
-  uint8_t* occL = reinterpret_cast<uint8_t*>(run + WP);
+  uint8_t* occL = row_all + (size_t)OB_MASK_ROWS * 3 * WP;
   uint8_t* occR = occL + ((ocw + 3) & ~3);
-  __shared__ int red[OB_T / 64];
-  const int s = blockIdx.y, tid = threadIdx.x;
-  for (int i = tid; i < ocw; i += OB_T) { occL[i] = 0; occR[i] = 0; }
-  for (int y = blockIdx.x * OB_MASK_ROWS; y < min((int)(blockIdx.x + 1) * OB_MASK_ROWS, H); y++) {
+  for (int i = tid; i < ocw; i += OB_MASK_T) { occL[i] = 0; occR[i] = 0; }
+  __syncthreads();
+  const int y = blockIdx.x * OB_MASK_ROWS + wave;
+  if (y < H) {
     const uint8_t* M = A.idmask + (size_t)s * A.mask_pitch + (size_t)y * A.mask_stride;
-    __syncthreads();
-    for (int x = tid; x < WP; x += OB_T) row_sm[x] = x < W ? M[x] : (uint8_t)0;
-    __syncthreads();
-    // run[c] = rightmost labelled column <= c (-1: none): per-thread chunks, block-wide prefix maximum of the chunk maxima
-    const int per = (W + OB_T - 1) / OB_T, c0 = tid * per, c1 = min(c0 + per, W);
+    // the lane's pixels [c0, c0 + per) as (unaligned) dwords into LDS; its rightmost labelled column on the way
+    const int c0 = lane * per;
     int local = -1;
-    for (int c = c0; c < c1; c++) if (row_sm[c] != 0) local = c;
-    int incl = local;
-    {
-      const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
-      if (lane == 63) red[wave] = incl;
-      __syncthreads();
-      int base = -1;
-      for (int w = 0; w < wave; w++) base = max(base, red[w]);
-      const int prev_lane = __shfl_up(incl, 1);
-      int excl = lane == 0 ? -1 : prev_lane;
-      excl = max(excl, base);
-      int r = excl;
-      for (int c = c0; c < c1; c++) { if (row_sm[c] != 0) r = c; run[c] = (int16_t)r; }
+    for (int q = 0; q < per; q += 4) {
+      const int x = c0 + q;
+      uint32_t v = 0;
+      if (x + 3 < W) __builtin_memcpy(&v, M + x, 4);
+      else
+        for (int j = 0; j < 4; j++) if (x + j < W) v |= (uint32_t)M[x + j] << (8 * j);
+      *reinterpret_cast<uint32_t*>(row_sm + x) = v;
+      if (v) local = x + 3 - (__builtin_clz(v) >> 3);
     }
-    __syncthreads();
+    // run[c] = rightmost labelled column <= c (-1: none): the exclusive prefix maximum over the lanes, then the lane's own pixels
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
+    int r = __shfl_up(incl, 1);
+    if (lane == 0) r = -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int q = 0; q < per; q += 4) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(row_sm + c0 + q);
+      int16_t rr[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { if ((v >> (8 * j)) & 0xFFu) r = c0 + q + j; rr[j] = (int16_t)r; }
+      *reinterpret_cast<uint2*>(run + c0 + q) = make_uint2((uint32_t)(uint16_t)rr[0] | ((uint32_t)(uint16_t)rr[1] << 16), (uint32_t)(uint16_t)rr[2] | ((uint32_t)(uint16_t)rr[3] << 16));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     uint8_t* L = objmask + ((size_t)(2 * s) * H + y) * ostride;
     uint8_t* R = objmask + ((size_t)(2 * s + 1) * H + y) * ostride;
-    for (int x4 = tid * 4; x4 < ostride; x4 += OB_T * 4) {   // four pixels per thread, one aligned dword per mask (columns beyond W: 0)
+    for (int x4 = lane * 4; x4 < ostride; x4 += 256) {       // four pixels per lane, one aligned dword per mask (columns beyond W: 0)
       uint32_t lv = 0, rv = 0;
+      const uint32_t m4 = *reinterpret_cast<const uint32_t*>(row_sm + x4);     // bytes beyond W are zero
+#pragma unroll
       for (int j = 0; j < 4; j++) {
         const int x = x4 + j;
         if (x >= W) break;
-        const uint8_t m = row_sm[x];
+        const uint32_t m = (m4 >> (8 * j)) & 0xFFu;
         const uint32_t lb = (m != 0 && m != 255) ? 255u : 0u;
-        const int r = run[min(x + 49, W - 1)];
-        const uint8_t lab = (r > x && x > 0) ? row_sm[r] : m;
+        const int rr = run[min(x + 49, W - 1)];
+        const uint32_t lab = (rr > x && x > 0) ? (uint32_t)row_sm[rr] : m;
         const uint32_t rb = (lab != 0 && lab != 255) ? 255u : 0u;
         lv |= lb << (8 * j); rv |= rb << (8 * j);
       }
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(OB_T) void ob_masks(ObArrays A, uint8_t* objmask, i
   }
   __syncthreads();
   if ((int)blockIdx.x < och)
-    for (int i = tid; i < ocw; i += OB_T) {
+    for (int i = tid; i < ocw; i += OB_MASK_T) {
       occ[((size_t)(2 * s) * och + blockIdx.x) * ocw + i] = occL[i];
       occ[((size_t)(2 * s + 1) * och + blockIdx.x) * ocw + i] = occR[i];
     }
@@ -1057,9 +1068,9 @@ __global__ __launch_bounds__(64) void ob_bf_blocks(const BfProb* probs, BfBlock*
 
 extern "C" {
 void psk_ob_masks(const ObArrays* A, uint8_t* objmask, int W, int H, int ostride, uint8_t* occ, int ocw, int och, hipStream_t st) {
-  const size_t WP = (W + 63) & ~63;
-  const size_t lds = WP + WP * 2 + 2 * (size_t)((ocw + 3) & ~3) + 64;
-  hipLaunchKernelGGL(ob_masks, dim3((H + OB_MASK_ROWS - 1) / OB_MASK_ROWS, A->S), dim3(OB_T), lds, st, *A, objmask, W, H, ostride, occ, ocw, och);
+  const size_t WP = (W + 255) & ~255;
+  const size_t lds = (size_t)OB_MASK_ROWS * 3 * WP + 2 * (size_t)((ocw + 3) & ~3) + 64;
+  hipLaunchKernelGGL(ob_masks, dim3((H + OB_MASK_ROWS - 1) / OB_MASK_ROWS, A->S), dim3(OB_MASK_T), lds, st, *A, objmask, W, H, ostride, occ, ocw, och);
 }
 void psk_ob_begin(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_begin, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
 void psk_ob_track(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_track, dim3(A->K, A->S), dim3(OB_T), 0, st, *A, step); }
