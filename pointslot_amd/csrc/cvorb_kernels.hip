@@ -919,15 +919,19 @@ __global__ __launch_bounds__(CVB_TT) void cvb_blur(CvbPlan P) {
 // one workgroup per (image, level): the level's keypoints in raster order (the emission order is arbitrary: bitonic sort by
 // (y, x)), then computeKeyPoints' two culls - retainBest(2 * quota) by FAST score, retainBest(quota) by Harris response - run by
 // one lane with the library's algorithms (retain_best.h) when a level holds more than its quota
+// Two launches: candidate lists of up to 512 entries (the usual case) run with 8 KB of LDS - twenty workgroups per CU instead of
+// five, which is what counts for a kernel whose retainBest steps are one lane's serial walk through LDS -, longer lists with 32 KB
+template <int CAP, int LO>
 __global__ __launch_bounds__(256) void cvb_select(CvbPlan P) {
-  __shared__ uint32_t key[CVB_CAND_CAP];
-  __shared__ int32_t idx[CVB_CAND_CAP];
-  __shared__ float resp[CVB_CAND_CAP];
-  __shared__ int32_t pay[CVB_CAND_CAP];
+  __shared__ uint32_t key[CAP];
+  __shared__ int32_t idx[CAP];
+  __shared__ float resp[CAP];
+  __shared__ int32_t pay[CAP];
   __shared__ int nkeep;
   const int slot = blockIdx.x, l = slot % P.nlevels, img = slot / P.nlevels, tid = threadIdx.x;
   const int total = P.ncand[slot];
   const int n = min(total, CVB_CAND_CAP);
+  if (n <= LO || n > CAP) return;                                  // the other launch's list (LO = -1: the empty lists too)
   if (total > CVB_CAND_CAP && tid == 0) atomicAdd(&P.overflow[img], 1);
   if (n == 0) { if (tid == 0) P.nsel[slot] = 0; return; }
   const float4* C = P.cand + (size_t)slot * CVB_CAND_CAP;
@@ -1106,7 +1110,8 @@ void psk_cvb_run(const CvbPlan* Pin, int nimg, const uint8_t* imgs, int stride, 
   for (int l = 1; l < NL; l++) hipLaunchKernelGGL(cvb_resize, dim3(grid), dim3(CVB_TT), 0, st, *P, l);
   hipLaunchKernelGGL(cvb_detect, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
   hipLaunchKernelGGL(cvb_blur, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
-  hipLaunchKernelGGL(cvb_select, dim3(nimg * NL), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL((cvb_select<512, -1>), dim3(nimg * NL), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL((cvb_select<CVB_CAND_CAP, 512>), dim3(nimg * NL), dim3(256), 0, st, *P);
   hipLaunchKernelGGL(cvb_describe, dim3(32, nimg), dim3(256), 0, st, *P);
 }
 }

@@ -77,8 +77,10 @@ struct ps_tracker {
   BfBlock* d_bf_blocks = nullptr; int32_t* d_bf_count = nullptr; int bf_blocks_per_prob = 0;
   PjArrays pj_obj;
   double* ob_chi2 = nullptr; uint8_t* ob_state = nullptr;
-  // ExtractObjORB does not depend on the camera chain of its frame: it runs on a second stream beside the latency-bound part of that
-  // chain (stereo matching, the searches, PoseOptimization) and joins before ComputeObjStereoMatches.  PS_TRK_SERIAL=1: one stream.
+  // ExtractObjORB does not depend on the camera chain of its frame: with PS_TRK_OVERLAP=1 it runs on a second (low-priority) stream
+  // beside the stereo matching, the searches and PoseOptimization and joins before ComputeObjStereoMatches.  Measured (r03, 512
+  // sequences): 16.16 against 16.34 ms per step - the kernels of both streams slow each other down by what the overlap saves - so
+  // the default is one stream, where the stage times add up to the step.
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_obj[64][2] = {};     // timing of the object features on stream2 (ring as below)
@@ -410,9 +412,11 @@ int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out) {
     for (ObMapObject& m : mo) m.id = -1;
     hipMemcpy(O.mobj, mo.data(), mo.size() * sizeof(ObMapObject), hipMemcpyHostToDevice);
     O.cam_traj = A.traj; O.cam_stats = (const int32_t*)A.stats; O.cam_stat_words = (int32_t)(sizeof(TrkStat) / 4);
-    t->overlap = getenv("PS_TRK_SERIAL") == nullptr;
+    t->overlap = getenv("PS_TRK_OVERLAP") != nullptr;
     if (t->overlap) {
-      if (hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      int least = 0, greatest = 0;
+      hipDeviceGetStreamPriorityRange(&least, &greatest);          // the camera chain is the critical path: the object features fill in behind it
+      if (hipStreamCreateWithPriority(&t->stream2, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) != hipSuccess) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_HIP, "ps_tracker_create: second stream"); }
       for (int r = 0; r < ps_tracker::RING; r++) { hipEventCreate(&t->ev_obj[r][0]); hipEventCreate(&t->ev_obj[r][1]); }
     }

@@ -8,10 +8,9 @@
 #           are 64 B wide - MI355X_MICROARCH.md, HBM) by the request sizes themselves: no calibration factor per access pattern.
 #   writes  TCC_EA0_WRREQ and TCC_EA0_WRREQ_64B: bytes = 64 n64 + 32 (n - n64)
 #   issue   SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_WAVES
-# PS_TRK_SERIAL=1: the object features in line with the camera chain (one stream), as in the kernel-stats profile.
 NAME=${1:-pmc}; STEPS=${2:-3}; WARM=${3:-2}
 R=$PWD
-export TMPDIR=/tmp PS_TRK_SERIAL=1
+export TMPDIR=/tmp
 run() {   # <tag> <counters>
   cd /tmp
   rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $R/gpurun_out/${NAME}_$1 -o pmc -- python3 $R/bench.py --no-cpu --no-secondary --distinct 2 --steps $STEPS --warmup $WARM > $R/gpurun_out/${NAME}_$1.log 2>&1 || true

@@ -58,7 +58,7 @@ for k, c in wr.items():
 for k, e in out.items():
     e["hbm_bytes_per_step"] = e.get("read_bytes_per_step", 0.0) + e.get("write_bytes_per_step", 0.0)
 json.dump({"images_per_launch": 1024, "method": "tools/pmc_step.sh: TCC_EA0_RDREQ size classes (32 / 64 / 128 B) and TCC_EA0_WRREQ(_64B), separate passes, "
-           "bench.py --no-cpu --no-secondary --distinct 2, PS_TRK_SERIAL=1; per kernel summed over its launches of one step, mean of %d timed steps" % steps,
+           "bench.py --no-cpu --no-secondary --distinct 2; per kernel summed over its launches of one step, mean of %d timed steps" % steps,
            "kernels": out}, open("gpurun_out/%s_traffic.json" % name, "w"), indent=1)
 iss = collections.OrderedDict()
 for k, c in sq.items():
