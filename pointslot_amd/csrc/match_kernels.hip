@@ -30,6 +30,59 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 }
 
 #define TOPK_T 256
+#define BF_SMALL_NT PS_BF_SMALL_NT
+// unsigned minimum inside a 16-lane DPP row (every lane of the row gets the result)
+__device__ __forceinline__ uint32_t bf_row_min_u32(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+  return v;
+}
+// Problems with at most 256 train descriptors (an object's features in the tracker: ~150): FOUR queries per wave, one per 16-lane
+// row, the row's keys in registers (16 per lane) - no LDS, so the occupancy is not the 64 KB key store's two workgroups per CU.
+// Same keys, same order of the eight results as bf_topk.
+__global__ __launch_bounds__(TOPK_T) void bf_topk_small(const BfBlock* blocks, const BfProb* probs, const uint8_t* qdesc,
+                                                         const uint8_t* tdesc, uint32_t* topk, const int32_t* count) {
+  const int nb = count ? *count : (int)gridDim.x;
+  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
+    const BfBlock blk = blocks[bi];
+    const BfProb P = probs[blk.prob];
+    if (P.nt > BF_SMALL_NT) continue;
+    const uint4* td = reinterpret_cast<const uint4*>(tdesc + (size_t)P.t_off * 32);
+    for (int q0 = 0; q0 < blk.q_count; q0 += TOPK_T / 16) {
+      const bool live = q0 + grp < blk.q_count;
+      const int qi = blk.q_first + min(q0 + grp, blk.q_count - 1);
+      const uint4* qd = reinterpret_cast<const uint4*>(qdesc + (size_t)(P.q_off + qi) * 32);
+      const uint4 a0 = qd[0], a1 = qd[1];
+      uint32_t key[BF_SMALL_NT / 16];
+      const int nu = (P.nt + 15) >> 4;            // key registers in use (uniform): the loops below leave at nu
+#pragma unroll
+      for (int u = 0; u < BF_SMALL_NT / 16; u++) {
+        const int j = l16 + 16 * u;
+        key[u] = 0xFFFFFFFFu;
+        if (u < nu && j < P.nt) key[u] = ((uint32_t)hamming256(a0, a1, td[2 * j], td[2 * j + 1]) << 16) | (uint32_t)j;
+      }
+      uint32_t prev = 0, mine = 0xFFFFFFFFu;
+      bool first = true;
+#pragma unroll 1
+      for (int r = 0; r < PS_BF_TOPK; r++) {
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < BF_SMALL_NT / 16; u++) {
+          if (u >= nu) break;
+          m = ((first || key[u] > prev) && key[u] < m) ? key[u] : m;
+        }
+        m = bf_row_min_u32(m);
+        if (l16 == r) mine = m;
+        prev = m;                    // an exhausted row stays at 0xFFFFFFFF: nothing is greater
+        first = false;
+      }
+      if (live && l16 < PS_BF_TOPK) topk[(size_t)(P.q_off + qi) * PS_BF_TOPK + l16] = mine;
+    }
+  }
+}
 // keys[w][j] = dist << 16 | j for the wave's current query (LDS), then 8 rounds of "smallest key greater
 // than the previous one".
 // `count` (nullable): the number of entries of `blocks` when the table was built on the device (the lockstep tracker); the grid then
@@ -38,9 +91,11 @@ __global__ __launch_bounds__(TOPK_T) void bf_topk(const BfBlock* blocks, const B
                                                    const uint8_t* tdesc, uint32_t* topk, const int32_t* count) {
   __shared__ uint32_t keys[TOPK_T / 64][PS_BF_MAX_TRAIN];
   const int nb = count ? *count : (int)gridDim.x;
+  if (count && count[1] == 0) return;             // device-built table: count[1] = some problem has more than BF_SMALL_NT trains
   for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
   const BfBlock blk = blocks[bi];
   const BfProb P = probs[blk.prob];
+  if (P.nt <= BF_SMALL_NT) continue;              // bf_topk_small's problem
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint4* td = reinterpret_cast<const uint4*>(tdesc + (size_t)P.t_off * 32);
   for (int qi = blk.q_first + wave; qi < blk.q_first + blk.q_count; qi += TOPK_T / 64) {
@@ -189,7 +244,10 @@ extern "C" void psk_bf_launch(const BfBlock* blocks, int nblocks, const BfProb* 
                               const float* qang, const uint8_t* qvalid, const uint8_t* tdesc, const float* tang,
                               uint32_t* topk, int32_t* out, int32_t* nmatch, float nn_ratio, int check_ori,
                               hipStream_t st) {
-  if (nblocks > 0) hipLaunchKernelGGL(bf_topk, dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
+  if (nblocks > 0) {
+    hipLaunchKernelGGL(bf_topk_small, dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
+    hipLaunchKernelGGL(bf_topk, dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
+  }
   hipLaunchKernelGGL(bf_resolve, dim3(nprob), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
                      nmatch, nn_ratio, check_ori);
 }
@@ -197,6 +255,7 @@ extern "C" void psk_bf_launch(const BfBlock* blocks, int nblocks, const BfProb* 
 extern "C" void psk_bf_launch_dev(const BfBlock* blocks, const int32_t* d_count, int grid, const BfProb* probs, int nprob, const uint8_t* qdesc,
                                   const float* qang, const uint8_t* qvalid, const uint8_t* tdesc, const float* tang, uint32_t* topk, int32_t* out,
                                   int32_t* nmatch, float nn_ratio, int check_ori, hipStream_t st) {
+  hipLaunchKernelGGL(bf_topk_small, dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
   hipLaunchKernelGGL(bf_topk, dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
   hipLaunchKernelGGL(bf_resolve, dim3(nprob), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
                      nmatch, nn_ratio, check_ori);

@@ -326,9 +326,18 @@ __device__ void ob_cam_points(const ObArrays& A, const ObFrame& F, size_t fo, in
 // the RANSAC centroid of InitializeCurrentObjPose / MapObjectInit / MapObjectReInit (Tracking.cc:1656-1700): `iterations` draws
 // of cv::RNG (default state), score = points within fmax of the drawn one, the first best draw's inliers (flags, ascending) and
 // their mean summed in that order.  score / draw scratch: scr[0 .. iterations) ints.  Returns the inlier count.
-__device__ int ob_ransac(const double* pts, int l, float fmax, int iterations, int32_t* scr, uint8_t* flag, double* mean, ObShared& sh) {
+// (the points and the inlier flags of the usual detection - up to OB_RANSAC_LDS stereo points - are worked on in LDS: every draw walks
+// all points, and the centroid is one lane's sequential sum, in the reference's order)
+#define OB_RANSAC_LDS 384
+__device__ int ob_ransac(const double* pts_g, int l, float fmax, int iterations, int32_t* scr, uint8_t* flag_g, double* mean, ObShared& sh) {
+  __shared__ double pl[3 * OB_RANSAC_LDS];
+  __shared__ uint8_t fl[OB_RANSAC_LDS];
   const int tid = threadIdx.x;
   if (l == 0 || iterations <= 0) { if (tid < 3) mean[tid] = 0; __syncthreads(); return 0; }
+  const bool in_lds = l <= OB_RANSAC_LDS;
+  if (in_lds)
+    for (int i = tid; i < 3 * l; i += OB_T) pl[i] = pts_g[i];
+  const double* pts = in_lds ? pl : pts_g;
   if (tid == 0) {
     unsigned long long state = 0xFFFFFFFFull;
     for (int k = 0; k < iterations; k++) {
@@ -368,12 +377,14 @@ __device__ int ob_ransac(const double* pts, int l, float fmax, int iterations, i
   for (int u = tid; u < l; u += OB_T) {
     const double dx = pts[3 * u] - px, dy = pts[3 * u + 1] - py, dz = pts[3 * u + 2] - pz;
     const bool in = sqrt(dx * dx + dy * dy + dz * dz) < fm;
-    flag[u] = in ? 1 : 0;
+    flag_g[u] = in ? 1 : 0;
+    if (in_lds) fl[u] = in ? 1 : 0;
     cntl += in ? 1 : 0;
   }
   const int ninl = ob_block_sum(cntl, sh.red);
   __syncthreads();
   if (tid == 0) {
+    const uint8_t* flag = in_lds ? fl : flag_g;
     double sx = 0, sy = 0, sz = 0;
     for (int u = 0; u < l; u++) if (flag[u]) { sx += pts[3 * u]; sy += pts[3 * u + 1]; sz += pts[3 * u + 2]; }
     const double m = (double)ninl;
@@ -410,6 +421,49 @@ __device__ __forceinline__ void ob_project_box(const ObCam& C, const double* R, 
 
 // Tracking::FineTuningUsing2dBox (Tracking.cc:1704-1786): executed by every lane of the calling wave (all lanes end with the
 // same translation); t is updated in place
+// One search of Tracking::FineTuningUsing2dBox: t[axis] moves by `step` towards a zero of the box metric (0: vertical centre offset,
+// 1: height difference, 2: horizontal centre offset) until |metric| < 1, at most 400 times; the direction is the sign of the metric
+// of the state before each move.  The moves are sequential in the reference; here the wave evaluates the next EIGHT states at once
+// (8 lanes = the 8 cuboid corners of one state) on the assumption that the direction does not change, and takes the first state that
+// ends the search or changes the direction - every value is produced by the same operations in the same order.  Called by one wave.
+__device__ __forceinline__ int ob_box_metric(int which, const int* pb, int rcx, int rcy, int bh) {
+  return which == 0 ? (pb[1] + pb[1] + pb[3]) / 2 - rcy : which == 1 ? pb[3] - bh : (pb[0] + pb[0] + pb[2]) / 2 - rcx;
+}
+__device__ void ob_tune_search(const ObCam& C, const double* R, const double* scale, double* t, int* pb, int axis, int which, bool plus, double step,
+                               int rcx, int rcy, int bh) {
+  const int g = (threadIdx.x & 63) >> 3;
+  int m = ob_box_metric(which, pb, rcx, rcy, bh);
+  int done = 0;
+  // the predicted directions of the next eight moves: all like the first one, or - once a move has overshot the one-pixel window, where
+  // the reference's search steps back and forth until its 400 moves are used up - alternating
+  bool alt = false;
+  while (done < 400) {
+    const int dir = m < 0 ? -1 : 1;
+    double tc[3] = {t[0], t[1], t[2]};
+    double v = tc[axis];
+    for (int s = 0; s <= g; s++) {                                        // the state after g + 1 moves
+      const double inc = ((alt && (s & 1)) ? -dir : dir) * step;
+      v = plus ? v + inc : v - inc;
+    }
+    tc[axis] = v;
+    int pc[4];
+    ob_project_box(C, R, tc, scale, pc);
+    const int mc = ob_box_metric(which, pc, rcx, rcy, bh);
+    const int predicted = (alt && ((g + 1) & 1)) ? -dir : dir;            // of the move after this state
+    const bool stop = abs(mc) < 1, miss = (mc < 0 ? -1 : 1) != predicted;
+    const unsigned long long ev = __ballot(stop || miss);
+    int j = ev ? (int)((__ffsll((long long)ev) - 1) >> 3) : 7;            // the first state that ends the search or breaks the prediction, else all eight
+    j = min(j, 400 - done - 1);
+    const int src = 8 * j;
+    t[axis] = __shfl(v, src);
+#pragma unroll
+    for (int q = 0; q < 4; q++) pb[q] = __shfl(pc[q], src);
+    m = __shfl(mc, src);
+    done += j + 1;
+    if (abs(m) < 1) break;
+    if (__shfl((int)miss, src)) alt = !alt;
+  }
+}
 __device__ void ob_fine_tune(const ObCam& C, const ObDet& det, const double* q, const double* scale, double* t) {
   double R[9];
   se3_quat_to_R(q, R);
@@ -417,32 +471,9 @@ __device__ void ob_fine_tune(const ObCam& C, const ObDet& det, const double* q, 
   const int rcx = (bx + (bx + bw)) / 2, rcy = (by + (by + bh)) / 2;
   int pb[4];
   ob_project_box(C, R, t, scale, pb);
-  int dcx = (pb[0] + pb[0] + pb[2]) / 2 - rcx, dcy = (pb[1] + pb[1] + pb[3]) / 2 - rcy;
-  for (int i = 0; i < 400; i++) {
-    const int direction = dcy < 0 ? -1 : 1;
-    t[1] = t[1] - direction * 0.01;
-    ob_project_box(C, R, t, scale, pb);
-    dcx = (pb[0] + pb[0] + pb[2]) / 2 - rcx; dcy = (pb[1] + pb[1] + pb[3]) / 2 - rcy;
-    if (abs(dcy) < 1) break;
-  }
-  if (t[2] > 8) {
-    int dh = pb[3] - bh;
-    for (int i = 0; i < 400; i++) {
-      const int direction = dh < 0 ? -1 : 1;
-      t[2] = t[2] + direction * 0.05;
-      ob_project_box(C, R, t, scale, pb);
-      dh = pb[3] - bh;
-      if (abs(dh) < 1) break;
-    }
-  }
-  dcx = (pb[0] + pb[0] + pb[2]) / 2 - rcx;
-  for (int i = 0; i < 400; i++) {
-    const int direction = dcx < 0 ? -1 : 1;
-    t[0] = t[0] - direction * 0.01;
-    ob_project_box(C, R, t, scale, pb);
-    dcx = (pb[0] + pb[0] + pb[2]) / 2 - rcx;
-    if (abs(dcx) < 1) break;
-  }
+  ob_tune_search(C, R, scale, t, pb, 1, 0, false, 0.01, rcx, rcy, bh);
+  if (t[2] > 8) ob_tune_search(C, R, scale, t, pb, 2, 1, true, 0.05, rcx, rcy, bh);
+  ob_tune_search(C, R, scale, t, pb, 0, 2, false, 0.01, rcx, rcy, bh);
 }
 
 __device__ __forceinline__ float ob_fmax(const double* scale) {   // float fMaxDis = scale.norm()
@@ -1062,6 +1093,7 @@ __global__ __launch_bounds__(64) void ob_bf_blocks(const BfProb* probs, BfBlock*
   const int first = b * PS_BF_QPB;
   if (!(P.nt > 0 && first < P.nq)) return;
   blocks[atomicAdd(count, 1)] = BfBlock{p, first, min(PS_BF_QPB, P.nq - first), 0};
+  if (P.nt > PS_BF_SMALL_NT && b == 0) atomicOr(&count[1], 1);   // bf_topk (the large-problem kernel) has work
 }
 
 }  // namespace
@@ -1075,7 +1107,7 @@ void psk_ob_masks(const ObArrays* A, uint8_t* objmask, int W, int H, int ostride
 void psk_ob_begin(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_begin, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
 void psk_ob_track(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_track, dim3(A->K, A->S), dim3(OB_T), 0, st, *A, step); }
 void psk_ob_bf_blocks(const BfProb* probs, BfBlock* blocks, int32_t* count, int nprob, int blocks_per_prob, hipStream_t st) {
-  hipMemsetAsync(count, 0, 4, st);
+  hipMemsetAsync(count, 0, 8, st);
   hipLaunchKernelGGL(ob_bf_blocks, dim3((nprob * blocks_per_prob + 63) / 64), dim3(64), 0, st, probs, blocks, count, nprob, blocks_per_prob);
 }
 void psk_ob_after_bf(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_bf, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
