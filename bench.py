@@ -50,30 +50,44 @@ def _profile_json(name):
 
 
 def pmc_traffic(kernel, nimg):
-    """HBM bytes per launch of `kernel` from the committed PMC measurement (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate passes, same launch shape).  FETCH_SIZE is corrected as MI355X_MICROARCH.md prescribes for the
-    kernel's access width; None when no measurement for this launch shape is on file.  PMC counters
-    need rocprofv3 around the process, so this figure is read from profiles/, not measured in this run: `traffic_source`."""
+    """HBM bytes per step of `kernel` (a name, or a tuple of names whose bytes are added) from the committed PMC measurement.  r03
+    (tools/pmc_step.sh): TCC_EA0_RDREQ in its 32 / 64 / 128 B size classes and TCC_EA0_WRREQ(_64B), separate passes over this bench's own
+    step - bytes = requests x their size, no calibration factor (FETCH_SIZE = RDREQ x 64 B reports half of a 128-byte request).  Older
+    files (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE calibrated on known-byte kernels) are read when r03's has no entry.  None when no
+    measurement for this launch shape is on file.  PMC counters need rocprofv3 around the process, so this figure is read from
+    profiles/, not measured in this run: `traffic_source`."""
+    names = kernel if isinstance(kernel, tuple) else (kernel,)
     for name in (PROFILE_ROUND + "_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         t = _profile_json(name)
         if not t or t.get("images_per_launch") != nimg:
             continue
+        tot, found = 0.0, 0
         for k, v in t.get("kernels", {}).items():
-            if k.split("<")[0] == kernel:
-                return v.get("hbm_bytes_per_launch", v.get("hbm_bytes_per_launch_fetch_doubled")), "profiles/" + name
+            if k.split("<")[0] in names:
+                b = v.get("hbm_bytes_per_step", v.get("hbm_bytes_per_launch", v.get("hbm_bytes_per_launch_fetch_doubled")))
+                if b is not None:
+                    tot += b
+                    found += 1
+        if found:
+            return tot, "profiles/" + name
     return None, None
 
 
-def pmc_valu_issue(kernel, nimg):
-    """Share of the launch that VALU issue alone accounts for (waves x VALU instructions x 4 cycles / 1024 SIMDs / clock), from the
-    committed PMC pass (tools/pmc_issue.sh: SQ_INSTS_VALU, SQ_WAVES, own run).  Explains a low HBM fraction: the kernel is bound by
-    instruction issue, not by memory.  None when no measurement for this launch shape is on file."""
+def pmc_valu_issue(kernel, nimg, ms_per_step=None):
+    """Share of the kernel's time per step that VALU issue alone accounts for (waves x VALU instructions x 4 cycles / 1024 SIMDs /
+    clock), from the committed PMC pass (tools/pmc_step.sh: SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_WAVES, own run).  Explains a low HBM
+    fraction: the kernel is bound by instruction issue, not by memory.  None when no measurement for this launch shape is on file."""
     for name in (PROFILE_ROUND + "_valu_issue.json", "r02_valu_issue.json", "r01_valu_issue.json"):
         t = _profile_json(name)
         if not t or t.get("images_per_launch") != nimg:
             continue
         for k, v in t.get("kernels", {}).items():
             if k.split("<")[0] == kernel:
+                if "valu_issue_ms_per_step" in v:
+                    return {"valu_issue_ms_per_step": v["valu_issue_ms_per_step"],
+                            "valu_issue_share": (v["valu_issue_ms_per_step"] / ms_per_step) if ms_per_step else None,
+                            "valu_instructions_per_wave": v.get("valu_per_wave"), "salu_instructions_per_wave": v.get("salu_per_wave"),
+                            "waves_per_step": v.get("waves_per_step"), "source": "profiles/" + name}
                 return {"valu_issue_share": v.get("valu_issue_share"), "valu_instructions_per_wave": v.get("valu_per_wave"),
                         "waves_per_launch": v.get("waves_per_launch"), "source": "profiles/" + name}
     return None
@@ -852,9 +866,9 @@ def main():
         # ---- one roofline entry per stage / kernel of the timed step (HIP events on the stream the kernels run on) ----
         rl = []
 
-        def hbm(name, ms, algo, note):
+        def hbm(name, ms, algo, note, kernels=None):
             a = algo / (ms * 1e-3) / 1e9 if ms > 0 else None
-            traffic, src = pmc_traffic(name.split("/")[-1], nimg)
+            traffic, src = pmc_traffic(kernels or name.split("/")[-1], nimg)
             rl.append({"stage": name, "bound": "hbm", "ms_per_step": round(ms, 5), "algorithmic_bytes_per_step": algo, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": a / HBM_PEAK_GBS if a else None, "traffic": traffic, "traffic_source": src, "note": note})
 
@@ -871,7 +885,8 @@ def main():
         other("track_glue", stage.get("track_glue", 0.0), "latency", "the host side of Tracking::Track between the kernels, on the device")
         if objects:
             hbm("object_features", stage.get("object_features", 0.0), 2 * 465750 * nimg + 465750 * S,
-                "8f-2 + masks: image + object mask of %d images and %d id masks read once; the work is the part of the pyramid a masked keypoint can reach (tile kernels, latency-bound)" % (nimg, S))
+                "8f-2 + masks: image + object mask of %d images and %d id masks read once; the work is the part of the pyramid a masked keypoint can reach (tile kernels, latency-bound)" % (nimg, S),
+                kernels=("ob_masks", "cvb_plan", "cvb_level0", "cvb_resize", "cvb_detect", "cvb_blur", "cvb_select", "cvb_describe"))
             other("object_stereo_match", stage.get("object_stereo_match", 0.0), "latency", "8f-1 ComputeObjStereoMatches on the object keys")
             ob = head["objects"] or {}
             other("object_bruteforce", stage.get("object_bruteforce", 0.0), "int-alu", "a10: one problem per tracked detection (last-frame x current features of the object); pairs / s in secondary_metrics.object_kernels")
@@ -910,8 +925,8 @@ def main():
                                            "detections with a MapObject / with mbTrackOK, cuboid centres of the distinct sequences against the labels"},
             "roofline": {"bound": "hbm", "kernel": dom["stage"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
                          "traffic": dom["traffic"], "traffic_source": dom.get("traffic_source"), "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_step"],
-                         "avg_launch_ms": dom["ms_per_step"], "images_per_launch": nimg, "issue": pmc_valu_issue(dom["stage"].split("/")[-1], nimg),
-                         "note": "the stage with the largest time among those SURVEY 8d prices in bytes; every stage is in `rooflines`"},
+                         "avg_launch_ms": dom["ms_per_step"], "images_per_launch": nimg, "issue": pmc_valu_issue(dom["stage"].split("/")[-1], nimg, dom["ms_per_step"]),
+                         "note": "the single kernel with the largest time per step among those SURVEY 8d prices in bytes (orb_level_fused runs once per pyramid level: bytes, time and traffic are per step = its 8 launches); every stage is in `rooflines`"},
             "rooflines": rl,
             "stage_ms": {k: round(v, 5) for k, v in stage.items()},
             "stage_ms_note": "HIP events on group 0's stream over the timed steps; with %d groups the stages of different groups overlap in time" % args.groups,
