@@ -587,6 +587,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
       ox = __shfl(mn, 0); oy = __shfl(mn, 32);
       nx = min(__shfl(mxv, 0), Sb.w - 1) - ox + 1; ny = min(__shfl(mxv, 32), Sb.h - 1) - oy + 1;
     }
+    int mask_mode = 0;                            // 0 no mask on this tile, 1 interpolate, 2 all 255, 3 all 0
     {
       // 16 lanes per source row (13 aligned dwords), four rows per pass: every load is issued before the first LDS store.  A row's
       // first pixel sits `shift` bytes into its first dword (rows of the image / the tight mask planes start at any byte address).
@@ -597,6 +598,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
       const uint32_t o0 = __umul24((uint32_t)(oy + (tid >> 4)), (uint32_t)sstride) + (uint32_t)ox, ostep = 4u * (uint32_t)sstride;
       const uint32_t m0 = __umul24((uint32_t)(oy + (tid >> 4)), (uint32_t)mstride) + (uint32_t)ox, mstep = 4u * (uint32_t)mstride;
       uint32_t so = o0, mo = m0;
+      bool not255 = false, not0 = false;
 #pragma unroll
       for (int ry = 0; ry < PS / 4; ry++, so += ostep, mo += mstep) {
         const int yy = (tid >> 4) + 4 * ry;
@@ -606,9 +608,19 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
           if (4 * q < (int)(a & 3) + nx) v[ry] = *reinterpret_cast<const uint32_t*>((a & ~(uintptr_t)3) + 4 * q);
           if (with_mask) {
             const uintptr_t ma = mb + mo;
-            if (4 * q < (int)(ma & 3) + nx) mv[ry] = *reinterpret_cast<const uint32_t*>((ma & ~(uintptr_t)3) + 4 * q);
+            if (4 * q < (int)(ma & 3) + nx) {
+              mv[ry] = *reinterpret_cast<const uint32_t*>((ma & ~(uintptr_t)3) + 4 * q);
+              not255 = not255 || mv[ry] != 0xFFFFFFFFu; not0 = not0 || mv[ry] != 0u;
+            }
           }
         }
+      }
+      // a mask patch that is 255 (inside an object) or 0 (outside) throughout - every dword that was loaded, the bytes around the
+      // patch included - interpolates to that value at every pixel of the tile: only tiles on a mask boundary do the arithmetic
+      if (with_mask) {
+        if (!__any(not255)) mask_mode = 2;
+        else if (!__any(not0)) mask_mode = 3;
+        else mask_mode = 1;
       }
       so = o0; mo = m0;
 #pragma unroll
@@ -616,10 +628,10 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
         const int yy = (tid >> 4) + 4 * ry;
         if (yy < ny && q < 13) {
           *reinterpret_cast<uint32_t*>(patch + yy * PW + 4 * q) = v[ry];
-          if (with_mask) *reinterpret_cast<uint32_t*>(mpatch + yy * PW + 4 * q) = mv[ry];
+          if (mask_mode == 1) *reinterpret_cast<uint32_t*>(mpatch + yy * PW + 4 * q) = mv[ry];
           if (q == 0) {
             shf[yy] = (uint8_t)((sb + so) & 3);
-            if (with_mask) mshf[yy] = (uint8_t)((mb + mo) & 3);
+            if (mask_mode == 1) mshf[yy] = (uint8_t)((mb + mo) & 3);
           }
         }
       }
@@ -652,8 +664,9 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
       uint32_t o[4];
       interp4(patch + ra + shf[r0], patch + rb + shf[r1], yw, o);
       if (px0 < L.stride) *reinterpret_cast<uint32_t*>(L.pad + (__umul24((uint32_t)py, (uint32_t)L.stride) + (uint32_t)px0)) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-      if (with_mask) {
-        interp4(mpatch + ra + mshf[r0], mpatch + rb + mshf[r1], yw, o);
+      if (mask_mode != 0) {
+        if (mask_mode == 1) interp4(mpatch + ra + mshf[r0], mpatch + rb + mshf[r1], yw, o);
+        else o[0] = o[1] = o[2] = o[3] = mask_mode == 2 ? 255u : 0u;
         const int iy = py - CV_BORDER;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -721,6 +734,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
   __shared__ uint8_t sc[SS * SS + 4];
   __shared__ uint16_t surv[SS * SS];
   __shared__ int nsurv;
+  __shared__ unsigned long long rowmask[SS];   // per score row: the columns whose score a keypoint cell of this tile can read
   const int l = blockIdx.y, tid = threadIdx.x, th = P.fast_th;
   CVB_TILE_LOOP(P, 1, l) {
     const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
@@ -765,12 +779,29 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
         if (i < TS * (TS / 4)) *reinterpret_cast<uint32_t*>(tile + (i / (TS / 4)) * TS + 4 * (i % (TS / 4))) = v[k];
       }
     }
+    {
+      // scores are only read on the tile's keypoint cells and one pixel around them: cell (cx, cy) covers score columns 8 cx .. 8 cx + 9
+      // and rows 8 cy .. 8 cy + 9 of the 34 x 34 score map.  (kpm[r] of the lanes 2 cx, 2 cx + 1 is the flag of cell (cx, r).)
+      unsigned long long cm[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const unsigned long long bal = __ballot(kpm[r] != 0);
+        cm[r] = ((bal & 1) ? 0x3FFull : 0) | ((bal & 4) ? 0x3FFull << 8 : 0) | ((bal & 16) ? 0x3FFull << 16 : 0) | ((bal & 64) ? 0x3FFull << 24 : 0);
+      }
+      if (tid < SS) {
+        const int chi = tid >> 3, clo = (tid - 2) >> 3;                   // the cell rows whose 10-row band holds score row tid
+        unsigned long long m = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) if (r == chi || r == clo) m |= cm[r];
+        rowmask[tid] = m;
+      }
+    }
     cvb_wave_sync();
     for (int i = tid; i < SS * SS; i += CVB_TT) {
       const int sx = i % SS, sy = i / SS;                                // score pixel: padded (bx + 3 + sx, by + 3 + sy)
       const int x = bx + 3 + sx - CV_BORDER, y = by + 3 + sy - CV_BORDER;
       bool cand = false;
-      if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
+      if (((rowmask[sy] >> sx) & 1) && x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
         const uint8_t* c = tile + (sy + 3) * TS + sx + 3;
         const int v = c[0], n = c[3 * TS], ea = c[3], so = c[-3 * TS], w = c[-3];
         const int M = min(min(max(n, ea), max(ea, so)), min(max(so, w), max(w, n)));
