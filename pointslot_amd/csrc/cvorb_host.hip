@@ -310,6 +310,7 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
     L.cw = (L.w + 2 * CV_BORDER + 7) / 8; L.ch = (L.h + 2 * CV_BORDER + 7) / 8;
     L.cw = std::max(L.cw, 4 * L.tw); L.ch = std::max(L.ch, 4 * L.th);   // every tile owns 4 x 4 cells (cw is a multiple of 4: a tile's cell row is one aligned dword)
     L.cw = (L.cw + 3) & ~3;
+    if (L.cw > 1024 || L.ch > 512) return ps_set_error(PS_ERR_INVALID, "image too large for the batched object detector's planning kernel");   // CVB_PLAN_MAXCW / MAXCH
     L.cell_off = P.cell_total; P.cell_total += L.cw * L.ch; P.cell_max = std::max(P.cell_max, L.cw * L.ch);
     L.tile_off = P.tile_total; P.tile_total += L.tw * L.th;
     L.quota = quota[l];

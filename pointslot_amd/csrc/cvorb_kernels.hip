@@ -329,23 +329,8 @@ __device__ __forceinline__ void cvb_reflect_range(int lo, int hi, int len, int& 
 }
 
 #define CVB_PLAN_T 512
-// marks the tiles of level l that hold a flagged cell in the workgroup's tile-flag array (bit `which`; bit 3: the tile also holds a cell of `cells2`)
-__device__ __forceinline__ void cvb_flag_tiles(const CvbPlan& P, int l, int which, const uint8_t* cells, int grow, const uint8_t* cells2, uint8_t* tflag) {
-  const CvbLevel& B = P.lv[l];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int ty = wave; ty < B.th; ty += CVB_PLAN_T / 64)
-    for (int tx = lane; tx < B.tw; tx += 64) {
-      bool a = false, m = false;
-      const int cx0 = max(4 * tx - grow, 0), cx1 = min(4 * tx + 3 + grow, B.cw - 1), cy0 = max(4 * ty - grow, 0), cy1 = min(4 * ty + 3 + grow, B.ch - 1);
-      for (int cy = cy0; cy <= cy1; cy++)
-        for (int cx = cx0; cx <= cx1; cx++) { a = a || cells[cy * B.cw + cx]; if (cells2) m = m || cells2[cy * B.cw + cx]; }
-      a = a || m;
-      uint8_t& f = tflag[B.tile_off + ty * B.tw + tx];               // one thread per tile: a plain read-modify-write
-      if (a) f |= (uint8_t)(1u << which);
-      if (m) f |= 8u;
-    }
-}
-
+#define CVB_PLAN_MAXCW 1024     // cells per row / per column of a level's padded plane that cvb_plan's row tables hold (host check)
+#define CVB_PLAN_MAXCH 512
 // one workgroup per image: kp cells and needed cells of every level (dynamic LDS: per level a byte per cell for the plane need and
 // one for the mask need, two scratch planes of the largest level, the summed-area table of the occupancy), the three tile
 // worklists per level (0 planes, 1 FAST, 2 blur).  An entry of worklist 0 carries bit 31 when the tile also holds cells of the
@@ -359,6 +344,8 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
   uint16_t* sat = reinterpret_cast<uint16_t*>(tmp + cmax4);   // (och + 1) x (ocw + 1), first row / column zero; at an even offset
   uint8_t* tflag = reinterpret_cast<uint8_t*>(sat + (P.ocw + 1) * (P.och + 1));   // per tile of every level: bits 0..2 = the three worklists, bit 3 = mask chain
   __shared__ int s_cnt[3 * CV_MAX_LEVELS], s_base[3 * CV_MAX_LEVELS];
+  __shared__ uint32_t s_xr[CVB_PLAN_MAXCW];
+  __shared__ uint8_t s_kprow[CVB_PLAN_MAXCH], s_drow[CVB_PLAN_MAXCH];
   for (int i = tid; i < P.tile_total; i += CVB_PLAN_T) tflag[i] = 0;
   if (tid < 3 * CV_MAX_LEVELS) s_cnt[tid] = 0;
   const uint8_t* occ = P.occ + (size_t)img * P.ocw * P.och;
@@ -371,48 +358,112 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
   __syncthreads();
   for (int x = 1 + tid; x <= P.ocw; x += CVB_PLAN_T) { uint16_t acc = 0; for (int y = 1; y <= P.och; y++) { acc += sat[y * SW + x]; sat[y * SW + x] = acc; } }
   __syncthreads();
+  // Per level: the cells are walked as rows by waves; a row band without an occupied level-0 cell (most rows: the objects cover a part
+  // of the image) is cleared with dword stores and skipped by the passes behind it.  The dilations work on four cells per lane.
   for (int l = 0; l < P.nlevels; l++) {
     const CvbLevel& B = P.lv[l];
     uint8_t* need = sm + B.cell_off;
+    const int cw4 = B.cw >> 2;
+    uint32_t* need4 = reinterpret_cast<uint32_t*>(need);
+    uint32_t* kp4 = reinterpret_cast<uint32_t*>(kp);
+    uint32_t* tmp4 = reinterpret_cast<uint32_t*>(tmp);
+    uint32_t* kpmap4 = reinterpret_cast<uint32_t*>(kpmap + B.cell_off);
     const float Rx = (float)P.w0 / (float)B.w, Ry = (float)P.h0 / (float)B.h;
     const float mx = 6.f * (Rx - 1.f) + 3.f, my = 6.f * (Ry - 1.f) + 3.f;
+    // the occupancy columns a cell column can see: X0 | X1 << 16 (0xFFFFFFFF: the column holds no level pixel)
+    for (int cx = tid; cx < B.cw; cx += CVB_PLAN_T) {
+      const int x0 = max(8 * cx - CV_BORDER, 0), x1 = min(8 * cx - CV_BORDER + 7, B.w - 1);
+      uint32_t e = 0xFFFFFFFFu;
+      if (x0 <= x1) {
+        const int X0 = max((int)floorf((float)x0 * Rx - mx), 0) >> 3, X1 = min((int)ceilf((float)(x1 + 1) * Rx + mx), P.w0 - 1) >> 3;
+        e = (uint32_t)X0 | ((uint32_t)X1 << 16);
+      }
+      s_xr[cx] = e;
+    }
+    __syncthreads();
     for (int cy = wave; cy < B.ch; cy += NW) {
       const int y0 = max(8 * cy - CV_BORDER, 0), y1 = min(8 * cy - CV_BORDER + 7, B.h - 1);
-      const int Y0 = max((int)floorf((float)y0 * Ry - my), 0) >> 3, Y1 = min((int)ceilf((float)(y1 + 1) * Ry + my), P.h0 - 1) >> 3;
-      for (int cx = lane; cx < B.cw; cx += 64) {
-        const int x0 = max(8 * cx - CV_BORDER, 0), x1 = min(8 * cx - CV_BORDER + 7, B.w - 1);
-        bool any = false;
-        if (x0 <= x1 && y0 <= y1) {
-          const int X0 = max((int)floorf((float)x0 * Rx - mx), 0) >> 3, X1 = min((int)ceilf((float)(x1 + 1) * Rx + mx), P.w0 - 1) >> 3;
-          const int cnt = (int)sat[(Y1 + 1) * SW + X1 + 1] - (int)sat[Y0 * SW + X1 + 1] - (int)sat[(Y1 + 1) * SW + X0] + (int)sat[Y0 * SW + X0];
-          any = cnt > 0;
+      bool anyrow = false;
+      int Y0 = 0, Y1 = 0, band = 0;
+      if (y0 <= y1) {
+        Y0 = max((int)floorf((float)y0 * Ry - my), 0) >> 3; Y1 = min((int)ceilf((float)(y1 + 1) * Ry + my), P.h0 - 1) >> 3;
+        band = (int)sat[(Y1 + 1) * SW + P.ocw] - (int)sat[Y0 * SW + P.ocw];       // occupied cells anywhere in the band of occupancy rows
+      }
+      if (band > 0) {
+        for (int cx = lane; cx < B.cw; cx += 64) {
+          const uint32_t e = s_xr[cx];
+          bool any = false;
+          if (e != 0xFFFFFFFFu) {
+            const int X0 = (int)(e & 0xFFFFu), X1 = (int)(e >> 16);
+            const int cnt = (int)sat[(Y1 + 1) * SW + X1 + 1] - (int)sat[Y0 * SW + X1 + 1] - (int)sat[(Y1 + 1) * SW + X0] + (int)sat[Y0 * SW + X0];
+            any = cnt > 0;
+          }
+          const int c = cy * B.cw + cx;
+          kp[c] = any ? 1 : 0;
+          need[c] = any ? 2 : 0;
+          kpmap[B.cell_off + c] = any ? 1 : 0;
+          anyrow = anyrow || any;
         }
-        const int c = cy * B.cw + cx;
-        kp[c] = any ? 1 : 0;
-        need[c] = any ? 2 : 0;
-        kpmap[B.cell_off + c] = any ? 1 : 0;
+        anyrow = __any(anyrow);
+      } else {
+        for (int q = lane; q < cw4; q += 64) { kp4[cy * cw4 + q] = 0; need4[cy * cw4 + q] = 0; kpmap4[cy * cw4 + q] = 0; }
+      }
+      if (lane == 0) s_kprow[cy] = anyrow ? 1 : 0;
+    }
+    __syncthreads();
+    // FAST + NMS tiles: a tile with a kp cell in its 4 x 4 cells or one cell around them
+    for (int ty = wave; ty < B.th; ty += NW) {
+      bool rows = false;
+      for (int cy = max(4 * ty - 1, 0); cy <= min(4 * ty + 4, B.ch - 1); cy++) rows = rows || s_kprow[cy];
+      if (!rows) continue;
+      for (int tx = lane; tx < B.tw; tx += 64) {
+        uint32_t acc = 0;
+        for (int cy = max(4 * ty - 1, 0); cy <= min(4 * ty + 4, B.ch - 1); cy++) {
+          const uint32_t cur = kp4[cy * cw4 + tx];
+          const uint32_t prv = tx > 0 ? kp4[cy * cw4 + tx - 1] & 0xFF000000u : 0u, nxt = tx + 1 < cw4 ? kp4[cy * cw4 + tx + 1] & 0xFFu : 0u;
+          acc |= cur | prv | nxt;
+        }
+        if (acc) tflag[B.tile_off + ty * B.tw + tx] |= 2u;
+      }
+    }
+    // dilation by 3 cells along the rows: byte j of a dword = OR of the cells j - 3 .. j + 3 (byte-aligned windows of the three dwords around it)
+    for (int cy = wave; cy < B.ch; cy += NW) {
+      if (!s_kprow[cy]) { for (int q = lane; q < cw4; q += 64) tmp4[cy * cw4 + q] = 0; continue; }
+      for (int q = lane; q < cw4; q += 64) {
+        const uint32_t cur = kp4[cy * cw4 + q], prv = q > 0 ? kp4[cy * cw4 + q - 1] : 0u, nxt = q + 1 < cw4 ? kp4[cy * cw4 + q + 1] : 0u;
+        uint32_t v = cur;
+        v |= __builtin_amdgcn_alignbyte(cur, prv, 1u) | __builtin_amdgcn_alignbyte(cur, prv, 2u) | __builtin_amdgcn_alignbyte(cur, prv, 3u);   // cells j - 3, j - 2, j - 1
+        v |= __builtin_amdgcn_alignbyte(nxt, cur, 1u) | __builtin_amdgcn_alignbyte(nxt, cur, 2u) | __builtin_amdgcn_alignbyte(nxt, cur, 3u);   // cells j + 1, j + 2, j + 3
+        tmp4[cy * cw4 + q] = v;
       }
     }
     __syncthreads();
-    cvb_flag_tiles(P, l, 1, kp, 1, nullptr, tflag);               // FAST + NMS: kp cells and one cell around them
-    for (int cy = wave; cy < B.ch; cy += NW)                      // dilation by 3 cells, rows then columns
-      for (int cx = lane; cx < B.cw; cx += 64) {
-        uint8_t v = 0;
-        for (int d = -3; d <= 3; d++) { const int x = cx + d; if (x >= 0 && x < B.cw) v |= kp[cy * B.cw + x]; }
-        tmp[cy * B.cw + cx] = v;
+    // ... and along the columns; kp now holds the dilated set, whose cells also need the plane (bit 0 of need)
+    for (int cy = wave; cy < B.ch; cy += NW) {
+      bool rows = false;
+      for (int y = max(cy - 3, 0); y <= min(cy + 3, B.ch - 1); y++) rows = rows || s_kprow[y];
+      if (lane == 0) s_drow[cy] = rows ? 1 : 0;
+      if (!rows) { for (int q = lane; q < cw4; q += 64) kp4[cy * cw4 + q] = 0; continue; }
+      for (int q = lane; q < cw4; q += 64) {
+        uint32_t v = 0;
+        for (int y = max(cy - 3, 0); y <= min(cy + 3, B.ch - 1); y++) v |= tmp4[y * cw4 + q];
+        kp4[cy * cw4 + q] = v;
+        need4[cy * cw4 + q] |= v;
       }
+    }
     __syncthreads();
-    for (int cy = wave; cy < B.ch; cy += NW)
-      for (int cx = lane; cx < B.cw; cx += 64) {
-        uint8_t v = 0;
-        for (int d = -3; d <= 3; d++) { const int y = cy + d; if (y >= 0 && y < B.ch) v |= tmp[y * B.cw + cx]; }
-        kp[cy * B.cw + cx] = v;                                    // (kp now holds the dilated set; its cells' owners also set bit 0 of need)
-        need[cy * B.cw + cx] |= v;
+    // blur tiles: the tiles with a cell of the dilated set (level 0: also the tiles of its padded plane, which is only read around
+    // its own keypoints - level 1 reads the image)
+    for (int ty = wave; ty < B.th; ty += NW) {
+      bool rows = false;
+      for (int cy = 4 * ty; cy <= min(4 * ty + 3, B.ch - 1); cy++) rows = rows || s_drow[cy];
+      if (!rows) continue;
+      for (int tx = lane; tx < B.tw; tx += 64) {
+        uint32_t acc = 0;
+        for (int cy = 4 * ty; cy <= min(4 * ty + 3, B.ch - 1); cy++) acc |= kp4[cy * cw4 + tx];
+        if (acc) tflag[B.tile_off + ty * B.tw + tx] |= (l == 0 ? 5u : 4u);
       }
-    __syncthreads();
-    cvb_flag_tiles(P, l, 2, kp, 0, nullptr, tflag);               // blur
-    __syncthreads();
-    if (l == 0) cvb_flag_tiles(P, 0, 0, kp, 0, nullptr, tflag);   // level 0's padded plane is only read around its own keypoints (level 1 reads the image)
+    }
     __syncthreads();
   }
   // a level's needed cells need their source pixels one level down (level 1's come from the image itself)
