@@ -599,10 +599,11 @@ class StereoOdometryBatch {
 // the library between the hot-path kernels, nothing is packed or copied per call, and results are read when asked for.
 class StereoOdometryDevice {
  public:
+  // maxObjects > 0 (at most 8): the handle also carries the object half of Tracking::Track in SLOT.MODE 4 (TrackAllSlotDevice)
   StereoOdometryDevice(int nSequences, float fx, float fy, float cx, float cy, float bf, int width, int height, int maxFrames, float thDepth = 35.f,
-                       int nFeatures = 2000, float scale = 1.2f, int nLevels = 8, int iniTh = 20, int minTh = 5, int device = 0)
-      : nseq(nSequences) {
-    ps_tracker_config cfg{nSequences, width, height, fx, fy, cx, cy, bf, thDepth, nFeatures, scale, nLevels, iniTh, minTh, maxFrames, device};
+                       int nFeatures = 2000, float scale = 1.2f, int nLevels = 8, int iniTh = 20, int minTh = 5, int device = 0, int maxObjects = 0)
+      : nseq(nSequences), nobj(maxObjects) {
+    ps_tracker_config cfg{nSequences, width, height, fx, fy, cx, cy, bf, thDepth, nFeatures, scale, nLevels, iniTh, minTh, maxFrames, device, maxObjects};
     if (ps_tracker_create(&cfg, &trk) != PS_OK) throw std::runtime_error(std::string("ps_tracker_create: ") + ps_last_error());
   }
   ~StereoOdometryDevice() { ps_tracker_destroy(trk); }
@@ -617,6 +618,34 @@ class StereoOdometryDevice {
   }
   // ... or images that already are in device memory: sequence k's left image at d_imgs + 2k * pitch, right one pitch further
   void TrackAllDevice(const uint8_t* d_imgs, int stride, size_t pitch) { check(ps_tracker_step_device(trk, d_imgs, stride, pitch)); }
+  // SLOT.MODE 4: the camera chain on the background keypoints and the object chain behind it.  d_masks: the
+  // instance-id images of Segmentation/ (one per sequence, rows mask_stride apart, images mask_pitch apart), d_dets: [size()][maxObjects]
+  // detections of the frame (id < 0: empty slot), everything in device memory
+  void TrackAllSlotDevice(const uint8_t* d_imgs, int stride, size_t pitch, const uint8_t* d_masks, int mask_stride, size_t mask_pitch, const ps_detection* d_dets) {
+    check(ps_tracker_step_slot_device(trk, d_imgs, stride, pitch, d_masks, mask_stride, mask_pitch, d_dets));
+  }
+  // one `Car` row of ObjectTracking.txt as Tracking::ReadKittiObjectInfo (src/Tracking.cc:485-640) and DetectionObject's constructor
+  // (src/DetectionObject.cc:22-73) turn it into a detection: mrectBBox = cv::Rect of the truncated doubles, mScale = (length, height,
+  // width), mTruthPosInCameraFrame = fromMinimalVector(X, Y - height / 2, Z, 0, ry, 0)
+  static ps_detection MakeDetection(int trackId, double x1, double y1, double x2, double y2, double h, double w, double l, double X, double Y, double Z, double ry) {
+    ps_detection d{};
+    d.id = trackId;
+    d.bbox[0] = (int)x1; d.bbox[1] = (int)y1; d.bbox[2] = (int)(x2 - x1); d.bbox[3] = (int)(y2 - y1);
+    d.scale[0] = l; d.scale[1] = h; d.scale[2] = w;
+    // zyx Euler (roll 0, pitch ry, yaw 0) -> quaternion (matrix_utils.cc:18-31), w >= 0, unit norm (SE3Quat::normalizeRotation)
+    double q[4] = {0.0, std::sin(ry * 0.5), 0.0, std::cos(ry * 0.5)};
+    if (q[3] < 0) { q[1] = -q[1]; q[3] = -q[3]; }
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    d.pose7[0] = X; d.pose7[1] = Y - h / 2; d.pose7[2] = Z;
+    for (int i = 0; i < 4; i++) d.pose7[3 + i] = q[i] / n;
+    return d;
+  }
+  // blocks; objects[(step * size() + k) * maxObjects + slot]
+  void FetchObjects(std::vector<ps_object_stat>& objects) {
+    const int n = Steps();
+    objects.assign((size_t)n * nseq * (nobj > 0 ? nobj : 0), ps_object_stat{});
+    if (nobj > 0 && n > 0) check(ps_tracker_fetch_objects(trk, 0, n, objects.data()));
+  }
   void Sync() { check(ps_tracker_sync(trk)); }
   int Steps() const { int n = 0; ps_tracker_steps(trk, &n); return n; }
   // blocks; trajectories[k][step] = Tcw (16 floats), empty for a frame without a pose; stats[step * size() + k]
@@ -635,7 +664,7 @@ class StereoOdometryDevice {
   }
 
  private:
-  int nseq;
+  int nseq, nobj = 0;
   ps_tracker* trk = nullptr;
   static void check(int rc) { if (rc != PS_OK) throw std::runtime_error(ps_last_error()); }
 };

@@ -97,3 +97,22 @@ def test_object_chain_on_a_generated_sequence():
     # camera: the two moving boxes no longer feed the static tracker
     err = max(float(np.abs(-(t[:3, :3].T @ t[:3, 3]) - seq["twc"][k][:, 3]).max()) for k, t in enumerate(vo.trajectory))
     assert err < 0.05
+
+
+def test_cpp_make_detection_equals_the_python_twin(tmp_path):
+    """StereoOdometryDevice::MakeDetection (host/StereoOdometry.h) packs a label row exactly like object_tracker.detection_from_label"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = [(7, 100.7, 50.2, 300.9, 180.4, 1.5, 1.6, 3.9, 2.5, 1.7, 14.0, -1.2), (0, 0.0, 0.0, 1241.0, 374.0, 2.1, 1.9, 4.4, -6.0, 1.2, 31.5, 2.9),
+            (311, 640.49, 170.51, 700.5, 230.49, 1.4, 1.5, 3.5, 0.3, 1.6, 60.0, 3.3)]
+    src = tmp_path / "md.cpp"
+    body = "".join('  show(ORB_SLAM2::StereoOdometryDevice::MakeDetection(%d, %r, %r, %r, %r, %r, %r, %r, %r, %r, %r, %r));\n' % r for r in rows)
+    src.write_text('#include "StereoOdometry.h"\n#include <cstdio>\nstatic void show(const ps_detection& d) {\n'
+                   '  printf("%d %d %d %d %d %.17g %.17g %.17g", d.id, d.bbox[0], d.bbox[1], d.bbox[2], d.bbox[3], d.scale[0], d.scale[1], d.scale[2]);\n'
+                   '  for (int i = 0; i < 7; i++) printf(" %.17g", d.pose7[i]);\n  printf("\\n");\n}\nint main() {\n' + body + '  return 0;\n}\n')
+    exe = tmp_path / "md"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "pointslot_amd", "host"), "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for r, line in zip(rows, out):
+        d = detection_from_label(*r)
+        want = [d["id"], *d["bbox"], *d["scale"], *d["pose7"]]
+        assert [float(x) for x in line.split()] == [float(x) for x in want]
