@@ -42,6 +42,8 @@ __device__ __forceinline__ uint32_t bf_row_min_u32(uint32_t v) {
 // Problems with at most 256 train descriptors (an object's features in the tracker: ~150): FOUR queries per wave, one per 16-lane
 // row, the row's keys in registers (16 per lane) - no LDS, so the occupancy is not the 64 KB key store's two workgroups per CU.
 // Same keys, same order of the eight results as bf_topk.
+// Two instances: NT = 256 (16 key registers) for the usual object, NT = 512 for the close ones.
+template <int NT, int LO>
 __global__ __launch_bounds__(TOPK_T) void bf_topk_small(const BfBlock* blocks, const BfProb* probs, const uint8_t* qdesc,
                                                          const uint8_t* tdesc, uint32_t* topk, const int32_t* count) {
   const int nb = count ? *count : (int)gridDim.x;
@@ -49,17 +51,17 @@ __global__ __launch_bounds__(TOPK_T) void bf_topk_small(const BfBlock* blocks, c
   for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
     const BfBlock blk = blocks[bi];
     const BfProb P = probs[blk.prob];
-    if (P.nt > BF_SMALL_NT) continue;
+    if (P.nt > NT || P.nt <= LO) continue;
     const uint4* td = reinterpret_cast<const uint4*>(tdesc + (size_t)P.t_off * 32);
     for (int q0 = 0; q0 < blk.q_count; q0 += TOPK_T / 16) {
       const bool live = q0 + grp < blk.q_count;
       const int qi = blk.q_first + min(q0 + grp, blk.q_count - 1);
       const uint4* qd = reinterpret_cast<const uint4*>(qdesc + (size_t)(P.q_off + qi) * 32);
       const uint4 a0 = qd[0], a1 = qd[1];
-      uint32_t key[BF_SMALL_NT / 16];
+      uint32_t key[NT / 16];
       const int nu = (P.nt + 15) >> 4;            // key registers in use (uniform): the loops below leave at nu
 #pragma unroll
-      for (int u = 0; u < BF_SMALL_NT / 16; u++) {
+      for (int u = 0; u < NT / 16; u++) {
         const int j = l16 + 16 * u;
         key[u] = 0xFFFFFFFFu;
         if (u < nu && j < P.nt) key[u] = ((uint32_t)hamming256(a0, a1, td[2 * j], td[2 * j + 1]) << 16) | (uint32_t)j;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(TOPK_T) void bf_topk_small(const BfBlock* blocks, c
       for (int r = 0; r < PS_BF_TOPK; r++) {
         uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-        for (int u = 0; u < BF_SMALL_NT / 16; u++) {
+        for (int u = 0; u < NT / 16; u++) {
           if (u >= nu) break;
           m = ((first || key[u] > prev) && key[u] < m) ? key[u] : m;
         }
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(TOPK_T) void bf_topk(const BfBlock* blocks, const B
   }
 }
 
+#define BF_RES_TANG 1024      // train angles kept in LDS by bf_resolve (larger problems read them from memory)
 __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint8_t* qdesc, const float* qang,
                                                   const uint8_t* qvalid, const uint8_t* tdesc, const float* tang,
                                                   const uint32_t* topk, int32_t* query_of_train, int32_t* nmatch,
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint
   __shared__ uint32_t taken[PS_BF_MAX_TRAIN / 32];
   __shared__ uint8_t bin_of[PS_BF_MAX_TRAIN];
   __shared__ int hist[32];
+  __shared__ float tang_s[BF_RES_TANG];
   const BfProb P = probs[blockIdx.x];
   const int lane = threadIdx.x;
   if (P.nt == 0 || P.nq == 0) {   // nothing to match (bf_topk was not run for this problem)
@@ -146,16 +150,34 @@ __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint
   __syncthreads();
   const uint4* td = reinterpret_cast<const uint4*>(tdesc + (size_t)P.t_off * 32);
   const float factor = 30 / 360.0f;   // HISTO_LENGTH / 360.0f
+  // The queries are resolved one after the other (the reference's order decides who gets a train).  What a query needs from memory
+  // - its eight keys, its angle, the matched train's angle - is fetched per chunk of 64 queries (lane = query) and per problem (train
+  // angles in LDS), not per query: the serial loop then runs on registers and LDS instead of one L2 round trip or two per query.
+  const bool tang_lds = check_ori && P.nt <= BF_RES_TANG;
+  if (tang_lds)
+    for (int j = lane; j < P.nt; j += 64) tang_s[j] = tang[P.t_off + j];
+  __syncthreads();
   int nm = 0;
   for (int q0 = 0; q0 < P.nq; q0 += 64) {
     const bool v = (q0 + lane < P.nq) && qvalid[P.q_off + q0 + lane] != 0;
+    uint32_t kk[PS_BF_TOPK];
+    float qa = 0.f;
+    {
+      const int qc = min(q0 + lane, P.nq - 1);
+      const uint4* kp = reinterpret_cast<const uint4*>(topk + (size_t)(P.q_off + qc) * PS_BF_TOPK);
+      const uint4 ka = kp[0], kb = kp[1];
+      kk[0] = ka.x; kk[1] = ka.y; kk[2] = ka.z; kk[3] = ka.w; kk[4] = kb.x; kk[5] = kb.y; kk[6] = kb.z; kk[7] = kb.w;
+      if (check_ori) qa = qang[P.q_off + qc];
+    }
     unsigned long long vm = __ballot(v);
     while (vm) {
       const int b = __ffsll((long long)vm) - 1;
       vm &= vm - 1;
       const int q = q0 + b;
-      const uint32_t key = lane < PS_BF_TOPK ? topk[(size_t)(P.q_off + q) * PS_BF_TOPK + lane] : 0xFFFFFFFFu;
-      const uint32_t k0 = (uint32_t)__shfl((int)key, 0);
+      uint32_t key = 0xFFFFFFFFu;                // lane j < 8: key j of query q (out of lane b's registers)
+#pragma unroll
+      for (int j = 0; j < PS_BF_TOPK; j++) { const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)kk[j], b); if (lane == j) key = kj; }
+      const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)kk[0], b);
       if ((k0 >> 16) > 50u) continue;   // best possible distance already above TH_LOW: can never match
       const uint32_t idx = key & 0xFFFF;
       const bool untaken = key != 0xFFFFFFFFu && !((taken[idx >> 5] >> (idx & 31)) & 1u);
@@ -186,11 +208,12 @@ __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint
       const int d1 = (int)(best >> 16), d2 = (int)(second >> 16);
       if (d1 <= 50 && (float)d1 < __fmul_rn(nn_ratio, (float)d2)) {
         const int bi = (int)(best & 0xFFFF);
+        const float qangle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qa), b));
         if (lane == 0) {
           taken[bi >> 5] |= 1u << (bi & 31);
           out[bi] = q;
           if (check_ori) {
-            float rot = __fsub_rn(qang[P.q_off + q], tang[P.t_off + bi]);
+            float rot = __fsub_rn(qangle, tang_lds ? tang_s[bi] : tang[P.t_off + bi]);
             if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
             int bin = (int)roundf(__fmul_rn(rot, factor));
             if (bin == 30) bin = 0;
@@ -245,7 +268,8 @@ extern "C" void psk_bf_launch(const BfBlock* blocks, int nblocks, const BfProb* 
                               uint32_t* topk, int32_t* out, int32_t* nmatch, float nn_ratio, int check_ori,
                               hipStream_t st) {
   if (nblocks > 0) {
-    hipLaunchKernelGGL(bf_topk_small, dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
+    hipLaunchKernelGGL((bf_topk_small<256, -1>), dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
+    hipLaunchKernelGGL((bf_topk_small<BF_SMALL_NT, 256>), dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
     hipLaunchKernelGGL(bf_topk, dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
   }
   hipLaunchKernelGGL(bf_resolve, dim3(nprob), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
@@ -255,7 +279,8 @@ extern "C" void psk_bf_launch(const BfBlock* blocks, int nblocks, const BfProb* 
 extern "C" void psk_bf_launch_dev(const BfBlock* blocks, const int32_t* d_count, int grid, const BfProb* probs, int nprob, const uint8_t* qdesc,
                                   const float* qang, const uint8_t* qvalid, const uint8_t* tdesc, const float* tang, uint32_t* topk, int32_t* out,
                                   int32_t* nmatch, float nn_ratio, int check_ori, hipStream_t st) {
-  hipLaunchKernelGGL(bf_topk_small, dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
+  hipLaunchKernelGGL((bf_topk_small<256, -1>), dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
+  hipLaunchKernelGGL((bf_topk_small<BF_SMALL_NT, 256>), dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
   hipLaunchKernelGGL(bf_topk, dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
   hipLaunchKernelGGL(bf_resolve, dim3(nprob), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
                      nmatch, nn_ratio, check_ori);
