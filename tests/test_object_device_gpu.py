@@ -134,3 +134,33 @@ def test_overflow_is_reported_per_sequence_and_step_not_by_a_failing_fetch():
     assert st["overflowed"].tolist() == [[0, 0, 0], [0, 5, 0], [0, 0, 0]]
     assert (st["tracked"] == 1).all()
     trk.close()
+
+
+def test_object_features_on_a_second_stream_give_the_same_results():
+    """PS_TRK_OVERLAP=1 (ExtractObjORB on a second stream beside the camera chain, joined before ComputeObjStereoMatches) is a
+    scheduling option: every pose, statistic and object record must come out bit for bit as on one stream.  The option is read when
+    the handle is created, so the second run happens in a fresh process."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    n = 5
+    code = ("import sys, pickle, numpy as np\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from pointslot_amd import sequence\n"
+            "from test_object_device_gpu import _run_device\n"
+            "seqs = [sequence.generate_drive(n_frames=%d, seed=81 + i, texture=sequence.kitti_texture()) for i in range(3)]\n"
+            "tcw, st, obj = _run_device(seqs, %d)\n"
+            "sys.stdout.buffer.write(pickle.dumps((tcw.tobytes(), st.tobytes(), obj.tobytes())))\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), n, n))
+    outs = []
+    for overlap in (False, True):
+        env = dict(os.environ)
+        env.pop("PS_TRK_OVERLAP", None)
+        if overlap:
+            env["PS_TRK_OVERLAP"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(pickle.loads(r.stdout))
+    assert outs[0] == outs[1]
+    assert len(outs[0][2]) > 0
