@@ -9,9 +9,15 @@ sequence:
     TrackLocalMap           isInFrustum + SearchByProjection(F, points, th) (a12) -> PoseOptimization   src/Tracking.cc:3097-3160
     motion model            mVelocity = Tcw * LastTwc                                        src/Tracking.cc:1260-1272
 
-Only this data flow is kept; keyframes, local mapping, relocalisation, loop closing and the object pipeline are the
-reference's control plane and are not rebuilt.  The loop is backend-agnostic: the product backend below drives
-libpointslot_hip.so; the tests plug the CPU checker in through the same five calls and compare trajectories.
+With `mask` and `detections` (SLOT.MODE 4) `track()` also runs the object half of Tracking::Track on the frame - AssignFeatures on
+the static keypoints here, and `object_tracker.ObjectTracker` for ExtractObjORB, ComputeObjStereoMatches, TrackMapObject,
+TrackLastFrameObjectPoint and TrackObjectLocalMap (src/Tracking.cc:1224-1233, 2288-2712) over four more backend calls.
+
+Only this data flow is kept; keyframes, local mapping, relocalisation and loop closing are the reference's control plane and are
+not rebuilt.  The loop is backend-agnostic: the product backend below drives libpointslot_hip.so; the tests plug the CPU checker in
+through the same calls and compare trajectories and object records.  Matrix products and inverses are written out operation by
+operation in float32 (`mul4`, `inverse_rt`), as the glue kernels of the device-resident chain evaluate them, so that the two
+chains agree bit for bit.
 """
 import numpy as np
 
@@ -19,8 +25,8 @@ from .matcher import build_grid, FRAME_GRID_COLS, FRAME_GRID_ROWS
 
 
 class HipBackend:
-    """The five hot-path calls on the GPU (ORBextractor x2, ComputeStereoMatches, two SearchByProjection overloads,
-    PoseOptimization)."""
+    """The hot-path calls on the GPU: ORBextractor x2, ComputeStereoMatches, two SearchByProjection overloads, PoseOptimization;
+    for the object half cv::ORB x2 + ComputeObjStereoMatches, SearchByBruceMatching, SearchByProjection(F, nOrder, MOPs), CFSE3."""
 
     def __init__(self, nfeatures=2000, scale=1.2, nlevels=8, ini_th=20, min_th=5, device=0):
         from .extractor import ORBextractor
