@@ -833,22 +833,12 @@ def main():
                     "untracked_frames": o["untracked_frames"], "max_abs_position_error_m": o["max_abs_position_error_m"], "objects": o["objects"],
                     "stage_ms_group0": {k: round(v, 5) for k, v in o["stage_ms_group0"].items()}}
 
-        def two_groups():
-            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, 2 * args.groups, barrier, scene=args.scene,
-                             n_distinct=args.distinct, objects=objects, seqs=head["seqs"])
-            odt = parallel.max_over_ranks(dist, o["dt"], RED_DEV)
-            return {"workload": "the headline loop with the same sequences in twice as many lockstep groups, each on its own stream: one group's latency-bound "
-                                "kernels run under another's extraction (not the headline: per-kernel times are then those of kernels sharing the chip)",
-                    "lockstep_groups_per_gpu": 2 * args.groups, "tracked_frames_per_s": world * o["frames_per_step_per_gpu"] * osteps / odt,
-                    "ms_per_step": odt / osteps * 1e3, "untracked_frames": o["untracked_frames"], "max_abs_position_error_m": o["max_abs_position_error_m"]}
-
         # a failure of a secondary leg must not take the bench line down; every rank runs every leg (they hold barriers), and a leg
         # that failed on one rank is skipped... by all of them at the next barrier only if it fails before its first collective: the
         # launcher's timeout (parallel.launch_ranks) bounds the rest
         fp64_peak = fp64_mfma_peak(local_rank)
         for name, fn in (("camera_chain_only", camera_only),
                          ("lateral_scene", lateral_scene),
-                         ("two_lockstep_groups", two_groups),
                          ("orb_extraction", lambda: orb_leg(rank, local_rank, barrier, with_cpu)),
                          ("optimizers", lambda: optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak)),
                          ("lockstep_tracking_host_images", lambda: pcie_leg(rank, world, local_rank, dist, head["seqs"], args.sequences, args.groups, barrier)),
