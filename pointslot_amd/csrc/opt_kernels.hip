@@ -349,8 +349,10 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
           __syncthreads();
           for (int i = tid; i < k * 7; i += PO_T) (&s.backup[0][0])[i] = (&s.pose[0][0])[i];
           __syncthreads();
-          if (tid == 0) {
-            for (int o = 0; o < k; o++) {
+          if (tid < 64) {   // wave 0: lane o solves vertex o (k <= 16 blocks side by side; PoseOptimization has one)
+            bool okv = true;
+            const int o = tid < k ? tid : 0;
+            {
               // unpivoted LDL^T of the 6x6 block (LinearSolverDense uses Eigen::LDLT + isPositive()).  Every loop has
               // compile-time bounds and there is no early exit, so A / D / y live in registers (a `break` or a data-dependent
               // bound sends them to scratch memory, one L2 round trip per access); a failed pivot only clears ok2.
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
                 double d = A[j][j];
 #pragma unroll
                 for (int q = 0; q < j; q++) d -= A[j][q] * A[j][q] * D[q];
-                if (!(d > 0)) ok2 = false;
+                if (!(d > 0)) okv = false;
                 D[j] = d;
                 double r = __builtin_amdgcn_rcp(d);
                 double e = __builtin_fma(-d, r, 1.0);
@@ -405,18 +407,20 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
                 for (int q = i + 1; q < 6; q++) v -= A[q][i] * xv[q];
                 xv[i] = v;
               }
+              if (tid < k) {
 #pragma unroll
-              for (int i = 0; i < 6; i++) s.xnew[o][i] = xv[i];
+                for (int i = 0; i < 6; i++) s.xnew[o][i] = xv[i];
+              }
             }
-            if (ok2)
-              for (int o = 0; o < k; o++)
+            const bool ok_all = !__any(tid < k && !okv);                 // x only changes when every block factorises
+            if (tid < k) {
+              if (ok_all)
                 for (int j = 0; j < 6; j++) s.x[o][j] = s.xnew[o][j];
-            s.icount = ok2 ? 1 : 0;
-            // update: estimate <- exp(x) * estimate (VertexSE3Expmap::oplusImpl), with whatever x holds
-            for (int o = 0; o < k; o++) {
+              // update: estimate <- exp(x) * estimate (VertexSE3Expmap::oplusImpl), with whatever x holds
               const Se3 Tn = se3_mul(se3_exp(s.x[o], false), load_pose(s.pose[o]));
               store_pose(s.pose[o], Tn);
             }
+            if (tid == 0) s.icount = ok_all ? 1 : 0;
           }
           __syncthreads();
           ok2 = s.icount != 0;
