@@ -32,6 +32,8 @@ namespace {
 struct PoShared {
   double red[PO_T / 64][28];
   double out[28];
+  double outg[PO_T / 64][28];       // group_sum: the sums of the vertices worked on side by side
+  double chiv[PS_PO_MAX_K];         // robust chi2 per vertex of the last linearisation
   double pose[PS_PO_MAX_K][7];      // current estimates
   double pose0[PS_PO_MAX_K][7];     // estimates at entry (PoseOptimization restarts every round from them)
   double backup[PS_PO_MAX_K][7];
@@ -98,6 +100,40 @@ __device__ void block_sum(double* acc, PoShared& s) {
 #pragma unroll
     for (int w = 0; w < PO_T / 64; w++) v += s.red[w][threadIdx.x];
     s.out[threadIdx.x] = v;
+  }
+  __syncthreads();
+}
+
+// The same reduction per GROUP of waves: the workgroup is split into G = 1, 2 or 4 groups of PO_T / G threads that work on different
+// vertices of a CFSE3 graph at the same time (g = the thread's group, tg its index inside it); sums land in s.outg[g][0..N).
+// With G = 1 this is block_sum: same order of additions.
+template <int N>
+__device__ void group_sum(double* acc, PoShared& s, int G, int g, int tg) {
+  static_assert(N > 4 && N <= 32, "group_sum: 5 .. 32 values");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) v[i] = i < N ? acc[i] : 0.0;
+#pragma unroll
+  for (int step = 0; step < 5; step++) {
+    const int d = 32 >> step, half = 16 >> step;
+    const bool upper = (lane & d) != 0;
+#pragma unroll
+    for (int i = 0; i < half; i++) {
+      const double keep = upper ? v[i + half] : v[i];
+      const double send = upper ? v[i] : v[i + half];
+      v[i] = keep + shfl_xor_d(send, d);
+    }
+  }
+  const double total = v[0] + shfl_xor_d(v[0], 1);
+  __syncthreads();   // protect s.outg / s.red from the previous use
+  if ((lane & 1) == 0 && (lane >> 1) < N) s.red[wave][lane >> 1] = total;
+  __syncthreads();
+  const int wpg = (PO_T / 64) / G;
+  if (tg < N) {
+    double sum = 0;
+    for (int w = 0; w < wpg; w++) sum += s.red[g * wpg + w][tg];
+    s.outg[g][tg] = sum;
   }
   __syncthreads();
 }
@@ -172,6 +208,8 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
   const PoProb P = probs[blockIdx.x];
   const int tid = threadIdx.x;
   const int k = P.k;
+  // CFSE3 graphs: G vertices are linearised side by side, each by a group of GT threads (whole waves)
+  const int G = min(k >= 4 ? 4 : (k >= 2 ? 2 : 1), PO_T / 64), GT = PO_T / G, g = tid / GT, tg = tid - g * GT;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   double* tr = trace ? trace + (size_t)blockIdx.x * PS_PO_TRACE * 3 : nullptr;
   int ntr = 0;
@@ -244,17 +282,20 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
         // ---- computeActiveErrors + buildSystem ----
         POP_MARK(0);
         double chi_total = 0;
-        for (int o = 0; o < k; o++) {
-          const PoVertex V = verts[P.v_off + o];
+        for (int o0 = 0; o0 < k; o0 += G) {
+          // G vertices at a time, each by its group of GT threads (PoseOptimization: one vertex, the whole workgroup)
+          const int o = min(o0 + g, k - 1);
+          const bool have = o0 + g < k;
+          const PoVertex V = have ? verts[P.v_off + o] : PoVertex{0, 0};
           const Se3 T = load_pose(s.pose[o]);
           double acc[28];
 #pragma unroll
           for (int a = 0; a < 28; a++) acc[a] = 0;
           PoEdge nx = {};
-          if (V.e_begin + tid < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, V.e_begin + tid);
-          for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
+          if (V.e_begin + tg < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, V.e_begin + tg);
+          for (int i = V.e_begin + tg; i < V.e_end; i += GT) {
             const PoEdge ed = nx;
-            if (i + PO_T < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, i + PO_T);
+            if (i + GT < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, i + GT);
             const uint8_t st = ed.st;
             if ((st & (ST_VALID | ST_LVL1)) != ST_VALID) continue;
             const bool mono = st & ST_MONO;
@@ -292,7 +333,7 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
 #pragma unroll
             for (int r = 0; r < 6; r++) acc[21 + r] -= wo * (J[0][r] * e[0] + J[1][r] * e[1] + J[2][r] * e[2]);
           }
-          if (P.mode == 1 && tid == 0) {
+          if (P.mode == 1 && tg == 0 && have) {
             // EdgeTransConstraintFromDetction: error = obs - t, information 50 I, Huber(sqrt 5.991) that is never
             // removed, Jacobian by central differences with delta = 1e-9 through oplus (base_unary_edge.hpp:83-121)
             double e[3] = {s.prior_obs[o][0] - T.t[0], s.prior_obs[o][1] - T.t[1], s.prior_obs[o][2] - T.t[2]};
@@ -321,11 +362,22 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
               for (int c = r; c < 6; c++) { acc[a] += wo * (J[0][r] * J[0][c] + J[1][r] * J[1][c] + J[2][r] * J[2][c]); a++; }
             for (int r = 0; r < 6; r++) acc[21 + r] -= wo * (J[0][r] * e[0] + J[1][r] * e[1] + J[2][r] * e[2]);
           }
-          block_sum<28>(acc, s);
-          if (tid < 21) s.H[o][tid] = s.out[tid];
-          if (tid >= 21 && tid < 27) s.b[o][tid - 21] = s.out[tid];
-          chi_total += s.out[27];
+          if (G == 1) {          // PoseOptimization, or a single object: the plain workgroup reduction
+            block_sum<28>(acc, s);
+            if (tid < 21) s.H[o][tid] = s.out[tid];
+            if (tid >= 21 && tid < 27) s.b[o][tid - 21] = s.out[tid];
+            if (tid == 27) s.chiv[o] = s.out[27];
+          } else {
+            group_sum<28>(acc, s, G, g, tg);
+            if (have) {
+              if (tg < 21) s.H[o][tg] = s.outg[g][tg];
+              if (tg >= 21 && tg < 27) s.b[o][tg - 21] = s.outg[g][tg];
+              if (tg == 27) s.chiv[o] = s.outg[g][27];
+            }
+          }
         }
+        __syncthreads();
+        for (int o = 0; o < k; o++) chi_total += s.chiv[o];      // in vertex order, as the sequential loop added them
         __syncthreads();
         POP_MARK(1);
         double currentChi = chi_total;
@@ -429,21 +481,23 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
           // ---- computeActiveErrors at the trial estimate ----
           POP_MARK(2);
           double c1[1] = {0};
-          for (int o = 0; o < k; o++) {
-            const PoVertex V = verts[P.v_off + o];
+          for (int o0 = 0; o0 < k; o0 += G) {
+            const int o = min(o0 + g, k - 1);
+            const bool have = o0 + g < k;
+            const PoVertex V = have ? verts[P.v_off + o] : PoVertex{0, 0};
             const Se3 T = load_pose(s.pose[o]);
             // four edges per step, all loads issued before the first use: the pass is short (an error and a Huber weight per
             // edge), so the memory round trip would otherwise be paid once per edge
-            for (int i0 = V.e_begin + tid; i0 < V.e_end; i0 += 4 * PO_T) {
+            for (int i0 = V.e_begin + tg; i0 < V.e_end; i0 += 4 * GT) {
               PoEdge eds[4];
 #pragma unroll
               for (int u = 0; u < 4; u++) {
-                const int i = i0 + u * PO_T;
+                const int i = i0 + u * GT;
                 eds[u] = po_load(xw, obs, inv_sigma2, state, i < V.e_end ? i : i0);
               }
 #pragma unroll
               for (int u = 0; u < 4; u++) {
-                const int i = i0 + u * PO_T;
+                const int i = i0 + u * GT;
                 const PoEdge ed = eds[u];
                 const uint8_t st = ed.st;
                 if (i >= V.e_end || (st & (ST_VALID | ST_LVL1)) != ST_VALID) continue;
@@ -458,7 +512,7 @@ __global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVer
                 c1[0] += rho0;
               }
             }
-            if (P.mode == 1 && tid == 0) {
+            if (P.mode == 1 && tg == 0 && have) {
               const double e0 = s.prior_obs[o][0] - T.t[0], e1 = s.prior_obs[o][1] - T.t[1], e2 = s.prior_obs[o][2] - T.t[2];
               const double chi2 = (e0 * e0 + e1 * e1 + e2 * e2) * 50.0;
               double rho0 = chi2, rho1;
