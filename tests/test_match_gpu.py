@@ -31,7 +31,9 @@ def test_hamming_matrix(matcher):
 def test_bruteforce_batch_matches_oracle(check_ori, ratio):
     from pointslot_amd.matcher import ORBmatcher
     m = ORBmatcher(ratio, check_ori)
-    shapes = [(300, 320), (1000, 1000), (5, 3), (64, 65), (200, 7), (1, 1), (700, 1500), (33, 4000)]
+    shapes = [(300, 320), (1000, 1000), (5, 3), (64, 65), (200, 7), (1, 1), (700, 1500), (33, 4000),
+              # the kernels' tier boundaries: register keys up to 256 / 512 train descriptors, train angles in LDS up to 1024
+              (40, 256), (40, 257), (70, 512), (40, 513), (20, 1024), (20, 1025)]
     probs = [synth.bruteforce_problem(0x51070010 + k, nq, nt) for k, (nq, nt) in enumerate(shapes)]
     # adversarial: many identical descriptors (exhausts the top-8 lists and forces the rescan path)
     dup = synth.bruteforce_problem(0x51070099, 120, 100)
