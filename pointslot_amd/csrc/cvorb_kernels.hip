@@ -599,10 +599,10 @@ __global__ __launch_bounds__(CVB_TT) void cvb_level0(CvbPlan P) {
 // interpolates four consecutive pixels of four rows and stores each quad as one dword; the mask likewise on the tiles of the mask chain
 __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
   constexpr int PS = 48;                          // source patch edge: 32 * 1.2 + taps + rounding
-  constexpr int PW = 52;                          // LDS row pitch: 13 aligned dwords cover 48 bytes at any byte offset
+  constexpr int PW = 64;                          // LDS row pitch: four aligned 16-byte chunks cover 48 bytes at any byte offset
   __shared__ __attribute__((aligned(16))) uint8_t patch[PS * PW];
   __shared__ __attribute__((aligned(16))) uint8_t mpatch[PS * PW];
-  __shared__ uint8_t shf[PS], mshf[PS];           // byte offset of a row's first source pixel inside its first dword
+  __shared__ uint8_t shf[PS], mshf[PS];           // byte offset of a row's first source pixel inside its first 16-byte chunk
   __shared__ int4 xt[CVB_TILE], yt[CVB_TILE];     // table entries of the tile's columns / rows, source offsets resolved
   const int tid = threadIdx.x;
   const CvbLevel& Sb = P.lv[l - 1];
@@ -640,49 +640,54 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
     }
     int mask_mode = 0;                            // 0 no mask on this tile, 1 interpolate, 2 all 255, 3 all 0
     {
-      // 16 lanes per source row (13 aligned dwords), four rows per pass: every load is issued before the first LDS store.  A row's
-      // first pixel sits `shift` bytes into its first dword (rows of the image / the tight mask planes start at any byte address).
-      uint32_t v[PS / 4], mv[PS / 4];
-      const int q = tid & 15;
-      // 32-bit offsets from the image's base (24-bit products), one add per pass
+      // FOUR lanes per source row (four aligned 16-byte chunks), sixteen rows per pass, three passes: every load is issued before the
+      // first LDS store.  A row's first pixel sits `shift` bytes into its first chunk (rows of the image / the tight mask planes
+      // start at any byte address).  (r03: with one dword per lane the 24 predicated loads and their address arithmetic were a
+      // third of the tile's instructions.)
+      uint4 v[PS / 16], mv[PS / 16];
+      const int q = tid & 3, r16 = tid >> 2;
       const uintptr_t sb = reinterpret_cast<uintptr_t>(src), mb = reinterpret_cast<uintptr_t>(msrc);
-      const uint32_t o0 = __umul24((uint32_t)(oy + (tid >> 4)), (uint32_t)sstride) + (uint32_t)ox, ostep = 4u * (uint32_t)sstride;
-      const uint32_t m0 = __umul24((uint32_t)(oy + (tid >> 4)), (uint32_t)mstride) + (uint32_t)ox, mstep = 4u * (uint32_t)mstride;
+      const uint32_t o0 = __umul24((uint32_t)(oy + r16), (uint32_t)sstride) + (uint32_t)ox, ostep = 16u * (uint32_t)sstride;
+      const uint32_t m0 = __umul24((uint32_t)(oy + r16), (uint32_t)mstride) + (uint32_t)ox, mstep = 16u * (uint32_t)mstride;
       uint32_t so = o0, mo = m0;
-      bool not255 = false, not0 = false;
+      uint32_t mloaded = 0;                        // which of this lane's mask chunks were loaded (looked at only after every load is issued)
 #pragma unroll
-      for (int ry = 0; ry < PS / 4; ry++, so += ostep, mo += mstep) {
-        const int yy = (tid >> 4) + 4 * ry;
-        v[ry] = 0; mv[ry] = 0;
-        if (yy < ny && q < 13) {
+      for (int ry = 0; ry < PS / 16; ry++, so += ostep, mo += mstep) {
+        const int yy = r16 + 16 * ry;
+        v[ry] = make_uint4(0, 0, 0, 0); mv[ry] = make_uint4(0, 0, 0, 0);
+        if (yy < ny) {
           const uintptr_t a = sb + so;
-          if (4 * q < (int)(a & 3) + nx) v[ry] = *reinterpret_cast<const uint32_t*>((a & ~(uintptr_t)3) + 4 * q);
+          if (16 * q < (int)(a & 15) + nx) v[ry] = *reinterpret_cast<const uint4*>((a & ~(uintptr_t)15) + 16 * q);
           if (with_mask) {
             const uintptr_t ma = mb + mo;
-            if (4 * q < (int)(ma & 3) + nx) {
-              mv[ry] = *reinterpret_cast<const uint32_t*>((ma & ~(uintptr_t)3) + 4 * q);
-              not255 = not255 || mv[ry] != 0xFFFFFFFFu; not0 = not0 || mv[ry] != 0u;
-            }
+            if (16 * q < (int)(ma & 15) + nx) { mv[ry] = *reinterpret_cast<const uint4*>((ma & ~(uintptr_t)15) + 16 * q); mloaded |= 1u << ry; }
           }
         }
       }
-      // a mask patch that is 255 (inside an object) or 0 (outside) throughout - every dword that was loaded, the bytes around the
+      // a mask patch that is 255 (inside an object) or 0 (outside) throughout - every chunk that was loaded, the bytes around the
       // patch included - interpolates to that value at every pixel of the tile: only tiles on a mask boundary do the arithmetic
       if (with_mask) {
+        bool not255 = false, not0 = false;
+#pragma unroll
+        for (int ry = 0; ry < PS / 16; ry++)
+          if ((mloaded >> ry) & 1u) {
+            const uint4 m = mv[ry];
+            not255 = not255 || (m.x & m.y & m.z & m.w) != 0xFFFFFFFFu; not0 = not0 || (m.x | m.y | m.z | m.w) != 0u;
+          }
         if (!__any(not255)) mask_mode = 2;
         else if (!__any(not0)) mask_mode = 3;
         else mask_mode = 1;
       }
       so = o0; mo = m0;
 #pragma unroll
-      for (int ry = 0; ry < PS / 4; ry++, so += ostep, mo += mstep) {
-        const int yy = (tid >> 4) + 4 * ry;
-        if (yy < ny && q < 13) {
-          *reinterpret_cast<uint32_t*>(patch + yy * PW + 4 * q) = v[ry];
-          if (mask_mode == 1) *reinterpret_cast<uint32_t*>(mpatch + yy * PW + 4 * q) = mv[ry];
+      for (int ry = 0; ry < PS / 16; ry++, so += ostep, mo += mstep) {
+        const int yy = r16 + 16 * ry;
+        if (yy < ny) {
+          *reinterpret_cast<uint4*>(patch + yy * PW + 16 * q) = v[ry];
+          if (mask_mode == 1) *reinterpret_cast<uint4*>(mpatch + yy * PW + 16 * q) = mv[ry];
           if (q == 0) {
-            shf[yy] = (uint8_t)((sb + so) & 3);
-            if (mask_mode == 1) mshf[yy] = (uint8_t)((mb + mo) & 3);
+            shf[yy] = (uint8_t)((sb + so) & 15);
+            if (mask_mode == 1) mshf[yy] = (uint8_t)((mb + mo) & 15);
           }
         }
       }
@@ -696,6 +701,8 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
 #pragma unroll
     for (int j = 0; j < 4; j++) { const int4 v = xt[c4 + j]; cx[j] = v.x - ox; xw[j] = __builtin_bit_cast(cvb_us2, (uint32_t)v.y | ((uint32_t)v.z << 16)); }
     auto interp4 = [&](const uint8_t* rowa, const uint8_t* rowb, cvb_us2 yw, uint32_t* o) {
+      // (one unaligned 8-byte LDS read per source row + v_perm_b32 per pixel instead of the byte reads: 16 % fewer instructions, 3 %
+      // slower - a misaligned ds_read_b64 takes several passes)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const uint32_t wa = (uint32_t)rowa[cx[j]] | ((uint32_t)rowa[cx[j] + 1] << 8), wb = (uint32_t)rowb[cx[j]] | ((uint32_t)rowb[cx[j] + 1] << 8);
