@@ -789,9 +789,10 @@ __device__ __forceinline__ float cvb_harris_wave(const uint8_t* c, int lane) {
 __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
   constexpr int TS = 40, SS = 34;
   __shared__ __attribute__((aligned(16))) uint8_t tile[TS * TS];
-  __shared__ uint8_t sc[SS * SS + 4];
+  __shared__ __attribute__((aligned(16))) uint8_t sc[SS * SS + 12];     // 1168 bytes: cleared as 292 dwords
   __shared__ uint16_t surv[SS * SS];
-  __shared__ int nsurv;
+  __shared__ uint16_t kpl[256];                  // the tile's keypoints (NMS leaves at most one per 2 x 2 block)
+  __shared__ uint32_t mtile[CVB_TILE * 8];       // the mask bytes of the tile's 32 x 32 pixels
   __shared__ unsigned long long rowmask[SS];   // per score row: the columns whose score a keypoint cell of this tile can read
   const int l = blockIdx.y, tid = threadIdx.x, th = P.fast_th;
   CVB_TILE_LOOP(P, 1, l) {
@@ -804,7 +805,6 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
     const int mks = l == 0 ? P.mask_stride : L.w;
     uint32_t kpm[4], mrow[4];
     cvb_wave_sync();
-    if (tid == 0) nsurv = 0;
     // 40 rows of 10 aligned dwords (the plane's row stride is a multiple of 64 and wider than the padded width)
     {
       constexpr int NIT = (TS * (TS / 4) + CVB_TT - 1) / CVB_TT;
@@ -836,7 +836,11 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
         const int i = tid + k * CVB_TT;
         if (i < TS * (TS / 4)) *reinterpret_cast<uint32_t*>(tile + (i / (TS / 4)) * TS + 4 * (i % (TS / 4))) = v[k];
       }
+#pragma unroll
+      for (int r = 0; r < 4; r++) mtile[((tid >> 3) + 8 * r) * 8 + (tid & 7)] = mrow[r];
+      for (int q = tid; q < (SS * SS + 12) / 4; q += CVB_TT) reinterpret_cast<uint32_t*>(sc)[q] = 0;
     }
+    uint32_t kpbits = 0;                          // bit 4 cy + cx: cell (cx, cy) of the tile is a keypoint cell
     {
       // scores are only read on the tile's keypoint cells and one pixel around them: cell (cx, cy) covers score columns 8 cx .. 8 cx + 9
       // and rows 8 cy .. 8 cy + 9 of the 34 x 34 score map.  (kpm[r] of the lanes 2 cx, 2 cx + 1 is the flag of cell (cx, r).)
@@ -845,6 +849,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
       for (int r = 0; r < 4; r++) {
         const unsigned long long bal = __ballot(kpm[r] != 0);
         cm[r] = ((bal & 1) ? 0x3FFull : 0) | ((bal & 4) ? 0x3FFull << 8 : 0) | ((bal & 16) ? 0x3FFull << 16 : 0) | ((bal & 64) ? 0x3FFull << 24 : 0);
+        kpbits |= (uint32_t)(((bal & 1) ? 1u : 0u) | ((bal & 4) ? 2u : 0u) | ((bal & 16) ? 4u : 0u) | ((bal & 64) ? 8u : 0u)) << (4 * r);
       }
       if (tid < SS) {
         const int chi = tid >> 3, clo = (tid - 2) >> 3;                   // the cell rows whose 10-row band holds score row tid
@@ -855,48 +860,61 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
       }
     }
     cvb_wave_sync();
-    for (int i = tid; i < SS * SS; i += CVB_TT) {
-      const int sx = i % SS, sy = i / SS;                                // score pixel: padded (bx + 3 + sx, by + 3 + sy)
-      const int x = bx + 3 + sx - CV_BORDER, y = by + 3 + sy - CV_BORDER;
-      bool cand = false;
-      if (((rowmask[sy] >> sx) & 1) && x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
-        const uint8_t* c = tile + (sy + 3) * TS + sx + 3;
-        const int v = c[0], n = c[3 * TS], ea = c[3], so = c[-3 * TS], w = c[-3];
-        const int M = min(min(max(n, ea), max(ea, so)), min(max(so, w), max(w, n)));
-        const int m = max(max(min(n, ea), min(ea, so)), max(min(so, w), min(w, n)));
-        cand = v - M > th || m - v > th;
+    // compass test (two adjacent compass points both darker / brighter: necessary for a 9-arc) over the score pixels that are read;
+    // (sx, sy) advance with i += 64 = 34 + 30; the survivors are numbered by ballot, no LDS counter
+    int ns = 0;
+    {
+      int sx = tid < SS ? tid : tid - SS, sy = tid < SS ? 0 : 1;
+      for (int i = tid; i < SS * SS + CVB_TT - 1 - (SS * SS - 1) % CVB_TT; i += CVB_TT) {
+        bool cand = false;
+        if (i < SS * SS && ((rowmask[sy] >> sx) & 1)) {
+          const int x = bx + 3 + sx - CV_BORDER, y = by + 3 + sy - CV_BORDER;  // score pixel: padded (bx + 3 + sx, by + 3 + sy)
+          if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
+            const uint8_t* c = tile + (sy + 3) * TS + sx + 3;
+            const int v = c[0], n = c[3 * TS], ea = c[3], so = c[-3 * TS], w = c[-3];
+            const int M = min(min(max(n, ea), max(ea, so)), min(max(so, w), max(w, n)));
+            const int m = max(max(min(n, ea), min(ea, so)), max(min(so, w), min(w, n)));
+            cand = v - M > th || m - v > th;
+          }
+        }
+        const unsigned long long bm = __ballot(cand);
+        if (cand) surv[ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = (uint16_t)i;
+        ns += __popcll(bm);
+        sx += CVB_TT - SS; sy += 1;
+        if (sx >= SS) { sx -= SS; sy += 1; }
       }
-      sc[i] = 0;
-      if (cand) surv[atomicAdd(&nsurv, 1)] = (uint16_t)i;
     }
     cvb_wave_sync();
-    const int ns = nsurv;
     for (int k = tid; k < ns; k += CVB_TT) {
       const int i = surv[k], sx = i % SS, sy = i / SS;
       const int best = cvb_fast_score_full<TS>(tile + (sy + 3) * TS + sx + 3);
       if (best > th) sc[i] = (uint8_t)best;
     }
     cvb_wave_sync();
-    // keypoints of the tile into an LDS list (NMS leaves at most one per 2 x 2 block: 256), then the whole wave on each one's
-    // Harris response, then one reservation in the (image, level) candidate list for the tile
-    if (tid == 0) nsurv = 0;                     // every lane is past the survivor loop (barrier above)
-    cvb_wave_sync();
-    for (int r = 0; r < 4; r++)
-      for (int j = 0; j < 4; j++) {
-        const int lx = (tid & 7) * 4 + j, ly = (tid >> 3) + 8 * r;
-        const int px = CVB_TILE * tx + lx, py = CVB_TILE * ty + ly;
-        const int x = px - CV_BORDER, y = py - CV_BORDER;
-        if (x < P.edge || x >= L.w - P.edge || y < P.edge || y >= L.h - P.edge) continue;
-        const uint8_t* s = sc + (ly + 1) * SS + lx + 1;
-        const int v = s[0];
-        if (v == 0) continue;
-        if (!(v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] && v > s[SS - 1] && v > s[SS] && v > s[SS + 1])) continue;
-        if (!kpm[r]) continue;
-        if (((mrow[r] >> (8 * j)) & 0xFFu) == 0) continue;
-        surv[atomicAdd(&nsurv, 1)] = (uint16_t)(ly * CVB_TILE + lx);
+    // keypoints of the tile: the scored survivors inside the tile that pass cv_is_keypoint - strict 3 x 3 maximum, border rectangle,
+    // keypoint cell, mask - into an LDS list; then the whole wave on each one's Harris response, then one reservation in the
+    // (image, level) candidate list for the tile
+    int nk = 0;
+    for (int k0 = 0; k0 < ns; k0 += CVB_TT) {
+      bool kp = false;
+      int q = 0;
+      if (k0 + tid < ns) {
+        const int i = surv[k0 + tid], sx = i % SS, sy = i / SS, lx = sx - 1, ly = sy - 1;
+        if ((unsigned)lx < (unsigned)CVB_TILE && (unsigned)ly < (unsigned)CVB_TILE) {
+          const int x = CVB_TILE * tx + lx - CV_BORDER, y = CVB_TILE * ty + ly - CV_BORDER;
+          const uint8_t* s = sc + i;
+          const int v = s[0];
+          kp = v != 0 && x >= P.edge && x < L.w - P.edge && y >= P.edge && y < L.h - P.edge &&
+               v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] && v > s[SS - 1] && v > s[SS] && v > s[SS + 1] &&
+               ((kpbits >> (4 * (ly >> 3) + (lx >> 3))) & 1u) && reinterpret_cast<const uint8_t*>(mtile)[ly * CVB_TILE + lx] != 0;
+          q = ly * CVB_TILE + lx;
+        }
       }
+      const unsigned long long bm = __ballot(kp);
+      if (kp) kpl[nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = (uint16_t)q;
+      nk += __popcll(bm);
+    }
     cvb_wave_sync();
-    const int nk = nsurv;
     if (nk > 0) {
       const int slot = img * P.nlevels + l;
       int base0 = 0;
@@ -905,13 +923,13 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
         float mine = 0.f;
         const int kn = min(CVB_TT, nk - k0);
         for (int k = 0; k < kn; k++) {
-          const int q = surv[k0 + k];
+          const int q = kpl[k0 + k];
           const float hr = cvb_harris_wave<TS>(tile + ((q >> 5) + 4) * TS + (q & 31) + 4, tid);
           if (tid == k) mine = hr;
         }
         const int base = __shfl(base0, 0);
         if (tid < kn && base + k0 + tid < CVB_CAND_CAP) {
-          const int q = surv[k0 + tid], lx = q & 31, ly = q >> 5;
+          const int q = kpl[k0 + tid], lx = q & 31, ly = q >> 5;
           const int v = sc[(ly + 1) * SS + lx + 1];
           P.cand[(size_t)slot * CVB_CAND_CAP + base + k0 + tid] =
               make_float4((float)(CVB_TILE * tx + lx - CV_BORDER), (float)(CVB_TILE * ty + ly - CV_BORDER), (float)(v - 1), mine);
