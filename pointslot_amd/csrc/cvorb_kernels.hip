@@ -559,6 +559,7 @@ typedef unsigned short cvb_us2 __attribute__((ext_vector_type(2)));
 // A workgroup of these kernels is ONE wave: its LDS instructions execute in program order, so lanes exchange data through LDS
 // without s_barrier and - what matters - without the vmcnt(0) wait a workgroup barrier brings (the prefetched worklist entry and
 // the stores of the previous tile stay in flight).  What is needed is that the compiler keeps the order.
+static_assert(CVB_TT == 64, "cvb_wave_sync orders LDS traffic inside ONE wave: the tile kernels must be launched with 64-thread workgroups");
 __device__ __forceinline__ void cvb_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
