@@ -495,7 +495,9 @@ int ps_tracker_step(ps_tracker* t, const uint8_t* const* left, const uint8_t* co
  * - in the localisation-mode slice pointslot_amd/object_tracker.py documents (an object's local map is the object keyframe of its
  * (re-)initialisation).  d_masks: per sequence the LEFT 8-bit id mask of Frame::ReadKittiSegmentationImage (0 background, 255
  * ignored, instance + 1), sequence k at d_masks + k * mask_pitch; d_dets: [n_sequences][max_objects] detections of the frame in
- * label order, unused slots with id < 0 behind the used ones.  Both in HBM; they must stay unchanged until the step has run. */
+ * label order, unused slots with id < 0 behind the used ones.  Both in HBM; they must stay unchanged until the step has run.
+ * (Environment, read at ps_tracker_create: PS_TRK_OVERLAP=1 runs ExtractObjORB on a second stream beside the camera chain - same
+ * results; PS_TRK_DEBUG_SYNC=1 waits after every launch group and reports it on stderr.) */
 typedef struct ps_detection {
   int32_t id;            /* DetectionObject::mnObjectID (the label's track id); < 0: empty slot                               */
   int32_t bbox[4];       /* mrectBBox: x, y, width, height (cv::Rect of the label's truncated doubles)                         */
