@@ -977,11 +977,15 @@ __global__ __launch_bounds__(NT) void orb_quadtree(OrbPlan plan, uint8_t* arena,
         }
         s.rank[i] = r;
       }
-      s.tmp[t] = local;
+      // number of candidates: wave sums, then the NT / 64 partial sums by every thread (r03: one thread adding NT LDS words was a tenth
+      // of a level-0 workgroup's time)
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+      if ((t & 63) == 0) s.tmp[t >> 6] = local;
       __syncthreads();
-      if (t == 0) { int acc = 0; for (int k = 0; k < NT; k++) acc += s.tmp[k]; s.total = acc; }
-      __syncthreads();
-      ncand = s.total;
+      ncand = 0;
+#pragma unroll
+      for (int w = 0; w < NT / 64; w++) ncand += s.tmp[w];
       __syncthreads();
     }
     for (int i = t; i < A; i += NT) if (s.rank[i] >= 0) s.ord[s.rank[i]] = i;
