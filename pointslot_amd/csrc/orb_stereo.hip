@@ -148,18 +148,25 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
     const int b0 = min(max((int)floorf((float)rowL - rmax) >> 3, 0), nb - 1), b1 = min(max((int)ceilf((float)rowL + rmax) >> 3, 0), nb - 1);
     const int k_end = boff[b1 + 1];
     const uint32_t rowk = (uint32_t)(rowL + 1024);
-    for (int k = boff[b0] + l16; k < k_end; k += 16) {
-      const st_u2 ri = rinfo[k];
-      const int iR = bidx[k];
-      const uint32_t minr = ri.y & 0x1FFF, maxr = (ri.y >> 13) & 0x1FFF;
-      const int oct = (int)(ri.y >> 26);
-      if (rowk < minr || rowk > maxr) continue;
-      if ((uint32_t)(oct - levelL + 1) > 2u) continue;
-      const float rx = __uint_as_float(ri.x);
-      if (!(rx >= minU && rx <= maxU)) continue;
-      ST_G(st_u4)* dr = st_g(reinterpret_cast<const st_u4*>(S.desc_r + (size_t)iR * 32));
-      const uint32_t d = (uint32_t)hamming256(a0, a1, dr[0], dr[1]);
-      if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR);   // bestDist starts at TH_HIGH, strict <, first wins
+    // the band records are walked four per lane and step, all four requested before the first is looked at (a record is a round
+    // trip to L2; few pass the row / octave / column tests and go on to a descriptor)
+    for (int k = boff[b0] + l16; k < k_end; k += 64) {
+      st_u2 ri[4]; int iR[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int ku = min(k + 16 * u, k_end - 1); ri[u] = rinfo[ku]; iR[u] = bidx[ku]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (k + 16 * u >= k_end) continue;
+        const uint32_t minr = ri[u].y & 0x1FFF, maxr = (ri[u].y >> 13) & 0x1FFF;
+        const int oct = (int)(ri[u].y >> 26);
+        if (rowk < minr || rowk > maxr) continue;
+        if ((uint32_t)(oct - levelL + 1) > 2u) continue;
+        const float rx = __uint_as_float(ri[u].x);
+        if (!(rx >= minU && rx <= maxU)) continue;
+        ST_G(st_u4)* dr = st_g(reinterpret_cast<const st_u4*>(S.desc_r + (size_t)iR[u] * 32));
+        const uint32_t d = (uint32_t)hamming256(a0, a1, dr[0], dr[1]);
+        if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR[u]);   // bestDist starts at TH_HIGH, strict <, first wins
+      }
     }
   }
   best = row_min_u32(best);
