@@ -103,9 +103,15 @@ __global__ __launch_bounds__(TOPK_T) void bf_topk(const BfBlock* blocks, const B
   for (int qi = blk.q_first + wave; qi < blk.q_first + blk.q_count; qi += TOPK_T / 64) {
     const uint4* qd = reinterpret_cast<const uint4*>(qdesc + (size_t)(P.q_off + qi) * 32);
     const uint4 a0 = qd[0], a1 = qd[1];
-    for (int j = lane; j < P.nt; j += 64) {
-      const int d = hamming256(a0, a1, td[2 * j], td[2 * j + 1]);
-      keys[wave][j] = ((uint32_t)d << 16) | (uint32_t)j;
+    for (int j0 = lane; j0 < P.nt; j0 += 256) {       // four train descriptors per lane and step, requested together
+      uint4 b0[4], b1[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int j = min(j0 + 64 * u, P.nt - 1); b0[u] = td[2 * j]; b1[u] = td[2 * j + 1]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = j0 + 64 * u;
+        if (j < P.nt) keys[wave][j] = ((uint32_t)hamming256(a0, a1, b0[u], b1[u]) << 16) | (uint32_t)j;
+      }
     }
     uint32_t prev = 0;
     bool first = true;
