@@ -902,19 +902,30 @@ __global__ __launch_bounds__(NT) void orb_quadtree(OrbPlan plan, uint8_t* arena,
   auto passes = [&](auto kxy, auto kns) {
   if (t == 0) coff[ncell] = n;
   __syncthreads();
-  for (int j = t; j < n; j += NT) {
-    int lo = 0, hi = ncell;          // invariant: off[lo] <= j < off[hi]
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (coff[mid] <= j) lo = mid; else hi = mid;
+  for (int j0 = t; j0 < n; j0 += 4 * NT) {       // four keys per thread and step: their slot loads are in flight together
+    uint32_t ev[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = min(j0 + u * NT, n - 1);
+      int lo = 0, hi = ncell;          // invariant: off[lo] <= j < off[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (coff[mid] <= j) lo = mid; else hi = mid;
+      }
+      ev[u] = slots[(size_t)lo * L.cell_cap + (j - coff[lo])];
     }
-    const uint32_t e = slots[(size_t)lo * L.cell_cap + (j - coff[lo])];
-    const uint32_t x = e & 0xFFF, y = (e >> 12) & 0xFFF, sc = e >> 24;
-    // vpIniNodes[kp.pt.x / hX] (ORBextractor.cc:569): float division, truncation
-    const int ni = (int)__fdiv_rn((float)x, L.h_x);
-    kxy[j] = x | (y << 16);
-    kns[j] = (uint32_t)ni | (sc << 16);
-    atomicAdd(&s.child[ni], 1u);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = j0 + u * NT;
+      if (j >= n) continue;
+      const uint32_t e = ev[u];
+      const uint32_t x = e & 0xFFF, y = (e >> 12) & 0xFFF, sc = e >> 24;
+      // vpIniNodes[kp.pt.x / hX] (ORBextractor.cc:569): float division, truncation
+      const int ni = (int)__fdiv_rn((float)x, L.h_x);
+      kxy[j] = x | (y << 16);
+      kns[j] = (uint32_t)ni | (sc << 16);
+      atomicAdd(&s.child[ni], 1u);
+    }
   }
   __syncthreads();
   QTP_MARK(0);
