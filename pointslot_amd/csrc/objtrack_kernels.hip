@@ -91,14 +91,26 @@ __global__ __launch_bounds__(OB_MASK_T) void ob_masks(ObArrays A, uint8_t* objma
     // the lane's pixels [c0, c0 + per) as (unaligned) dwords into LDS; its rightmost labelled column on the way
     const int c0 = lane * per;
     int local = -1;
-    for (int q = 0; q < per; q += 4) {
-      const int x = c0 + q;
-      uint32_t v = 0;
-      if (x + 3 < W) __builtin_memcpy(&v, M + x, 4);
-      else
-        for (int j = 0; j < 4; j++) if (x + j < W) v |= (uint32_t)M[x + j] << (8 * j);
-      *reinterpret_cast<uint32_t*>(row_sm + x) = v;
-      if (v) local = x + 3 - (__builtin_clz(v) >> 3);
+    for (int q0 = 0; q0 < per; q0 += 32) {             // up to eight dwords of the row per lane and step, requested together
+      uint32_t vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int x = c0 + q0 + 4 * u;
+        uint32_t v = 0;
+        if (q0 + 4 * u < per) {
+          if (x + 3 < W) __builtin_memcpy(&v, M + x, 4);
+          else
+            for (int j = 0; j < 4; j++) if (x + j < W) v |= (uint32_t)M[x + j] << (8 * j);
+        }
+        vv[u] = v;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int x = c0 + q0 + 4 * u;
+        if (q0 + 4 * u >= per) continue;
+        *reinterpret_cast<uint32_t*>(row_sm + x) = vv[u];
+        if (vv[u]) local = x + 3 - (__builtin_clz(vv[u]) >> 3);
+      }
     }
     // run[c] = rightmost labelled column <= c (-1: none): the exclusive prefix maximum over the lanes, then the lane's own pixels
     int incl = local;
