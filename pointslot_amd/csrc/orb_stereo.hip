@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
   const int iL = iL0 + grp;
   const bool live = iL < N;
   ST_G(PsKeyPoint)* KL = st_g(reinterpret_cast<const PsKeyPoint*>(S.kps_l));
-  ST_G(PsKeyPoint)* KR = st_g(reinterpret_cast<const PsKeyPoint*>(S.kps_r));
   const int iLc = live ? iL : N - 1;
   PsKeyPoint kpL;
   kpL.x = KL[iLc].x; kpL.y = KL[iLc].y; kpL.octave = KL[iLc].octave;
@@ -136,6 +135,7 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
   const int rowL = (int)vL;                      // vRowIndices[vL]
   const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
   uint32_t best = 0xFFFFFFFFu;
+  float best_rx = 0.f;
   if (live && !(maxU < 0)) {
     ST_G(st_u4)* dl = st_g(reinterpret_cast<const st_u4*>(S.desc_l + (size_t)iL * 32));
     const st_u4 a0 = dl[0], a1 = dl[1];
@@ -165,18 +165,26 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
         if (!(rx >= minU && rx <= maxU)) continue;
         ST_G(st_u4)* dr = st_g(reinterpret_cast<const st_u4*>(S.desc_r + (size_t)iR[u] * 32));
         const uint32_t d = (uint32_t)hamming256(a0, a1, dr[0], dr[1]);
-        if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR[u]);   // bestDist starts at TH_HIGH, strict <, first wins
+        if (d < 100u) {                                  // bestDist starts at TH_HIGH, strict <, first wins
+          const uint32_t key = (d << 16) | (uint32_t)iR[u];
+          if (key < best) { best = key; best_rx = rx; }  // the record carries the right keypoint's x: no second look-up for the winner
+        }
       }
     }
   }
+  const uint32_t lane_best = best;
   best = row_min_u32(best);
+  // the x of the best candidate, out of the lane that found it (keys are unique: they end in the candidate's index)
+  float uR0 = 0.f;
+  {
+    const uint32_t owners = (uint32_t)(__ballot(lane_best == best && best != 0xFFFFFFFFu) >> (lane & 48)) & 0xFFFFu;
+    uR0 = __shfl(best_rx, (lane & 48) + (owners ? __ffs((int)owners) - 1 : 0));
+  }
   const int bestDist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
   if (bestDist < 75) {   // thOrbDist = (TH_HIGH + TH_LOW) / 2
-    const int bestIdxR = (int)(best & 0xFFFF);
     const float Lscale = s_scale[levelL], Linv = s_inv[levelL];
     const int Lw = s_w[levelL], Lstride = s_stride[levelL];
     const uint32_t Lplane = s_plane[levelL];
-    const float uR0 = KR[bestIdxR].x;
     const float scaleduL = roundf(__fmul_rn(kpL.x, Linv));
     const float scaledvL = roundf(__fmul_rn(kpL.y, Linv));
     const float scaleduR0 = roundf(__fmul_rn(uR0, Linv));
