@@ -466,6 +466,22 @@ __device__ void ob_tune_search(const ObCam& C, const double* R, const double* sc
     const unsigned long long ev = __ballot(stop || miss);
     int j = ev ? (int)((__ffsll((long long)ev) - 1) >> 3) : 7;            // the first state that ends the search or breaks the prediction, else all eight
     j = min(j, 400 - done - 1);
+    // A search that steps back and forth returns to the same value after two moves ((t - s) + s == t, bit for bit, when nothing is
+    // rounded away): the direction of a move depends on t alone, so the remaining moves repeat these two states until the 400 are
+    // used up - the result is the current state or the one after one more move, by the parity of what is left.
+    if (alt && !ev && j == 7) {
+      const double v2 = __shfl(v, 8);                                      // the state after two moves
+      if (__double_as_longlong(v2) == __double_as_longlong(t[axis])) {
+        if ((400 - done) & 1) {                                            // an odd number of moves left: one more move
+          t[axis] = __shfl(v, 0);
+#pragma unroll
+          for (int q = 0; q < 4; q++) pb[q] = __shfl(pc[q], 0);
+          m = __shfl(mc, 0);
+        }
+        done = 400;
+        break;
+      }
+    }
     const int src = 8 * j;
     t[axis] = __shfl(v, src);
 #pragma unroll
