@@ -350,15 +350,22 @@ __device__ int ob_ransac(const double* pts_g, int l, float fmax, int iterations,
   if (in_lds)
     for (int i = tid; i < 3 * l; i += OB_T) pl[i] = pts_g[i];
   const double* pts = in_lds ? pl : pts_g;
+  // cv::RNG's multiply-with-carry stream is a serial recurrence; only the recurrence runs on one lane, the reduction of a state to
+  // a point index (RNG::operator()(unsigned): next() % l) is done by the draws' own threads
   if (tid == 0) {
     unsigned long long state = 0xFFFFFFFFull;
     for (int k = 0; k < iterations; k++) {
       state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32);
-      scr[k] = (int)((unsigned)state % (unsigned)l);
+      scr[k] = (int)(unsigned)state;
     }
   }
   __syncthreads();
+  for (int k = tid; k < iterations; k += OB_T) scr[k] = (int)((unsigned)scr[k] % (unsigned)l);
+  __syncthreads();
   const double fm = (double)fmax;
+  // "sqrt(d2) < fm" without the square root where the answer is clear: sqrt is monotone and correctly rounded, so d2 below
+  // fm^2 (1 - 2^-50) or above fm^2 (1 + 2^-50) decides; only a value inside that band takes the root itself
+  const double fm2 = fm * fm, fm2_lo = fm2 * (1.0 - 0x1p-50), fm2_hi = fm2 * (1.0 + 0x1p-50);
   unsigned long long best = 0;   // (score + 1) << 32 | ~k : the largest is the first draw with the best score
   for (int k = tid; k < iterations; k += OB_T) {
     const int i1 = scr[k];
@@ -366,7 +373,9 @@ __device__ int ob_ransac(const double* pts_g, int l, float fmax, int iterations,
     int score = 0;
     for (int u = 0; u < l; u++) {
       const double dx = pts[3 * u] - px, dy = pts[3 * u + 1] - py, dz = pts[3 * u + 2] - pz;
-      score += sqrt(dx * dx + dy * dy + dz * dz) < fm ? 1 : 0;
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      const bool in = d2 < fm2_lo ? true : (d2 > fm2_hi ? false : sqrt(d2) < fm);
+      score += in ? 1 : 0;
     }
     const unsigned long long key = ((unsigned long long)(unsigned)(score + 1) << 32) | (unsigned)(0x7FFFFFFF - k);
     best = key > best ? key : best;
@@ -388,7 +397,8 @@ __device__ int ob_ransac(const double* pts_g, int l, float fmax, int iterations,
   int cntl = 0;
   for (int u = tid; u < l; u += OB_T) {
     const double dx = pts[3 * u] - px, dy = pts[3 * u + 1] - py, dz = pts[3 * u + 2] - pz;
-    const bool in = sqrt(dx * dx + dy * dy + dz * dz) < fm;
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    const bool in = d2 < fm2_lo ? true : (d2 > fm2_hi ? false : sqrt(d2) < fm);
     flag_g[u] = in ? 1 : 0;
     if (in_lds) fl[u] = in ? 1 : 0;
     cntl += in ? 1 : 0;
