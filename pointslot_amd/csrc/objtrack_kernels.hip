@@ -285,12 +285,16 @@ __global__ __launch_bounds__(OB_T) void ob_begin(ObArrays A, int step) {
     o.id = -1;
     A.stats[((size_t)step * A.S + s) * K + j] = o;
   }
+  // the detector's capacity flags live in the area it clears before every batch: remembered here, per sequence, for every step
+  if (tid == 0 && (A.cv_overflow[2 * s] | A.cv_overflow[2 * s + 1])) A.det_overflow[s]++;
   if (tid == 0 && init) {
     ObMapObject* T = A.mobj + (size_t)s * A.M;
     uint32_t reserved = 0;
     for (int j = 0; j < ndet; j++) {
       const int id = F.det[(size_t)s * K + j].id;
       int slot = -1;
+      // an unused slot (id < 0) in front of the last used one is no detection: no MapObject (free table slots carry id -1 too)
+      if (id < 0) { F.mo[(size_t)s * K + j] = -1; continue; }
       for (int m = 0; m < A.M; m++) if (T[m].id == id) { slot = m; break; }
       if (slot < 0) {
         int fr = -1;
@@ -522,7 +526,7 @@ __device__ __forceinline__ float ob_fmax(const double* scale) {   // float fMaxD
 // lies within fmax, position (float), descriptor of the keypoint, one observation, UpdateNormalAndDepth against the keyframe's
 // camera centre mPoc = -Roc * tco; the keyframe lists its points by feature index (sel[i] = 1 for the features that get a point)
 __device__ void ob_keyframe_points(const ObArrays& A, const ObFrame& F, int s, int slot, size_t fo, int n, const Se3& pose, const double* pts,
-                                   const int32_t* pidx, const uint8_t* flag, int l, float fmax, uint8_t* sel, float* selpo, int step, ObShared& sh) {
+                                   const int32_t* pidx, const uint8_t* flag, int l, float fmax, uint8_t* sel, float* selpo, int step, bool init, ObShared& sh) {
   const ObCam& C = A.cam;
   const int tid = threadIdx.x;
   const Se3 inv = se3_inverse(pose);
@@ -573,7 +577,10 @@ __device__ void ob_keyframe_points(const ObArrays& A, const ObFrame& F, int s, i
   if (tid == 0) {
     ObMapObject& O = A.mobj[(size_t)s * A.M + slot];
     O.npts = base < A.LC ? base : A.LC;
-    O.kf_frame = step; O.local_valid = 0;
+    // mnLastKeyFrameId is written by MapObjectInit (Tracking.cc:1875) and CreateNewObjectKeyFrame (:2835) only: after a
+    // MapObjectReInit (:1908-2031) the next frame's TrackLastFrameObjectPoint does not skip the object at :2302
+    if (init) O.kf_frame = step;
+    O.local_valid = 0;
   }
   __syncthreads();
 }
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(OB_T) void ob_track(ObArrays A, int step) {
     }
     __syncthreads();
     const Se3 pose = s_pose;
-    ob_keyframe_points(A, F, s, slot, fo, n, pose, pts, pidx, flag, l, fmax_det, A.occupied + fo, A.po_obs + 3 * fo, step, sh);
+    ob_keyframe_points(A, F, s, slot, fo, n, pose, pts, pidx, flag, l, fmax_det, A.occupied + fo, A.po_obs + 3 * fo, step, true, sh);
     return;
   }
   // ---- an object seen before (Tracking.cc:1553-1622) ----
@@ -983,6 +990,10 @@ __global__ __launch_bounds__(OB_T) void ob_finish(ObArrays A, int step) {
   ObFrame& L = A.last;
   const size_t fb = (size_t)s * A.OC;
   const int nd = F.ndet[s];
+  if (tid == 0) {   // windows of SearchByProjection(F, nOrder, MOPs) that held more candidates than the store: counted, then re-armed
+    const int ov = A.pj_overflow[(size_t)s * K + j];
+    if (ov) { atomicAdd(&A.search_overflow[s], ov); A.pj_overflow[(size_t)s * K + j] = 0; }
+  }
   if (j < nd) {
     const int b0 = F.off[(size_t)s * (K + 1) + j], n = F.off[(size_t)s * (K + 1) + j + 1] - b0;
     const size_t fo = fb + b0;
@@ -1084,7 +1095,7 @@ __global__ __launch_bounds__(OB_T) void ob_finish(ObArrays A, int step) {
             }
             __syncthreads();
             const Se3 pose = s_pose;
-            ob_keyframe_points(A, F, s, slot, fo, n, pose, pts, pidx, flag, l, fmax_det, A.occupied + fo, A.po_obs + 3 * fo, step, sh);
+            ob_keyframe_points(A, F, s, slot, fo, n, pose, pts, pidx, flag, l, fmax_det, A.occupied + fo, A.po_obs + 3 * fo, step, false, sh);
           }
         }
       }

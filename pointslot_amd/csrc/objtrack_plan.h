@@ -75,4 +75,9 @@ struct ObArrays {
   // results
   ObStat* stats;                                                     // [max_steps][S][K]
   int32_t* dropped;                                                  // [S] detections ignored because the MapObject table was full
+  // capacity events, sticky per sequence until ps_tracker_reset (the sources are cleared / reused by every step):
+  const int32_t* cv_overflow;                                        // [2 S] the batched cv::ORB's flags of THIS step (images 2s, 2s + 1)
+  int32_t* pj_overflow;                                              // [S][K] overflowed windows of this step's object searches
+  int32_t* det_overflow;                                             // [S] steps in which the object detector hit a keypoint capacity
+  int32_t* search_overflow;                                          // [S] object search windows beyond the candidate store, all steps
 };

@@ -184,6 +184,7 @@ size_t carve_obj(ps_tracker* t, uint8_t* base) {
   A.po_pose = c.take<double>(S * K * 7); A.po_result = c.take<int32_t>(S); A.po_vmap = c.take<int32_t>(S * K);
   A.stats = c.take<ObStat>((size_t)A.max_steps * S * K);
   A.dropped = c.take<int32_t>(S);
+  A.det_overflow = c.take<int32_t>(S); A.search_overflow = c.take<int32_t>(S);
   t->ob_chi2 = c.take<double>(n); t->ob_state = c.take<uint8_t>(n);
   t->d_objmask = c.take<uint8_t>(2 * S * (size_t)((t->cfg.width + 15) & ~15) * t->cfg.height);
   t->d_obj_pairs = c.take<StPair>(S);
@@ -197,6 +198,7 @@ size_t carve_obj(ps_tracker* t, uint8_t* base) {
   uint32_t* cand = c.take<uint32_t>(S * K * LC * PS_PJ_CAP);
   int32_t* ncand = c.take<int32_t>(nl); int32_t* qbest = c.take<int32_t>(nl); uint8_t* qbin = c.take<uint8_t>(nl); uint4* ttop = c.take<uint4>(nl);
   int32_t* ovf = c.take<int32_t>(S * K);
+  A.pj_overflow = ovf;
   A.st_uright = st_ur; A.st_depth = st_dp;
   PjArrays P;
   memset(&P, 0, sizeof(P));
@@ -213,7 +215,9 @@ size_t carve_obj(ps_tracker* t, uint8_t* base) {
     const OrbPlan* plan = psi_orb_plan(t->orb);
     uint8_t* arena = psi_orb_arena(t->orb);
     const ps_keypoint* ckps = nullptr; const uint8_t* cdesc = nullptr; const int32_t* ccnt = nullptr; int32_t ccap = 0;
-    ps_cvorb_batch_device_outputs(t->cvorb, &ckps, &cdesc, &ccnt, nullptr, &ccap);
+    const int32_t* covf = nullptr;
+    ps_cvorb_batch_device_outputs(t->cvorb, &ckps, &cdesc, &ccnt, &covf, &ccap);
+    A.cv_overflow = covf;
     std::vector<StPair> pairs(S);
     for (size_t k = 0; k < S; k++) {
       StPair& p = pairs[k];
@@ -375,6 +379,11 @@ int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out) {
   if (cfg->max_objects > 0) {
     // the object half: its own cv::ORB detector (Frame.cc:2625: cv::ORB::create(1000, 1.2, 8, 19)) and the arrays of objtrack_plan.h
     if (cfg->max_objects > OB_MAXK) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_INVALID, "max_objects: at most %d detections per frame", OB_MAXK); }
+    // ob_masks keeps 8 rows x 3 planes of the padded width in LDS (at most the 64 KB a kernel gets without asking for more)
+    if (8 * 3 * (size_t)((cfg->width + 255) & ~255) + 2 * (size_t)(cfg->width / 8 + 8) + 64 > 64 * 1024) {
+      ps_tracker_destroy(t);
+      return ps_set_error(PS_ERR_CAPACITY, "ps_tracker_create: the object chain serves images up to 2560 pixels wide (%d asked)", cfg->width);
+    }
     rc = ps_cvorb_create(1000, 1.2f, 8, 19, 20, cfg->device, &t->cvorb);
     if (rc == PS_OK) {
       // plan the detector for 2 S images of this size (one untimed batch over zero masks: allocations happen here, not in the first step)
@@ -481,14 +490,16 @@ int ps_tracker_fetch_objects(ps_tracker* t, int first_step, int nsteps, ps_objec
   static_assert(sizeof(ps_detection) == sizeof(ObDet), "ps_detection layout");
   const size_t per = (size_t)t->OA.S * t->OA.K;
   if (nsteps) PS_HIP(hipMemcpy(out, t->OA.stats + (size_t)first_step * per, (size_t)nsteps * per * sizeof(ObStat), hipMemcpyDeviceToHost));
-  // the detector's limits and the MapObject table are part of the result's validity
-  const int32_t* d_ovf = nullptr;
-  ps_cvorb_batch_device_outputs(t->cvorb, nullptr, nullptr, nullptr, &d_ovf, nullptr);
-  std::vector<int32_t> ovf(2 * (size_t)t->OA.S, 0), drop(t->OA.S, 0);
-  PS_HIP(hipMemcpy(ovf.data(), d_ovf, ovf.size() * 4, hipMemcpyDeviceToHost));
+  // the detector's limits, the object searches' candidate store and the MapObject table are part of the result's validity: their
+  // flags are kept per sequence over ALL queued steps (ob_begin / ob_finish), until ps_tracker_reset
+  std::vector<int32_t> ovf(t->OA.S, 0), sov(t->OA.S, 0), drop(t->OA.S, 0);
+  PS_HIP(hipMemcpy(ovf.data(), t->OA.det_overflow, ovf.size() * 4, hipMemcpyDeviceToHost));
+  PS_HIP(hipMemcpy(sov.data(), t->OA.search_overflow, sov.size() * 4, hipMemcpyDeviceToHost));
   PS_HIP(hipMemcpy(drop.data(), t->OA.dropped, drop.size() * 4, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < ovf.size(); i++)
-    if (ovf[i]) return ps_set_error(PS_ERR_CAPACITY, "sequence %zu: the object detector exceeded its per-level / per-image keypoint capacity in the last step", i / 2);
+    if (ovf[i]) return ps_set_error(PS_ERR_CAPACITY, "sequence %zu: the object detector exceeded its per-level / per-image keypoint capacity in %d step(s) since the last reset", i, ovf[i]);
+  for (size_t i = 0; i < sov.size(); i++)
+    if (sov[i]) return ps_set_error(PS_ERR_CAPACITY, "sequence %zu: %d object search windows held more than %d candidates since the last reset", i, sov[i], PS_PJ_CAP);
   for (size_t i = 0; i < drop.size(); i++)
     if (drop[i]) return ps_set_error(PS_ERR_CAPACITY, "sequence %zu: more than %d objects over the sequence (%d detections ignored)", i, OB_MAXM, drop[i]);
   return PS_OK;
@@ -552,6 +563,9 @@ int ps_tracker_reset(ps_tracker* t) {
     PS_HIP(hipMemcpy(t->OA.mobj, mo.data(), mo.size() * sizeof(ObMapObject), hipMemcpyHostToDevice));
     PS_HIP(hipMemsetAsync(t->OA.last.ndet, 0, sizeof(int32_t) * t->OA.S, t->stream));
     PS_HIP(hipMemsetAsync(t->OA.dropped, 0, sizeof(int32_t) * t->OA.S, t->stream));
+    PS_HIP(hipMemsetAsync(t->OA.det_overflow, 0, sizeof(int32_t) * t->OA.S, t->stream));
+    PS_HIP(hipMemsetAsync(t->OA.search_overflow, 0, sizeof(int32_t) * t->OA.S, t->stream));
+    PS_HIP(hipMemsetAsync(t->OA.pj_overflow, 0, sizeof(int32_t) * t->OA.S * t->OA.K, t->stream));
   }
   t->step = 0;
   return PS_OK;

@@ -336,7 +336,7 @@ class ObjectTracker:
         idx = [i for i in range(o.n) if o.depth[i] > 0] if order is None else order
         return [tuple(float(v) for v in self._unproject(o, i)) for i in idx], idx
 
-    def _keyframe_points(self, o, mo, pose, inl, pts, idx, fmax):
+    def _keyframe_points(self, o, mo, pose, inl, pts, idx, fmax, init):
         """the MapObjectPoints of a new ObjectKeyFrame (MapObjectInit / MapObjectReInit tail): object-frame position, one
         observation, descriptor of the keypoint, UpdateNormalAndDepth against the keyframe's camera centre"""
         inv = se3_inverse(pose)
@@ -370,7 +370,8 @@ class ObjectTracker:
             P["po"][pid] = po; P["normal"][pid] = nrm; P["max_dist"][pid] = maxd; P["min_dist"][pid] = mind; P["desc"][pid] = o.desc[n]
             o.mp_valid[n] = True; o.mp_observed[n] = True; o.mp_id[n] = pid; o.mp_po[n] = po; o.outlier[n] = 0
         mo["points"] = P
-        mo["kf_frame"] = self.frame_id
+        if init:                                     # mnLastKeyFrameId: MapObjectInit (Tracking.cc:1875), never MapObjectReInit (:1908-2031)
+            mo["kf_frame"] = self.frame_id
         mo["local_valid"] = False                    # mvLocalObjectKeyFrames is filled by the first UpdateObjectLocalKeyFrames that finds observations
 
     # ---- Tracking::MapObjectInit ----
@@ -393,7 +394,7 @@ class ObjectTracker:
         mo = {"id": det["id"], "first_frame": self.frame_id, "scale": scale, "tco": pose, "tco_frame": self.frame_id}
         self.objects[det["id"]] = mo
         o.mo = mo
-        self._keyframe_points(o, mo, pose, inl, pts, idx, fmax)
+        self._keyframe_points(o, mo, pose, inl, pts, idx, fmax, True)
         o.new = True
 
     # ---- Tracking::MapObjectReInit ----
@@ -427,7 +428,7 @@ class ObjectTracker:
         truth = from_pose7(det["pose7"])
         pose = self._fine_tune(det, (tuple(c), truth[1]), scale)
         mo["tco"] = pose; mo["tco_frame"] = self.frame_id
-        self._keyframe_points(o, mo, pose, inl, pts, idx, fmax)
+        self._keyframe_points(o, mo, pose, inl, pts, idx, fmax, False)
 
     # ---- Tracking::TrackMapObject ----
     def _track_map_object(self, F, tcl):

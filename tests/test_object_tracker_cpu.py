@@ -99,6 +99,48 @@ def test_object_chain_on_a_generated_sequence():
     assert err < 0.05
 
 
+def test_reinit_does_not_count_as_an_object_keyframe():
+    """MapObject::mnLastKeyFrameId is written by MapObjectInit (Tracking.cc:1875) and CreateNewObjectKeyFrame (:2835), never by
+    MapObjectReInit (:1908-2031): in the frame after a re-initialisation TrackLastFrameObjectPoint does not skip the object at :2302
+    but walks its last-frame stereo features for temporal points (in this scene the re-initialisation gave every feature within
+    fMaxDis a point, so the walk is observed through its calls, and the skip of the frame after MapObjectInit through their absence)."""
+    n = 5
+    seq = sequence.generate(n_frames=n, seed=4, texture=sequence.kitti_texture())
+    h, w = seq["left"][0].shape
+    vo = StereoOdometry(OracleBackend(), seq["K"], seq["bf"], w, h)
+    walked = {}
+    ot = None
+    for k in range(n):
+        if ot is None and vo.objects is not None:
+            ot = vo.objects
+            local_map, last_frame, fmax = ot._track_local_map, ot._track_last_frame, ot._fmax
+            inside = [False]
+
+            def lose_object_1(F):            # frame 2: object 1 does not keep its inliers -> MapObjectReInit at the end of Track
+                local_map(F)
+                if ot.frame_id == 2:
+                    F.obj[1].track_ok = False
+
+            def spy_last_frame(F):
+                inside[0] = True
+                try:
+                    last_frame(F)
+                finally:
+                    inside[0] = False
+
+            def spy_fmax(scale):             # TrackLastFrameObjectPoint evaluates fMaxDis once per object it does not skip
+                if inside[0]:
+                    walked[ot.frame_id] = walked.get(ot.frame_id, 0) + 1
+                return fmax(scale)
+            ot._track_local_map, ot._track_last_frame, ot._fmax = lose_object_1, spy_last_frame, spy_fmax
+        vo.track(seq["left"][k], seq["right"][k], sequence.frame_mask(seq, k), sequence.frame_detections(seq, k))
+    for o in ot.last.obj:
+        assert o.mo["kf_frame"] == 1 and o.mo["first_frame"] == 1  # the frame of MapObjectInit, not the re-initialisation's
+    assert 2 not in walked                                         # frame 1 was the objects' first frame and keyframe: skipped (:2302-2308)
+    assert walked[3] == 2 and walked[4] == 2                       # frame 3 follows the re-initialisation of object 1: both objects are walked
+    assert ot.stats[3]["objects"][1]["bf_matches"] > 30 and ot.stats[3]["objects"][1]["track_ok"]
+
+
 def test_cpp_make_detection_equals_the_python_twin(tmp_path):
     """StereoOdometryDevice::MakeDetection (host/StereoOdometry.h) packs a label row exactly like object_tracker.detection_from_label"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
