@@ -13,7 +13,7 @@
 #include "ps_common.h"
 
 
-extern "C" void psk_ba_global_step(const BaArrays*, int, int, int, int, int, int, hipStream_t);
+extern "C" void psk_ba_global_step(const BaArrays*, int, int, int, int, int, int, int, hipStream_t);
 
 struct ps_optimizer;   // defined in opt_host.hip; BA keeps its own arena inside this small side struct
 struct BaCtx {
@@ -180,7 +180,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   // stream drain + PCIe round trip.
   const int steps_per_sync = 3;
   for (;;) {
-    for (int k = 0; k < steps_per_sync; k++) psk_ba_global_step(&A, nprob, max_np, max_nl, max_ne, max_tilepairs, max_free, st);
+    for (int k = 0; k < steps_per_sync; k++) psk_ba_global_step(&A, nprob, max_np, max_nl, max_ne, max_tilepairs, max_free, steps + k == 0, st);
     PS_HIP(hipGetLastError());
     PS_HIP(hipMemcpyAsync(h_done, A.ndone, 4, hipMemcpyDeviceToHost, st));
     PS_HIP(hipStreamSynchronize(st));

@@ -144,7 +144,7 @@ __device__ __forceinline__ bool inv3(const double M[9], double O[9]) {
 // stage 1: chi2 > 5.991|7.815 or depth <= 0 -> level 1, Huber off, 10 iterations (:959-986).
 // stage 2: the same test fills the erase list (:988-1012) and the problem is DONE.
 // -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_begin(BaArrays A) {
+__device__ void ba_stage_entry(const BaArrays& A) {
   const BaProb P = A.prob[blockIdx.x];
   BaState& S = A.state[blockIdx.x];
   const int tid = threadIdx.x;
@@ -171,33 +171,57 @@ __global__ __launch_bounds__(256) void ba_begin(BaArrays A) {
       if (tid == 0) { S.phase = BA_PH_DONE; atomicAdd(A.ndone, 1); }
       return;
     }
-    // active sets: a pose / point takes part iff it has a level-0 edge (and the pose is not fixed)
-    for (int i = tid; i < P.np; i += 256) {
-      const int b = A.csr_off[P.csr_pose_base + i], e = A.csr_off[P.csr_pose_base + i + 1];
-      bool any = false;
-      for (int k = b; k < e; k++) any |= !(A.e_state[P.edge_base + A.csr_edges[P.csr_pose_edges_base + k]] & ES_LVL1);
-      A.pidx[P.pose_base + i] = (any && !(A.pose_flags[P.pose_base + i] & 1)) ? 0 : -1;
-    }
+    // active sets: a pose / point takes part iff it has a level-0 edge (and the pose is not fixed).  Edge-parallel: every level-0
+    // edge marks its two vertices (the per-vertex walks over the CSR lists this replaces were 300 dependent loads per pose; with the
+    // single-thread compaction behind them the stage entry took 175 us)
+    for (int i = tid; i < P.np; i += 256) A.pidx[P.pose_base + i] = -1;
     for (int l = tid; l < P.nl; l += 256) {
-      const int b = A.csr_off[P.csr_point_base + l], e = A.csr_off[P.csr_point_base + l + 1];
-      bool any = false;
-      for (int k = b; k < e; k++) any |= !(A.e_state[P.edge_base + A.csr_edges[P.csr_point_edges_base + k]] & ES_LVL1);
-      A.lact[P.point_base + l] = any ? 1 : 0;
+      A.lact[P.point_base + l] = 0;
       A.xl[(size_t)(P.point_base + l) * 3] = 0; A.xl[(size_t)(P.point_base + l) * 3 + 1] = 0; A.xl[(size_t)(P.point_base + l) * 3 + 2] = 0;
     }
+    for (int i = tid; i < P.np * 6; i += 256) A.xp[(size_t)P.pose_base * 6 + i] = 0;
     __syncthreads();
-    if (tid == 0) {
-      int npa = 0, nla = 0;
-      for (int i = 0; i < P.np; i++)
-        if (A.pidx[P.pose_base + i] == 0) { A.pidx[P.pose_base + i] = npa; A.pact[P.pose_base + npa] = i; npa++; }
-      for (int l = 0; l < P.nl; l++) nla += A.lact[P.point_base + l];
-      for (int i = 0; i < P.np * 6; i++) A.xp[(size_t)P.pose_base * 6 + i] = 0;
-      S.npa = npa; S.nla = nla;
-      S.robust = stage == 0 ? 1 : 0;
-      S.iter = 0; S.max_iter = stage == 0 ? 5 : 10; S.trial = 0; S.n_bad = 0;
-      if (npa + nla == 0) S.stage = stage + 1;   // "0 vertices to optimize": optimize() returns without touching anything
-      else S.phase = BA_PH_LINEARIZE;
-      s_stage = S.stage;
+    for (int e = tid; e < P.ne; e += 256) {
+      const int ge = P.edge_base + e;
+      if (A.e_state[ge] & ES_LVL1) continue;
+      A.pidx[P.pose_base + A.e_pose[ge]] = 0;      // (every writer stores the same value)
+      A.lact[P.point_base + A.e_point[ge]] = 1;
+    }
+    __syncthreads();
+    // compact indices of the active free poses in pose order, count of the active points
+    {
+      __shared__ int s_cnt[4], s_base, s_nla[4];
+      if (tid == 0) s_base = 0;
+      int nla = 0;
+      for (int l = tid; l < P.nl; l += 256) nla += A.lact[P.point_base + l];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) nla += __shfl_xor(nla, d);
+      if ((tid & 63) == 0) s_nla[tid >> 6] = nla;
+      __syncthreads();
+      for (int i0 = 0; i0 < P.np; i0 += 256) {
+        const int i = i0 + tid;
+        const bool act = i < P.np && A.pidx[P.pose_base + i] == 0 && !(A.pose_flags[P.pose_base + i] & 1);
+        const unsigned long long b = __ballot(act);
+        if ((tid & 63) == 0) s_cnt[tid >> 6] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < (tid >> 6); w++) off += s_cnt[w];
+        const int a = off + __popcll(b & ((1ull << (tid & 63)) - 1ull));
+        if (i < P.np) A.pidx[P.pose_base + i] = act ? a : -1;
+        if (act) A.pact[P.pose_base + a] = i;
+        __syncthreads();
+        if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+      }
+      if (tid == 0) {
+        const int npa = s_base, nlat = s_nla[0] + s_nla[1] + s_nla[2] + s_nla[3];
+        S.npa = npa; S.nla = nlat;
+        S.robust = stage == 0 ? 1 : 0;
+        S.iter = 0; S.max_iter = stage == 0 ? 5 : 10; S.trial = 0; S.n_bad = 0;
+        if (npa + nlat == 0) S.stage = stage + 1;   // "0 vertices to optimize": optimize() returns without touching anything
+        else S.phase = BA_PH_LINEARIZE;
+        s_stage = S.stage;
+      }
     }
     __syncthreads();
     if (S.phase != BA_PH_BEGIN) return;
@@ -205,14 +229,17 @@ __global__ __launch_bounds__(256) void ba_begin(BaArrays A) {
   }
 }
 
+// the first global step's stage entry; later ones run at the end of ba_decide, in the workgroup that made the stage change
+__global__ __launch_bounds__(256) void ba_begin(BaArrays A) { ba_stage_entry(A); }
+
 // -------------------------------------------------------------------------------------------------------
 // computeActiveErrors + buildSystem, pose-major: one wave per pose, lanes over the pose's edges.
 // -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_lin_pose(BaArrays A) {
+__device__ __forceinline__ void ba_lin_pose(const BaArrays& A, int bx) {
   const BaProb P = A.prob[blockIdx.y];
   const BaState& S = A.state[blockIdx.y];
   if (S.phase != BA_PH_LINEARIZE) return;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int i = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= P.np) return;
   const Se3 T = load_pose(A.poses + (size_t)(P.pose_base + i) * 7);
   double R[9];
@@ -297,11 +324,11 @@ __device__ __forceinline__ void ba_jx(const double R[9], const BaProb& P, const 
     }
   }
 }
-__global__ __launch_bounds__(256) void ba_lin_point(BaArrays A) {
+__device__ __forceinline__ void ba_lin_point(const BaArrays& A, int bx) {
   const BaProb P = A.prob[blockIdx.y];
   const BaState& S = A.state[blockIdx.y];
   if (S.phase != BA_PH_LINEARIZE) return;
-  const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const int l = bx * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
   const bool lv = l < P.nl;
   const bool robust = S.robust != 0;
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // H00 H01 H02 H11 H12 H22 b0 b1 b2
@@ -320,7 +347,8 @@ __global__ __launch_bounds__(256) void ba_lin_point(BaArrays A) {
       ba_jx(R, P, p, mono, Jx);
       const double w = (double)A.e_is2[ge];
       double rho0, rho1 = 1.0;
-      if (robust) huber(A.chi2c[ge], mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
+      // (the edge's chi2 evaluated here as ba_lin_pose evaluates it: the two halves run in one launch, the cache is not written yet)
+      if (robust) huber((er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * w, mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
       const double wo = rho1 * w;
       acc[0] += wo * (Jx[0][0] * Jx[0][0] + Jx[1][0] * Jx[1][0] + Jx[2][0] * Jx[2][0]);
       acc[1] += wo * (Jx[0][0] * Jx[0][1] + Jx[1][0] * Jx[1][1] + Jx[2][0] * Jx[2][1]);
@@ -343,11 +371,16 @@ __global__ __launch_bounds__(256) void ba_lin_point(BaArrays A) {
   }
 }
 
-// chi2 total, lambda init on the first iteration of a stage (levenberg.cpp:93-97,166-180)
-__global__ __launch_bounds__(256) void ba_post_lin(BaArrays A) {
-  const BaProb P = A.prob[blockIdx.x];
-  BaState& S = A.state[blockIdx.x];
-  if (S.phase != BA_PH_LINEARIZE) return;
+// both halves of buildSystem in one launch: blocks [0, nbpose) linearise pose-major, the others point-major
+__global__ __launch_bounds__(256) void ba_linearize(BaArrays A, int nbpose) {
+  if ((int)blockIdx.x < nbpose) ba_lin_pose(A, blockIdx.x);
+  else ba_lin_point(A, blockIdx.x - nbpose);
+}
+
+// chi2 total, lambda init on the first iteration of a stage (levenberg.cpp:93-97,166-180): evaluated by EVERY workgroup of ba_prep for
+// itself (1 200 diagonal entries, a fixed-order reduction: the same bits everywhere); the first workgroup records it.  The phase
+// stays LINEARIZE until ba_decide: the kernels of a trial run in both phases.
+__device__ __forceinline__ double ba_post_lin(const BaArrays& A, const BaProb& P, BaState& S, bool record) {
   __shared__ double red[4];
   const int tid = threadIdx.x;
   double m = 0;
@@ -365,27 +398,24 @@ __global__ __launch_bounds__(256) void ba_post_lin(BaArrays A) {
   m = wave_max(m);
   if ((tid & 63) == 0) red[tid >> 6] = m;
   __syncthreads();
-  if (tid == 0) {
+  const double lambda = S.iter == 0 ? 1e-5 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) : S.lambda;
+  if (record && tid == 0) {
     double chi = 0;
     for (int i = 0; i < P.np; i++) chi += A.part[P.part_base + i];   // fixed order
     S.current_chi = chi;
     S.ini_chi = chi;
-    if (S.iter == 0) {
-      S.lambda = 1e-5 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-      S.ni = 2;
-      S.n_bad = 0;
-    }
+    if (S.iter == 0) { S.lambda = lambda; S.ni = 2; S.n_bad = 0; }
     S.trial = 0;
-    S.phase = BA_PH_TRIAL;
   }
+  return lambda;
 }
 
 // D^-1 per point; b_s per active pose (block_solver.hpp:367-439)
 __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
   const BaProb P = A.prob[blockIdx.y];
-  const BaState& S = A.state[blockIdx.y];
-  if (S.phase != BA_PH_TRIAL) return;
-  const double lambda = S.lambda;
+  BaState& S = A.state[blockIdx.y];
+  if (S.phase != BA_PH_TRIAL && S.phase != BA_PH_LINEARIZE) return;
+  const double lambda = S.phase == BA_PH_LINEARIZE ? ba_post_lin(A, P, S, blockIdx.x == 0) : S.lambda;
   const int nbl = (P.nl + 255) / 256;
   if ((int)blockIdx.x < nbl) {
     const int l = blockIdx.x * 256 + threadIdx.x;
@@ -433,7 +463,7 @@ typedef double sch_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
   const BaProb P = A.prob[blockIdx.y];
   const BaState& St = A.state[blockIdx.y];
-  if (St.phase != BA_PH_TRIAL) return;
+  if (St.phase != BA_PH_TRIAL && St.phase != BA_PH_LINEARIZE) return;
   const int npa = St.npa, nt = (npa + PS_BA_TILE - 1) / PS_BA_TILE;
   int ta = 0, rem = blockIdx.x;   // blockIdx.x -> (ta, tb), tb <= ta
   while (ta < nt && rem > ta) { rem -= ta + 1; ta++; }
@@ -539,7 +569,7 @@ template <int NB>
 __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   const BaProb P = A.prob[blockIdx.x];
   BaState& St = A.state[blockIdx.x];
-  if (St.phase != BA_PH_TRIAL) return;
+  if (St.phase != BA_PH_TRIAL && St.phase != BA_PH_LINEARIZE) return;
   const int n = 6 * St.npa, lda = 6 * P.np, tid = threadIdx.x, lane = tid & 63;
   double* Sm = A.S + P.S_base;
   extern __shared__ __attribute__((aligned(16))) double sol_smem[];
@@ -796,7 +826,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
 __global__ __launch_bounds__(256) void ba_update(BaArrays A) {
   const BaProb P = A.prob[blockIdx.y];
   const BaState& S = A.state[blockIdx.y];
-  if (S.phase != BA_PH_TRIAL) return;
+  if (S.phase != BA_PH_TRIAL && S.phase != BA_PH_LINEARIZE) return;
   __shared__ double red[4];
   const int tid = threadIdx.x;
   const int nbl = (P.nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB;
@@ -867,7 +897,7 @@ __global__ __launch_bounds__(256) void ba_update(BaArrays A) {
 __global__ __launch_bounds__(256) void ba_error_k(BaArrays A, int err_part_off) {
   const BaProb P = A.prob[blockIdx.y];
   const BaState& S = A.state[blockIdx.y];
-  if (S.phase != BA_PH_TRIAL) return;
+  if (S.phase != BA_PH_TRIAL && S.phase != BA_PH_LINEARIZE) return;
   __shared__ double red[4];
   const int tid = threadIdx.x, e = blockIdx.x * 256 + tid;
   double chi = 0;
@@ -896,7 +926,7 @@ __global__ __launch_bounds__(256) void ba_error_k(BaArrays A, int err_part_off) 
 __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
   const BaProb P = A.prob[blockIdx.x];
   BaState& S = A.state[blockIdx.x];
-  if (S.phase != BA_PH_TRIAL) return;
+  if (S.phase != BA_PH_TRIAL && S.phase != BA_PH_LINEARIZE) return;
   __shared__ int s_restore;
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -937,13 +967,16 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
       S.iter++;
       if (terminate || S.iter >= S.max_iter) { S.stage++; S.phase = BA_PH_BEGIN; }
       else S.phase = BA_PH_LINEARIZE;
-    }
+    } else S.phase = BA_PH_TRIAL;   // another damping trial on the same linearisation
   }
   __syncthreads();
   if (s_restore) {   // _optimizer->pop()
     for (int q = tid; q < P.np * 7; q += 256) A.poses[(size_t)P.pose_base * 7 + q] = A.poses_bak[(size_t)P.pose_base * 7 + q];
     for (int q = tid; q < P.nl * 3; q += 256) A.points[(size_t)P.point_base * 3 + q] = A.points_bak[(size_t)P.point_base * 3 + q];
   }
+  // a stage ended: its successor's entry (classification, active sets) right here instead of in a launch of its own per global step
+  __syncthreads();
+  if (S.phase == BA_PH_BEGIN) ba_stage_entry(A);
 }
 
 }  // namespace
@@ -951,14 +984,12 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
 // one "global step": every unfinished problem advances by one LM trial (plus linearisation / stage entry
 // when it is due).  max_* are maxima over the batch.
 extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int max_nl, int max_ne, int max_tilepairs,
-                                   int max_free, hipStream_t st) {
+                                   int max_free, int first, hipStream_t st) {
   const int nbl = (max_nl + 255) / 256, nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
   const int nblu = (max_nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB;   // ba_update's point blocks
   const int err_off = max_np + nblu + nbp;   // layout of `part`: [np chi partials][update partials][error partials]
-  hipLaunchKernelGGL(ba_begin, dim3(nprob), dim3(256), 0, st, *A);
-  hipLaunchKernelGGL(ba_lin_pose, dim3((max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
-  hipLaunchKernelGGL(ba_lin_point, dim3((max_nl + 15) / 16, nprob), dim3(256), 0, st, *A);
-  hipLaunchKernelGGL(ba_post_lin, dim3(nprob), dim3(256), 0, st, *A);
+  if (first) hipLaunchKernelGGL(ba_begin, dim3(nprob), dim3(256), 0, st, *A);
+  hipLaunchKernelGGL(ba_linearize, dim3((max_np + 3) / 4 + (max_nl + 15) / 16, nprob), dim3(256), 0, st, *A, (max_np + 3) / 4);
   hipLaunchKernelGGL(ba_prep, dim3(nbl + (max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), 0, st, *A);
   {
