@@ -565,7 +565,7 @@ static_assert(6 * PS_BA_MAX_POSES <= SOL_T - 64, "ba_solve: one thread per row o
 #endif
 typedef double sol_d4 __attribute__((ext_vector_type(4)));
 typedef double sol_d2 __attribute__((ext_vector_type(2)));
-template <int NB>
+template <int NB, bool PB>
 __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   const BaProb P = A.prob[blockIdx.x];
   BaState& St = A.state[blockIdx.x];
@@ -581,7 +581,15 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   double* Lt2 = rdj2 + 2 * NB;                  // [2][NB][NB] the block's multipliers again, column-major: Lt[q][c] = L[c][q]
   double* rhs = Lt2 + 2 * NB * NB;              // [n]
   double* dall = rhs + 6 * PS_BA_MAX_POSES;     // [n]
-  double* panel = dall + 6 * PS_BA_MAX_POSES;   // [rows below][NB + 1]
+  // panel row stride: NB + 1 doubles keeps a tile's 16 rows on different banks; with PB it is NB + 2 (16-byte aligned rows: the
+  // trailing update then reads a lane's NB / 4 K-steps of an operand as 128-bit words)
+  constexpr int PST = PB ? NB + 2 : NB + 1;
+  double* panel = dall + 6 * PS_BA_MAX_POSES;   // [rows below][PST]
+  // PB: the panel a second time as -D L (= the negated un-divided values of the panel solve): the B operand of the trailing update
+  // without the FP64 multiply and the read of d per K-step.  The trailing update was bound by its LDS reads (18 64-bit reads per
+  // tile update, 12 600 per solve, next to 28 us of matrix-core time in a 97 us phase): with both operands K-contiguous per lane
+  // (the K index of a lane's step i is (NB / 4) lk + i on BOTH operands, which is all the contraction asks for) they are 6 128-bit reads.
+  double* panelB = panel + (PB ? (size_t)(n - min(NB, n) + 4) * PST : 0);
   __shared__ int fail;
   if (tid == 0) fail = 0;
   // LDS keeps whatever the previous kernel on this CU left there, NaN bit patterns included, and 0 * NaN is not 0: every slot
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     const int m0 = J + jb, m = n - m0;
     for (int q = tid; q < m * jb; q += SOL_T) {
       const int i = q / jb, c = q - i * jb;
-      panel[(size_t)i * (NB + 1) + c] = Sm[(size_t)(m0 + i) * lda + J + c];
+      panel[(size_t)i * PST + c] = Sm[(size_t)(m0 + i) * lda + J + c];
     }
     __syncthreads();
     SOLP_MARK(5);
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       // of each other (the dot-product order makes each column one serial FMA chain); every column still receives its
       // subtractions in the order q = 0, 1, 2, ..., i.e. the result is bit-identical.  Only full blocks have rows below them.
       // (Broadcasting the multipliers with v_readlane from registers instead of reading them from LDS was measured slower.)
-      double* prow = panel + (size_t)i * (NB + 1);
+      double* prow = panel + (size_t)i * PST;
       double v[NB];
 #pragma unroll
       for (int c = 0; c < NB; c++) v[c] = c < jb ? prow[c] : 0.0;
@@ -670,13 +678,14 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
           v[c + 1] -= xq * l2.y;
         }
         prow[q] = xq * rdj[q];
+        if (PB) panelB[(size_t)i * PST + q] = -xq;
       }
     }
     __syncthreads();
     SOLP_MARK(6);
     for (int q = tid; q < m * jb; q += SOL_T) {
       const int i = q / jb, c = q - i * jb;
-      Sm[(size_t)(m0 + i) * lda + J + c] = panel[(size_t)i * (NB + 1) + c];
+      Sm[(size_t)(m0 + i) * lda + J + c] = panel[(size_t)i * PST + c];
     }
     // forward substitution of this block column while its panel is still in LDS: y_J = L_JJ^-1 b_J (wave 0, after
     // which the rows below subtract L_panel y_J) — no extra pass over L in global memory
@@ -698,7 +707,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     SOLP_MARK(7);
     for (int i = tid; i < m; i += SOL_T) {
       double v = rhs[m0 + i];
-      const double* prow = panel + (size_t)i * (NB + 1);
+      const double* prow = panel + (size_t)i * PST;
       double pr[NB], yj[NB];   // all operands first (only full blocks have rows below them), then the chain
 #pragma unroll
       for (int c = 0; c < NB; c++) { pr[c] = prow[c]; yj[c] = rhs[J + c]; }
@@ -727,12 +736,25 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
           const int row = I0 + lk + 4 * r;
           acc[r] = (row < m && col <= row) ? Sm[(size_t)(m0 + row) * lda + m0 + col] : 0.0;
         }
-        const double* pa = panel + (size_t)min(I0 + li, m - 1) * (NB + 1);
-        const double* pb = panel + (size_t)min(J0 + li, m - 1) * (NB + 1);
+        if (PB && NB % 8 == 0) {
+          const double* pa = panel + (size_t)min(I0 + li, m - 1) * PST + (NB / 4) * lk;
+          const double* pb = panelB + (size_t)min(J0 + li, m - 1) * PST + (NB / 4) * lk;
+          sol_d2 a2[NB / 8], b2[NB / 8];
 #pragma unroll
-        for (int kc = 0; kc < NB / 4; kc++) {
-          const int k = 4 * kc + lk;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k], -dj[k] * pb[k], acc, 0, 0, 0);
+          for (int i = 0; i < NB / 8; i++) { a2[i] = *reinterpret_cast<const sol_d2*>(pa + 2 * i); b2[i] = *reinterpret_cast<const sol_d2*>(pb + 2 * i); }
+#pragma unroll
+          for (int i = 0; i < NB / 8; i++) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i].x, b2[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i].y, b2[i].y, acc, 0, 0, 0);
+          }
+        } else {
+          const double* pa = panel + (size_t)min(I0 + li, m - 1) * PST;
+          const double* pb = panel + (size_t)min(J0 + li, m - 1) * PST;
+#pragma unroll
+          for (int kc = 0; kc < NB / 4; kc++) {
+            const int k = 4 * kc + lk;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k], -dj[k] * pb[k], acc, 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -994,18 +1016,22 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), 0, st, *A);
   {
     const int n_max = 6 * max_free;
-    auto lds = [&](int nb) { return (size_t)(2 * nb * (nb + 1) + 4 * nb + 2 * nb * nb + 12 * PS_BA_MAX_POSES + (size_t)(n_max > nb ? n_max - nb + 4 : 4) * (nb + 1) + 8) * sizeof(double); };
+    auto lds = [&](int nb, bool pb) { return (size_t)(2 * nb * (nb + 1) + 4 * nb + 2 * nb * nb + 12 * PS_BA_MAX_POSES + (size_t)(pb ? 2 * (nb + 2) : nb + 1) * (n_max > nb ? n_max - nb + 4 : 4) + 8) * sizeof(double); };
     // > 64 KB of dynamic LDS has to be requested per kernel
     static const int force_nb = getenv("PS_BA_NB") ? atoi(getenv("PS_BA_NB")) : 0;
-    if (force_nb == 48 && lds(48) <= 150 * 1024) {   // measured slower than 24 at n = 294 (single-wave diagonal factor)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(48));
-      hipLaunchKernelGGL(ba_solve<48>, dim3(nprob), dim3(SOL_T), lds(48), st, *A);
-    } else if (force_nb != 12 && lds(24) <= 150 * 1024) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(24));
-      hipLaunchKernelGGL(ba_solve<24>, dim3(nprob), dim3(SOL_T), lds(24), st, *A);
+    static const bool no_pb = getenv("PS_BA_NO_PB") != nullptr;   // developer knob: one panel, the B operand scaled on the fly
+    if (force_nb == 48 && lds(48, false) <= 150 * 1024) {   // measured slower than 24 at n = 294 (single-wave diagonal factor)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<48, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(48, false));
+      hipLaunchKernelGGL((ba_solve<48, false>), dim3(nprob), dim3(SOL_T), lds(48, false), st, *A);
+    } else if (force_nb != 12 && !no_pb && lds(24, true) <= 156 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<24, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(24, true));
+      hipLaunchKernelGGL((ba_solve<24, true>), dim3(nprob), dim3(SOL_T), lds(24, true), st, *A);
+    } else if (force_nb != 12 && lds(24, false) <= 150 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<24, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(24, false));
+      hipLaunchKernelGGL((ba_solve<24, false>), dim3(nprob), dim3(SOL_T), lds(24, false), st, *A);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(12));
-      hipLaunchKernelGGL(ba_solve<12>, dim3(nprob), dim3(SOL_T), lds(12), st, *A);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(12, false));
+      hipLaunchKernelGGL((ba_solve<12, false>), dim3(nprob), dim3(SOL_T), lds(12, false), st, *A);
     }
   }
   hipLaunchKernelGGL(ba_update, dim3(nblu + nbp, nprob), dim3(256), 0, st, *A);
