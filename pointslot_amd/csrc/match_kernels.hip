@@ -134,6 +134,7 @@ __global__ __launch_bounds__(TOPK_T) void bf_topk(const BfBlock* blocks, const B
 }
 
 #define BF_RES_TANG 1024      // train angles kept in LDS by bf_resolve (larger problems read them from memory)
+#define BF_CLAIM 512
 __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint8_t* qdesc, const float* qang,
                                                   const uint8_t* qvalid, const uint8_t* tdesc, const float* tang,
                                                   const uint32_t* topk, int32_t* query_of_train, int32_t* nmatch,
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint
   __shared__ uint8_t bin_of[PS_BF_MAX_TRAIN];
   __shared__ int hist[32];
   __shared__ float tang_s[BF_RES_TANG];
+  __shared__ uint32_t claim[BF_CLAIM];   // hashed train -> earliest pending lane of the chunk whose best it is
   const BfProb P = probs[blockIdx.x];
   const int lane = threadIdx.x;
   if (P.nt == 0 || P.nq == 0) {   // nothing to match (bf_topk was not run for this problem)
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint
   int32_t* out = query_of_train + P.t_off;
   for (int j = lane; j < PS_BF_MAX_TRAIN / 32; j += 64) taken[j] = 0;
   if (lane < 32) hist[lane] = 0;
+  for (int j = lane; j < BF_CLAIM; j += 64) claim[j] = 0xFFFFFFFFu;
   for (int j = lane; j < P.nt; j += 64) out[j] = -1;
   __syncthreads();
   const uint4* td = reinterpret_cast<const uint4*>(tdesc + (size_t)P.t_off * 32);
@@ -175,60 +178,120 @@ __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint
       kk[0] = ka.x; kk[1] = ka.y; kk[2] = ka.z; kk[3] = ka.w; kk[4] = kb.x; kk[5] = kb.y; kk[6] = kb.z; kk[7] = kb.w;
       if (check_ori) qa = qang[P.q_off + qc];
     }
-    unsigned long long vm = __ballot(v);
-    while (vm) {
-      const int b = __ffsll((long long)vm) - 1;
-      vm &= vm - 1;
-      const int q = q0 + b;
-      uint32_t key = 0xFFFFFFFFu;                // lane j < 8: key j of query q (out of lane b's registers)
+    // ---- the 64 queries of the chunk, lane = query.  A query's outcome depends on the earlier ones only through the trains they take,
+    // and it reads only its first two untaken keys (best / second of the ratio test): every pending lane enters its best train into a
+    // hashed table with an atomic min of the lane number; a lane whose two keys have no earlier lane in the table keeps both whatever
+    // the earlier lanes decide (they can only take their own best), so its decision is the sequential loop's.  The lanes before the
+    // first one that fails this test are decided at once, that one is then resolved alone (its keys may have shifted; it may need the
+    // exact rescan), and the test is repeated on what is left.  Hash collisions only make the test stricter.
+    const uint32_t k0 = kk[0];
+    unsigned long long pend = __ballot(v && (k0 >> 16) <= 50u);   // best possible distance above TH_LOW: can never match
+    while (pend) {
+      const bool mine = (pend >> lane) & 1ull;
+      uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
+      int nun = 0;
+      if (mine) {
 #pragma unroll
-      for (int j = 0; j < PS_BF_TOPK; j++) { const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)kk[j], b); if (lane == j) key = kj; }
-      const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)kk[0], b);
-      if ((k0 >> 16) > 50u) continue;   // best possible distance already above TH_LOW: can never match
-      const uint32_t idx = key & 0xFFFF;
-      const bool untaken = key != 0xFFFFFFFFu && !((taken[idx >> 5] >> (idx & 31)) & 1u);
-      const unsigned long long um = __ballot(untaken);
-      uint32_t best, second;
-      if (__popcll(um) >= 2 || P.nt <= PS_BF_TOPK) {
-        const int f = um ? __ffsll((long long)um) - 1 : -1;
-        const unsigned long long um2 = um & (um - 1);
-        const int s = um2 ? __ffsll((long long)um2) - 1 : -1;
-        best = f >= 0 ? (uint32_t)__shfl((int)key, f) : (256u << 16);
-        second = s >= 0 ? (uint32_t)__shfl((int)key, s) : (256u << 16);
-      } else {
-        // the list is exhausted: exact rescan of the row over untaken trains (two smallest keys)
-        const uint4* qd = reinterpret_cast<const uint4*>(qdesc + (size_t)(P.q_off + q) * 32);
-        const uint4 a0 = qd[0], a1 = qd[1];
-        uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
-        for (int j = lane; j < P.nt; j += 64) {
-          if ((taken[j >> 5] >> (j & 31)) & 1u) continue;
-          const uint32_t k = ((uint32_t)hamming256(a0, a1, td[2 * j], td[2 * j + 1]) << 16) | (uint32_t)j;
-          if (k < m1) { m2 = m1; m1 = k; } else if (k < m2) m2 = k;
+        for (int j = 0; j < PS_BF_TOPK; j++) {
+          const uint32_t key = kk[j];
+          if (key != 0xFFFFFFFFu && nun < 2) {
+            const uint32_t idx = key & 0xFFFF;
+            if (!((taken[idx >> 5] >> (idx & 31)) & 1u)) { if (nun == 0) b1 = key; else b2 = key; nun++; }
+          }
         }
-        best = wave_min_u32(m1);
-        const uint32_t cand = (m1 == best) ? m2 : m1;
-        second = wave_min_u32(cand);
-        if (best == 0xFFFFFFFFu) best = 256u << 16;
-        if (second == 0xFFFFFFFFu) second = 256u << 16;
       }
-      const int d1 = (int)(best >> 16), d2 = (int)(second >> 16);
-      if (d1 <= 50 && (float)d1 < __fmul_rn(nn_ratio, (float)d2)) {
-        const int bi = (int)(best & 0xFFFF);
-        const float qangle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qa), b));
-        if (lane == 0) {
-          taken[bi >> 5] |= 1u << (bi & 31);
-          out[bi] = q;
+      const bool rescan = mine && nun < 2 && P.nt > PS_BF_TOPK;   // the list is exhausted: only the serial path can decide
+      if (mine && b1 != 0xFFFFFFFFu) atomicMin(&claim[(b1 & 0xFFFF) & (BF_CLAIM - 1)], (uint32_t)lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      bool dirty = rescan;
+      if (mine && b1 != 0xFFFFFFFFu) dirty = dirty || claim[(b1 & 0xFFFF) & (BF_CLAIM - 1)] < (uint32_t)lane;
+      if (mine && b2 != 0xFFFFFFFFu) dirty = dirty || claim[(b2 & 0xFFFF) & (BF_CLAIM - 1)] < (uint32_t)lane;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (mine && b1 != 0xFFFFFFFFu) claim[(b1 & 0xFFFF) & (BF_CLAIM - 1)] = 0xFFFFFFFFu;
+      const unsigned long long dm = __ballot(mine && dirty);
+      const int fd = dm ? __ffsll((long long)dm) - 1 : 64;
+      const unsigned long long cleanm = fd < 64 ? (pend & ((1ull << fd) - 1ull)) : pend;
+      {
+        const int d1 = b1 == 0xFFFFFFFFu ? 256 : (int)(b1 >> 16), d2 = b2 == 0xFFFFFFFFu ? 256 : (int)(b2 >> 16);
+        const bool accept = ((cleanm >> lane) & 1ull) && d1 <= 50 && (float)d1 < __fmul_rn(nn_ratio, (float)d2);
+        if (accept) {
+          const int bi = (int)(b1 & 0xFFFF);
+          atomicOr(&taken[bi >> 5], 1u << (bi & 31));
+          out[bi] = q0 + lane;
           if (check_ori) {
-            float rot = __fsub_rn(qangle, tang_lds ? tang_s[bi] : tang[P.t_off + bi]);
+            float rot = __fsub_rn(qa, tang_lds ? tang_s[bi] : tang[P.t_off + bi]);
             if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
             int bin = (int)roundf(__fmul_rn(rot, factor));
             if (bin == 30) bin = 0;
-            hist[bin]++;
+            atomicAdd(&hist[bin], 1);
             bin_of[bi] = (uint8_t)bin;
           }
         }
-        nm++;
-        __syncthreads();   // single wave: orders the LDS updates before the next query's reads
+        nm += __popcll(__ballot(accept));
+      }
+      pend &= ~cleanm;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (fd < 64) {
+        // ---- the first query that shares a train with an earlier one: alone, on the bitmap as the lanes before it left it ----
+        const int b = fd;
+        pend &= ~(1ull << b);
+        const int q = q0 + b;
+        uint32_t key = 0xFFFFFFFFu;                // lane j < 8: key j of query q (out of lane b's registers)
+#pragma unroll
+        for (int j = 0; j < PS_BF_TOPK; j++) { const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)kk[j], b); if (lane == j) key = kj; }
+        const uint32_t idx = key & 0xFFFF;
+        const bool untaken = key != 0xFFFFFFFFu && !((taken[idx >> 5] >> (idx & 31)) & 1u);
+        const unsigned long long um = __ballot(untaken);
+        uint32_t best, second;
+        if (__popcll(um) >= 2 || P.nt <= PS_BF_TOPK) {
+          const int f = um ? __ffsll((long long)um) - 1 : -1;
+          const unsigned long long um2 = um & (um - 1);
+          const int s2 = um2 ? __ffsll((long long)um2) - 1 : -1;
+          best = f >= 0 ? (uint32_t)__shfl((int)key, f) : (256u << 16);
+          second = s2 >= 0 ? (uint32_t)__shfl((int)key, s2) : (256u << 16);
+        } else {
+          // the list is exhausted: exact rescan of the row over untaken trains (two smallest keys)
+          const uint4* qd = reinterpret_cast<const uint4*>(qdesc + (size_t)(P.q_off + q) * 32);
+          const uint4 a0 = qd[0], a1 = qd[1];
+          uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+          for (int j = lane; j < P.nt; j += 64) {
+            if ((taken[j >> 5] >> (j & 31)) & 1u) continue;
+            const uint32_t k = ((uint32_t)hamming256(a0, a1, td[2 * j], td[2 * j + 1]) << 16) | (uint32_t)j;
+            if (k < m1) { m2 = m1; m1 = k; } else if (k < m2) m2 = k;
+          }
+          best = wave_min_u32(m1);
+          const uint32_t cand = (m1 == best) ? m2 : m1;
+          second = wave_min_u32(cand);
+          if (best == 0xFFFFFFFFu) best = 256u << 16;
+          if (second == 0xFFFFFFFFu) second = 256u << 16;
+        }
+        const int d1 = (int)(best >> 16), d2 = (int)(second >> 16);
+        if (d1 <= 50 && (float)d1 < __fmul_rn(nn_ratio, (float)d2)) {
+          const int bi = (int)(best & 0xFFFF);
+          const float qangle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qa), b));
+          if (lane == 0) {
+            taken[bi >> 5] |= 1u << (bi & 31);
+            out[bi] = q;
+            if (check_ori) {
+              float rot = __fsub_rn(qangle, tang_lds ? tang_s[bi] : tang[P.t_off + bi]);
+              if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+              int bin = (int)roundf(__fmul_rn(rot, factor));
+              if (bin == 30) bin = 0;
+              hist[bin]++;
+              bin_of[bi] = (uint8_t)bin;
+            }
+          }
+          nm++;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
   }
