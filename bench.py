@@ -94,11 +94,12 @@ def pmc_valu_issue(kernel, nimg, ms_per_step=None):
 
 
 def _make_one(job):
-    scene, n_frames, seed, k, texture = job
+    scene, n_frames, seed, k, texture = job[:5]
+    n_objects = job[5] if len(job) > 5 else 2
     from pointslot_amd import sequence
     tex = sequence.kitti_texture() if texture == "kitti" else None
     if scene == "drive":
-        q = sequence.generate_drive(n_frames=n_frames, seed=seed, speed=0.55 + 0.02 * (k % 16), yaw_rate_deg=0.3 + 0.05 * (k % 9), texture=tex)
+        q = sequence.generate_drive(n_frames=n_frames, seed=seed, speed=0.55 + 0.02 * (k % 16), yaw_rate_deg=0.3 + 0.05 * (k % 9), texture=tex, n_objects=n_objects)
     else:
         q = sequence.generate(n_frames=n_frames, seed=seed, step=0.05 + 0.01 * (k % 4), texture=tex)
     q["masks"] = np.stack([sequence.frame_mask(q, i) for i in range(n_frames)])
@@ -107,10 +108,10 @@ def _make_one(job):
     return q
 
 
-def make_sequences(rank, n_frames, n_distinct, texture, scene="drive"):
+def make_sequences(rank, n_frames, n_distinct, texture, scene="drive", n_objects=2):
     """n_distinct generated stereo sequences (seeds differ per rank), rendered by a pool of fresh processes (the ray-cast drive scene
     costs about 0.3 s of numpy per frame)."""
-    jobs = [(scene, n_frames, 40 + 64 * rank + k, k, texture) for k in range(n_distinct)]
+    jobs = [(scene, n_frames, 40 + 64 * rank + k, k, texture, n_objects) for k in range(n_distinct)]
     if n_distinct <= 2:
         return [_make_one(j) for j in jobs]
     import multiprocessing as mp
@@ -119,10 +120,10 @@ def make_sequences(rank, n_frames, n_distinct, texture, scene="drive"):
         return list(pool.map(_make_one, jobs))
 
 
-MAX_OBJECTS = 4
+MAX_OBJECTS = 8     # detections per frame the tracker is created for (KITTI tracking frames carry up to ~15; the device chain serves 8)
 
 
-def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barrier, scene="drive", n_distinct=32, objects=True, seqs=None):
+def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barrier, scene="drive", n_distinct=32, objects=True, seqs=None, n_objects=2):
     """The headline loop: `n_seq` sequences per GPU in `n_groups` lockstep groups (one ps_tracker and one stream each), images - and
     with `objects` the instance masks and the detections (SLOT.MODE 4 inputs) - of all frames resident in HBM.  Every step is one
     frame of every sequence through the camera chain and, with `objects`, the object chain behind it.  Returns the timing, the
@@ -132,7 +133,7 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
     n_frames = warmup + steps
     n_distinct = min(n_distinct, n_seq)
     if seqs is None:
-        seqs = make_sequences(rank, n_frames, n_distinct, texture, scene)
+        seqs = make_sequences(rank, n_frames, n_distinct, texture, scene, n_objects)
     h, w = seqs[0]["left"][0].shape
     per_group = n_seq // n_groups
     base = torch.from_numpy(np.stack([np.stack([q["left"][:n_frames], q["right"][:n_frames]], 1) for q in seqs], 1)).cuda()   # [n, nd, 2, h, w]
@@ -180,13 +181,15 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
     out = {"dt": dt, "stage_ms_group0": stage, "frames_per_step_per_gpu": per_group * n_groups, "images_per_launch": 2 * per_group,
            "h": h, "w": w, "n_distinct": n_distinct}
     # every trajectory against the ground truth of the generator, every frame's tracked flag
-    err, untracked, tracked_timed = 0.0, 0, 0
+    err, untracked, tracked_timed, overflowed = 0.0, 0, 0, 0
     tcw0 = st0 = obj0 = None
     ob = {"detections": 0, "with_object": 0, "track_ok": 0, "max_abs_centre_error_m": 0.0, "reinit": 0}
     for g, t in enumerate(trks):
         tcw, st = t.fetch()
         untracked += int((st["tracked"] == 0).sum())
-        tracked_timed += int((st["tracked"][warmup:] != 0).sum())
+        # a frame whose search windows overflowed the candidate store is not the reference's result: it does not count as tracked
+        overflowed += int((st["overflowed"] != 0).sum())
+        tracked_timed += int(((st["tracked"][warmup:] != 0) & (st["overflowed"][warmup:] == 0)).sum())
         if g == 0:
             tcw0, st0 = tcw, st
         R = tcw[:, :, :3, :3]
@@ -209,7 +212,7 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
                     for k, d in enumerate(q["dets"][i]):
                         if o[i, j, k]["track_ok"]:
                             ob["max_abs_centre_error_m"] = max(ob["max_abs_centre_error_m"], float(np.abs(o[i, j, k]["tco"][:3] - d["pose7"][:3]).max()))
-    out.update(max_abs_position_error_m=err, untracked_frames=untracked, tracked_frames_timed=tracked_timed, seqs=seqs, tcw_group0=tcw0, stats_group0=st0, obj_group0=obj0,
+    out.update(max_abs_position_error_m=err, untracked_frames=untracked, tracked_frames_timed=tracked_timed, overflowed_frames=overflowed, seqs=seqs, tcw_group0=tcw0, stats_group0=st0, obj_group0=obj0,
                objects=ob if objects else None)
     for t in trks:
         t.close()
@@ -281,6 +284,75 @@ def _cpu_worker(job):
     return n, dt
 
 
+_ONE_THREAD_ENV = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS", "VECLIB_MAXIMUM_THREADS")
+
+
+def _physical_cores():
+    """physical cores of the host (distinct (package, core) pairs of the logical CPUs)"""
+    try:
+        seen = set()
+        base = "/sys/devices/system/cpu"
+        for d in os.listdir(base):
+            if d.startswith("cpu") and d[3:].isdigit():
+                t = os.path.join(base, d, "topology")
+                with open(os.path.join(t, "physical_package_id")) as f:
+                    pk = f.read().strip()
+                with open(os.path.join(t, "core_id")) as f:
+                    seen.add((pk, f.read().strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def _cpu_quota():
+    """CPUs this process may actually use: the scheduler affinity, cut by the cgroup's CPU-time quota (cpu.max) when there is one -
+    the GPU boxes of this pool show 256 logical CPUs and grant 16 CPUs of time"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            with open(path) as f:
+                q, per = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(per))))
+        except (OSError, ValueError):
+            pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _cpp_camera_chain_baseline(q, n=8):
+    """tests/cpp/odo_oracle_driver (pointslot_amd/host/StereoOdometry.h's OdoSequence with oracle/liboracle.so serving its requests) on the
+    first n frames of a generated sequence: the camera chain on all keypoints, one thread, image decode outside the timer."""
+    import subprocess
+    import tempfile
+    from pointslot_amd import sequence
+    exe = os.path.join(ROOT, "tests", "cpp", "odo_oracle_driver")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(exe + ".cpp"):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "pointslot_amd", "host"), "-I", os.path.join(ROOT, "include"), exe + ".cpp", "-o", exe,
+                               "-L", os.path.join(ROOT, "oracle"), "-loracle", "-L", os.path.join(ROOT, "pointslot_amd"), "-lpointslot_hip", "-pthread",
+                               "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,-rpath," + os.path.join(ROOT, "pointslot_amd"), "-Wl,-rpath-link,/opt/rocm/lib"])
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        sub = {k: (v[:n] if k in ("left", "right", "twc", "boxes", "masks", "dets") and hasattr(v, "__len__") else v) for k, v in q.items()}
+        sequence.write_pgm(os.path.join(d, "0000"), sub)
+        out = subprocess.run([exe, os.path.join(d, "0000")], capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-300:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("timing:")][-1].split()
+    frames, secs = int(line[1]), float(line[3])
+    tracked = sum(1 for l in out.stdout.splitlines() if l.startswith("frame") and ": ok" in l)
+    return {"value": frames / secs, "unit": "frames/s", "cores": 1, "kind": "port", "tracked_frames": tracked,
+            "sample": "%d frames of the first generated sequence through the C++ host loop (OdoSequence) over the CPU checker: camera chain on all "
+                      "keypoints (no object chain), one thread, no Python in the loop" % frames}
+
+
 def cpu_tracking_baseline(seqs, tcw_gpu, obj_gpu, objects, budget_s=10.0):
     """The CPU restatement of the same loop (tests/oracle_backend.py over oracle/liboracle.so) on the sequences the GPU just tracked:
     (a) one core, the reference's per-frame call structure - the `cpu_baseline` and the parity spot check of the timed run (sequence j of
@@ -319,7 +391,10 @@ def cpu_tracking_baseline(seqs, tcw_gpu, obj_gpu, objects, budget_s=10.0):
     threaded = {"value": t_frames / t_spent, "unit": "frames/s", "cores": 2, "kind": "port",
                 "sample": "%d frames, the reference's thread model: ExtractORB left / right on two threads, the two cv::ORB detectors of ExtractObjORB on two "
                           "threads, everything else on the tracking thread (src/Frame.cc:709-714,2648-2651)" % t_frames}
-    # (c) all cores: independent sequence slices, one single-threaded process each
+    # (c) all cores: independent sequence slices, one single-threaded process each.  The workers' numeric libraries are pinned to one
+    # thread (numpy's BLAS pool otherwise starts a thread per core in every one of them), the pool is as large as the host has
+    # PHYSICAL cores, it is warm before the timer starts (imports, library load, one frame), and the scaling against the one-core
+    # figure is part of the result.
     allc = None
     try:
         import multiprocessing as mp
@@ -327,22 +402,50 @@ def cpu_tracking_baseline(seqs, tcw_gpu, obj_gpu, objects, budget_s=10.0):
         import tempfile
         from concurrent.futures import ProcessPoolExecutor
         ncpu = os.cpu_count() or 1
-        nproc = max(1, min(ncpu, 192))
+        phys = _physical_cores() or ncpu
+        quota = _cpu_quota()
+        nproc = max(1, min(phys, quota, 256))
         n_all = 5
         slim = [{kk2: (q[kk2][:n_all] if kk2 in ("left", "right", "masks", "dets") else q[kk2]) for kk2 in ("left", "right", "masks", "dets", "K", "bf")} for q in seqs[:8]]
         fd, path = tempfile.mkstemp(suffix=".pkl", dir="/tmp")
         with os.fdopen(fd, "wb") as f:
             pickle.dump(slim, f, protocol=4)
-        with ProcessPoolExecutor(max_workers=nproc, mp_context=mp.get_context("spawn")) as pool:
-            list(pool.map(_cpu_worker, [(path, i, 1, objects) for i in range(nproc)]))          # start the workers (imports, library load)
-            t0 = time.perf_counter()
-            res = list(pool.map(_cpu_worker, [(path, i, n_all, objects) for i in range(nproc)]))
-            wall = time.perf_counter() - t0
+        saved = {k2: os.environ.get(k2) for k2 in _ONE_THREAD_ENV}
+        os.environ.update({k2: "1" for k2 in _ONE_THREAD_ENV})     # inherited by the spawned workers
+        try:
+            with ProcessPoolExecutor(max_workers=nproc, mp_context=mp.get_context("spawn")) as pool:
+                list(pool.map(_cpu_worker, [(path, i, 1, objects) for i in range(nproc)]))          # start the workers (imports, library load)
+                t0 = time.perf_counter()
+                res = list(pool.map(_cpu_worker, [(path, i, n_all, objects) for i in range(nproc)]))
+                wall = time.perf_counter() - t0
+        finally:
+            for k2, v2 in saved.items():
+                if v2 is None:
+                    os.environ.pop(k2, None)
+                else:
+                    os.environ[k2] = v2
         os.unlink(path)
-        allc = {"value": sum(r[0] for r in res) / wall, "unit": "frames/s", "cores": nproc, "kind": "port", "nproc_host": ncpu,
-                "sample": "%d processes x %d frames, one independent sequence slice each (single-threaded chains side by side)" % (nproc, n_all)}
+        per = sorted(r[0] / r[1] for r in res)
+        val = sum(r[0] for r in res) / wall
+        allc = {"value": val, "unit": "frames/s", "cores": nproc, "kind": "port", "logical_cpus": ncpu, "physical_cores": phys, "cpu_quota_of_this_process": quota,
+                "per_process_frames_per_s": {"min": per[0], "median": per[len(per) // 2], "max": per[-1]},
+                "scaling_efficiency_vs_one_core": val / (nproc * one["value"]),
+                "sample": "%d single-threaded processes (one per core this process may use: physical cores cut by the cgroup's CPU quota - r03's 192 "
+                          "processes shared the 16 CPUs of time the box grants; OMP / OpenBLAS / MKL threads = 1) x %d frames, one independent sequence slice "
+                          "each, pool warm before the timer; efficiency = value / (processes x the one-core figure): what is missing is the host, not the "
+                          "chain - the per-process rates show whether the cores slow each other down (shared L3 / memory bandwidth / clocks under an "
+                          "all-core load)" % (nproc, n_all)}
     except Exception as e:   # noqa: BLE001
         allc = {"error": "%s: %s" % (type(e).__name__, e)}
+    # (d) the camera chain through the C++ host state machine with the same checker behind it: no Python in the loop
+    cpp = None
+    try:
+        cpp = _cpp_camera_chain_baseline(seqs[0])
+    except Exception as e:   # noqa: BLE001
+        cpp = {"error": "%s: %s" % (type(e).__name__, e)}
+    one["note"] = ("a scalar port: ~90 % of this time is oracle C++ (ORBextractor 49 ms / image, cv::ORB 36 ms / image), ~10 % Python glue; the real "
+                   "OpenCV (SIMD FAST / resize / blur) would be faster - it cannot be built in this image")
+    one["camera_chain_cpp_driver"] = cpp
     return one, threaded, allc, worst, checked, obj_checked, obj_bad
 
 
@@ -408,7 +511,7 @@ def orb_leg(rank, local_rank, barrier, with_cpu):
     return out
 
 
-def optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak):
+def optimizer_legs(rank, world, local_rank, guard, with_cpu, fp64_peak):
     """BASELINE configs[2] and [3]: per-frame pose optimisation (batch of 64 frames x 2000 stereo edges) and the object local BA
     (8 objects x 50 keyframes x 300 points, SURVEY.md 8d's own perturbation: +-0.3 m / +-5 deg yaw / +-0.1 m).  Frames / objects
     are independent units and are sharded over the ranks; times are max-over-ranks."""
@@ -429,8 +532,8 @@ def optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak):
     opt.enable_trace(False)
     iters = sum(len(t) for t in traces)
     trials = sum(int(t[:, 2].sum()) for t in traces)
-    wall = parallel.max_over_ranks(dist, wall, RED_DEV)
-    kern_ms = parallel.max_over_ranks(dist, kern_ms, RED_DEV)
+    wall = guard.max(wall)
+    kern_ms = guard.max(kern_ms)
     # roofline of the persistent kernel (58 KB per frame and LM iteration in the streaming model; every damping
     # trial re-reads the edges once more): the kernel is latency-bound, the fraction says by how much
     algo = (iters + trials) * ALGO_BYTES_PER_FRAME_POSE_ITER
@@ -456,12 +559,12 @@ def optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak):
     else:
         ms, iters, trials, sum_trials = 0.0, 1, 1, 0
         ms1, iters1 = 0.0, 1
-    ms = parallel.max_over_ranks(dist, ms, RED_DEV)
-    iters = int(parallel.max_over_ranks(dist, iters, RED_DEV))
+    ms = guard.max(ms)
+    iters = int(guard.max(iters))
     ba = {"workload": "BASELINE configs[3]: 8 objects x 50 ObjectKeyFrames x 300 MapObjectPoints (15 000 stereo edges each), Schur LM 5 + 10 "
                       "iterations, SURVEY 8d perturbation (+-0.3 m, +-5 deg yaw, points +-0.1 m)", "objects": 8, "gpu_ms_per_batch": ms,
-          "lm_iterations": iters, "lm_trials": int(parallel.max_over_ranks(dist, trials, RED_DEV)), "ms_per_iter": ms / max(iters, 1),
-          "ms_per_iter_1_object": parallel.max_over_ranks(dist, ms1 / iters1, RED_DEV)}
+          "lm_iterations": iters, "lm_trials": int(guard.max(trials)), "ms_per_iter": ms / max(iters, 1),
+          "ms_per_iter_1_object": guard.max(ms1 / iters1)}
     if graphs and ms > 0:
         # every damping trial is one linearise + Schur + solve (103 MFLOP per object): FP64 rate over the batch
         flop = sum_trials * ALGO_FLOP_PER_OBJECT_BA_ITER
@@ -470,6 +573,8 @@ def optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak):
                           "frac": ach / fp64_peak if fp64_peak else None, "traffic": None, "algorithmic_flop_per_batch": flop,
                           "peak_source": "v_mfma_f64_16x16x4_f64 microbenchmark measured in this run (ps_debug_mfma_f64_peak)",
                           "note": "latency-bound: one object's reduced system is 300 unknowns; see DESIGN.md section 7"}
+    ba["objects_per_gpu"] = len(mine)
+    ba["n_gpus"] = world   # objects are the units: 8 -> 4 / 2 / 1 per GPU at 2 / 4 / 8 GPUs, gpu_ms_per_batch is the slowest rank's
     if graphs and world == 1:
         # where the latency floor ends: the same schedule for 1, 8, 16, 32, 64 independent objects in one batch (seeds 0x51070004 + j)
         scale = {}
@@ -640,7 +745,7 @@ def next_rows_leg(local_rank):
     return out
 
 
-def pcie_leg(rank, world, local_rank, dist, seqs, n_seq, n_groups, barrier):
+def pcie_leg(rank, world, local_rank, guard, seqs, n_seq, n_groups, barrier):
     """The same lockstep loop with the images in page-locked HOST memory (ps_tracker_step): every frame's 2 x 0.47 MB cross PCIe
     inside the timed region.  This is the rate a caller with host buffers sees; it is never `value`."""
     from pointslot_amd import parallel
@@ -675,7 +780,7 @@ def pcie_leg(rank, world, local_rank, dist, seqs, n_seq, n_groups, barrier):
     for t in trks:
         t.sync()
     barrier()
-    dt = parallel.max_over_ranks(dist, time.perf_counter() - t0, RED_DEV)
+    dt = guard.max(time.perf_counter() - t0)
     untracked = sum(int((t.fetch()[1]["tracked"] == 0).sum()) for t in trks)
     for t in trks:
         t.close()
@@ -686,7 +791,7 @@ def pcie_leg(rank, world, local_rank, dist, seqs, n_seq, n_groups, barrier):
             "host_to_device_GBps_per_gpu": per_group * n_groups * (n - warm) * 2 * pitch / dt / 1e9}
 
 
-def config5_leg(rank, world, local_rank, dist, n_frames=154):
+def config5_leg(rank, world, local_rank, guard, n_frames=154):
     """BASELINE configs[4]: one generated 154-frame stereo sequence per GPU (seed = rank) through the
     tracking chain with a single frame in flight (ps_tracker with one sequence: the latency of the chain, not its throughput),
     then ONE gather of the [154][12] float32 trajectories — the only collective of the workflow, timed separately."""
@@ -714,17 +819,16 @@ def config5_leg(rank, world, local_rank, dist, n_frames=154):
             twc = -(Rwc @ tcw[k, 0, :3, 3])
             traj[k] = np.concatenate([Rwc, twc[:, None]], 1).reshape(12)      # System::SaveTrajectoryKITTI row
             err = max(err, float(np.abs(twc - seq["twc"][k][:, 3]).max()))
-    if dist is not None:
-        dist.barrier()
+    guard.barrier()
     t0 = time.perf_counter()
-    allt = parallel.gather_trajectories(dist, traj, RED_DEV)
+    allt = guard.gather_trajectories(traj)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t0) * 1e3
-    ms = parallel.max_over_ranks(dist, dt / (n_frames - 1) * 1e3, RED_DEV)
+    ms = guard.max(dt / (n_frames - 1) * 1e3)
     return {"workload": "BASELINE configs[4]: %d generated 1242x375 stereo sequence(s) x %d frames, one per GPU, one frame in flight per sequence" % (world, n_frames),
             "ms_per_frame": ms, "frames_per_s_all_sequences": world * 1e3 / ms, "tracked": int(st["tracked"].sum()),
-            "max_abs_position_error_m": parallel.max_over_ranks(dist, err, RED_DEV), "trajectory_gather_ms": gather_ms,
+            "max_abs_position_error_m": guard.max(err), "trajectory_gather_ms": gather_ms,
             "gathered": [list(a.shape) for a in allt]}
 
 
@@ -789,10 +893,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # (a collective that a dead peer never joins ends after ten minutes instead of the default thirty)
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=10))
 
     def barrier():
         torch.cuda.synchronize()
@@ -801,6 +907,15 @@ def main():
         torch.cuda.synchronize()
 
     from pointslot_amd import parallel
+    # the secondary legs' collectives go through a guard: a leg that raises on ONE rank (before, between or after its collectives) comes
+    # back as an error entry on EVERY rank and the next leg runs - nobody is left waiting inside a collective for the launcher's timeout
+    guard = parallel.Guard(dist, RED_DEV)
+
+    def gbarrier():
+        torch.cuda.synchronize()
+        guard.barrier()
+        torch.cuda.synchronize()
+
     with_cpu = not args.no_cpu and rank == 0 and world == 1
     objects = not args.no_objects
     head = tracking_leg(rank, local_rank, args.texture, args.steps, args.warmup, args.sequences, args.groups, barrier, scene=args.scene,
@@ -809,6 +924,7 @@ def main():
     untracked = int(parallel.max_over_ranks(dist, head["untracked_frames"], RED_DEV))
     err = parallel.max_over_ranks(dist, head["max_abs_position_error_m"], RED_DEV)
     tracked_timed = parallel.sum_over_ranks(dist, head["tracked_frames_timed"], RED_DEV)
+    overflowed = int(parallel.sum_over_ranks(dist, head["overflowed_frames"], RED_DEV))
 
     secondary = None
     if not args.no_secondary:
@@ -816,41 +932,55 @@ def main():
         osteps = min(args.steps, 10)
 
         def camera_only():
-            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, barrier, scene=args.scene,
+            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, gbarrier, scene=args.scene,
                              n_distinct=args.distinct, objects=False, seqs=head["seqs"])
-            odt = parallel.max_over_ranks(dist, o["dt"], RED_DEV)
+            odt = guard.max(o["dt"])
             return {"workload": "the headline loop without masks / detections: the camera chain alone on all keypoints (r02's headline definition)",
                     "tracked_frames_per_s": world * o["frames_per_step_per_gpu"] * osteps / odt, "ms_per_step": odt / osteps * 1e3,
                     "untracked_frames": o["untracked_frames"], "max_abs_position_error_m": o["max_abs_position_error_m"],
                     "stage_ms_group0": {k: round(v, 5) for k, v in o["stage_ms_group0"].items()}}
 
         def lateral_scene():
-            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, barrier, scene="lateral",
+            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, gbarrier, scene="lateral",
                              n_distinct=4, objects=objects)
-            odt = parallel.max_over_ranks(dist, o["dt"], RED_DEV)
+            odt = guard.max(o["dt"])
             return {"workload": "the headline loop on r02's scene: lateral translation over a ruled surface, two moving boxes, 4 distinct sequences",
                     "tracked_frames_per_s": world * o["frames_per_step_per_gpu"] * osteps / odt, "ms_per_step": odt / osteps * 1e3,
                     "untracked_frames": o["untracked_frames"], "max_abs_position_error_m": o["max_abs_position_error_m"], "objects": o["objects"],
                     "stage_ms_group0": {k: round(v, 5) for k, v in o["stage_ms_group0"].items()}}
 
-        # a failure of a secondary leg must not take the bench line down; every rank runs every leg (they hold barriers), and a leg
-        # that failed on one rank is skipped... by all of them at the next barrier only if it fails before its first collective: the
-        # launcher's timeout (parallel.launch_ranks) bounds the rest
+        def six_objects():
+            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, gbarrier, scene="drive",
+                             n_distinct=8, objects=True, n_objects=6)
+            odt = guard.max(o["dt"])
+            return {"workload": "sensitivity of the headline to the number of objects: the drive scene with SIX objects per sequence (three ahead, three at the "
+                                "sides; the headline's scenes carry two), 8 distinct sequences, tracker created for %d detections per frame" % MAX_OBJECTS,
+                    "tracked_frames_per_s": world * o["frames_per_step_per_gpu"] * osteps / odt, "ms_per_step": odt / osteps * 1e3,
+                    "untracked_frames": o["untracked_frames"], "max_abs_position_error_m": o["max_abs_position_error_m"], "objects": o["objects"],
+                    "stage_ms_group0": {k: round(v, 5) for k, v in o["stage_ms_group0"].items()}}
+
+        # a failure of a secondary leg must not take the bench line down, and with several ranks it must not leave the others inside a
+        # collective: every rank runs every leg under the guard (parallel.Guard; tests/test_parallel_cpu.py fails one rank of two at
+        # every kind of point)
         fp64_peak = fp64_mfma_peak(local_rank)
+        failed_legs = []
         for name, fn in (("camera_chain_only", camera_only),
                          ("lateral_scene", lateral_scene),
-                         ("orb_extraction", lambda: orb_leg(rank, local_rank, barrier, with_cpu)),
-                         ("optimizers", lambda: optimizer_legs(rank, world, local_rank, dist, with_cpu, fp64_peak)),
-                         ("lockstep_tracking_host_images", lambda: pcie_leg(rank, world, local_rank, dist, head["seqs"], args.sequences, args.groups, barrier)),
-                         ("sequence_tracking", lambda: config5_leg(rank, world, local_rank, dist))):
-            try:
-                r = fn()
-                if name == "optimizers":
-                    secondary.update(r)
-                else:
-                    secondary[name] = r
-            except Exception as e:   # noqa: BLE001
-                secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                         ("six_objects_per_sequence", six_objects),
+                         ("orb_extraction", lambda: orb_leg(rank, local_rank, gbarrier, with_cpu)),
+                         ("optimizers", lambda: optimizer_legs(rank, world, local_rank, guard, with_cpu, fp64_peak)),
+                         ("lockstep_tracking_host_images", lambda: pcie_leg(rank, world, local_rank, guard, head["seqs"], args.sequences, args.groups, gbarrier)),
+                         ("sequence_tracking", lambda: config5_leg(rank, world, local_rank, guard))):
+            r = guard.run(fn)
+            if isinstance(r, dict) and "error" in r and len(r) == 1:
+                failed_legs.append(name)
+                secondary[name] = r
+            elif name == "optimizers":
+                secondary.update(r)
+            else:
+                secondary[name] = r
+        if failed_legs:
+            secondary["failed_legs"] = failed_legs
         if rank == 0:
             for name, fn in (("object_kernels", lambda: object_legs(local_rank, fp64_peak)), ("next_rows", lambda: next_rows_leg(local_rank))):
                 try:
@@ -919,7 +1049,7 @@ def main():
                                    % (S, head["n_distinct"], " and object chain (cv::ORB object features, object stereo, SearchByBruceMatching, CFSE3 x 2, object SearchByProjection)" if objects else ""),
                        "sequences_per_gpu": S, "lockstep_groups_per_gpu": args.groups, "images_per_step_per_gpu": 2 * S, "object_chain": objects, "scene": args.scene,
                        "parallelism": "sequences sharded over %d GPU(s), no collective in the data path" % world},
-            "tracking_checks": {"untracked_frames": untracked, "max_abs_position_error_m": err, "distinct_sequences_per_gpu": head["n_distinct"],
+            "tracking_checks": {"untracked_frames": untracked, "frames_with_overflowed_search_windows": overflowed, "max_abs_position_error_m": err, "distinct_sequences_per_gpu": head["n_distinct"],
                                 "objects": head["objects"],
                                 "checked": "every frame of every sequence: tracked flag, position against the generator's ground truth; objects: "
                                            "detections with a MapObject / with mbTrackOK, cuboid centres of the distinct sequences against the labels"},

@@ -84,6 +84,65 @@ def gather_trajectories(dist, local, device="cpu"):
     return [o[:int(c.item())].cpu().numpy() for o, c in zip(outs, counts)]
 
 
+class PeerFailed(RuntimeError):
+    """another rank reported a failure at the handshake in front of a collective"""
+
+
+class Guard:
+    """Collectives of a leg that may fail on ONE rank without leaving the others waiting inside a collective.
+
+    Every collective issued through the guard is preceded by a handshake (an all-reduce MIN of an ok flag).  A rank whose leg
+    raises does exactly one handshake with ok = 0 (at the end of `run`); the others meet it at their next handshake - the one in
+    front of their next collective, or the one at the end of their own `run` - learn of the failure there, abandon the leg without
+    a further handshake, and every rank carries on with the next leg: the handshake counts of all ranks stay in step whatever the
+    point of failure.  With dist = None (one rank) it only catches the exception."""
+
+    def __init__(self, dist, device="cpu"):
+        self.dist, self.device = dist, device
+
+    def _handshake(self, ok):
+        if self.dist is None:
+            return bool(ok)
+        import torch
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def check(self):
+        if not self._handshake(True):
+            raise PeerFailed("a peer rank failed in this leg")
+
+    def max(self, value):
+        self.check()
+        return max_over_ranks(self.dist, value, self.device)
+
+    def sum(self, value):
+        self.check()
+        return sum_over_ranks(self.dist, value, self.device)
+
+    def gather_trajectories(self, local):
+        self.check()
+        return gather_trajectories(self.dist, local, self.device)
+
+    def barrier(self):
+        self.check()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def run(self, fn):
+        """fn() -> result, or {"error": ...} on every rank when any rank failed inside it"""
+        try:
+            r = fn()
+        except PeerFailed as e:
+            return {"error": "PeerFailed: %s" % e}
+        except Exception as e:   # noqa: BLE001
+            self._handshake(False)
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+        if not self._handshake(True):
+            return {"error": "PeerFailed: a peer rank failed in this leg"}
+        return r
+
+
 def launch_ranks(script, argv, n_ranks, timeout=None, extra_env=None):
     """`python bench.py --gpus N` without a launcher: starts N fresh child processes of `script` (one per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, the layout `python -m torch.distributed.run --nnodes=1

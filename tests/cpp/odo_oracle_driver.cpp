@@ -2,6 +2,9 @@
 // checker (oracle/liboracle.so) serving its requests instead of the GPU library.  Lets the CPU test suite exercise the C++ state
 // machine (request preparation, match application, outlier handling, motion model) against the Python twin of the same loop.
 //   usage: odo_oracle_driver path_to_sequence   -> path_to_sequence/CameraTrajectoryOracle.txt
+// Also bench.py's camera-chain CPU baseline without Python in the loop: every image is decoded first, the loop is timed on its own
+// (last line: "timing: <frames> frames <seconds> s").
+#include <chrono>
 #include <cstdio>
 #include "StereoOdometry.h"
 #include "../../examples/kitti_io.h"
@@ -57,15 +60,22 @@ int main(int argc, char** argv) {
   std::vector<float> sf(8), isf(8), s2(8), is2(8);
   std::vector<int> quota(8), umax(16);
   orc_orb_tables(exl, sf.data(), isf.data(), s2.data(), is2.data(), quota.data(), umax.data());
-  std::vector<unsigned char> L, R;
   int w = 0, h = 0;
-  if (!LoadPGM(vl[0], L, w, h)) return 1;
+  {
+    std::vector<unsigned char> first;
+    if (!LoadPGM(vl[0], first, w, h)) return 1;
+  }
   OdoCamera cam((float)calib["Camera.fx"], (float)calib["Camera.fy"], (float)calib["Camera.cx"], (float)calib["Camera.cy"], (float)calib["Camera.bf"], w, h,
                 (float)calib["ThDepth"], sf, is2);
   OdoSequence odo(&cam);
+  std::vector<std::vector<unsigned char>> allL(vl.size()), allR(vl.size());
   for (size_t ni = 0; ni < vl.size(); ni++) {
     int wr, hr;
-    if (!LoadPGM(vl[ni], L, w, h) || !LoadPGM(vr[ni], R, wr, hr)) return 1;
+    if (!LoadPGM(vl[ni], allL[ni], w, h) || !LoadPGM(vr[ni], allR[ni], wr, hr)) return 1;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (size_t ni = 0; ni < vl.size(); ni++) {
+    const std::vector<unsigned char>&L = allL[ni], &R = allR[ni];
     std::unique_ptr<OdoFrame> F(new OdoFrame);
     const int n = orc_orb_run(exl, L.data(), w, h, w);
     orc_orb_run(exr, R.data(), w, h, w);
@@ -85,7 +95,9 @@ int main(int argc, char** argv) {
     std::printf("frame %zu: %s matches %d map %d local inliers %d\n", ni, odo.lastFrameTracked ? "ok" : "not tracked", odo.lastMatches, odo.lastMapMatches,
                 odo.lastLocalInliers);
   }
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   SaveTrajectoryKITTI(seq + "/CameraTrajectoryOracle.txt", odo.trajectory);
+  std::printf("timing: %zu frames %.6f s\n", vl.size(), secs);
   orc_orb_destroy(exl); orc_orb_destroy(exr);
   return 0;
 }

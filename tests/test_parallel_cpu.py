@@ -59,6 +59,51 @@ def test_gloo_world2_gather_and_timing(tmp_path):
         assert "rank %d ok" % r in o
 
 
+GUARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+from pointslot_amd import parallel
+dist, rank, world, local = parallel.init_from_env("gloo")
+g = parallel.Guard(dist)
+mode = sys.argv[1]
+def leg():
+    a = g.max(1.0 + rank)                        # collective 1
+    if mode == "before" and rank == 1: raise ValueError("boom before the first collective")
+    if mode == "middle" and rank == 1: raise ValueError("boom between two collectives")
+    b = g.sum(2.0)                               # collective 2
+    if mode == "end" and rank == 0: raise ValueError("boom after the last collective")
+    return {"a": a, "b": b}
+def leg_first():
+    if mode == "before" and rank == 1: raise ValueError("boom before the first collective")
+    return {"a": g.max(1.0 + rank), "b": g.sum(2.0)}
+r = g.run(leg_first if mode == "before" else leg)
+if mode == "none":
+    assert r == {"a": 2.0, "b": 4.0}, r
+else:
+    assert "error" in r, r                       # EVERY rank learns of the failure ...
+after = g.run(lambda: g.max(10.0 + rank))        # ... and the next leg's collectives line up again
+assert after == 11.0, after
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", r)
+'''
+
+
+def test_a_leg_that_fails_on_one_rank_fails_on_all_and_the_next_leg_runs(tmp_path):
+    """bench.py's secondary legs: a rank-local exception before, between or after the collectives of a leg must neither hang the other
+    ranks nor desynchronise the following legs (parallel.Guard)."""
+    script = tmp_path / "guard_worker.py"
+    script.write_text(GUARD_WORKER % ROOT)
+    for k, mode in enumerate(("none", "before", "middle", "end")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29541 + k), WORLD_SIZE="2")
+        procs = [subprocess.Popen([sys.executable, str(script), mode], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                 for r in range(2)]
+        outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+        for r, (p, o) in enumerate(zip(procs, outs)):
+            assert p.returncode == 0, (mode, o)
+            assert "rank %d ok" % r in o, (mode, o)
+
+
 def _bench(args, **env):
     e = dict(os.environ, PS_BENCH_LAUNCH_ONLY="1", **env)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
