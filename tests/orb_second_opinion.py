@@ -341,3 +341,193 @@ def cv_harris(level_img, xs, ys):
         a, b, c = np.float32(int((Ix * Ix).sum())), np.float32(int((Iy * Iy).sum())), np.float32(int((Ix * Iy).sum()))
         out[n] = (a * b - c * c - np.float32(0.04) * (a + b) * (a + b)) * s4
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# r04: the stages behind the keypoint selection, again from the definitions: IC_Angle + fastAtan2, the steered BRIEF
+# comparisons, Frame::ComputeStereoMatches, cv::RNG.
+# ------------------------------------------------------------------------------------------------------------------------------------
+HALF_PATCH = 15
+
+
+def umax_table():
+    """ORBextractor.cc:452-470: the half-widths of the 31-pixel disc's rows, from the circle equation and its mirror-symmetric completion"""
+    umax = np.zeros(HALF_PATCH + 1, np.int64)
+    vmax = int(np.floor(HALF_PATCH * np.sqrt(2.0) / 2 + 1))
+    vmin = int(np.ceil(HALF_PATCH * np.sqrt(2.0) / 2))
+    hp2 = HALF_PATCH * HALF_PATCH
+    for v in range(vmax + 1):
+        umax[v] = int(cv_round(np.sqrt(float(hp2 - v * v))))
+    v0 = 0
+    for v in range(HALF_PATCH, vmin - 1, -1):
+        while umax[v0] == umax[v0 + 1]:
+            v0 += 1
+        umax[v] = v0
+        v0 += 1
+    return umax
+
+
+def fast_atan2_deg(y, x):
+    """OpenCV's scalar fastAtan2 (degrees) in IEEE float32, operation by operation: a 7th-order odd polynomial in min / max of |x|, |y|
+    (+ DBL_EPSILON rounded to float in the denominator), then the octant and quadrant reflections"""
+    f = np.float32
+    p1 = f(0.9997878412794807) * f(180.0 / np.pi)
+    p3 = f(-0.3258083974640975) * f(180.0 / np.pi)
+    p5 = f(0.1555786518463281) * f(180.0 / np.pi)
+    p7 = f(-0.04432655554792128) * f(180.0 / np.pi)
+    y = np.asarray(y, f); x = np.asarray(x, f)
+    ax, ay = np.abs(x), np.abs(y)
+    eps = f(2.220446049250313e-16)
+    big, small = np.maximum(ax, ay), np.minimum(ax, ay)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        c = (small / (big + eps)).astype(f)
+    c2 = (c * c).astype(f)
+    a = ((((((p7 * c2).astype(f) + p5).astype(f) * c2).astype(f) + p3).astype(f) * c2).astype(f) + p1).astype(f)
+    a = (a * c).astype(f)
+    a = np.where(ax >= ay, a, (f(90.0) - a).astype(f)).astype(f)
+    a = np.where(x < 0, (f(180.0) - a).astype(f), a).astype(f)
+    a = np.where(y < 0, (f(360.0) - a).astype(f), a).astype(f)
+    return a
+
+
+def ic_angles(padded_plane, xs, ys, border=EDGE):
+    """IC_Angle (ORBextractor.cc:77-104) as two masked sums over the 31 x 31 neighbourhood: m10 = sum u I, m01 = sum v I over the disc"""
+    um = umax_table()
+    v, u = np.mgrid[-HALF_PATCH:HALF_PATCH + 1, -HALF_PATCH:HALF_PATCH + 1]
+    disc = np.abs(u) <= um[np.abs(v)]
+    out = np.zeros(len(xs), np.float32)
+    m01s = np.zeros(len(xs), np.int64); m10s = np.zeros(len(xs), np.int64)
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        cx, cy = int(cv_round(float(x))) + border, int(cv_round(float(y))) + border
+        patch = padded_plane[cy - HALF_PATCH:cy + HALF_PATCH + 1, cx - HALF_PATCH:cx + HALF_PATCH + 1].astype(np.int64)
+        m10s[i] = int((patch * u)[disc].sum()); m01s[i] = int((patch * v)[disc].sum())
+    out = fast_atan2_deg(m01s.astype(np.float32), m10s.astype(np.float32))
+    return out
+
+
+def steered_brief(blurred_level, xs, ys, angles_deg, pattern):
+    """computeOrbDescriptor (ORBextractor.cc:108-147): the 256 comparisons of the pattern rotated by the keypoint angle - cos / sin of
+    the float angle in radians, every product and sum rounded to float32, cvRound = round-half-to-even"""
+    f = np.float32
+    pat = np.asarray(pattern, np.int64).reshape(256, 2, 2)            # [bit][tap 0 / 1][x, y]
+    out = np.zeros((len(xs), 32), np.uint8)
+    factor = f(np.pi / 180.0)
+    for i, (x, y, ang) in enumerate(zip(xs, ys, angles_deg)):
+        rad = f(f(ang) * factor)
+        a, b = f(np.cos(np.float64(rad))), f(np.sin(np.float64(rad)))
+        px = pat[:, :, 0].astype(f); py = pat[:, :, 1].astype(f)
+        yy = np.rint(((px * b).astype(f) + (py * a).astype(f)).astype(f)).astype(np.int64)
+        xx = np.rint(((px * a).astype(f) - (py * b).astype(f)).astype(f)).astype(np.int64)
+        cx, cy = int(cv_round(float(x))), int(cv_round(float(y)))
+        vals = blurred_level[cy + yy, cx + xx]                          # [256][2]
+        bits = (vals[:, 0] < vals[:, 1]).astype(np.uint8)
+        out[i] = np.packbits(bits.reshape(32, 8), axis=1, bitorder="little")[:, 0]
+    return out
+
+
+def _popcount_rows(a, b):
+    return np.unpackbits(a ^ b, axis=-1).sum(-1)
+
+
+def stereo_matches(kps_l, desc_l, kps_r, desc_r, pyr_l, pyr_r, scale, inv_scale, mb, mbf):
+    """Frame::ComputeStereoMatches (/root/reference/src/Frame.cc:2142-2316) read off the reference: the row table of the right keypoints,
+    best Hamming distance inside the disparity range and one octave, the 11 x 11 L1 slide over +-5 columns with `int bestDist` receiving
+    the float SAD, the parabola, the disparity clamp (in DOUBLE where the reference subtracts the literal 0.01), the 1.5f * 1.4f * median cut.
+    kps: structured arrays with x, y, octave.  pyr: the (unpadded) level images."""
+    f = np.float32
+    n = len(kps_l)
+    u_right = np.full(n, -1.0, f); depth = np.full(n, -1.0, f)
+    n_rows = pyr_l[0].shape[0]
+    rows = [[] for _ in range(n_rows)]
+    for ir in range(len(kps_r)):
+        ky = f(kps_r["y"][ir]); r = f(f(2.0) * f(scale[int(kps_r["octave"][ir])]))
+        for yi in range(int(np.floor(f(ky - r))), int(np.ceil(f(ky + r))) + 1):
+            if 0 <= yi < n_rows:
+                rows[yi].append(ir)
+    min_z, min_d = f(mb), f(0)
+    max_d = f(f(mbf) / min_z)
+    th_orb = (100 + 50) // 2
+    dist_idx = []
+    xr = kps_r["x"].astype(f); octr = kps_r["octave"].astype(np.int64)
+    for il in range(n):
+        ul, vl, lev = f(kps_l["x"][il]), f(kps_l["y"][il]), int(kps_l["octave"][il])
+        cand = np.asarray(rows[int(vl)], np.int64)
+        if len(cand) == 0:
+            continue
+        min_u, max_u = f(ul - max_d), f(ul - min_d)
+        if max_u < 0:
+            continue
+        ok = (octr[cand] >= lev - 1) & (octr[cand] <= lev + 1) & (xr[cand] >= min_u) & (xr[cand] <= max_u)
+        cand = cand[ok]
+        best_dist, best_r = 100, 0
+        if len(cand):
+            d = _popcount_rows(desc_r[cand], desc_l[il][None, :])
+            k = int(np.argmin(d))                                       # the first smallest: `dist < bestDist` keeps the earliest
+            if d[k] < best_dist:
+                best_dist, best_r = int(d[k]), int(cand[k])
+        if best_dist >= th_orb:
+            continue
+        ur0 = xr[best_r]
+        sf = f(inv_scale[lev])
+        su_l = f(np.floor(abs(f(ul * sf)) + 0.5) * np.sign(f(ul * sf)))   # round(): half away from zero
+        sv_l = f(np.floor(abs(f(vl * sf)) + 0.5) * np.sign(f(vl * sf)))
+        su_r0 = f(np.floor(abs(f(ur0 * sf)) + 0.5) * np.sign(f(ur0 * sf)))
+        w = L = 5
+        il_img, ir_img = pyr_l[lev], pyr_r[lev]
+        cy, cxl = int(sv_l), int(su_l)
+        iniu, endu = f(su_r0 + L - w), f(su_r0 + L + w + 1)
+        if iniu < 0 or endu >= ir_img.shape[1]:
+            continue
+        pl = il_img[cy - w:cy + w + 1, cxl - w:cxl + w + 1].astype(f)
+        pl = pl - pl[w, w]
+        best_s, best_inc = 2 ** 31 - 1, 0
+        dists = np.zeros(2 * L + 1, f)
+        for inc in range(-L, L + 1):
+            cxr = int(f(su_r0 + inc))
+            pr = ir_img[cy - w:cy + w + 1, cxr - w:cxr + w + 1].astype(f)
+            pr = pr - pr[w, w]
+            dist = f(np.abs(pl - pr).astype(np.float64).sum())           # cv::norm accumulates in double; the values are integers
+            if dist < best_s:
+                best_s, best_inc = int(dist), inc
+            dists[L + inc] = dist
+        if best_inc == -L or best_inc == L:
+            continue
+        d1, d2, d3 = dists[L + best_inc - 1], dists[L + best_inc], dists[L + best_inc + 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta = f(f(d1 - d3) / f(f(2.0) * f(f(d1 + d3) - f(f(2.0) * d2))))
+        if not (delta >= -1 and delta <= 1):                              # (a NaN parabola passes `deltaR<-1 || deltaR>1` in C++ ...)
+            if not np.isnan(delta):
+                continue
+        best_ur = f(f(scale[lev]) * f(f(su_r0 + f(best_inc)) + delta))
+        disparity = f(ul - best_ur)
+        if disparity >= min_d and disparity < max_d:                      # (... and fails here)
+            if disparity <= 0:
+                disparity = f(0.01)
+                best_ur = f(np.float64(ul) - 0.01)
+            depth[il] = f(f(mbf) / disparity); u_right[il] = best_ur
+            dist_idx.append((best_s, il))
+    if not dist_idx:
+        return 0, u_right, depth
+    dist_idx.sort()
+    median = f(dist_idx[len(dist_idx) // 2][0])
+    th = f(f(f(1.5) * f(1.4)) * median)
+    kept = len(dist_idx)
+    for s, il in reversed(dist_idx):
+        if s < th:
+            break
+        u_right[il] = -1; depth[il] = -1; kept -= 1
+    return kept, u_right, depth
+
+
+def cv_rng_closed_form(n_draws, state0=0xFFFFFFFF):
+    """cv::RNG's multiply-with-carry stream WITHOUT iterating its update rule: with b = 2^32 and a = 4164903690 the 64-bit state
+    s = carry * b + x satisfies b * s' = s (mod a b - 1), so s_k = s_0 * b^-k mod (a b - 1); the k-th output is s_k mod 2^32."""
+    a, b = 4164903690, 1 << 32
+    m = a * b - 1
+    binv = pow(b, -1, m)
+    out = np.zeros(n_draws, np.uint64)
+    s = state0
+    for k in range(n_draws):
+        s = (s * binv) % m
+        out[k] = s & 0xFFFFFFFF
+    return out

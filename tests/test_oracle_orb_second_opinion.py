@@ -125,3 +125,92 @@ def test_cv_orb_stages_second_opinion():
         table = {(int(x), int(y)): (s, hsc) for x, y, s, hsc in f}
         assert all((x, y) in table for x, y in zip(lx, ly))
         assert np.array_equal(np.array([table[(x, y)][1] for x, y in zip(lx, ly)], np.float32).view(np.uint32), sel["response"].view(np.uint32))
+
+
+# ---- r04: orientation, descriptor, stereo matcher, cv::RNG --------------------------------------------------------
+def _pattern():
+    import re
+    txt = open(os.path.join(ROOT, "oracle", "orb_pattern.inc")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    v = np.array([int(t) for t in re.findall(r"-?\d+", txt)], np.int64)
+    assert v.size == 1024
+    return v
+
+
+@pytest.mark.parametrize("name", ["synthetic", "kitti"])
+def test_orientation_bits(runs, name):
+    """IC_Angle's integer moments over the 31-pixel disc and OpenCV's fastAtan2 polynomial, float bits of every keypoint's angle"""
+    img, orc = runs[name]
+    n = 0
+    for l in range(8):
+        kp = orc.level_keypoints(l)
+        if len(kp) == 0:
+            continue
+        ang = so.ic_angles(orc.padded(l), kp["x"], kp["y"])
+        assert np.array_equal(ang.view(np.uint32), kp["angle"].view(np.uint32)), "level %d: %d of %d angles differ" % (
+            l, int((ang.view(np.uint32) != kp["angle"].view(np.uint32)).sum()), len(kp))
+        n += len(kp)
+    assert n >= 1900
+    # the polynomial against the mathematical atan2 (its documented accuracy) on a sweep that includes the octant boundaries
+    t = np.linspace(-np.pi, np.pi, 7201)
+    got = so.fast_atan2_deg(np.sin(t).astype(np.float32) * 100, np.cos(t).astype(np.float32) * 100)
+    want = np.degrees(np.arctan2(np.sin(t), np.cos(t))) % 360.0
+    d = np.abs(((got - want) + 180.0) % 360.0 - 180.0)
+    assert d.max() < 0.3
+
+
+@pytest.mark.parametrize("name", ["synthetic", "kitti"])
+def test_steered_brief_bits(runs, name):
+    """the 256 steered comparisons of every keypoint (float32 rotation, round-half-to-even taps) on the blurred level"""
+    img, orc = runs[name]
+    kps, desc = orc.run(img)
+    pat = _pattern()
+    o = 0
+    for l in range(8):
+        kp = orc.level_keypoints(l)
+        if len(kp) == 0:
+            continue
+        mine = so.steered_brief(orc.blur(l), kp["x"], kp["y"], kp["angle"], pat)
+        assert np.array_equal(mine, desc[o:o + len(kp)]), "level %d: %d of %d descriptors differ" % (l, int((mine != desc[o:o + len(kp)]).any(1).sum()), len(kp))
+        assert np.array_equal(kps["octave"][o:o + len(kp)], np.full(len(kp), l))
+        o += len(kp)
+    assert o == len(kps)
+    # the rounding rule itself: cvRound is round-half-to-even (a tap at exactly .5 goes to the even pixel)
+    assert [int(np.rint(np.float32(v))) for v in (0.5, 1.5, 2.5, -0.5, -1.5)] == [0, 2, 2, 0, -2]
+
+
+def test_stereo_matcher_second_opinion():
+    """Frame::ComputeStereoMatches restated from the reference's text in numpy against the oracle's: uRight / depth float bits, the
+    kept count - on the synthetic pair and on the KITTI frame against a shifted copy of itself"""
+    from PIL import Image
+    left, right = synth.stereo_pair()
+    kitti = np.ascontiguousarray(np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti_000212_gray.png"))))
+    shifted = np.roll(kitti, -9, axis=1).copy()
+    shifted[:, -9:] = kitti[:, -1:]
+    for tag, (a, b) in {"synthetic": (left, right), "kitti": (kitti, shifted)}.items():
+        ol, orr = oracle_lib.OracleORB(2000), oracle_lib.OracleORB(2000)
+        kl, dl = ol.run(a)
+        kr, dr = orr.run(b)
+        mb, mbf = np.float32(0.5327), np.float32(384.38148)
+        kept, ur, dp = oracle_lib.stereo_match(ol, orr, float(mb), float(mbf))
+        sf, isf = so.scale_tables()
+        pl = [ol.padded(l)[so.EDGE:-so.EDGE, so.EDGE:-so.EDGE] for l in range(8)]
+        pr = [orr.padded(l)[so.EDGE:-so.EDGE, so.EDGE:-so.EDGE] for l in range(8)]
+        k2, ur2, dp2 = so.stereo_matches(kl, dl, kr, dr, pl, pr, sf, isf, mb, mbf)
+        assert kept == k2 and kept > 300, (tag, kept, k2)
+        assert np.array_equal(ur.view(np.uint32), ur2.view(np.uint32)), (tag, int((ur.view(np.uint32) != ur2.view(np.uint32)).sum()))
+        assert np.array_equal(dp.view(np.uint32), dp2.view(np.uint32)), (tag, int((dp.view(np.uint32) != dp2.view(np.uint32)).sum()))
+
+
+def test_cv_rng_second_opinion():
+    """cv::RNG's multiply-with-carry stream (the RANSAC centroid of TrackMapObject draws from it, Tracking.cc:1664,1817) against the
+    closed form of the same generator: s_k = s_0 2^(-32 k) mod (a 2^32 - 1) - no update rule shared with the restatement"""
+    from pointslot_amd.object_tracker import CvRng
+    ref = so.cv_rng_closed_form(5000)
+    r = CvRng()
+    for k in range(5000):
+        n = 1 + (k * 7919) % 1000
+        assert r(n) == int(ref[k]) % n, k
+    # the generator's invariants: the modulus is what makes it a full-period Lehmer sequence in disguise
+    a, b = 4164903690, 1 << 32
+    assert pow(b, -1, a * b - 1) * b % (a * b - 1) == 1
