@@ -39,7 +39,7 @@ ALGO_BYTES_PER_FRAME_POSE_ITER = 2000 * 29 + 224      # pose-opt, 
 ALGO_FLOP_PER_OBJECT_BA_ITER = 103e6                  # object BA, per LM iteration per object (P=50, L=300, E=15000)
 RED_DEV = "cuda"              # device of the tensors used for cross-rank reductions
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def _profile_json(name):
@@ -47,6 +47,24 @@ def _profile_json(name):
         return json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
         return None
+
+
+def legs_pmc(leg, prefixes):
+    """HBM bytes per launch SEQUENCE of a leg outside the headline step, from the committed counter passes of tools/prof_legs.sh
+    (profiles/<round>_legs_pmc.json: rocprofv3 --kernel-trace + separate --pmc passes of the leg's tool script, TCC_EA0_RDREQ size
+    classes / TCC_EA0_WRREQ(_64B)): the sum over the kernels whose name starts with one of `prefixes` of (read + write bytes per
+    launch), i.e. one of each - a damping trial of the object BA, one call of the matcher / optimiser.  (bytes, per-kernel mean us,
+    source) or (None, None, None)."""
+    t = _profile_json(PROFILE_ROUND + "_legs_pmc.json")
+    if not t or leg not in t.get("legs", {}):
+        return None, None, None
+    tot, found, us = 0.0, 0, {}
+    for k, v in t["legs"][leg].items():
+        if any(k.startswith(p) for p in prefixes) and "read_bytes_per_launch" in v:
+            tot += v["read_bytes_per_launch"] + v.get("write_bytes_per_launch", 0.0)
+            us[k] = v["mean_us"]
+            found += 1
+    return (tot, us, "profiles/%s_legs_pmc.json (leg %s), kernel table profiles/%s_%s_kernel_stats.csv" % (PROFILE_ROUND, leg, PROFILE_ROUND, leg)) if found else (None, None, None)
 
 
 def pmc_traffic(kernel, nimg):
@@ -542,7 +560,8 @@ def optimizer_legs(rank, world, local_rank, guard, with_cpu, fp64_peak):
                                 "frames_per_s_kernel": 64 / (kern_ms * 1e-3), "inliers_frame0": int(res[0][0]) if res else None,
                                 "lm_iterations": iters, "damping_trials": trials,
                                 "roofline": {"bound": "hbm", "kernel": "pose_lm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                             "unit": "GB/s", "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                             "unit": "GB/s", "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "traffic": legs_pmc("pose", ("pose_lm",))[0], "traffic_source": legs_pmc("pose", ("pose_lm",))[2],
                                              "algorithmic_bytes_per_launch": algo, "avg_launch_ms": kern_ms,
                                              "note": "edge passes x 58 KB (SURVEY 8d streaming model); the persistent kernel keeps its edges in L2 and is latency-bound"}}
     mine = list(parallel.shard_units(8, world, rank))
@@ -569,8 +588,16 @@ def optimizer_legs(rank, world, local_rank, guard, with_cpu, fp64_peak):
         # every damping trial is one linearise + Schur + solve (103 MFLOP per object): FP64 rate over the batch
         flop = sum_trials * ALGO_FLOP_PER_OBJECT_BA_ITER
         ach = flop / (ms * 1e-3) / 1e12
-        ba["roofline"] = {"bound": "mfma", "kernel": "ba_* (10 kernels per damping trial)", "achieved": ach, "peak": fp64_peak, "unit": "TFLOP/s",
-                          "frac": ach / fp64_peak if fp64_peak else None, "traffic": None, "algorithmic_flop_per_batch": flop,
+        tr_bytes, tr_us, tr_src = legs_pmc("ba", ("ba_linearize", "ba_prep", "ba_schur", "ba_solve", "ba_update", "ba_error_k", "ba_decide"))
+        flop_iter = iters * len(graphs) * ALGO_FLOP_PER_OBJECT_BA_ITER      # SURVEY 8d prices an LM ITERATION (0.82 GFLOP for 8 objects)
+        ach_iter = flop_iter / (ms * 1e-3) / 1e12
+        ba["roofline"] = {"bound": "mfma", "kernel": "ba_* (7 kernels per damping trial)", "achieved": ach, "peak": fp64_peak, "unit": "TFLOP/s",
+                          "frac": ach / fp64_peak if fp64_peak else None, "achieved_per_iteration": ach_iter,
+                          "frac_per_iteration": ach_iter / fp64_peak if fp64_peak else None,
+                          "fractions": "frac prices every damping trial (one linearise / Schur / solve each, %d in this run) at SURVEY 8d's 103 MFLOP per "
+                                       "object; frac_per_iteration prices the %d LM iterations only, as SURVEY 8d does" % (sum_trials, iters),
+                          "traffic": tr_bytes, "traffic_unit": "HBM bytes per damping trial of the 8-object batch (one launch of each kernel)",
+                          "traffic_source": tr_src, "kernel_mean_us": tr_us, "algorithmic_flop_per_batch": flop,
                           "peak_source": "v_mfma_f64_16x16x4_f64 microbenchmark measured in this run (ps_debug_mfma_f64_peak)",
                           "note": "latency-bound: one object's reduced system is 300 unknowns; see DESIGN.md section 7"}
     ba["objects_per_gpu"] = len(mine)
@@ -629,7 +656,9 @@ def object_legs(local_rank, fp64_peak):
             "workload": "a10: SearchByBruceMatching, %d object(s) x 1000 x 1000 descriptors, nn ratio 0.9, rotation check" % k,
             "kernel_ms": ms, "wall_ms_incl_pcie": wall * 1e3, "pairs_per_s": pairs / (ms * 1e-3),
             "roofline": {"bound": "int-alu", "kernel": "bf_topk + bf_resolve", "achieved": ops / (ms * 1e-3) / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
-                         "unit": "T lane-op/s", "frac": ops / (ms * 1e-3) / VALU_LANE_OPS_PER_S, "traffic": None,
+                         "unit": "T lane-op/s", "frac": ops / (ms * 1e-3) / VALU_LANE_OPS_PER_S,
+                         "traffic": legs_pmc("bf", ("bf_topk", "bf_resolve"))[0], "traffic_source": legs_pmc("bf", ("bf_topk", "bf_resolve"))[2],
+                         "traffic_unit": "HBM bytes per call, mean over the leg's 1 / 8 / 64-object calls",
                          "note": "integer ALU / latency bound as SURVEY 8d states: %d KB of descriptors per object stay in LDS / L2; bf_resolve is the "
                                  "order-dependent serial part" % (2000 * 32 // 1024)}}
     # ---- a13 SearchByProjection(F, nOrder, MOPs): k objects x (300 local points into 400 features) ----
@@ -671,7 +700,8 @@ def object_legs(local_rank, fp64_peak):
         edges = sum(int(np.asarray(o["valid"]).sum()) for f in frames for o in f["objs"])
         out["cfse3_%d_objects" % k] = {"workload": "a15: CFSE3ObjStateOptimization, 64 frames x %d object(s) x 150 points (one graph per frame, 4 x 10 LM)" % k,
                                        "kernel_ms_per_64_calls": ms, "wall_ms_incl_pcie": wall * 1e3, "edges": edges,
-                                       "roofline": {"bound": "latency", "kernel": "pose_lm (mode 1)", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                                       "roofline": {"bound": "latency", "kernel": "pose_lm (mode 1)", "achieved": None, "peak": None, "unit": None, "frac": None,
+                                                    "traffic": legs_pmc("cfse3", ("pose_lm",))[0] if k == 4 else None, "traffic_source": legs_pmc("cfse3", ("pose_lm",))[2] if k == 4 else None,
                                                     "note": "one workgroup per frame, %d x 6 unknowns: the serial LM control flow dominates" % k}}
     opt.close()
     # ---- 8f-2 the object detector: 64 stereo pairs with their object masks, device resident ----

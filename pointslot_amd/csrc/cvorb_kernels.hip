@@ -696,7 +696,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
     cvb_wave_sync();
     // cv_interp on the patch.  Both passes carry 8.8 weights that add up to 256 (an edge sample has weight 256, its neighbour 0),
     // so the horizontal sums are at most 255 * 256 (16 bits), the 16.16 total fits 32 bits and never exceeds 255 after the one
-    // rounding.  Each pass is one v_dot2_u32_u16 on a packed pair (32-bit integer multiplies run at a quarter of that rate).
+    // rounding.  Each pass is one v_dot2_u32_u16 on a packed pair (one instruction instead of two multiplies and an add; all of them issue at the same rate, tools/ubench/int_issue.hip).
     const int c4 = (tid & 7) * 4, px0 = CVB_TILE * tx + c4;
     int cx[4]; cvb_us2 xw[4];
 #pragma unroll
