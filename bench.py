@@ -878,13 +878,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sequences", type=int, default=512, help="independent stereo sequences tracked in lockstep per GPU")
-    ap.add_argument("--groups", type=int, default=1, help="lockstep groups per GPU (one tracker handle and stream each)")
+    ap.add_argument("--groups", type=int, default=2, help="lockstep groups per GPU (one tracker handle and stream each; 2: one group's latency-bound kernels run under the other's issue-bound ones)")
     ap.add_argument("--texture", choices=["kitti", "synthetic"], default="kitti", help="texture of the generated sequences of the headline run")
     ap.add_argument("--scene", choices=["drive", "lateral"], default="drive", help="generator of the headline sequences: forward drive with yaw / lateral translation")
     ap.add_argument("--distinct", type=int, default=32, help="distinct generated sequences per GPU (the tracked ones cycle through them)")
     ap.add_argument("--no-objects", action="store_true", help="headline without the object chain (camera chain only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the headline loop")
+    ap.add_argument("--no-alone", action="store_true", help="skip the single-group pass behind the timed region (profiling runs: the kernel trace then holds the timed loop only)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with no launcher around it: this process only starts N ranks (fresh children, one per GPU)
@@ -956,6 +957,13 @@ def main():
     tracked_timed = parallel.sum_over_ranks(dist, head["tracked_frames_timed"], RED_DEV)
     overflowed = int(parallel.sum_over_ranks(dist, head["overflowed_frames"], RED_DEV))
 
+    # the kernels of the step on their own: a short single-group pass over the same sequences (one stream: no overlap between kernels)
+    alone = None
+    if args.groups > 1 and not args.no_alone:
+        a1 = tracking_leg(rank, local_rank, args.texture, min(args.steps, 6), max(args.warmup, 2), args.sequences, 1, barrier, scene=args.scene,
+                          n_distinct=args.distinct, objects=objects, seqs=head["seqs"])
+        alone = {"ms_per_step": parallel.max_over_ranks(dist, a1["dt"], RED_DEV) / min(args.steps, 6) * 1e3, "stage_ms": a1["stage_ms_group0"],
+                 "images_per_launch": a1["images_per_launch"]}
     secondary = None
     if not args.no_secondary:
         secondary = {}
@@ -1026,9 +1034,14 @@ def main():
         # ---- one roofline entry per stage / kernel of the timed step (HIP events on the stream the kernels run on) ----
         rl = []
 
+        G = args.groups
+        nimg_step = nimg * G     # the committed counter tables are per STEP (all groups); a launch of group 0 handles 1 / G of it
+
         def hbm(name, ms, algo, note, kernels=None):
             a = algo / (ms * 1e-3) / 1e9 if ms > 0 else None
-            traffic, src = pmc_traffic(kernels or name.split("/")[-1], nimg)
+            traffic, src = pmc_traffic(kernels or name.split("/")[-1], nimg_step)
+            if traffic is not None:
+                traffic /= G
             rl.append({"stage": name, "bound": "hbm", "ms_per_step": round(ms, 5), "algorithmic_bytes_per_step": algo, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": a / HBM_PEAK_GBS if a else None, "traffic": traffic, "traffic_source": src, "note": note})
 
@@ -1056,6 +1069,27 @@ def main():
         # the headline roofline is a single KERNEL's (the stages that are several kernels stay in `rooflines`)
         dom = max((r for r in rl if r["bound"] == "hbm" and r["stage"].startswith("orb/")), key=lambda r: r["ms_per_step"])
         value = tracked_timed / dt
+        roofline_timed = {"bound": "hbm", "kernel": dom["stage"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                          "traffic": dom["traffic"], "traffic_source": dom.get("traffic_source"), "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_step"],
+                          "avg_launch_ms": dom["ms_per_step"], "images_per_launch": nimg, "issue": pmc_valu_issue(dom["stage"].split("/")[-1], nimg_step, dom["ms_per_step"] * G),
+                          "note": "HIP events on group 0's stream over the TIMED region (orb_level_fused runs once per pyramid level: bytes, time and traffic are its 8 launches = %d images). With %d lockstep "
+                                  "groups on %d streams the other group's kernels run beside it, so the event-to-event time is not the kernel's own duration: the roofline of the kernel is `roofline`" % (nimg, G, G)}
+        if alone is None:
+            roofline_main = dict(roofline_timed, note="the single kernel with the largest time per step among those SURVEY 8d prices in bytes (orb_level_fused runs once per pyramid level: bytes, time and "
+                                                      "traffic are per step = its 8 launches); every stage is in `rooflines`")
+        else:
+            kdom = dom["stage"].split("/")[-1]
+            ams = alone["stage_ms"]["orb/" + kdom]
+            abytes = ALGO_BYTES_PER_IMAGE[kdom] * alone["images_per_launch"]
+            atr, asrc = pmc_traffic(kdom, alone["images_per_launch"])
+            roofline_main = {"bound": "hbm", "kernel": "orb/" + kdom, "achieved": abytes / (ams * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": abytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": atr, "traffic_source": asrc, "algorithmic_bytes_per_launch": abytes,
+                             "avg_launch_ms": ams, "images_per_launch": alone["images_per_launch"], "issue": pmc_valu_issue(kdom, alone["images_per_launch"], ams),
+                             "note": "the single kernel with the largest time per step among those SURVEY 8d prices in bytes (orb_level_fused runs once per pyramid level: bytes, time and traffic are per "
+                                     "step = its 8 launches), measured live in this run with HIP events on the kernel's stream in a SINGLE-GROUP pass of the same step over the same sequences right after "
+                                     "the timed region (%d steps, %.3f ms per step): the timed region runs %d lockstep groups on %d streams, where a kernel's event-to-event time includes the other group's "
+                                     "kernels (`roofline_timed_region_group0`); profiles/%s_bench_kernel_stats_1group_timed.csv is the rocprofv3 table of this pass's command (--groups 1)"
+                                     % (min(args.steps, 6), alone["ms_per_step"], G, G, PROFILE_ROUND)}
         out = {
             "metric": "tracked frames/sec KITTI stereo 1242x375",
             "value": value,
@@ -1083,11 +1117,19 @@ def main():
                                 "objects": head["objects"],
                                 "checked": "every frame of every sequence: tracked flag, position against the generator's ground truth; objects: "
                                            "detections with a MapObject / with mbTrackOK, cuboid centres of the distinct sequences against the labels"},
-            "roofline": {"bound": "hbm", "kernel": dom["stage"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
-                         "traffic": dom["traffic"], "traffic_source": dom.get("traffic_source"), "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_step"],
-                         "avg_launch_ms": dom["ms_per_step"], "images_per_launch": nimg, "issue": pmc_valu_issue(dom["stage"].split("/")[-1], nimg, dom["ms_per_step"]),
-                         "note": "the single kernel with the largest time per step among those SURVEY 8d prices in bytes (orb_level_fused runs once per pyramid level: bytes, time and traffic are per step = its 8 launches); every stage is in `rooflines`"},
+            "roofline": roofline_main,
+            "roofline_timed_region_group0": roofline_timed,
             "rooflines": rl,
+            "roofline_kernels_alone": None if alone is None else {
+                "what": "the same step with ONE lockstep group of %d sequences on one stream (%d images per launch, kernels never overlap): %.3f ms per step = %.0f frames/s; the "
+                        "headline runs %d groups of %d on %d streams - one group's latency-bound kernels (quadtree, pose_lm, glue) under the other's issue-bound ones"
+                        % (S, alone["images_per_launch"], alone["ms_per_step"], S / (alone["ms_per_step"] * 1e-3), G, S // G, G),
+                "ms_per_step": alone["ms_per_step"], "stage_ms": {k: round(v, 5) for k, v in alone["stage_ms"].items()},
+                "kernels": [{"kernel": k, "bound": "hbm", "avg_ms_per_step": alone["stage_ms"]["orb/" + k],
+                             "achieved": ALGO_BYTES_PER_IMAGE[k] * alone["images_per_launch"] / (alone["stage_ms"]["orb/" + k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ALGO_BYTES_PER_IMAGE[k] * alone["images_per_launch"] / (alone["stage_ms"]["orb/" + k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": pmc_traffic(k, alone["images_per_launch"])[0], "traffic_source": pmc_traffic(k, alone["images_per_launch"])[1]}
+                            for k in ("orb_level_fused", "orb_fast_cells", "orb_describe") if "orb/" + k in alone["stage_ms"]]},
             "stage_ms": {k: round(v, 5) for k, v in stage.items()},
             "stage_ms_note": "HIP events on group 0's stream over the timed steps; with %d groups the stages of different groups overlap in time" % args.groups,
         }

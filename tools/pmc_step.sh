@@ -13,7 +13,7 @@ R=$PWD
 export TMPDIR=/tmp
 run() {   # <tag> <counters>
   cd /tmp
-  rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $R/gpurun_out/${NAME}_$1 -o pmc -- python3 $R/bench.py --no-cpu --no-secondary --distinct 2 --steps $STEPS --warmup $WARM > $R/gpurun_out/${NAME}_$1.log 2>&1 || true
+  rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $R/gpurun_out/${NAME}_$1 -o pmc -- python3 $R/bench.py --no-cpu --no-secondary --no-alone --distinct 2 --steps $STEPS --warmup $WARM > $R/gpurun_out/${NAME}_$1.log 2>&1 || true
   cd $R
 }
 run rd "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B"
