@@ -458,8 +458,11 @@ __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
 // One workgroup = one 48 x 48 tile (8 x 8 poses); the points are streamed in chunks of 16.  Staging: thread t takes
 // ONE (pose, point) pair of one side — its 6x3 W block is 18 contiguous doubles — the A side multiplies by D_l^-1 on
 // the fly; then every thread accumulates a 3 x 3 register block from the two LDS tiles.
-#define SCH_LC 16
+#define SCH_LC 32     // points per chunk: a chunk is one L2 round trip for the W blocks (19 chunks of 16 were 19 x 1.5 us of a 48 us kernel)
+#define SCH_RS (SCH_LC * 3 + 2)   // LDS row stride in doubles: 16-byte aligned rows (128-bit operand reads), 16 rows on 64 different banks
+#define SCH_LDS_BYTES (2 * 48 * SCH_RS * 8)
 typedef double sch_d4 __attribute__((ext_vector_type(4)));
+typedef double sch_d2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
   const BaProb P = A.prob[blockIdx.y];
   const BaState& St = A.state[blockIdx.y];
@@ -469,77 +472,120 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
   while (ta < nt && rem > ta) { rem -= ta + 1; ta++; }
   if (ta >= nt) return;
   const int tb = rem;
-  __shared__ double As[48][SCH_LC * 3 + 1];
-  __shared__ double Bs[48][SCH_LC * 3 + 1];
+  extern __shared__ __attribute__((aligned(16))) double sch_smem[];
+  double (*As)[SCH_RS] = reinterpret_cast<double (*)[SCH_RS]>(sch_smem);
+  double (*Bs)[SCH_RS] = reinterpret_cast<double (*)[SCH_RS]>(sch_smem + 48 * SCH_RS);
   const int tid = threadIdx.x;
-  // staging role of this thread
+  // staging role of this thread: TWO (pose, point) pairs of one side per chunk (points lc and lc + 16)
   const int side = tid >> 7, pl = (tid & 127) >> 4, lc = tid & 15;
   const int pc = (side == 0 ? ta : tb) * PS_BA_TILE + pl;               // compact pose index
   const bool pose_ok = pc < npa;
   const double* Wrow = pose_ok ? A.W + P.W_base + (size_t)A.pact[P.pose_base + pc] * P.nl * 18 : nullptr;
-  double (*dstT)[SCH_LC * 3 + 1] = side == 0 ? As : Bs;
+  double (*dstT)[SCH_RS] = side == 0 ? As : Bs;
   // 48 x 48 tile = 3 x 3 tiles of the FP64 matrix cores (v_mfma_f64_16x16x4_f64); wave w (< 3) owns tile row w.  The vector
   // form of this contraction (3 x 3 register blocks, six LDS reads per nine FMAs) was bound by LDS instruction issue.
   const int wv = tid >> 6, ln = tid & 63, li = ln & 15, lk = ln >> 4;
-  sch_d4 acc[3];
+  sch_d4 acc[3][3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) acc[c] = sch_d4{0.0, 0.0, 0.0, 0.0};
-  for (int l0 = 0; l0 < P.nl; l0 += SCH_LC) {
-    const int l = l0 + lc;
-    double w[18];
-    const bool ok = pose_ok && l < P.nl && A.lact[P.point_base + l];
-    if (ok) {
-      const double2* src = reinterpret_cast<const double2*>(Wrow + (size_t)l * 18);
+  for (int a = 0; a < 3; a++)
 #pragma unroll
-      for (int q = 0; q < 9; q++) { const double2 v = src[q]; w[2 * q] = v.x; w[2 * q + 1] = v.y; }
+    for (int c = 0; c < 3; c++) acc[a][c] = sch_d4{0.0, 0.0, 0.0, 0.0};
+  // the chunk's W blocks (and, for the A side, D^-1) of this thread's two (pose, point) pairs: requested one chunk AHEAD, before the
+  // matrix instructions of the current chunk, so that the L2 round trip (two dependent ones: activity flag, then the blocks) runs under them
+  double w[2][18], dv[2][9];
+  bool okv[2];
+  uint8_t lactv[2];
+  auto request = [&](int l0) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int l = l0 + lc + 16 * h;
+      const int lcl = min(l, P.nl - 1);
+      okv[h] = pose_ok && l < P.nl;
+      lactv[h] = A.lact[P.point_base + lcl];   // (looked at when the chunk is used: testing it here would wait for it before the matrix instructions)
+      const double2* src = reinterpret_cast<const double2*>((pose_ok ? Wrow : A.W + P.W_base) + (size_t)lcl * 18);
+#pragma unroll
+      for (int q = 0; q < 9; q++) { const double2 v = src[q]; w[h][2 * q] = v.x; w[h][2 * q + 1] = v.y; }
       if (side == 0) {
-        const double* Di = A.Dinv + (size_t)(P.point_base + l) * 9;
-        double d[9];
+        const double* Di = A.Dinv + (size_t)(P.point_base + lcl) * 9;
 #pragma unroll
-        for (int q = 0; q < 9; q++) d[q] = Di[q];
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-          const double w0 = w[r * 3], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
-          w[r * 3] = w0 * d[0] + w1 * d[3] + w2 * d[6];
-          w[r * 3 + 1] = w0 * d[1] + w1 * d[4] + w2 * d[7];
-          w[r * 3 + 2] = w0 * d[2] + w1 * d[5] + w2 * d[8];
-        }
+        for (int q = 0; q < 9; q++) dv[h][q] = Di[q];
       }
-    } else {
+    }
+  };
+  request(0);
+  for (int l0 = 0; l0 < P.nl; l0 += SCH_LC) {
 #pragma unroll
-      for (int q = 0; q < 18; q++) w[q] = 0.0;
+    for (int h = 0; h < 2; h++) {
+      if (okv[h] && lactv[h]) {
+        if (side == 0) {
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+            const double w0 = w[h][r * 3], w1 = w[h][r * 3 + 1], w2 = w[h][r * 3 + 2];
+            w[h][r * 3] = w0 * dv[h][0] + w1 * dv[h][3] + w2 * dv[h][6];
+            w[h][r * 3 + 1] = w0 * dv[h][1] + w1 * dv[h][4] + w2 * dv[h][7];
+            w[h][r * 3 + 2] = w0 * dv[h][2] + w1 * dv[h][5] + w2 * dv[h][8];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 18; q++) w[h][q] = 0.0;
+      }
     }
     __syncthreads();   // the previous chunk's tiles are no longer being read
 #pragma unroll
-    for (int r = 0; r < 6; r++)
+    for (int h = 0; h < 2; h++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) dstT[pl * 6 + r][lc * 3 + k] = w[r * 3 + k];
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) dstT[pl * 6 + r][(lc + 16 * h) * 3 + k] = w[h][r * 3 + k];
     __syncthreads();
-    if (wv < 3) {
+    if (l0 + SCH_LC < P.nl) request(l0 + SCH_LC);
+    {
+      // All FOUR waves on the matrix cores: the chunk's K range is split over them (every wave all nine 16 x 16 tiles, a quarter of the
+      // K-steps: 54 matrix instructions per chunk instead of 72 on three waves with the fourth idle - the kernel is bound by them,
+      // PS_BA_PROFILE-style timers: 6 400 of a chunk's 9 000 cycles); the four partial tiles are added in a fixed order at the end.
+      // The K index of a lane's step i is (SCH_LC * 3 / 4) lk + i on both operands (any one-to-one assignment of the chunk's K values
+      // to (step, lk) is a valid contraction): a lane's operands are contiguous, two K-steps per 128-bit LDS read.
+      constexpr int KL = SCH_LC * 3 / 4, KW = KL / 4;
+      static_assert(4 * 2304 * 8 <= SCH_LDS_BYTES && KW % 2 == 0, "ba_schur: two K-steps per 128-bit read");
+      const int k0 = KL * lk + KW * wv;
 #pragma unroll
-      for (int kc = 0; kc < SCH_LC * 3 / 4; kc++) {
-        const double a = As[wv * 16 + li][4 * kc + lk];
+      for (int i = 0; i < KW; i += 2) {
+        sch_d2 a2[3], b2[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[c * 16 + li][4 * kc + lk], acc[c], 0, 0, 0);
+        for (int a = 0; a < 3; a++) { a2[a] = *reinterpret_cast<const sch_d2*>(&As[a * 16 + li][k0 + i]); b2[a] = *reinterpret_cast<const sch_d2*>(&Bs[a * 16 + li][k0 + i]); }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[a].x, b2[c].x, acc[a][c], 0, 0, 0);
+            acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[a].y, b2[c].y, acc[a][c], 0, 0, 0);
+          }
       }
     }
   }
-  const int lda = 6 * P.np, n = 6 * npa;
-  double* Sm = A.S + P.S_base;
-  if (wv < 3) {
+  // the four waves' partial tiles through LDS (the staging area is free now), added in wave order
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; a++)
 #pragma unroll
     for (int c = 0; c < 3; c++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {   // C/D layout of the f64 MFMA: row (lane >> 4) + 4 r, column lane & 15
-        const int gr = ta * 48 + wv * 16 + lk + 4 * r, gc = tb * 48 + c * 16 + li;
-        if (gr >= n || gc >= n) continue;
-        double h = 0;
-        if (gr / 6 == gc / 6) {
-          h = A.Hpp[(size_t)(P.pose_base + A.pact[P.pose_base + gr / 6]) * 36 + (gr % 6) * 6 + (gc % 6)];
-          if (gr == gc) h += St.lambda;
-        }
-        Sm[(size_t)gr * lda + gc] = h - acc[c][r];
-      }
+      for (int r = 0; r < 4; r++) sch_smem[wv * 2304 + (a * 3 + c) * 256 + r * 64 + ln] = acc[a][c][r];
+  __syncthreads();
+  const int lda = 6 * P.np, n = 6 * npa;
+  double* Sm = A.S + P.S_base;
+  for (int e = tid; e < 2304; e += 256) {
+    const double v = ((sch_smem[e] + sch_smem[2304 + e]) + sch_smem[2 * 2304 + e]) + sch_smem[3 * 2304 + e];
+    const int t = e >> 8, r = (e >> 6) & 3, l6 = e & 63;
+    const int gr = ta * 48 + (t / 3) * 16 + (l6 >> 4) + 4 * r, gc = tb * 48 + (t % 3) * 16 + (l6 & 15);   // C/D layout of the f64 MFMA: row (lane >> 4) + 4 r, column lane & 15
+    if (gr >= n || gc >= n) continue;
+    double h = 0;
+    if (gr / 6 == gc / 6) {
+      h = A.Hpp[(size_t)(P.pose_base + A.pact[P.pose_base + gr / 6]) * 36 + (gr % 6) * 6 + (gc % 6)];
+      if (gr == gc) h += St.lambda;
+    }
+    Sm[(size_t)gr * lda + gc] = h - v;
   }
 }
 
@@ -1016,7 +1062,8 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   if (first) hipLaunchKernelGGL(ba_begin, dim3(nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_linearize, dim3((max_np + 3) / 4 + (max_nl + 15) / 16, nprob), dim3(256), 0, st, *A, (max_np + 3) / 4);
   hipLaunchKernelGGL(ba_prep, dim3(nbl + (max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
-  hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), 0, st, *A);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_schur), hipFuncAttributeMaxDynamicSharedMemorySize, SCH_LDS_BYTES);
+  hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), SCH_LDS_BYTES, st, *A);
   {
     const int n_max = 6 * max_free;
     auto lds = [&](int nb, bool pb) { return (size_t)(2 * nb * (nb + 1) + 4 * nb + 2 * nb * nb + 12 * PS_BA_MAX_POSES + (size_t)(pb ? 2 * (nb + 2) : nb + 1) * (n_max > nb ? n_max - nb + 4 : 4) + 8) * sizeof(double); };
