@@ -611,6 +611,11 @@ static_assert(6 * PS_BA_MAX_POSES <= SOL_T - 64, "ba_solve: one thread per row o
 #endif
 typedef double sol_d4 __attribute__((ext_vector_type(4)));
 typedef double sol_d2 __attribute__((ext_vector_type(2)));
+// workgroup barrier that waits for LDS traffic only.  __syncthreads() also waits for every outstanding global access of the wave: behind
+// the panel's store that is a write round trip to L2 per block step, and in the backward substitution it waited for the loads that
+// had been requested ahead precisely so that they would NOT be waited for.  Used where the waves hand each other LDS data only; the
+// barriers that publish trailing tiles through global memory stay __syncthreads().
+__device__ __forceinline__ void sol_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int NB, bool PB>
 __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   const BaProb P = A.prob[blockIdx.x];
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       const int i = q / jb, c = q - i * jb;
       panel[(size_t)i * PST + c] = Sm[(size_t)(m0 + i) * lda + J + c];
     }
-    __syncthreads();
+    sol_lds_barrier();
     SOLP_MARK(5);
     for (int i = tid; i < m; i += SOL_T) {
       // x L_JJ^T D = row of S: column q of the row is final once columns < q have been eliminated from it.  Right-looking order:
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
         if (PB) panelB[(size_t)i * PST + q] = -xq;
       }
     }
-    __syncthreads();
+    sol_lds_barrier();
     SOLP_MARK(6);
     for (int q = tid; q < m * jb; q += SOL_T) {
       const int i = q / jb, c = q - i * jb;
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       }
       if (lane < jb) rhs[J + lane] = y;
     }
-    __syncthreads();
+    sol_lds_barrier();   // (the panel's global stores above are read by the backward substitution only)
     SOLP_MARK(7);
     for (int i = tid; i < m; i += SOL_T) {
       double v = rhs[m0 + i];
@@ -877,14 +882,14 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
 #pragma unroll
         for (int c = 0; c < NB; c++) lc[c] = c < jb ? Sm[(size_t)(J + c) * lda + k] : 0.0;
       }
-      __syncthreads();
+      sol_lds_barrier();
       if (tid >= 64 && k < J) {
         double v = rhs[k];
 #pragma unroll
         for (int c = 0; c < NB; c++) if (c < jb) v -= lc[c] * rhs[J + c];
         rhs[k] = v;
       }
-      __syncthreads();
+      sol_lds_barrier();
     }
   }
   SOLP_MARK(4);
