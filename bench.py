@@ -970,16 +970,18 @@ def main():
         osteps = min(args.steps, 10)
 
         def camera_only():
-            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, gbarrier, scene=args.scene,
+            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, 1, gbarrier, scene=args.scene,
                              n_distinct=args.distinct, objects=False, seqs=head["seqs"])
             odt = guard.max(o["dt"])
-            return {"workload": "the headline loop without masks / detections: the camera chain alone on all keypoints (r02's headline definition)",
+            return {"workload": "the headline loop without masks / detections: the camera chain alone on all keypoints (r02's headline definition); one lockstep group, like every secondary leg "
+                                "(two groups on two streams are faster in a fresh process - the headline - and were slower than one, 29 - 33 k against 36.6 k on the lateral scene, behind other "
+                                "legs in the same process: stream-to-hardware-queue placement)",
                     "tracked_frames_per_s": world * o["frames_per_step_per_gpu"] * osteps / odt, "ms_per_step": odt / osteps * 1e3,
                     "untracked_frames": o["untracked_frames"], "max_abs_position_error_m": o["max_abs_position_error_m"],
                     "stage_ms_group0": {k: round(v, 5) for k, v in o["stage_ms_group0"].items()}}
 
         def lateral_scene():
-            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, gbarrier, scene="lateral",
+            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, 1, gbarrier, scene="lateral",
                              n_distinct=4, objects=objects)
             odt = guard.max(o["dt"])
             return {"workload": "the headline loop on r02's scene: lateral translation over a ruled surface, two moving boxes, 4 distinct sequences",
@@ -988,7 +990,7 @@ def main():
                     "stage_ms_group0": {k: round(v, 5) for k, v in o["stage_ms_group0"].items()}}
 
         def six_objects():
-            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, args.groups, gbarrier, scene="drive",
+            o = tracking_leg(rank, local_rank, args.texture, osteps, max(args.warmup, 2), args.sequences, 1, gbarrier, scene="drive",
                              n_distinct=8, objects=True, n_objects=6)
             odt = guard.max(o["dt"])
             return {"workload": "sensitivity of the headline to the number of objects: the drive scene with SIX objects per sequence (three ahead, three at the "
@@ -1007,7 +1009,7 @@ def main():
                          ("six_objects_per_sequence", six_objects),
                          ("orb_extraction", lambda: orb_leg(rank, local_rank, gbarrier, with_cpu)),
                          ("optimizers", lambda: optimizer_legs(rank, world, local_rank, guard, with_cpu, fp64_peak)),
-                         ("lockstep_tracking_host_images", lambda: pcie_leg(rank, world, local_rank, guard, head["seqs"], args.sequences, args.groups, gbarrier)),
+                         ("lockstep_tracking_host_images", lambda: pcie_leg(rank, world, local_rank, guard, head["seqs"], args.sequences, 1, gbarrier)),
                          ("sequence_tracking", lambda: config5_leg(rank, world, local_rank, guard))):
             r = guard.run(fn)
             if isinstance(r, dict) and "error" in r and len(r) == 1:
