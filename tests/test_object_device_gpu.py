@@ -136,6 +136,48 @@ def test_overflow_is_reported_per_sequence_and_step_not_by_a_failing_fetch():
     trk.close()
 
 
+def test_a_detector_overflow_in_an_earlier_queued_step_is_not_lost():
+    """The batched cv::ORB clears its overflow flags at the start of every step; the tracker is meant to queue many steps before a fetch.
+    A frame of noise under an all-object mask overflows the per-level candidate capacity in step 0 of sequence 1; two ordinary steps
+    follow; ps_tracker_fetch_objects must still say so (per-sequence sticky counters, cleared by ps_tracker_reset)."""
+    import torch
+    from pointslot_amd._lib import PointslotError
+    from pointslot_amd.tracker_device import LockstepTracker, pack_detections
+    n, S = 3, 2
+    seqs = [sequence.generate(n_frames=n, seed=90 + i) for i in range(S)]
+    h, w = seqs[0]["left"][0].shape
+    rng = np.random.default_rng(5)
+    imgs = np.stack([np.stack([q["left"][:n], q["right"][:n]], 1) for q in seqs], 1).copy()      # [n, S, 2, h, w]
+    masks = np.stack([np.stack([sequence.frame_mask(q, k) for q in seqs]) for k in range(n)]).copy()
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    imgs[0, 1, 0] = noise; imgs[0, 1, 1] = noise
+    masks[0, 1] = 1                                                    # every pixel belongs to detection id 0
+    d_imgs, d_masks = torch.from_numpy(imgs).cuda(), torch.from_numpy(masks).cuda()
+    trk = LockstepTracker(S, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=2 * n, max_objects=4)
+    keep = []
+
+    def run():
+        for k in range(n):
+            d = torch.from_numpy(pack_detections([sequence.frame_detections(q, k) for q in seqs], 4).view(np.uint8)).cuda()
+            keep.append(d)
+            trk.step_slot_device(d_imgs[k].data_ptr(), d_masks[k].data_ptr(), d.data_ptr())
+    run()
+    with pytest.raises(PointslotError) as e:
+        trk.fetch_objects()
+    assert "sequence 1" in str(e.value) and "capacity" in str(e.value)
+    tcw, st = trk.fetch()                                              # the camera results are not withheld
+    assert tcw.shape[0] == n
+    # after a reset the counters are clear: the same tracker on ordinary frames only
+    trk.reset()
+    imgs[0, 1, 0] = seqs[1]["left"][0]; imgs[0, 1, 1] = seqs[1]["right"][0]
+    masks[0, 1] = sequence.frame_mask(seqs[1], 0)
+    d_imgs, d_masks = torch.from_numpy(imgs).cuda(), torch.from_numpy(masks).cuda()
+    run()
+    obj = trk.fetch_objects()
+    assert (obj["id"][:, :, :2] >= 0).all()
+    trk.close()
+
+
 def test_object_features_on_a_second_stream_give_the_same_results():
     """PS_TRK_OVERLAP=1 (ExtractObjORB on a second stream beside the camera chain, joined before ComputeObjStereoMatches) is a
     scheduling option: every pose, statistic and object record must come out bit for bit as on one stream.  The option is read when
