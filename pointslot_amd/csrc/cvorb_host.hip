@@ -339,6 +339,7 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
   const size_t o_cand = take((size_t)cap * h->nlevels * CVB_CAND_CAP * sizeof(float4));
   const size_t o_sel = take((size_t)cap * h->nlevels * CVB_CAND_CAP * sizeof(CvSel));
   const size_t o_kps = take((size_t)cap * P.ocap * sizeof(ps_keypoint)), o_desc = take((size_t)cap * P.ocap * 32);
+  const size_t o_dump = take(1024);
   // cleared before every batch: occupancy, worklist counters, candidate counters, selection counts, counts, overflow
   const size_t z0 = off;
   const size_t o_occ = take((size_t)cap * P.ocw * P.och), o_wlc = take(3 * CV_MAX_LEVELS * 4), o_ncand = take((size_t)cap * h->nlevels * 4);
@@ -355,7 +356,7 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
     PS_HIP(hipMemcpyAsync(D + o_yt[l], yt[l].data(), yt[l].size() * 16, hipMemcpyHostToDevice, h->stream));
   }
   P.wl = (uint32_t*)(D + o_wl); P.cand = (float4*)(D + o_cand); P.sel = (CvSel*)(D + o_sel);
-  P.kps = (ps_keypoint_pod*)(D + o_kps); P.desc = D + o_desc;
+  P.kps = (ps_keypoint_pod*)(D + o_kps); P.desc = D + o_desc; P.dump = D + o_dump;
   P.occ = D + o_occ; P.kpmap = D + o_kpmap; P.wl_count = (int32_t*)(D + o_wlc); P.ncand = (int32_t*)(D + o_ncand); P.nsel = (int32_t*)(D + o_nsel);
   P.count = (int32_t*)(D + o_count); P.overflow = (int32_t*)(D + o_ovf);
   h->b_zero = D + z0; h->b_zero_bytes = z1 - z0;
@@ -387,6 +388,17 @@ int psi_cvorb_batch_run(ps_cvorb* h, const uint8_t* d_imgs, const uint8_t* d_mas
   psk_cvb_run(&h->bplan, nimg, d_imgs, stride, image_pitch, d_masks, mask_stride, mask_pitch, occupancy_given, st);
   PS_HIP(hipGetLastError());
   h->b_last_n = nimg;
+  return PS_OK;
+}
+
+// developer access (tools/cvorb_batch_bench.py): entries of the three tile worklists per level after the last batch and the tiles of
+// one image's level - how much of the pyramid the batch worked on
+int psi_cvorb_batch_worklist_counts(ps_cvorb* h, int32_t* counts /* [3][CV_MAX_LEVELS] */, int32_t* tiles /* [CV_MAX_LEVELS] */) {
+  if (!h || !h->bplanned || !counts || !tiles) return ps_set_error(PS_ERR_INVALID, "no batch plan yet");
+  PS_HIP(hipSetDevice(h->device));
+  PS_HIP(hipDeviceSynchronize());
+  PS_HIP(hipMemcpy(counts, h->bplan.wl_count, 3 * CV_MAX_LEVELS * 4, hipMemcpyDeviceToHost));
+  for (int l = 0; l < CV_MAX_LEVELS; l++) tiles[l] = l < h->nlevels ? h->bplan.lv[l].tw * h->bplan.lv[l].th : 0;
   return PS_OK;
 }
 

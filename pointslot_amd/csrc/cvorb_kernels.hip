@@ -9,6 +9,7 @@
 // keypoint), they are not on the throughput-critical part of the path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "cvorb_plan.h"
 #include "retain_best.h"
 
@@ -539,15 +540,28 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
 
 // the next worklist entry is requested while the current tile is worked on (a tile is a chain of dependent round trips: every one
 // taken off the chain counts)
-#define CVB_TILE_LOOP(P, which, l)                                                                      \
+// (the entry is the same for the whole wave: read through the scalar cache - s_load_dword - it lands in an SGPR without the
+// vmcnt(0) wait that v_readfirstlane of a vector load puts right behind the load, which made the "prefetch" a round trip per tile.
+// The lists were written by the kernel before this one; the scalar cache is invalidated at every kernel start.)
+typedef const uint32_t __attribute__((address_space(4))) * cvb_scalar_ptr;
+__device__ __forceinline__ uint32_t cvb_sload(const uint32_t* p) { return *(cvb_scalar_ptr)(uintptr_t)p; }
+#ifndef CVB_RUN
+#define CVB_RUN 1            // consecutive worklist entries (horizontally adjacent tiles, mostly) a wave takes before it jumps by the stride
+#endif
+#define CVB_TILE_VARS(P, which, l)                                                                      \
   const CvbLevel& B = P.lv[l];                                                                          \
   const uint32_t* wl = P.wl + ((size_t)(which) * CV_MAX_LEVELS + (l)) * P.wl_cap;                       \
-  const int cnt = min(P.wl_count[(which) * CV_MAX_LEVELS + (l)], P.wl_cap);                             \
+  const int cnt = min((int)cvb_sload(reinterpret_cast<const uint32_t*>(P.wl_count) + (which) * CV_MAX_LEVELS + (l)), P.wl_cap); \
   const int xchunk = (cnt + 7) >> 3, xend = min(cnt, ((int)(blockIdx.x & 7) + 1) * xchunk);             \
-  const int xstep = (int)(gridDim.x >> 3);                                                              \
-  int it = (int)(blockIdx.x & 7) * xchunk + (int)(blockIdx.x >> 3);                                     \
-  uint32_t e_next = it < xend ? wl[it] : 0u;                                                            \
-  for (uint32_t e = e_next; it < xend && ((e = e_next), (e_next = it + xstep < xend ? wl[it + xstep] : 0u), true); it += xstep)
+  const int xstep = (int)(gridDim.x >> 3) * CVB_RUN;                                                    \
+  int it = (int)(blockIdx.x & 7) * xchunk + (int)(blockIdx.x >> 3) * CVB_RUN, run_i = 0;                \
+  auto cvb_next = [&](int i, int r) { return r + 1 < CVB_RUN ? i + 1 : i + xstep - (CVB_RUN - 1); };    \
+  uint32_t e_next = it < xend ? cvb_sload(wl + it) : 0u;
+#define CVB_TILE_FOR                                                                                    \
+  for (uint32_t e = e_next; it < xend && ((e = e_next), (e_next = cvb_next(it, run_i) < xend ? cvb_sload(wl + cvb_next(it, run_i)) : 0u), true); \
+       it = cvb_next(it, run_i), run_i = run_i + 1 < CVB_RUN ? run_i + 1 : 0)
+#define CVB_HAS_NEXT (cvb_next(it, run_i) < xend)
+#define CVB_TILE_LOOP(P, which, l) CVB_TILE_VARS(P, which, l) CVB_TILE_FOR
 
 // XCD-aware order: workgroup b runs on XCD b % 8, each XCD has its own L2, and a worklist keeps the tiles of one image together.
 // XCD k therefore takes the k-th eighth of the list front to back: neighbouring tiles - which share the 128-byte lines of their
@@ -726,12 +740,19 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
       if (mask_mode != 0) {
         if (mask_mode == 1) interp4(mpatch + ra + mshf[r0], mpatch + rb + mshf[r1], yw, o);
         else o[0] = o[1] = o[2] = o[3] = mask_mode == 2 ? 255u : 0u;
-        const int iy = py - CV_BORDER;
+        const int iy = py - CV_BORDER, ix0 = px0 - CV_BORDER;
+        if (iy >= 0 && iy < L.h) {
+          // threshold(currMask, currMask, 254, 0, THRESH_TOZERO).  The mask planes are tight (row stride = level width): the four bytes
+          // go out as ONE dword store at whatever alignment the row has (the kernel is bound by memory requests, not by arithmetic)
+          uint8_t* mp = L.mask + (__umul24((uint32_t)iy, (uint32_t)L.w) + ix0);
+          if (ix0 >= 0 && ix0 + 3 < L.w) {
+            const uint32_t pk = (o[0] > 254u ? o[0] : 0u) | ((o[1] > 254u ? o[1] : 0u) << 8) | ((o[2] > 254u ? o[2] : 0u) << 16) | ((o[3] > 254u ? o[3] : 0u) << 24);
+            __builtin_memcpy(mp, &pk, 4);
+          } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int ix = px0 + j - CV_BORDER;
-          // threshold(currMask, currMask, 254, 0, THRESH_TOZERO)
-          if (ix >= 0 && ix < L.w && iy >= 0 && iy < L.h) L.mask[__umul24((uint32_t)iy, (uint32_t)L.w) + (uint32_t)ix] = o[j] > 254u ? (uint8_t)o[j] : (uint8_t)0;
+            for (int j = 0; j < 4; j++)
+              if (ix0 + j >= 0 && ix0 + j < L.w) mp[j] = o[j] > 254u ? (uint8_t)o[j] : (uint8_t)0;
+          }
         }
       }
     }
@@ -940,85 +961,125 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
   }
 }
 
-// 7 x 7 blur of a tile: 38 x 38 neighbourhood in LDS (40-byte rows), horizontal pass into 16-bit sums, vertical pass, one rounding
+// 7 x 7 blur of a tile: 38 x 38 neighbourhood in LDS (40-byte rows), horizontal pass into 16-bit sums, vertical pass, one rounding.
+// GaussianBlur's fixed-point passes are exact integer sums (8.8 weights that add up to 257: a row sum is at most 255 * 257 = 65535,
+// the 16.16 total fits 32 bits), so they are taken as dot products: v_dot4_u32_u8 on the row's bytes (the weights are below 256),
+// v_dot2_u32_u16 on vertically adjacent row sums.  (r04: 723 -> ~400 VALU instructions per tile; the kernel is bound by them.)
 __global__ __launch_bounds__(CVB_TT) void cvb_blur(CvbPlan P) {
   constexpr int TS = 40, TR = 38;
   __shared__ __attribute__((aligned(16))) uint8_t tile[TS * TR];
   __shared__ __attribute__((aligned(16))) uint16_t hs[TR * 32 + 64];
   const int l = blockIdx.y, tid = threadIdx.x;
-  const uint32_t kq[7] = {(uint32_t)P.kq[0], (uint32_t)P.kq[1], (uint32_t)P.kq[2], (uint32_t)P.kq[3], (uint32_t)P.kq[2], (uint32_t)P.kq[1], (uint32_t)P.kq[0]};
-  CVB_TILE_LOOP(P, 2, l) {
+  const uint32_t k0 = (uint32_t)P.kq[0], k1 = (uint32_t)P.kq[1], k2 = (uint32_t)P.kq[2], k3 = (uint32_t)P.kq[3];
+  const uint32_t KA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), KB = k2 | (k1 << 8) | (k0 << 16);      // taps 0..3, taps 4..6 of a row window
+  const cvb_us2 W01 = __builtin_bit_cast(cvb_us2, k0 | (k1 << 16)), W23 = __builtin_bit_cast(cvb_us2, k2 | (k3 << 16)),
+                W45 = __builtin_bit_cast(cvb_us2, k2 | (k1 << 16)), W6L = __builtin_bit_cast(cvb_us2, k0), W6H = __builtin_bit_cast(cvb_us2, k0 << 16);
+  // The window of the NEXT tile is requested (into registers) before the current one is worked on: a tile is load -> LDS -> two passes ->
+  // store, and with the loads of one tile only a wave waited for memory 60 % of its time (r04 PMC: SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES).
+  // No predicates: a dword of the window that lies outside the plane, or beyond the window's last item, is taken from the clamped
+  // position instead - what a tile holds outside the plane is never read for a result (the outputs there are the plane's own border
+  // pixels; the lanes past the last item repeat it: same value, same LDS address).
+  constexpr int NIT = (TR * (TS / 4) + CVB_TT - 1) / CVB_TT;
+  uint32_t vn[NIT];
+  const int PHl = P.lv[l].h + 2 * CV_BORDER, strl = P.lv[l].stride, twl = P.lv[l].tw;
+  auto request = [&](uint32_t ee) {
+    const int img = (int)((ee >> 12) & 0x7FFFFu), t = (int)(ee & 4095u), tx = t % twl, ty = t / twl;
+    const uint8_t* pad = P.arena + (size_t)img * P.arena_pitch + P.lv[l].o_pad;
+    const int bx = CVB_TILE * tx - 4, by = CVB_TILE * ty - 3;
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      const int i = min(tid + k * CVB_TT, TR * (TS / 4) - 1), yy = i / (TS / 4), q = i % (TS / 4);
+      const int px = min(max(bx + 4 * q, 0), strl - 4), py = min(max(by + yy, 0), PHl - 1);
+      vn[k] = *reinterpret_cast<const uint32_t*>(pad + (__umul24((uint32_t)py, (uint32_t)strl) + (uint32_t)px));
+    }
+  };
+  CVB_TILE_VARS(P, 2, l)
+  if (it < xend) {
+    request(e_next);
+    // (four stores behind the first request as behind every later one: the compiler's wait for a prefetched dword is the most cautious
+    // over the ways into the loop, and coming from here it would otherwise be "everything but the loads behind it" - which, inside the
+    // loop, includes the four stores of the tile before)
+#pragma unroll
+    for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t*>(P.dump + 256 * r + 4 * tid) = 0u;
+  }
+  CVB_TILE_FOR {
     const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l);
-    const int PW = L.w + 2 * CV_BORDER, PH = L.h + 2 * CV_BORDER;
-    const int bx = CVB_TILE * tx - 4, by = CVB_TILE * ty - 3;           // tile[0] = padded (bx, by); bx is a multiple of 4, the window starts at bx + 1
+    const int PH = L.h + 2 * CV_BORDER;
     cvb_wave_sync();
-    {
-      constexpr int NIT = (TR * (TS / 4) + CVB_TT - 1) / CVB_TT;
-      uint32_t v[NIT];
 #pragma unroll
-      for (int k = 0; k < NIT; k++) {            // every load is issued before the first LDS store
-        const int i = tid + k * CVB_TT, yy = i / (TS / 4), q = i % (TS / 4);
-        const int px = bx + 4 * q, py = by + yy;
-        v[k] = (i < TR * (TS / 4) && px >= 0 && px < L.stride && py >= 0 && py < PH) ? *reinterpret_cast<const uint32_t*>(L.pad + (size_t)py * L.stride + px) : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < NIT; k++) {
-        const int i = tid + k * CVB_TT;
-        if (i < TR * (TS / 4)) *reinterpret_cast<uint32_t*>(tile + (i / (TS / 4)) * TS + 4 * (i % (TS / 4))) = v[k];
-      }
+    for (int k = 0; k < NIT; k++) {
+      const int i = min(tid + k * CVB_TT, TR * (TS / 4) - 1);
+      *reinterpret_cast<uint32_t*>(tile + (i / (TS / 4)) * TS + 4 * (i % (TS / 4))) = vn[k];
     }
+    if (CVB_HAS_NEXT) request(e_next);
     cvb_wave_sync();
-    // horizontal pass: four adjacent outputs per item from three aligned dwords of the row (bytes 4 q + 1 .. 4 q + 10)
-    for (int i = tid; i < TR * 8; i += CVB_TT) {
+    // horizontal pass: four adjacent outputs per item from three aligned dwords of the row (bytes 4 q + 1 .. 4 q + 10): output j is
+    // the dot product of bytes 1 + j .. 4 + j with taps 0..3 plus that of bytes 5 + j .. 7 + j with taps 4..6
+#pragma unroll
+    for (int k = 0; k < (TR * 8 + CVB_TT - 1) / CVB_TT; k++) {
+      const int i = min(tid + k * CVB_TT, TR * 8 - 1);
       const int r = i >> 3, q = i & 7;
       const uint32_t* rw = reinterpret_cast<const uint32_t*>(tile + r * TS + 4 * q);
       const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
-      uint32_t bb[10];
-      bb[0] = (d0 >> 8) & 255u; bb[1] = (d0 >> 16) & 255u; bb[2] = d0 >> 24;
-      bb[3] = d1 & 255u; bb[4] = (d1 >> 8) & 255u; bb[5] = (d1 >> 16) & 255u; bb[6] = d1 >> 24;
-      bb[7] = d2 & 255u; bb[8] = (d2 >> 8) & 255u; bb[9] = (d2 >> 16) & 255u;
       uint32_t h[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        uint32_t hsum = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) hsum += kq[k] * bb[j + k];
-        h[j] = min(hsum, 65535u);
-      }
+      for (int j = 0; j < 3; j++)
+        h[j] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, (uint32_t)(1 + j)), KB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, (uint32_t)(1 + j)), KA, 0u, false), false);
+      h[3] = __builtin_amdgcn_udot4(d2, KB, __builtin_amdgcn_udot4(d1, KA, 0u, false), false);
       *reinterpret_cast<uint2*>(hs + r * 32 + 4 * q) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     }
     cvb_wave_sync();
-    // vertical pass: a 4 x 4 block of outputs per thread from ten rows of four sums
+    // vertical pass: a 4 x 4 block of outputs per thread from ten rows of four sums.  pr[r][c]: the sums of rows r, r + 1 of column pair c
+    // as packed u16 (c = 0: columns 0 / 1 low halves ... see sel), so that two taps are one v_dot2_u32_u16
     {
       const int lx0 = (tid & 7) * 4, ly0 = (tid >> 3) * 4;
       const int px0 = CVB_TILE * tx + lx0;
-      uint32_t col[10][4];
+      uint2 rowv[10];
 #pragma unroll
-      for (int r = 0; r < 10; r++) {
-        const uint2 v = *reinterpret_cast<const uint2*>(hs + (ly0 + r) * 32 + lx0);
-        col[r][0] = v.x & 0xFFFFu; col[r][1] = v.x >> 16; col[r][2] = v.y & 0xFFFFu; col[r][3] = v.y >> 16;
+      for (int r = 0; r < 10; r++) rowv[r] = *reinterpret_cast<const uint2*>(hs + (ly0 + r) * 32 + lx0);
+      cvb_us2 pr[9][4];
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
+        pr[r][0] = __builtin_bit_cast(cvb_us2, __builtin_amdgcn_perm(rowv[r + 1].x, rowv[r].x, 0x05040100u));
+        pr[r][1] = __builtin_bit_cast(cvb_us2, __builtin_amdgcn_perm(rowv[r + 1].x, rowv[r].x, 0x07060302u));
+        pr[r][2] = __builtin_bit_cast(cvb_us2, __builtin_amdgcn_perm(rowv[r + 1].y, rowv[r].y, 0x05040100u));
+        pr[r][3] = __builtin_bit_cast(cvb_us2, __builtin_amdgcn_perm(rowv[r + 1].y, rowv[r].y, 0x07060302u));
       }
+      const int x0 = px0 - CV_BORDER;
+      const bool xin = x0 >= 0 && x0 + 3 < L.w;                            // the four columns of this thread lie inside the level
+      // The four stores of a thread are unconditional (a row below the plane goes to P.dump; px0 < stride always: the tiles of a row end
+      // at or before the row stride): with a store inside a branch the compiler no longer knows how many memory operations follow the
+      // prefetched loads and waits for ALL of them - the stores' acknowledgements, a round trip per tile (r04: 397 -> 212 us without stores)
+      uint32_t outv[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int ly = ly0 + r, py = CVB_TILE * ty + ly;
-        if (py >= PH) continue;
         const int y = py - CV_BORDER;
-        uint32_t out = 0;
+        uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const int x = px0 + j - CV_BORDER;
-          uint32_t o;
-          if (x < 0 || x >= L.w || y < 0 || y >= L.h) o = tile[(ly + 3) * TS + lx0 + j + 4];
-          else {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int k = 0; k < 7; k++) acc += kq[k] * col[r + k][j];
-            o = min((acc + 32768u) >> 16, 255u);
-          }
-          out |= o << (8 * j);
+          uint32_t acc = __builtin_amdgcn_udot2(pr[r][j], W01, 32768u, false);
+          acc = __builtin_amdgcn_udot2(pr[r + 2][j], W23, acc, false);
+          acc = __builtin_amdgcn_udot2(pr[r + 4][j], W45, acc, false);
+          acc = r < 3 ? __builtin_amdgcn_udot2(pr[r + 6][j], W6L, acc, false) : __builtin_amdgcn_udot2(pr[8][j], W6H, acc, false);
+          o[j] = min(acc >> 16, 255u);
         }
-        if (px0 < L.stride) *reinterpret_cast<uint32_t*>(L.blur + (size_t)py * L.stride + px0) = out;
+        if (!(xin && y >= 0 && y < L.h)) {
+          // outside the level (the border of the padded plane): the plane's own pixel
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int x = x0 + j;
+            if (x < 0 || x >= L.w || y < 0 || y >= L.h) o[j] = tile[(ly + 3) * TS + lx0 + j + 4];
+          }
+        }
+        outv[r] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int py = CVB_TILE * ty + ly0 + r;
+        uint8_t* dst = py < PH ? L.blur + (__umul24((uint32_t)py, (uint32_t)L.stride) + (uint32_t)px0) : P.dump + 256 * r + 4 * tid;
+        *reinterpret_cast<uint32_t*>(dst) = outv[r];
       }
     }
   }
@@ -1209,7 +1270,8 @@ void psk_cvb_run(const CvbPlan* Pin, int nimg, const uint8_t* imgs, int stride, 
   Q.imgs = imgs; Q.img_stride = stride; Q.img_pitch = pitch; Q.masks = masks; Q.mask_stride = mask_stride; Q.mask_pitch = mask_pitch;
   const CvbPlan* P = &Q;
   const int NL = P->nlevels;
-  const int grid = 16384;                                      // persistent loops over the worklists, one wave per tile
+  static const int grid_env = getenv("PS_CVB_GRID") ? atoi(getenv("PS_CVB_GRID")) : 0;   // developer knob (a multiple of 32)
+  const int grid = grid_env > 0 ? grid_env : 16384;            // persistent loops over the worklists, one wave per tile
   if (!occupancy_given) hipLaunchKernelGGL(cvb_occupancy, dim3((P->h0 + 31) / 32, nimg), dim3(256), 0, st, *P, masks, mask_stride, mask_pitch);
   const size_t plan_lds = (size_t)((P->cell_total + 3) & ~3) + 2 * (size_t)((P->cell_max + 3) & ~3) + 2 * (size_t)(P->ocw + 1) * (P->och + 1) + (size_t)P->tile_total + 16;
   if (plan_lds > 48 * 1024) hipFuncSetAttribute((const void*)cvb_plan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds);

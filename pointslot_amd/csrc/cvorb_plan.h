@@ -58,4 +58,5 @@ struct CvbPlan {
   CvSel* sel; int32_t* nsel;                         // [nimg][nlevels][CVB_CAND_CAP], [nimg][nlevels]
   ps_keypoint_pod* kps; uint8_t* desc; int32_t* count; int32_t* overflow;   // [nimg][ocap], [nimg][ocap][32], [nimg], [nimg]
   int32_t ocap;
+  uint8_t* dump;               // 1 KB nobody reads: where a tile kernel's lanes that have no output row send their (unconditional) store
 };

@@ -199,7 +199,10 @@ __device__ __forceinline__ PoEdge po_load(const float* xw, const float* obs, con
 #define POP_MARK(k)
 #define POP_PRINT()
 #endif
-__global__ __launch_bounds__(PO_T) void pose_lm(const PoProb* probs, const PoVertex* verts, const float* xw,
+#ifndef PO_OCC_ATTR
+#define PO_OCC_ATTR
+#endif
+__global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs, const PoVertex* verts, const float* xw,
                                                 const float* obs, const float* inv_sigma2, const uint8_t* valid,
                                                 uint8_t* outlier, double* chi2c, uint8_t* state, double* poses,
                                                 int32_t* results, double* trace) {

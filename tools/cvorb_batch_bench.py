@@ -29,3 +29,10 @@ for _ in range(10):
 kps, _ = det.batch_fetch(0)
 dt = (time.perf_counter() - t0) / 10
 print("cvorb batch: %d images, %.3f ms per call, %d keypoints in image 0, mask coverage %.3f" % (nimg, dt * 1e3, len(kps), float((np.stack(masks[:8]) != 0).mean())))
+
+import ctypes
+from pointslot_amd._lib import lib
+cnt = (ctypes.c_int32 * 24)(); tiles = (ctypes.c_int32 * 8)()
+if lib.psi_cvorb_batch_worklist_counts(det._h, cnt, tiles) == 0:
+    for w, name in enumerate(("planes", "FAST", "blur")):
+        print("worklist %-6s tiles per image and level: %s  (of %s)" % (name, [round(cnt[w * 8 + l] / nimg, 1) for l in range(8)], list(tiles)))
