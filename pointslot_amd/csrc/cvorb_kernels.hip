@@ -570,6 +570,7 @@ __device__ __forceinline__ uint32_t cvb_sload(const uint32_t* p) { return *(cvb_
 // tables -> source patch -> result), so what counts is how many tiles are in flight - 32 per CU instead of 8.
 #define CVB_TT 64
 typedef unsigned short cvb_us2 __attribute__((ext_vector_type(2)));
+typedef short cvb_s2 __attribute__((ext_vector_type(2)));
 // A workgroup of these kernels is ONE wave: its LDS instructions execute in program order, so lanes exchange data through LDS
 // without s_barrier and - what matters - without the vmcnt(0) wait a workgroup barrier brings (the prefetched worklist entry and
 // the stores of the previous tile stay in flight).  What is needed is that the compiler keeps the order.
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
   CVB_TILE_LOOP(P, 1, l) {
     const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
     const CvLevelDev L = cvb_level(P, img, l);
-    const int PW = L.w + 2 * CV_BORDER, PH = L.h + 2 * CV_BORDER;
+    const int PH = L.h + 2 * CV_BORDER;
     const int bx = CVB_TILE * tx - 4, by = CVB_TILE * ty - 4;           // padded coordinates of tile[0]; bx is a multiple of 4
     const uint8_t* kpmap = P.kpmap + (size_t)img * P.cell_total + B.cell_off;
     const uint8_t* mk = l == 0 ? P.masks + (size_t)img * P.mask_pitch : L.mask;
@@ -829,6 +830,8 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
     cvb_wave_sync();
     // 40 rows of 10 aligned dwords (the plane's row stride is a multiple of 64 and wider than the padded width)
     {
+      // (predicated loads: a lane without a dword of the window inside the plane sends no request - with clamped addresses instead of the
+      // predicates the kernel was 5 % slower: it is bound by memory requests, not by the branches around them)
       constexpr int NIT = (TS * (TS / 4) + CVB_TT - 1) / CVB_TT;
       uint32_t v[NIT];
 #pragma unroll
@@ -837,22 +840,20 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
         const int px = bx + 4 * q, py = by + yy;
         v[k] = (i < TS * (TS / 4) && px >= 0 && px < L.stride && py >= 0 && py < PH) ? *reinterpret_cast<const uint32_t*>(L.pad + (size_t)py * L.stride + px) : 0u;
       }
-      // ... and with them what the keypoint predicate reads at this lane's 4 x 4 pixels (four in a row, rows 8 apart): the cell
-      // flags of the keypoint map and the mask bytes - a second round trip otherwise, for the few pixels that survive the NMS
+      // ... and with them what the keypoint predicate reads at this lane's 4 x 4 pixels (four in a row, rows 8 apart): the mask bytes -
+      // a second round trip otherwise, for the few pixels that survive the NMS.  A quad that is not wholly inside the level holds no
+      // keypoint (they keep `edge` >= 3 pixels from the border): its mask reads as 0 and is not loaded.
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int px = CVB_TILE * tx + (tid & 7) * 4, py = CVB_TILE * ty + (tid >> 3) + 8 * r;
         const int x = px - CV_BORDER, y = py - CV_BORDER;
-        kpm[r] = kpmap[__umul24((uint32_t)(py >> 3), (uint32_t)B.cw) + (uint32_t)(px >> 3)];
         uint32_t m = 0;
-        if (y >= 0 && y < L.h) {
-          const uint8_t* mp = mk + (__umul24((uint32_t)y, (uint32_t)mks) + x);
-          if (x >= 0 && x + 3 < L.w) __builtin_memcpy(&m, mp, 4);
-          else
-            for (int j = 0; j < 4; j++) if (x + j >= 0 && x + j < L.w) m |= (uint32_t)mp[j] << (8 * j);
-        }
+        if (y >= 0 && y < L.h && x >= 0 && x + 3 < L.w) __builtin_memcpy(&m, mk + (__umul24((uint32_t)y, (uint32_t)mks) + x), 4);
         mrow[r] = m;
       }
+      // the tile's 4 x 4 cell flags of the keypoint map: one aligned dword per cell row, the same for every lane (scalar loads)
+#pragma unroll
+      for (int r = 0; r < 4; r++) kpm[r] = cvb_sload(reinterpret_cast<const uint32_t*>(kpmap + (4 * ty + r) * B.cw + 4 * tx));
 #pragma unroll
       for (int k = 0; k < NIT; k++) {
         const int i = tid + k * CVB_TT;
@@ -865,52 +866,113 @@ __global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
     uint32_t kpbits = 0;                          // bit 4 cy + cx: cell (cx, cy) of the tile is a keypoint cell
     {
       // scores are only read on the tile's keypoint cells and one pixel around them: cell (cx, cy) covers score columns 8 cx .. 8 cx + 9
-      // and rows 8 cy .. 8 cy + 9 of the 34 x 34 score map.  (kpm[r] of the lanes 2 cx, 2 cx + 1 is the flag of cell (cx, r).)
+      // and rows 8 cy .. 8 cy + 9 of the 34 x 34 score map.  (Byte cx of kpm[r] is the flag of cell (cx, r).)
       unsigned long long cm[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const unsigned long long bal = __ballot(kpm[r] != 0);
-        cm[r] = ((bal & 1) ? 0x3FFull : 0) | ((bal & 4) ? 0x3FFull << 8 : 0) | ((bal & 16) ? 0x3FFull << 16 : 0) | ((bal & 64) ? 0x3FFull << 24 : 0);
-        kpbits |= (uint32_t)(((bal & 1) ? 1u : 0u) | ((bal & 4) ? 2u : 0u) | ((bal & 16) ? 4u : 0u) | ((bal & 64) ? 8u : 0u)) << (4 * r);
+        const uint32_t f = kpm[r];
+        cm[r] = ((f & 0xFFu) ? 0x3FFull : 0) | ((f & 0xFF00u) ? 0x3FFull << 8 : 0) | ((f & 0xFF0000u) ? 0x3FFull << 16 : 0) | ((f & 0xFF000000u) ? 0x3FFull << 24 : 0);
+        kpbits |= (uint32_t)(((f & 0xFFu) ? 1u : 0u) | ((f & 0xFF00u) ? 2u : 0u) | ((f & 0xFF0000u) ? 4u : 0u) | ((f & 0xFF000000u) ? 8u : 0u)) << (4 * r);
       }
+      // ... restricted to the pixels FAST tests at all: 3 <= x < w - 3, 3 <= y < h - 3 (score pixel (sx, sy) is level pixel (bx + 3 + sx - CV_BORDER, ...))
+      const int xb = bx + 3 - CV_BORDER, yb = by + 3 - CV_BORDER;
+      const int sx_lo = min(max(3 - xb, 0), SS), sx_hi = min(max(L.w - 3 - xb, 0), SS);
+      const unsigned long long colok = ((1ull << sx_hi) - 1ull) & ~((1ull << sx_lo) - 1ull);
       if (tid < SS) {
         const int chi = tid >> 3, clo = (tid - 2) >> 3;                   // the cell rows whose 10-row band holds score row tid
         unsigned long long m = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) if (r == chi || r == clo) m |= cm[r];
-        rowmask[tid] = m;
+        const int y = yb + tid;
+        rowmask[tid] = (y >= 3 && y < L.h - 3) ? (m & colok) : 0ull;
       }
     }
     cvb_wave_sync();
-    // compass test (two adjacent compass points both darker / brighter: necessary for a 9-arc) over the score pixels that are read;
-    // (sx, sy) advance with i += 64 = 34 + 30; the survivors are numbered by ballot, no LDS counter
+    // compass test (two adjacent compass points both darker / brighter: necessary for a 9-arc) over the score pixels that are read,
+    // FOUR horizontally adjacent pixels per lane and step on packed u16 (as orb_fast_cells does): "some adjacent pair of compass points
+    // is below x" = (N < x or S < x) and (E < x or W < x) = max(min(N, S), min(E, W)) < x.  9 quads per score row (the last one holds
+    // two pixels), 306 items in 5 steps; the survivors are numbered by ballot, no LDS counter (their order does not matter: scores go
+    // into the score map, keypoints are sorted by cvb_select).  (r04: 18 one-pixel steps before - half of the tile's instructions.)
     int ns = 0;
     {
-      int sx = tid < SS ? tid : tid - SS, sy = tid < SS ? 0 : 1;
-      for (int i = tid; i < SS * SS + CVB_TT - 1 - (SS * SS - 1) % CVB_TT; i += CVB_TT) {
-        bool cand = false;
-        if (i < SS * SS && ((rowmask[sy] >> sx) & 1)) {
-          const int x = bx + 3 + sx - CV_BORDER, y = by + 3 + sy - CV_BORDER;  // score pixel: padded (bx + 3 + sx, by + 3 + sy)
-          if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
-            const uint8_t* c = tile + (sy + 3) * TS + sx + 3;
-            const int v = c[0], n = c[3 * TS], ea = c[3], so = c[-3 * TS], w = c[-3];
-            const int M = min(min(max(n, ea), max(ea, so)), min(max(so, w), max(w, n)));
-            const int m = max(max(min(n, ea), min(ea, so)), max(min(so, w), min(w, n)));
-            cand = v - M > th || m - v > th;
-          }
+      constexpr int NQ = (SS + 3) / 4;                                   // 9
+      const cvb_s2 thv = {(short)th, (short)th};
+#pragma unroll
+      for (int k = 0; k < (SS * NQ + CVB_TT - 1) / CVB_TT; k++) {
+        const int i = tid + k * CVB_TT, sy = min(i / NQ, SS - 1), q = i - (i / NQ) * NQ;
+        const uint32_t rm = i < SS * NQ ? (uint32_t)(rowmask[sy] >> (4 * q)) & 15u : 0u;
+        const uint32_t* up = reinterpret_cast<const uint32_t*>(tile + sy * TS + 4 * q);          // row sy: the N / S points of centre row sy + 3
+        const uint32_t* ce = reinterpret_cast<const uint32_t*>(tile + (sy + 3) * TS + 4 * q);
+        const uint32_t* dn = reinterpret_cast<const uint32_t*>(tile + (sy + 6) * TS + 4 * q);
+        const uint32_t n0 = up[0], n1 = up[1], c0 = ce[0], c1 = ce[1], c2 = ce[2], s0 = dn[0], s1 = dn[1];
+        bool cand[4];
+#pragma unroll
+        for (int pq = 0; pq < 2; pq++) {
+          // bytes (b, b + 1) of the 8-byte pair {hi, lo} as packed u16; the centre of pixel j sits at byte 3 + j of the row's three dwords
+#define PAIR(hi, lo, b) __builtin_bit_cast(cvb_us2, __builtin_amdgcn_perm(hi, lo, (uint32_t)(b) | 0x0c000c00u | ((uint32_t)((b) + 1) << 16)))
+          const cvb_us2 pN = PAIR(n1, n0, 3 + 2 * pq), pS = PAIR(s1, s0, 3 + 2 * pq), pW = PAIR(c1, c0, 2 * pq);
+          const cvb_us2 pE = pq == 0 ? PAIR(c1, c0, 6) : PAIR(c2, c1, 4);
+          const cvb_s2 cv = __builtin_bit_cast(cvb_s2, PAIR(c1, c0, 3 + 2 * pq));
+#undef PAIR
+          const cvb_us2 M = __builtin_elementwise_max(__builtin_elementwise_min(pN, pS), __builtin_elementwise_min(pE, pW));
+          const cvb_us2 m = __builtin_elementwise_min(__builtin_elementwise_max(pN, pS), __builtin_elementwise_max(pE, pW));
+          const cvb_s2 dd = cv - __builtin_bit_cast(cvb_s2, M);          // > th: two adjacent compass points darker than v - th
+          const cvb_s2 bb = __builtin_bit_cast(cvb_s2, m) - cv;          // > th: two adjacent compass points brighter than v + th
+          const cvb_s2 mx = __builtin_elementwise_max(dd, bb);
+          cand[2 * pq] = mx.x > thv.x && ((rm >> (2 * pq)) & 1u);
+          cand[2 * pq + 1] = mx.y > thv.y && ((rm >> (2 * pq + 1)) & 1u);
         }
-        const unsigned long long bm = __ballot(cand);
-        if (cand) surv[ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = (uint16_t)i;
-        ns += __popcll(bm);
-        sx += CVB_TT - SS; sy += 1;
-        if (sx >= SS) { sx -= SS; sy += 1; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const unsigned long long bm = __ballot(cand[j]);
+          if (cand[j]) surv[ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = (uint16_t)(sy * SS + 4 * q + j);
+          ns += __popcll(bm);
+        }
       }
     }
     cvb_wave_sync();
-    for (int k = tid; k < ns; k += CVB_TT) {
-      const int i = surv[k], sx = i % SS, sy = i / SS;
-      const int best = cvb_fast_score_full<TS>(tile + (sy + 3) * TS + sx + 3);
-      if (best > th) sc[i] = (uint8_t)best;
+    // exact scores of the survivors, TWO per lane on packed u16 halves: the maximum (dark arcs) and the minimum (bright arcs) of each of
+    // the 16 nine-pixel arcs from running maxima / minima of the ring's two 8-blocks - the arc that starts at i < 8 is the block-0
+    // suffix from i and the block-1 prefix up to i, the arc that starts at i + 8 wraps the other way (59 packed operations per
+    // polarity for two pixels; cvb_fast_score_full, which this restates, takes 176 for one)
+    for (int k0 = 0; k0 < ns; k0 += 2 * CVB_TT) {
+      int ii[2];
+      const uint8_t* c[2];
+#pragma unroll
+      for (int e2 = 0; e2 < 2; e2++) {
+        ii[e2] = surv[min(k0 + CVB_TT * e2 + tid, ns - 1)];            // lanes beyond the end repeat the last entry (their result is dropped)
+        const int sy = ii[e2] / SS, sx = ii[e2] - sy * SS;
+        c[e2] = tile + (sy + 3) * TS + sx + 3;
+      }
+      constexpr int st = TS;
+      constexpr int off[16] = {3 * st, 3 * st + 1, 2 * st + 2, st + 3, 3, -st + 3, -2 * st + 2, -3 * st + 1,
+                               -3 * st, -3 * st - 1, -2 * st - 2, -st - 3, -3, st - 3, 2 * st - 2, 3 * st - 1};
+      cvb_us2 x[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) x[i] = __builtin_bit_cast(cvb_us2, (uint32_t)c[0][off[i]] | ((uint32_t)c[1][off[i]] << 16));
+      const cvb_s2 cv = __builtin_bit_cast(cvb_s2, (uint32_t)c[0][0] | ((uint32_t)c[1][0] << 16));
+      cvb_us2 S0[8], P0[8], S1[8], P1[8];
+      S0[7] = x[7]; P0[0] = x[0]; S1[7] = x[15]; P1[0] = x[8];
+#pragma unroll
+      for (int i = 6; i >= 0; i--) { S0[i] = __builtin_elementwise_max(x[i], S0[i + 1]); S1[i] = __builtin_elementwise_max(x[8 + i], S1[i + 1]); }
+#pragma unroll
+      for (int i = 1; i < 8; i++) { P0[i] = __builtin_elementwise_max(x[i], P0[i - 1]); P1[i] = __builtin_elementwise_max(x[8 + i], P1[i - 1]); }
+      cvb_us2 lowest_max = __builtin_elementwise_min(__builtin_elementwise_max(S0[0], P1[0]), __builtin_elementwise_max(S1[0], P0[0]));
+#pragma unroll
+      for (int i = 1; i < 8; i++)
+        lowest_max = __builtin_elementwise_min(lowest_max, __builtin_elementwise_min(__builtin_elementwise_max(S0[i], P1[i]), __builtin_elementwise_max(S1[i], P0[i])));
+      S0[7] = x[7]; P0[0] = x[0]; S1[7] = x[15]; P1[0] = x[8];
+#pragma unroll
+      for (int i = 6; i >= 0; i--) { S0[i] = __builtin_elementwise_min(x[i], S0[i + 1]); S1[i] = __builtin_elementwise_min(x[8 + i], S1[i + 1]); }
+#pragma unroll
+      for (int i = 1; i < 8; i++) { P0[i] = __builtin_elementwise_min(x[i], P0[i - 1]); P1[i] = __builtin_elementwise_min(x[8 + i], P1[i - 1]); }
+      cvb_us2 highest_min = __builtin_elementwise_max(__builtin_elementwise_min(S0[0], P1[0]), __builtin_elementwise_min(S1[0], P0[0]));
+#pragma unroll
+      for (int i = 1; i < 8; i++)
+        highest_min = __builtin_elementwise_max(highest_min, __builtin_elementwise_max(__builtin_elementwise_min(S0[i], P1[i]), __builtin_elementwise_min(S1[i], P0[i])));
+      const cvb_s2 best = __builtin_elementwise_max(cv - __builtin_bit_cast(cvb_s2, lowest_max), __builtin_bit_cast(cvb_s2, highest_min) - cv);
+      if ((int)best.x > th && k0 + tid < ns) sc[ii[0]] = (uint8_t)best.x;
+      if ((int)best.y > th && k0 + CVB_TT + tid < ns) sc[ii[1]] = (uint8_t)best.y;
     }
     cvb_wave_sync();
     // keypoints of the tile: the scored survivors inside the tile that pass cv_is_keypoint - strict 3 x 3 maximum, border rectangle,
@@ -1168,14 +1230,48 @@ __global__ __launch_bounds__(256) void cvb_describe(CvbPlan P) {
     const CvSel S = P.sel[(size_t)(img * P.nlevels + l) * CVB_CAND_CAP + (k - base)];
     const CvLevelDev L = cvb_level(P, img, l);
     const int x0 = S.x, y0 = S.y;
-    const uint8_t* center = L.pad + (size_t)(CV_BORDER + y0) * L.stride + CV_BORDER + x0;
+    // Both neighbourhoods of the keypoint go to LDS with row-coalesced loads (4 lanes x 12 bytes per row, aligned down: the rows' common
+    // byte shift is added at the reads), requested together: the 31 x 31 disc of the level plane for the intensity centroid, and the
+    // 39 x 39 neighbourhood of the blurred plane for the steered pattern (its taps stay within 19 pixels of the keypoint) - the byte
+    // gathers they replace (62 + 32 per lane) touch some 60 cache lines per load instruction, and the kernel is bound by memory requests.
+    uint8_t* patch = patch_all[(threadIdx.x >> 6) * 4 + grp];
+    const float px = __fmul_rn((float)x0, L.scale), py = __fmul_rn((float)y0, L.scale);
+    const float inv = __fdiv_rn(1.f, L.scale);
+    const int r4 = l16 >> 2, c4 = l16 & 3;
+    const uint32_t sd = (uint32_t)L.stride >> 2;     // row stride in dwords (the planes' strides are multiples of 64)
+    const uint8_t* ca = L.pad + (size_t)(CV_BORDER + y0 - 15) * L.stride + CV_BORDER + x0 - 15;
+    const uint32_t ashift = (uint32_t)(reinterpret_cast<uintptr_t>(ca) & 3);
+    const uint8_t* cb = L.blur + (size_t)(CV_BORDER + __float2int_rn(__fmul_rn(py, inv)) - 19) * L.stride + CV_BORDER + __float2int_rn(__fmul_rn(px, inv)) - 19;
+    const uint32_t pshift = (uint32_t)(reinterpret_cast<uintptr_t>(cb) & 3);
+    uint32_t ta[8][3], tmp[10][3];
+    {
+      const uint32_t* qa = reinterpret_cast<const uint32_t*>(ca - ashift) + 3 * c4;
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(cb - pshift) + 3 * c4;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint32_t* r = qa + (uint32_t)(4 * i + r4) * sd;
+        ta[i][0] = r[0]; ta[i][1] = r[1]; ta[i][2] = r[2];
+      }
+#pragma unroll
+      for (int i = 0; i < 10; i++) {
+        const uint32_t* r = q + (uint32_t)(4 * i + r4) * sd;
+        tmp[i][0] = r[0]; tmp[i][1] = r[1]; tmp[i][2] = r[2];
+      }
+    }
+    cvb_wave_sync();                                 // the previous round's taps are read
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint32_t* d = reinterpret_cast<uint32_t*>(patch + (4 * i + r4) * 48) + 3 * c4;
+      d[0] = ta[i][0]; d[1] = ta[i][1]; d[2] = ta[i][2];
+    }
+    cvb_wave_sync();
     int m10 = 0, m01 = 0;
     {
-      // row +v and row -v of the disc on lane v of the keypoint's 16 lanes (lane 0: the centre row, counted once); every load of
-      // the 31-column span is issued (the padded plane holds it all), the disc mask picks the ones that count
+      // row +v and row -v of the disc on lane v of the keypoint's 16 lanes (lane 0: the centre row, counted once); the whole 31-column
+      // span is read, the disc mask picks the pixels that count
       const int v = l16, d = P.umax[v];
-      const uint8_t* rp = center + v * L.stride;
-      const uint8_t* rm = center - v * L.stride;
+      const uint8_t* rp = patch + (15 + v) * 48 + 15 + ashift;
+      const uint8_t* rm = patch + (15 - v) * 48 + 15 + ashift;
       int v_sum = 0;
 #pragma unroll
       for (int u = -15; u <= 15; ++u) {
@@ -1189,40 +1285,20 @@ __global__ __launch_bounds__(256) void cvb_describe(CvbPlan P) {
 #pragma unroll
     for (int dd = 8; dd >= 1; dd >>= 1) { m10 += __shfl_xor(m10, dd); m01 += __shfl_xor(m01, dd); }
     const float angle_deg = cv_fast_atan2_deg((float)m01, (float)m10);
-    const float px = __fmul_rn((float)x0, L.scale), py = __fmul_rn((float)y0, L.scale);
     if (live && l16 == 0) {
       ps_keypoint_pod o;
       o.x = px; o.y = py; o.size = __fmul_rn(31.f, L.scale); o.angle = angle_deg; o.response = S.response; o.octave = S.level; o.class_id = -1;
       P.kps[(size_t)img * P.ocap + k] = o;
     }
-    const float inv = __fdiv_rn(1.f, L.scale);
     const float angle = __fmul_rn(angle_deg, (float)(3.14159265358979323846 / 180.f));
     const float a = (float)cos((double)angle), b = (float)sin((double)angle);
-    // the taps of the steered pattern stay within 19 pixels of the keypoint: that 39 x 39 neighbourhood of the blurred plane goes to
-    // LDS with row-coalesced loads (4 lanes x 12 bytes per row, aligned down: the rows' common byte shift is added at the reads) -
-    // the 32 byte gathers per lane would otherwise touch some 60 cache lines per load instruction
-    uint8_t* patch = patch_all[(threadIdx.x >> 6) * 4 + grp];
-    uint32_t pshift;
-    {
-      const uint8_t* cb = L.blur + (size_t)(CV_BORDER + __float2int_rn(__fmul_rn(py, inv)) - 19) * L.stride + CV_BORDER + __float2int_rn(__fmul_rn(px, inv)) - 19;
-      pshift = (uint32_t)(reinterpret_cast<uintptr_t>(cb) & 3);
-      const int r4 = l16 >> 2, c4 = l16 & 3;
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(cb - pshift) + 3 * c4;
-      const uint32_t sd = (uint32_t)L.stride >> 2;     // row stride in dwords (the planes' strides are multiples of 64)
-      uint32_t tmp[10][3];
+    cvb_wave_sync();                                 // the disc is read
 #pragma unroll
-      for (int i = 0; i < 10; i++) {
-        const uint32_t* r = q + (uint32_t)(4 * i + r4) * sd;
-        tmp[i][0] = r[0]; tmp[i][1] = r[1]; tmp[i][2] = r[2];
-      }
-      cvb_wave_sync();                                 // the previous round's taps are read
-#pragma unroll
-      for (int i = 0; i < 10; i++) {
-        uint32_t* d = reinterpret_cast<uint32_t*>(patch + (4 * i + r4) * 48) + 3 * c4;
-        d[0] = tmp[i][0]; d[1] = tmp[i][1]; d[2] = tmp[i][2];
-      }
-      cvb_wave_sync();
+    for (int i = 0; i < 10; i++) {
+      uint32_t* d = reinterpret_cast<uint32_t*>(patch + (4 * i + r4) * 48) + 3 * c4;
+      d[0] = tmp[i][0]; d[1] = tmp[i][1]; d[2] = tmp[i][2];
     }
+    cvb_wave_sync();
     const uint8_t* c = patch + 19 * 48 + 19 + pshift;
     for (int half = 0; half < 2; half++) {
       const int byte = l16 + 16 * half;

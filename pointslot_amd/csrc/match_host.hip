@@ -15,7 +15,7 @@ extern "C" {
 void psk_bf_launch(const BfBlock*, int, const BfProb*, int, const uint8_t*, const float*, const uint8_t*, const uint8_t*,
                    const float*, uint32_t*, int32_t*, int32_t*, float, int, hipStream_t);
 void psk_hamming_matrix_launch(const uint8_t*, int, const uint8_t*, int, uint16_t*, hipStream_t);
-void psk_pj_launch(const PjArrays*, int, int, int, int, hipStream_t);
+void psk_pj_launch(const PjArrays*, int, int, int, int, int, hipStream_t);
 void psk_fuse_launch(const FuArrays*, int, int, hipStream_t);
 void psk_distinctive_launch(const uint8_t*, const int32_t*, int32_t*, int, hipStream_t);
 }
@@ -186,7 +186,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   std::lock_guard<std::mutex> lock(m->mu);
   PS_HIP(hipSetDevice(m->device));
   size_t NT = 0, NQ = 0;
-  int max_nq = 0, any_frame = 0;
+  int max_nq = 0, max_nt = 0, any_frame = 0;
   const int NCELL = PS_GRID_COLS * PS_GRID_ROWS;
   for (int p = 0; p < nprob; p++) {
     const ps_proj_problem& P = probs[p];
@@ -203,6 +203,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
     if (P.use_bbox && T.n > 0 && !T.in_bbox) return ps_set_error(PS_ERR_INVALID, "projection problem %d: use_bbox without in_bbox", p);
     NT += T.n; NQ += P.nq;
     max_nq = P.nq > max_nq ? P.nq : max_nq;
+    max_nt = T.n > max_nt ? T.n : max_nt;
   }
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t r = off; off += al(bytes + 64); return r; };
@@ -290,7 +291,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
   A.nmatch = (int32_t*)(D + o_nm); A.overflow = (int32_t*)(D + o_ovf); A.qbest = (int32_t*)(D + o_qbest); A.qbin = D + o_qbin;
   A.ttop = (uint4*)(D + o_tt);
   hipEventRecord(m->ev0, m->stream);
-  psk_pj_launch(&A, nprob, max_nq > 0 ? max_nq : 1, any_frame, 0, m->stream);
+  psk_pj_launch(&A, nprob, max_nq > 0 ? max_nq : 1, max_nt, any_frame, 0, m->stream);
   hipEventRecord(m->ev1, m->stream);
   PS_HIP(hipGetLastError());
   if (prof) PS_HIP(hipStreamSynchronize(m->stream));
@@ -339,7 +340,7 @@ int ps_search_by_projection(ps_matcher* m, ps_proj_problem* probs, int nprob) {
     // (pj_project runs again on these problems: it only repeats what it wrote; the queries it invalidated stay invalid)
     PjArrays A2 = A;
     A2.prob = (const PjProb*)(Wd + w_prob); A2.cand = (uint32_t*)(Wd + w_cand); A2.nmatch = (int32_t*)(Wd + w_nm); A2.overflow = (int32_t*)(Wd + w_ovf);
-    psk_pj_launch(&A2, (int)sub.size(), max_nq2, any_frame2, 1, m->stream);
+    psk_pj_launch(&A2, (int)sub.size(), max_nq2, max_nt, any_frame2, 1, m->stream);
     PS_HIP(hipGetLastError());
     std::vector<int32_t> ovf2(sub.size(), 0);
     PS_HIP(hipMemcpyAsync(H + o_match, D + o_match, NT * 4, hipMemcpyDeviceToHost, m->stream));

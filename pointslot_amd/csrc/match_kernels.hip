@@ -551,7 +551,9 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
   }
 }
 
+#ifndef PJ_TBL
 #define PJ_TBL 8192
+#endif
 template <int IDXB>
 __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   constexpr int CAP = 1 << (23 - IDXB);
@@ -559,7 +561,8 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   __shared__ uint32_t blocked[1024];   // up to 32768 train features
   __shared__ int hist[32];
   __shared__ uint32_t newly[1024];     // trains blocked by this call
-  __shared__ uint8_t loct[32768];      // train octaves (ratio test), staged once: no global load inside the serial loop
+  extern __shared__ uint8_t loct[];    // train octaves (ratio test), staged once: no global load inside the serial loop; sized by the launch
+                                       // for the call's largest train set (with room for all 32768 the workgroup took 72 KB: two per CU)
   __shared__ uint32_t first_lane[PJ_TBL];   // hashed train -> earliest lane of the current block that lists it among its four keys
   const PjProb P = A.prob[blockIdx.x];
   const int lane = threadIdx.x;
@@ -802,15 +805,17 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
 
 }  // namespace
 
-extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int any_frame_mode, int wide, hipStream_t st) {
+// max_nt: an upper bound of the problems' train counts (at most 32768)
+extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int max_nt, int any_frame_mode, int wide, hipStream_t st) {
   const PjArrays A = *arrays;
+  const size_t lds = (size_t)((max_nt < 1 ? 1 : max_nt > 32768 ? 32768 : max_nt) + 15) & ~(size_t)15;
   if (any_frame_mode) hipLaunchKernelGGL(pj_project, dim3((max_nq + 255) / 256, nprob), dim3(256), 0, st, A);
   if (wide) {
     hipLaunchKernelGGL(pj_gather<13>, dim3((max_nq + 15) / 16, nprob), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(pj_resolve<13>, dim3(nprob), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(pj_resolve<13>, dim3(nprob), dim3(64), lds, st, A);
   } else {
     hipLaunchKernelGGL(pj_gather<15>, dim3((max_nq + 15) / 16, nprob), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(pj_resolve<15>, dim3(nprob), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(pj_resolve<15>, dim3(nprob), dim3(64), lds, st, A);
   }
 }
 

@@ -19,7 +19,7 @@ extern "C" {
 hipStream_t psi_orb_stream(ps_orb*);
 const OrbPlan* psi_orb_plan(ps_orb*);
 int psi_orb_prepare(ps_orb*, int, int);
-void psk_pj_launch(const PjArrays*, int, int, int, int, hipStream_t);
+void psk_pj_launch(const PjArrays*, int, int, int, int, int, hipStream_t);
 void psk_pose_lm_launch(const PoProb*, int, const PoVertex*, const float*, const float*, const float*, const uint8_t*, uint8_t*,
                         double*, uint8_t*, double*, int32_t*, double*, hipStream_t);
 void psk_trk_begin(const TrkArrays*, int, hipStream_t);
@@ -278,15 +278,15 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
   if (rc != PS_OK) return rc;
   mark(TS_STEREO);
   psk_trk_begin(A, t->step, st); mark(TS_GLUE);
-  psk_pj_launch(&t->pj_mm1, S, cap, 1, 0, st); mark(TS_SEARCH);
+  psk_pj_launch(&t->pj_mm1, S, cap, cap, 1, 0, st); mark(TS_SEARCH);
   psk_trk_after_mm1(A, st); mark(TS_GLUE);
-  psk_pj_launch(&t->pj_mm2, S, cap, 1, 0, st); mark(TS_SEARCH);   // the 2 * th retry; empty problems where it is not needed
+  psk_pj_launch(&t->pj_mm2, S, cap, cap, 1, 0, st); mark(TS_SEARCH);   // the 2 * th retry; empty problems where it is not needed
   psk_trk_after_mm(A, t->step, st); mark(TS_GLUE);
   psk_pose_lm_launch(A->po_prob, S, A->po_vert, A->cur.xw, A->po_obs, A->po_is2, A->cur.mp_valid, A->cur.outlier, t->po_chi2, t->po_state,
                      A->po_pose, A->po_result, nullptr, st);
   mark(TS_POSE);
   psk_trk_after_pose1(A, t->step, st); mark(TS_GLUE);
-  psk_pj_launch(&t->pj_lm, S, cap, 0, 0, st); mark(TS_SEARCH);
+  psk_pj_launch(&t->pj_lm, S, cap, cap, 0, 0, st); mark(TS_SEARCH);
   psk_trk_after_lm(A, st); mark(TS_GLUE);
   psk_pose_lm_launch(A->po_prob, S, A->po_vert, A->cur.xw, A->po_obs, A->po_is2, A->cur.mp_valid, A->cur.outlier, t->po_chi2, t->po_state,
                      A->po_pose, A->po_result, nullptr, st);
@@ -315,7 +315,7 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
                        O->po_pose, O->po_result, nullptr, st);
     mark(TS_OBJ_CFSE3);
     psk_ob_after_cf1(O, t->step, st); mark(TS_OBJ_GLUE);
-    psk_pj_launch(&t->pj_obj, S * K, O->LC, 0, 0, st); mark(TS_OBJ_SEARCH);
+    psk_pj_launch(&t->pj_obj, S * K, O->LC, O->OC, 0, 0, st); mark(TS_OBJ_SEARCH);
     psk_ob_after_lm(O, t->step, st); mark(TS_OBJ_GLUE);
     psk_pose_lm_launch(O->po_prob, S, O->po_vert, O->cur.mp_po, O->po_obs, O->po_is2, O->cur.mp_valid, O->cur.outlier, t->ob_chi2, t->ob_state,
                        O->po_pose, O->po_result, nullptr, st);
