@@ -809,7 +809,10 @@ __device__ __forceinline__ float cvb_harris_wave(const uint8_t* c, int lane) {
 // the compass test (two adjacent compass points both darker / brighter: necessary for a 9-arc) over the tile and one ring around
 // it (34 x 34) leaves a list of survivors; their exact scores go into the LDS score map; then per tile pixel inside a kp cell the
 // keypoint predicate of cv_is_keypoint - strict 3 x 3 maximum, mask, border rectangle - and the append with the Harris response
-__global__ __launch_bounds__(CVB_TT) void cvb_detect(CvbPlan P) {
+#ifndef CVB_DET_OCC
+#define CVB_DET_OCC 4        // (5 spills: 489 -> 565 us)
+#endif
+__global__ __launch_bounds__(CVB_TT) __attribute__((amdgpu_waves_per_eu(CVB_DET_OCC, 8))) void cvb_detect(CvbPlan P) {
   constexpr int TS = 40, SS = 34;
   __shared__ __attribute__((aligned(16))) uint8_t tile[TS * TS];
   __shared__ __attribute__((aligned(16))) uint8_t sc[SS * SS + 12];     // 1168 bytes: cleared as 292 dwords
@@ -1205,7 +1208,10 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P) {
 
 // four keypoints per WAVE, one per 16-lane row: ICAngles, pt *= scale, computeOrbDescriptors - the arithmetic of cv_describe on the
 // image's own planes; keypoint k of an image is entry k of the concatenation of its levels' selections
-__global__ __launch_bounds__(256) void cvb_describe(CvbPlan P) {
+#ifndef CVB_DESC_OCC
+#define CVB_DESC_OCC 5       // waves per SIMD the register allocation aims at (the LDS admits five workgroups per CU); measured 3 / 4 / 5: 518 / 461 / 435 us
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CVB_DESC_OCC, 8))) void cvb_describe(CvbPlan P) {
   __shared__ __attribute__((aligned(16))) uint8_t patch_all[16][40 * 48];
   const int img = blockIdx.y, lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   int nsel[CV_MAX_LEVELS];
@@ -1231,9 +1237,9 @@ __global__ __launch_bounds__(256) void cvb_describe(CvbPlan P) {
     const CvLevelDev L = cvb_level(P, img, l);
     const int x0 = S.x, y0 = S.y;
     // Both neighbourhoods of the keypoint go to LDS with row-coalesced loads (4 lanes x 12 bytes per row, aligned down: the rows' common
-    // byte shift is added at the reads), requested together: the 31 x 31 disc of the level plane for the intensity centroid, and the
+    // byte shift is added at the reads): the 31 x 31 disc of the level plane for the intensity centroid, and the
     // 39 x 39 neighbourhood of the blurred plane for the steered pattern (its taps stay within 19 pixels of the keypoint) - the byte
-    // gathers they replace (62 + 32 per lane) touch some 60 cache lines per load instruction, and the kernel is bound by memory requests.
+    // gathers they replace (62 + 32 per lane) touch some 60 cache lines per load instruction.
     uint8_t* patch = patch_all[(threadIdx.x >> 6) * 4 + grp];
     const float px = __fmul_rn((float)x0, L.scale), py = __fmul_rn((float)y0, L.scale);
     const float inv = __fdiv_rn(1.f, L.scale);
@@ -1243,26 +1249,28 @@ __global__ __launch_bounds__(256) void cvb_describe(CvbPlan P) {
     const uint32_t ashift = (uint32_t)(reinterpret_cast<uintptr_t>(ca) & 3);
     const uint8_t* cb = L.blur + (size_t)(CV_BORDER + __float2int_rn(__fmul_rn(py, inv)) - 19) * L.stride + CV_BORDER + __float2int_rn(__fmul_rn(px, inv)) - 19;
     const uint32_t pshift = (uint32_t)(reinterpret_cast<uintptr_t>(cb) & 3);
-    uint32_t ta[8][3], tmp[10][3];
+    uint32_t tmp[10][3];
     {
+      uint32_t ta[8][3];
       const uint32_t* qa = reinterpret_cast<const uint32_t*>(ca - ashift) + 3 * c4;
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(cb - pshift) + 3 * c4;
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const uint32_t* r = qa + (uint32_t)(4 * i + r4) * sd;
         ta[i][0] = r[0]; ta[i][1] = r[1]; ta[i][2] = r[2];
       }
+      cvb_wave_sync();                               // the previous round's taps are read
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(patch + (4 * i + r4) * 48) + 3 * c4;
+        d[0] = ta[i][0]; d[1] = ta[i][1]; d[2] = ta[i][2];
+      }
+      // the blurred neighbourhood is requested now (the disc's staging registers are free again) and arrives under the moments
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(cb - pshift) + 3 * c4;
 #pragma unroll
       for (int i = 0; i < 10; i++) {
         const uint32_t* r = q + (uint32_t)(4 * i + r4) * sd;
         tmp[i][0] = r[0]; tmp[i][1] = r[1]; tmp[i][2] = r[2];
       }
-    }
-    cvb_wave_sync();                                 // the previous round's taps are read
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      uint32_t* d = reinterpret_cast<uint32_t*>(patch + (4 * i + r4) * 48) + 3 * c4;
-      d[0] = ta[i][0]; d[1] = ta[i][1]; d[2] = ta[i][2];
     }
     cvb_wave_sync();
     int m10 = 0, m01 = 0;
