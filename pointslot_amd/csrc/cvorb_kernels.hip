@@ -1156,18 +1156,22 @@ __global__ __launch_bounds__(CVB_TT) void cvb_blur(CvbPlan P) {
 // Two launches: candidate lists of up to 512 entries (the usual case) run with 8 KB of LDS - twenty workgroups per CU instead of
 // five, which is what counts for a kernel whose retainBest steps are one lane's serial walk through LDS -, longer lists with 32 KB
 template <int CAP, int LO>
-__global__ __launch_bounds__(256) void cvb_select(CvbPlan P) {
+__global__ __launch_bounds__(256) void cvb_select(CvbPlan P, int nslots) {
   __shared__ uint32_t key[CAP];
   __shared__ int32_t idx[CAP];
   __shared__ float resp[CAP];
   __shared__ int32_t pay[CAP];
   __shared__ int nkeep;
-  const int slot = blockIdx.x, l = slot % P.nlevels, img = slot / P.nlevels, tid = threadIdx.x;
+  // (the launch for the long lists - rare - is a few workgroups that walk over all slots: one workgroup per slot, each with 32 KB of LDS
+  // to find on a CU before it can start and return, waited 280 us for its turn beside the other lockstep groups' kernels; 5 us alone)
+  const int tid = threadIdx.x;
+  for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+  const int l = slot % P.nlevels, img = slot / P.nlevels;
   const int total = P.ncand[slot];
   const int n = min(total, CVB_CAND_CAP);
-  if (n <= LO || n > CAP) return;                                  // the other launch's list (LO = -1: the empty lists too)
+  if (n <= LO || n > CAP) continue;                                // the other launch's list (LO = -1: the empty lists too)
   if (total > CVB_CAND_CAP && tid == 0) atomicAdd(&P.overflow[img], 1);
-  if (n == 0) { if (tid == 0) P.nsel[slot] = 0; return; }
+  if (n == 0) { if (tid == 0) P.nsel[slot] = 0; continue; }
   const float4* C = P.cand + (size_t)slot * CVB_CAND_CAP;
   int npow = 1;
   while (npow < n) npow <<= 1;
@@ -1204,6 +1208,8 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P) {
   CvSel* S = P.sel + (size_t)slot * CVB_CAND_CAP;
   for (int i = tid; i < m; i += 256) { const float4 c = C[pay[i]]; S[i] = CvSel{(int32_t)c.x, (int32_t)c.y, l, resp[i]}; }
   if (tid == 0) P.nsel[slot] = m;
+  __syncthreads();                                                 // the lists in LDS are free for the next slot
+  }
 }
 
 // four keypoints per WAVE, one per 16-lane row: ICAngles, pt *= scale, computeOrbDescriptors - the arithmetic of cv_describe on the
@@ -1364,8 +1370,8 @@ void psk_cvb_run(const CvbPlan* Pin, int nimg, const uint8_t* imgs, int stride, 
   for (int l = 1; l < NL; l++) hipLaunchKernelGGL(cvb_resize, dim3(grid), dim3(CVB_TT), 0, st, *P, l);
   hipLaunchKernelGGL(cvb_detect, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
   hipLaunchKernelGGL(cvb_blur, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
-  hipLaunchKernelGGL((cvb_select<512, -1>), dim3(nimg * NL), dim3(256), 0, st, *P);
-  hipLaunchKernelGGL((cvb_select<CVB_CAND_CAP, 512>), dim3(nimg * NL), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL((cvb_select<512, -1>), dim3(nimg * NL), dim3(256), 0, st, *P, nimg * NL);
+  hipLaunchKernelGGL((cvb_select<CVB_CAND_CAP, 512>), dim3(nimg * NL < 256 ? nimg * NL : 256), dim3(256), 0, st, *P, nimg * NL);
   hipLaunchKernelGGL(cvb_describe, dim3(32, nimg), dim3(256), 0, st, *P);
 }
 }

@@ -267,15 +267,19 @@ __global__ __launch_bounds__(256) void st_match(OrbPlan plan, const StPair* pair
   if (l16 == 0 && live) { st_gm(S.u_right)[iL] = out_ur; st_gm(S.depth)[iL] = out_depth; st_gm(S.sad)[iL] = out_sad; }
 }
 
-__global__ __launch_bounds__(1024) void st_median(OrbPlan plan, const StPair* pairs) {
+#ifndef ST_MED_T
+#define ST_MED_T 256      // (1024 threads - sixteen wave slots of ONE CU free at the same moment - waited 200 us for its turn beside the other
+                          // lockstep groups' kernels; alone it ran 29 us)
+#endif
+__global__ __launch_bounds__(ST_MED_T) void st_median(OrbPlan plan, const StPair* pairs) {
   __shared__ __attribute__((aligned(16))) uint32_t keys[PS_ST_CAP + 4];
   __shared__ int nkeys, median_sad;
-  __shared__ int red[16];
+  __shared__ int red[ST_MED_T / 64];
   const StPair S = pairs[blockIdx.x];
   const int N = min(*S.cnt_l, PS_ST_CAP), tid = threadIdx.x;
   if (tid == 0) { nkeys = 0; median_sad = -1; }
   __syncthreads();
-  for (int i = tid; i < N; i += 1024) {
+  for (int i = tid; i < N; i += ST_MED_T) {
     const int sd = S.sad[i];
     if (sd >= 0) keys[atomicAdd(&nkeys, 1)] = ((uint32_t)sd << 12) | (uint32_t)i;   // order inside `keys` is irrelevant
   }
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(1024) void st_median(OrbPlan plan, const StPair* pa
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
       const int hi_bin = level == 1 ? sel_bin : 0;
-      for (int e = tid; e < n; e += 1024) {
+      for (int e = tid; e < n; e += ST_MED_T) {
         const uint32_t sd = keys[e] >> 12;
         if (level == 0) atomicAdd(&hist[sd >> 8], 1);
         else if ((int)(sd >> 8) == hi_bin) atomicAdd(&hist[sd & 255u], 1);
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(1024) void st_median(OrbPlan plan, const StPair* pa
   }
   const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), (float)median_sad);
   int kept = 0;
-  for (int e = tid; e < n; e += 1024) {
+  for (int e = tid; e < n; e += ST_MED_T) {
     const uint32_t k = keys[e];
     const int i = (int)(k & 0xFFF);
     if ((float)(int)(k >> 12) < thDist) kept++;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(1024) void st_median(OrbPlan plan, const StPair* pa
   kept = wave_sum_i32(kept);
   if ((tid & 63) == 0) red[tid >> 6] = kept;
   __syncthreads();
-  if (tid == 0) { int acc = 0; for (int w = 0; w < 16; w++) acc += red[w]; *S.kept = acc; }
+  if (tid == 0) { int acc = 0; for (int w = 0; w < ST_MED_T / 64; w++) acc += red[w]; *S.kept = acc; }
 }
 
 }  // namespace
@@ -330,5 +334,5 @@ __global__ __launch_bounds__(1024) void st_median(OrbPlan plan, const StPair* pa
 extern "C" void psk_stereo_launch(const OrbPlan* plan, const StPair* d_pairs, int npairs, int max_left, float mb, float mbf, hipStream_t st) {
   hipLaunchKernelGGL(st_bucket, dim3(npairs), dim3(256), 0, st, *plan, d_pairs);
   hipLaunchKernelGGL(st_match, dim3(((max_left + 15) / 16) * 8, (npairs + 7) / 8), dim3(256), 0, st, *plan, d_pairs, mb, mbf, npairs);
-  hipLaunchKernelGGL(st_median, dim3(npairs), dim3(1024), 0, st, *plan, d_pairs);
+  hipLaunchKernelGGL(st_median, dim3(npairs), dim3(ST_MED_T), 0, st, *plan, d_pairs);
 }

@@ -17,7 +17,9 @@
 namespace {
 
 #ifndef TRK_T
-#define TRK_T 1024      // threads per sequence: the glue kernels are chains of short dependent phases, more lanes shorten each (0.33 -> 0.23 ms per step)
+#define TRK_T 256       // threads per sequence.  The glue kernels are chains of short dependent phases and more lanes shorten each (alone: 0.33 ->
+                        // 0.23 ms per step with 1024), but a 1024-thread workgroup needs sixteen free wave slots on ONE CU at the same moment: beside
+                        // the other lockstep groups' kernels trk_finish waited 500 us for its turn (89 us alone).  r04: 256 -> +1.3 % frames/s
 #endif
 
 __device__ __forceinline__ void mul4(const float* a, const float* b, float* o) {   // OdoSequence::mul4
