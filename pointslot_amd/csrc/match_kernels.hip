@@ -349,7 +349,8 @@ extern "C" void psk_bf_launch_dev(const BfBlock* blocks, const int32_t* d_count,
                                   const float* qang, const uint8_t* qvalid, const uint8_t* tdesc, const float* tang, uint32_t* topk, int32_t* out,
                                   int32_t* nmatch, float nn_ratio, int check_ori, hipStream_t st) {
   hipLaunchKernelGGL((bf_topk_small<256, -1>), dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
-  hipLaunchKernelGGL((bf_topk_small<BF_SMALL_NT, 256>), dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
+  // (215 registers: two workgroups per CU - a grid beyond 512 adds waiting workgroups, not parallelism)
+  hipLaunchKernelGGL((bf_topk_small<BF_SMALL_NT, 256>), dim3(grid < 512 ? grid : 512), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
   // (the launch for the problems with more than BF_SMALL_NT trains - none in most steps, the workgroups then return at once - with one
   // workgroup per CU: each needs 64 KB of LDS before it can start, and 1024 of them waited 220 us for their turn beside the other
   // lockstep groups' kernels; 5 us alone)

@@ -70,23 +70,22 @@ __device__ __forceinline__ const float* ob_cam_pose(const ObArrays& A, int s, in
 // pixel writes its label 49 pixels to both sides, so a pixel ends up with the label of the RIGHTMOST labelled pixel within
 // (x, x + 49] or else with its own (column 0 is never written from the right).  One workgroup per image row.
 // ---------------------------------------------------------------------------------------------------------------------
-#define OB_MASK_ROWS 8
-// (eight rows per workgroup = one row of the detector's 8 x 8 occupancy cells, which this kernel fills on the way: occ[image][cell]).
-// ONE WAVE PER ROW: the row and its `run` table live in the wave's own LDS slice, the prefix maximum is a wave scan - no workgroup
-// barrier between the load and the stores of a row; the eight rows of a workgroup only meet for the occupancy flags.
-#define OB_MASK_T (64 * OB_MASK_ROWS)
+// ONE WAVE PER ROW, one row per workgroup: the row and its `run` table live in LDS, the prefix maximum is a wave scan - no workgroup
+// barrier anywhere.  The detector's 8 x 8 occupancy cells, which this kernel fills on the way (occ[image][cell], cleared by
+// psi_cvorb_batch_begin), get a 1 from every row that has a mask pixel in them.  (Until r04 eight rows shared a 512-thread workgroup
+// with 31 KB of LDS so that they could publish a cell row together; beside the other lockstep groups' kernels such a workgroup
+// waited for its place: 527 us per launch against 103 alone.)
+#define OB_MASK_T 64
 __global__ __launch_bounds__(OB_MASK_T) void ob_masks(ObArrays A, uint8_t* objmask, int W, int H, int ostride, uint8_t* occ, int ocw, int och) {
   extern __shared__ __attribute__((aligned(16))) uint8_t row_all[];
   const int WP = (W + 255) & ~255, per = WP >> 6;             // pixels per lane: a multiple of 4
-  const int s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint8_t* row_sm = row_all + (size_t)wave * 3 * WP;
+  const int s = blockIdx.y, lane = threadIdx.x;
+  uint8_t* row_sm = row_all;
   int16_t* run = reinterpret_cast<int16_t*>(row_sm + WP);
-  uint8_t* occL = row_all + (size_t)OB_MASK_ROWS * 3 * WP;
-  uint8_t* occR = occL + ((ocw + 3) & ~3);
-  for (int i = tid; i < ocw; i += OB_MASK_T) { occL[i] = 0; occR[i] = 0; }
-  __syncthreads();
-  const int y = blockIdx.x * OB_MASK_ROWS + wave;
-  if (y < H) {
+  const int y = blockIdx.x;
+  uint8_t* occL = occ + ((size_t)(2 * s) * och + (y >> 3)) * ocw;
+  uint8_t* occR = occ + ((size_t)(2 * s + 1) * och + (y >> 3)) * ocw;
+  {
     const uint8_t* M = A.idmask + (size_t)s * A.mask_pitch + (size_t)y * A.mask_stride;
     // the lane's pixels [c0, c0 + per) as (unaligned) dwords into LDS; its rightmost labelled column on the way
     const int c0 = lane * per;
@@ -149,12 +148,6 @@ __global__ __launch_bounds__(OB_MASK_T) void ob_masks(ObArrays A, uint8_t* objma
       if (rv) occR[x4 >> 3] = 1;
     }
   }
-  __syncthreads();
-  if ((int)blockIdx.x < och)
-    for (int i = tid; i < ocw; i += OB_MASK_T) {
-      occ[((size_t)(2 * s) * och + blockIdx.x) * ocw + i] = occL[i];
-      occ[((size_t)(2 * s + 1) * och + blockIdx.x) * ocw + i] = occR[i];
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1150,8 +1143,8 @@ __global__ __launch_bounds__(64) void ob_bf_blocks(const BfProb* probs, BfBlock*
 extern "C" {
 void psk_ob_masks(const ObArrays* A, uint8_t* objmask, int W, int H, int ostride, uint8_t* occ, int ocw, int och, hipStream_t st) {
   const size_t WP = (W + 255) & ~255;
-  const size_t lds = (size_t)OB_MASK_ROWS * 3 * WP + 2 * (size_t)((ocw + 3) & ~3) + 64;
-  hipLaunchKernelGGL(ob_masks, dim3((H + OB_MASK_ROWS - 1) / OB_MASK_ROWS, A->S), dim3(OB_MASK_T), lds, st, *A, objmask, W, H, ostride, occ, ocw, och);
+  const size_t lds = 3 * WP + 64;
+  hipLaunchKernelGGL(ob_masks, dim3(H, A->S), dim3(OB_MASK_T), lds, st, *A, objmask, W, H, ostride, occ, ocw, och);
 }
 void psk_ob_begin(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_begin, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
 void psk_ob_track(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_track, dim3(A->K, A->S), dim3(OB_T), 0, st, *A, step); }
