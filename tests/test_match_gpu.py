@@ -141,6 +141,23 @@ def test_search_windows_beyond_the_first_candidate_store(matcher):
         assert res[k][0] == no and np.array_equal(res[k][1], oo)
 
 
+def test_search_by_projection_with_the_largest_train_set(matcher):
+    """32 767 train features in one frame (the most a candidate key's index field holds): pj_resolve stages the train octaves in LDS sized
+    by the launch - here the full 32 KB -, the occupancy bitmaps are full length; beside it a small problem in the same call."""
+    from pointslot_amd.matcher import build_grid
+    sc = synth.projection_scene(0x51070040, n=32767, m=600)
+    tr = dict(sc["train"]); tr["cell_off"], tr["cell_idx"] = build_grid(tr["x"], tr["y"], *tr["grid"])
+    base = {"train": tr, "scale_factors": sc["scale_factors"]}
+    pts = dict(base, mode="points", query=sc["points_query"], th=1.0)
+    frame = dict(base, mode="frame", query=sc["frame_query"], tcw=sc["tcw"], tlw=sc["tlw"], K6=sc["K6"], bounds=sc["bounds"], th=sc["th"])
+    small = _scene_problems(0x51070022, n=50, m=10)[1]
+    res = matcher.SearchByProjection([pts, small, frame])
+    for pr, (n, out) in zip([pts, small, frame], res):
+        no, oo = oracle_lib.search_projection_frame(pr, True) if pr["mode"] == "frame" else oracle_lib.search_projection_points(pr, 0.9)
+        assert n == no and np.array_equal(out, oo), (pr["mode"], n, no)
+    assert res[0][0] > 100 and res[2][0] > 100
+
+
 def test_matchers_with_empty_inputs(matcher):
     from pointslot_amd.matcher import build_grid
     p = synth.bruteforce_problem(3, 0, 12)                      # no queries
