@@ -56,6 +56,32 @@ __device__ __forceinline__ double recip_d(double d) {
   e = __builtin_fma(-d, r, 1.0);
   return __builtin_fma(r, e, r);
 }
+// Broadcasts inside a 16-lane DPP row for FP64 (gfx90a+: 64-bit DPP with row_newbcast).  acc += row_lane_k(src) * mul is ONE instruction
+// where v_readlane x 2 -> SGPR pair -> v_fma were three; k is a compile-time constant after unrolling (the switch folds).  A DPP operand
+// that a VALU instruction wrote one or two issue slots earlier needs two wait states, which the compiler cannot see inside an asm
+// statement: `fresh` puts an s_nop 1 in front (the asm statements are volatile, so later ones stay behind the first).
+#define PS_DPP_CASES(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double src, double mul, int k, bool fresh) {
+  switch (k) {
+#define PS_OP(K) case K: \
+    if (fresh) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul)); \
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul)); \
+    break;
+    PS_DPP_CASES(PS_OP)
+#undef PS_OP
+    default: break;
+  }
+}
+__device__ __forceinline__ double row_bcast_d(double v, int k) {   // every lane of a row gets the row's lane k (v may just have been written)
+  double r = 0.0;
+  switch (k) {
+#define PS_OP(K) case K: asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); break;
+    PS_DPP_CASES(PS_OP)
+#undef PS_OP
+    default: break;
+  }
+  return r;
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += shfl_xor_d(v, d);
@@ -601,9 +627,9 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
 #define SOL_T 1024
 static_assert(6 * PS_BA_MAX_POSES <= SOL_T - 64, "ba_solve: one thread per row of the reduced system behind wave 0");
 #ifdef PS_BA_PROFILE   // developer build: per-phase wall-clock ticks (100 MHz) of problem 0, printed by the kernel
-#define SOLP_DECL long long T0 = wall_clock64(), tph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tt = T0
+#define SOLP_DECL long long T0 = wall_clock64(), tph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tt = T0; dgf = 0; dgl = 0
 #define SOLP_MARK(k) do { const long long _n = wall_clock64(); tph[k] += _n - tt; tt = _n; } while (0)
-#define SOLP_PRINT() do { if (tid == 0 && blockIdx.x == 0) printf("solve n=%d NB=%d ticks: diag + rest of trailing %lld panel (load %lld solve %lld store + forward %lld rhs %lld) trailing, next block column %lld fwd %lld bwd %lld total %lld\n", n, NB, tph[0], tph[5], tph[6], tph[7], tph[1], tph[2], tph[3], tph[4], wall_clock64() - T0); } while (0)
+#define SOLP_PRINT() do { if (tid == 0 && blockIdx.x == 0) printf("solve n=%d NB=%d ticks: diag + rest of trailing %lld panel (load %lld solve %lld store + forward %lld rhs %lld) trailing, next block column %lld fwd %lld bwd %lld total %lld, of which wave 0 in the diagonal blocks %lld (loads %lld, factorisation proper %lld)\n", n, NB, tph[0], tph[5], tph[6], tph[7], tph[1], tph[2], tph[3], tph[4], wall_clock64() - T0, tph[8], dgl, dgf); } while (0)
 #else
 #define SOLP_DECL
 #define SOLP_MARK(k)
@@ -642,6 +668,9 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   // (the K index of a lane's step i is (NB / 4) lk + i on BOTH operands, which is all the contraction asks for) they are 6 128-bit reads.
   double* panelB = panel + (PB ? (size_t)(n - min(NB, n) + 4) * PST : 0);
   __shared__ int fail;
+#ifdef PS_BA_PROFILE
+  long long dgf = 0, dgl = 0;
+#endif
   if (tid == 0) fail = 0;
   // LDS keeps whatever the previous kernel on this CU left there, NaN bit patterns included, and 0 * NaN is not 0: every slot
   // that a partial last block touches with a zero multiplier (rhs beyond n, pivots beyond jb) is given a finite value first
@@ -654,21 +683,53 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
   // the rank-1 update reads the other rows' multipliers straight out of their lanes' registers (v_readlane into a scalar pair
   // that feeds the FMA).  Entries above the diagonal are never consumed, so the update needs no masking.
   auto diag_block = [&](int J, int jb, double* Ljj, double* dj, double* rdj, double* Lt) {
+#ifdef PS_BA_PROFILE
+    const long long dg0b = wall_clock64();
+#endif
     double a[NB];
 #pragma unroll
     for (int c = 0; c < NB; c++) a[c] = (lane < jb && c <= lane) ? Sm[(size_t)(J + lane) * lda + J + c] : 0.0;
+#ifdef PS_BA_PROFILE
+    { double sink = 0; for (int c = 0; c < NB; c++) sink += a[c]; if (sink == 1.2345e-300) fail = 2; }   // the loads have arrived
+    const long long dg1 = wall_clock64();
+    dgl += dg1 - dg0b;
+#endif
     bool bad = false;
     // The critical path of a step is pivot -> reciprocal -> multiplier -> update of the NEXT pivot column; the other 22 updates
     // are off it.  The next pivot is therefore updated first and its reciprocal started before the rest of the row is touched.
     // No lane masks inside the loop and the reciprocals kept in a register per lane until the end (tools/ubench/ldlt_diag.hip: 11 100 ->
     // 7 600 cycles for a 24 x 24 block): every lane forms a "multiplier" a[j] / d_j, the rank-1 update uses a lane's un-divided
     // a[j] (= l d) and the multipliers of the lanes k > j only, so what rows <= j carry above the diagonal is never read.
-    double d = shfl_d(a[0], 0), rd = recip_d(d), myrd = 0.0;
+    double myrd = 0.0, mydiag = 0.0;
+    if (NB == 16) {
+      double d = row_bcast_d(a[0], 0), rd = recip_d(d);
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        if (j < jb) {
+          if (lane < 16 && d == 0) bad = true;
+          myrd = lane == j ? rd : myrd;
+          mydiag = lane == j ? d : mydiag;
+          const double l = a[j] * rd, nl = -l;
+          double dn = 1.0, rdn = 1.0;
+          if (j + 1 < NB) {
+            fmac_row_bcast(a[j + 1], nl, a[j], j + 1, true);
+            dn = row_bcast_d(a[j + 1], j + 1);
+            rdn = recip_d(dn);
+          }
+#pragma unroll
+          for (int k = j + 2; k < NB; k++) fmac_row_bcast(a[k], nl, a[j], k, false);
+          a[j] = lane > j ? l : a[j];
+          d = dn; rd = rdn;
+        }
+      }
+    } else {
+    double d = shfl_d(a[0], 0), rd = recip_d(d);
 #pragma unroll
     for (int j = 0; j < NB; j++) {
       if (j < jb) {
         if (d == 0) bad = true;
         myrd = lane == j ? rd : myrd;
+        mydiag = lane == j ? d : mydiag;
         const double l = a[j] * rd;
         double dn = 1.0, rdn = 1.0;
         if (j + 1 < NB) {
@@ -682,14 +743,22 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
         d = dn; rd = rdn;
       }
     }
-    if (lane < jb) rdj[lane] = myrd;
-    if (lane < jb) {
+    }
+#ifdef PS_BA_PROFILE
+    if (myrd == 1.2345e-300) fail = 2;
+    dgf += wall_clock64() - dg1;
+#endif
+    // The factor goes to LDS whole: every lane its row of Ljj and its column entries of Lt, above the diagonal included - what a row
+    // carries there is never read (the forward substitution takes Ljj below the diagonal, the panel solve Lt[q][c] for c > q, the copy
+    // to global memory c < r).  With a store per (row, column) under its own lane mask this epilogue was 650 instructions, 2.6 of the
+    // 7.5 us a block took (r04 phase timers); the pivot of a lane's own row is picked up in the loop (mydiag) instead of a[lane].
+    if (lane < NB) {
 #pragma unroll
-      for (int c = 0; c < NB; c++) {
-        if (c < lane) { Ljj[lane * (NB + 1) + c] = a[c]; Lt[c * NB + lane] = a[c]; Sm[(size_t)(J + lane) * lda + J + c] = a[c]; }
-        else if (c == lane) { dj[lane] = a[c]; dall[J + lane] = a[c]; }
-      }
-    } else if (lane < NB) { dj[lane] = 0.0; rdj[lane] = 0.0; }   // columns of a partial block that do not exist
+      for (int c = 0; c < NB; c++) { Ljj[lane * (NB + 1) + c] = a[c]; Lt[c * NB + lane] = a[c]; }
+      dj[lane] = lane < jb ? mydiag : 0.0;       // (columns of a partial block that do not exist: 0)
+      rdj[lane] = lane < jb ? myrd : 0.0;
+      if (lane < jb) dall[J + lane] = mydiag;
+    }
     if (bad && lane == 0) fail = 1;
   };
   if (tid < 64) diag_block(0, min(NB, n), Ljj2, dj2, rdj2, Lt2);
@@ -741,6 +810,12 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       const int i = q / jb, c = q - i * jb;
       Sm[(size_t)(m0 + i) * lda + J + c] = panel[(size_t)i * PST + c];
     }
+    // ... and the diagonal block's multipliers (wave 0 left them in LDS: 24 store instructions of 23 scattered rows each were 2 us of
+    // its serial path per block)
+    for (int q = SOL_T - 1 - tid; q < jb * jb; q += SOL_T) {
+      const int r = q / jb, c = q - r * jb;
+      if (c < r) Sm[(size_t)(J + r) * lda + J + c] = Ljj[r * (NB + 1) + c];
+    }
     // forward substitution of this block column while its panel is still in LDS: y_J = L_JJ^-1 b_J (wave 0, after
     // which the rows below subtract L_panel y_J) — no extra pass over L in global memory
     if (tid < 64) {
@@ -781,15 +856,21 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       const int wave = tid >> 6, nwave = SOL_T / 64;
       const int ntile = (m + 15) >> 4;
       const int li = lane & 15, lk = lane >> 4;
-      auto trail_tile = [&](int ti, int tj) {
-        const int I0 = ti * 16, J0 = tj * 16;
-        const int col = J0 + li;
+      // A tile is: its 16 x 16 of S from L2 (the accumulator), the panel rows from LDS, NB / 4 matrix instructions, the tile back to L2.
+      // A wave can request the accumulators of TB of its tiles before it works on the first (measured: see TB).
+      auto tile_load = [&](int ti, int tj) {
+        const int I0 = ti * 16, col = tj * 16 + li;
         sol_d4 acc;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = I0 + lk + 4 * r;
           acc[r] = (row < m && col <= row) ? Sm[(size_t)(m0 + row) * lda + m0 + col] : 0.0;
         }
+        return acc;
+      };
+      auto tile_finish = [&](int ti, int tj, sol_d4 acc) {
+        const int I0 = ti * 16, J0 = tj * 16;
+        const int col = J0 + li;
         if (PB && NB % 8 == 0) {
           const double* pa = panel + (size_t)min(I0 + li, m - 1) * PST + (NB / 4) * lk;
           const double* pb = panelB + (size_t)min(J0 + li, m - 1) * PST + (NB / 4) * lk;
@@ -816,28 +897,49 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
           if (row < m && col <= row) Sm[(size_t)(m0 + row) * lda + m0 + col] = acc[r];
         }
       };
+      // the tiles t0, t0 + stride, ... < nT of a phase, TB at a time; `decode` turns a tile number into its (row, column)
+      constexpr int TB = 1;       // (4: no faster - 90 against 86 us for the two phases; the early block steps are bound by the matrix pipe, the late ones by the diagonal block)
+      auto run_tiles = [&](int t0, int nT, int stride, auto decode) {
+        for (int t = t0; t < nT; t += TB * stride) {
+          sol_d4 acc[TB];
+          int ti[TB], tj[TB];
+#pragma unroll
+          for (int u = 0; u < TB; u++) {
+            ti[u] = 0; tj[u] = 0;
+            if (t + u * stride < nT) { decode(t + u * stride, ti[u], tj[u]); acc[u] = tile_load(ti[u], tj[u]); }
+          }
+#pragma unroll
+          for (int u = 0; u < TB; u++)
+            if (t + u * stride < nT) tile_finish(ti[u], tj[u], acc[u]);
+        }
+      };
       constexpr int TA = (NB + 15) / 16;          // tile columns of the next block column
       const int ta = min(TA, ntile);
       int nA = 0;
       for (int c = 0; c < ta; c++) nA += ntile - c;
-      for (int t = wave; t < nA; t += nwave) {
-        int tj = 0, u = t;
-        while (u >= ntile - tj) { u -= ntile - tj; tj++; }
-        trail_tile(tj + u, tj);
-      }
+      run_tiles(wave, nA, nwave, [&](int t, int& ti, int& tj) {
+        int c = 0, u = t;
+        while (u >= ntile - c) { u -= ntile - c; c++; }
+        ti = c + u; tj = c;
+      });
       __syncthreads();
       SOLP_MARK(2);
       const int nt2 = ntile - ta, nB = nt2 > 0 ? nt2 * (nt2 + 1) / 2 : 0;
       if (wave == 0) {
+#ifdef PS_BA_PROFILE
+        const long long dg0 = wall_clock64();
+#endif
         if (m > 0) diag_block(m0, min(NB, m), Ljj2 + (cur ^ 1) * NB * (NB + 1), dj2 + (cur ^ 1) * NB, rdj2 + (cur ^ 1) * NB, Lt2 + (cur ^ 1) * NB * NB);
+#ifdef PS_BA_PROFILE
+        tph[8] += wall_clock64() - dg0;
+#endif
       } else {
-        for (int t = wave - 1; t < nB; t += nwave - 1) {
-          int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-          while (ti * (ti + 1) / 2 > t) ti--;
-          while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-          const int tj = t - ti * (ti + 1) / 2;
-          trail_tile(ti + ta, tj + ta);
-        }
+        run_tiles(wave - 1, nB, nwave - 1, [&](int t, int& ti, int& tj) {
+          int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+          while (i * (i + 1) / 2 > t) i--;
+          while ((i + 1) * (i + 2) / 2 <= t) i++;
+          ti = i + ta; tj = t - i * (i + 1) / 2 + ta;
+        });
       }
     }
     __syncthreads();
@@ -1075,7 +1177,10 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
     // > 64 KB of dynamic LDS has to be requested per kernel
     static const int force_nb = getenv("PS_BA_NB") ? atoi(getenv("PS_BA_NB")) : 0;
     static const bool no_pb = getenv("PS_BA_NO_PB") != nullptr;   // developer knob: one panel, the B operand scaled on the fly
-    if (force_nb == 48 && lds(48, false) <= 150 * 1024) {   // measured slower than 24 at n = 294 (single-wave diagonal factor)
+    if (force_nb == 16 && lds(16, true) <= 156 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(16, true));
+      hipLaunchKernelGGL((ba_solve<16, true>), dim3(nprob), dim3(SOL_T), lds(16, true), st, *A);
+    } else if (force_nb == 48 && lds(48, false) <= 150 * 1024) {   // measured slower than 24 at n = 294 (single-wave diagonal factor)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_solve<48, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(48, false));
       hipLaunchKernelGGL((ba_solve<48, false>), dim3(nprob), dim3(SOL_T), lds(48, false), st, *A);
     } else if (force_nb != 12 && !no_pb && lds(24, true) <= 156 * 1024) {
