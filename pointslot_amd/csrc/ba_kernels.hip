@@ -1106,12 +1106,24 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
   BaState& S = A.state[blockIdx.x];
   if (S.phase != BA_PH_TRIAL && S.phase != BA_PH_LINEARIZE) return;
   __shared__ int s_restore;
+  __shared__ double s_part[1024];
   const int tid = threadIdx.x;
+  // the partial sums of the trial (scale: one per block of ba_update, chi2: one per block of ba_error_k) come in with one round trip for
+  // all of them; thread 0 then adds them in the order it always did (it used to fetch them one dependent load after the other: 15 us)
+  const int nbl = (P.nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB, nbp = (P.np + 255) / 256, nbe = (P.ne + 255) / 256;
+  const int ns = nbl + nbp, staged = ns + nbe <= 1024;
+  if (staged)
+    for (int b = tid; b < ns + nbe; b += 256) s_part[b] = b < ns ? A.part[P.part_base + P.np + b] : A.part[P.part_base + err_part_off + (b - ns)];
+  __syncthreads();
   if (tid == 0) {
-    const int nbl = (P.nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB, nbp = (P.np + 255) / 256, nbe = (P.ne + 255) / 256;
     double scale = 0, temp = 0;
-    for (int b = 0; b < nbl + nbp; b++) scale += A.part[P.part_base + P.np + b];
-    for (int b = 0; b < nbe; b++) temp += A.part[P.part_base + err_part_off + b];
+    if (staged) {
+      for (int b = 0; b < ns; b++) scale += s_part[b];
+      for (int b = 0; b < nbe; b++) temp += s_part[ns + b];
+    } else {
+      for (int b = 0; b < ns; b++) scale += A.part[P.part_base + P.np + b];
+      for (int b = 0; b < nbe; b++) temp += A.part[P.part_base + err_part_off + b];
+    }
     if (!S.ok2) temp = DBL_MAX;
     double rho = (S.current_chi - temp) / (scale + 1e-3);
     int restore = 0;
