@@ -49,6 +49,16 @@ __device__ __forceinline__ double shfl_d(double v, int src) {
 }
 // 1 / d to full double precision from the hardware estimate and two Newton steps: a third of the latency of the IEEE
 // division sequence, and the pivots' reciprocals are reused by every row of the panel
+// lane g (0..3, a constant after unrolling) of every DPP quad to the four lanes of the quad
+__device__ __forceinline__ double quad_bcast_d(double v, int g) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  switch (g) {
+    case 0: return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x00, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x00, 0xF, 0xF, true));
+    case 1: return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x55, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x55, 0xF, 0xF, true));
+    case 2: return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xAA, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xF, 0xF, true));
+    default: return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xFF, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xFF, 0xF, 0xF, true));
+  }
+}
 __device__ __forceinline__ double recip_d(double d) {
   double r = __builtin_amdgcn_rcp(d);
   double e = __builtin_fma(-d, r, 1.0);
@@ -688,7 +698,11 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
 #endif
     double a[NB];
 #pragma unroll
-    for (int c = 0; c < NB; c++) a[c] = (lane < jb && c <= lane) ? Sm[(size_t)(J + lane) * lda + J + c] : 0.0;
+    // (every lane loads - from a clamped position where it has no entry - and a select zeroes what does not exist: 24 loads under 24
+    // different lane masks were 250 instructions of mask bookkeeping; the same in the two substitutions below)
+    for (int c = 0; c < NB; c++) a[c] = Sm[(size_t)(J + min(lane, jb - 1)) * lda + min(J + c, n - 1)];      // all loads first, then the selects
+#pragma unroll
+    for (int c = 0; c < NB; c++) a[c] = (lane < jb && c <= lane) ? a[c] : 0.0;
 #ifdef PS_BA_PROFILE
     { double sink = 0; for (int c = 0; c < NB; c++) sink += a[c]; if (sink == 1.2345e-300) fail = 2; }   // the loads have arrived
     const long long dg1 = wall_clock64();
@@ -779,6 +793,47 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     }
     sol_lds_barrier();
     SOLP_MARK(5);
+    if (NB % 4 == 0) {
+      // x L_JJ^T D = row of S: column q of the row is final once columns < q have been eliminated from it.  Right-looking order: as
+      // soon as column q is final it is subtracted from every later column; every column receives its subtractions in the order
+      // q = 0, 1, 2, ... whoever does them, so the result does not depend on the split.  FOUR lanes per row (a DPP quad), lane g of
+      // the quad owns the columns 4 u + g: a step is the pivot column's value out of its owner's register (quad_perm broadcast) and
+      // at most NB / 4 FMAs per lane, where a thread per row did up to NB - 1 - with 270 rows on 1024 threads three quarters of the
+      // workgroup had no row at all, and the 24-step chain of each row was 2.7 of a block step's 16 us.  Only full blocks have rows below.
+      const int g = lane & 3;
+      for (int i = tid >> 2; i < m; i += SOL_T / 4) {
+        double* prow = panel + (size_t)i * PST;
+        double v[NB / 4];
+#pragma unroll
+        for (int u = 0; u < NB / 4; u++) v[u] = prow[4 * u + g];
+#pragma unroll
+        for (int uq = 0; uq < NB / 4; uq++) {
+          // the multipliers of the group's four steps first (LDS), then the four dependent steps on registers
+          double lt[4][NB / 4];
+#pragma unroll
+          for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+            for (int u = uq; u < NB / 4; u++) lt[gq][u] = Lt[(4 * uq + gq) * NB + 4 * u + g];
+#pragma unroll
+          for (int gq = 0; gq < 4; gq++) {
+            // x[q] * d_q, the un-divided value of column q = 4 uq + gq, from the lane that owns it
+            const double xq = quad_bcast_d(v[uq], gq);
+            {   // the owner's quad mates with a later column in the same group of four
+              const double t = v[uq] - xq * lt[gq][uq];
+              v[uq] = g > gq ? t : v[uq];
+            }
+#pragma unroll
+            for (int u = uq + 1; u < NB / 4; u++) v[u] -= xq * lt[gq][u];
+          }
+        }
+        // a lane's registers now hold the final un-divided values of its columns
+#pragma unroll
+        for (int u = 0; u < NB / 4; u++) {
+          prow[4 * u + g] = v[u] * rdj[4 * u + g];
+          if (PB) panelB[(size_t)i * PST + 4 * u + g] = -v[u];
+        }
+      }
+    } else
     for (int i = tid; i < m; i += SOL_T) {
       // x L_JJ^T D = row of S: column q of the row is final once columns < q have been eliminated from it.  Right-looking order:
       // as soon as column q is final it is subtracted from every later column, so the 23 .. 1 updates of a step are independent
@@ -822,12 +877,14 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       double y = lane < jb ? rhs[J + lane] : 0.0;
       double lrow[NB];   // the lane's row of the block factor, fetched before the chain of broadcasts starts
 #pragma unroll
-      for (int j = 0; j < NB; j++) lrow[j] = (lane > j && lane < jb) ? Ljj[lane * (NB + 1) + j] : 0.0;
+      for (int j = 0; j < NB; j++) lrow[j] = Ljj[min(lane, NB - 1) * (NB + 1) + j];
+#pragma unroll
+      for (int j = 0; j < NB; j++) lrow[j] = (lane > j && lane < jb) ? lrow[j] : 0.0;
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         if (j < jb) {
           const double yj = shfl_d(y, j);
-          if (lane > j && lane < jb) y -= lrow[j] * yj;
+          y -= lrow[j] * yj;                       // (lrow[j] is zero where the row has no entry)
         }
       }
       if (lane < jb) rhs[J + lane] = y;
@@ -960,7 +1017,9 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     if (tid < 64) {
       const int jb = min(NB, n - Jlast);
 #pragma unroll
-      for (int c = 0; c < NB; c++) Lc[c] = (c < jb && lane < c) ? Sm[(size_t)(Jlast + c) * lda + Jlast + lane] : 0.0;
+      for (int c = 0; c < NB; c++) Lc[c] = Sm[(size_t)min(Jlast + c, n - 1) * lda + min(Jlast + lane, n - 1)];
+#pragma unroll
+      for (int c = 0; c < NB; c++) Lc[c] = (c < jb && lane < c) ? Lc[c] : 0.0;
     }
     for (int J = Jlast; J >= 0; J -= NB) {
       const int jb = min(NB, n - J);
@@ -972,13 +1031,15 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
         for (int c = NB - 1; c >= 1; c--) {
           if (c < jb) {
             const double xc = shfl_d(x, c);
-            if (lane < c) x -= Lc[c] * xc;
+            x -= Lc[c] * xc;                       // (Lc[c] is zero for the lanes >= c)
           }
         }
         if (lane < jb) rhs[J + lane] = x;
         if (J >= NB) {   // the block above is a full one
 #pragma unroll
-          for (int c = 0; c < NB; c++) Lc[c] = lane < c ? Sm[(size_t)(J - NB + c) * lda + J - NB + lane] : 0.0;
+          for (int c = 0; c < NB; c++) Lc[c] = Sm[(size_t)(J - NB + c) * lda + J - NB + min(lane, NB - 1)];
+#pragma unroll
+          for (int c = 0; c < NB; c++) Lc[c] = lane < c ? Lc[c] : 0.0;
         }
       } else if (k < J) {
 #pragma unroll
