@@ -200,8 +200,8 @@ __device__ __forceinline__ PoEdge po_load(const float* xw, const float* obs, con
 #define POP_PRINT()
 #endif
 #ifndef PO_OCC_ATTR
-#define PO_OCC_ATTR
-#endif
+#define PO_OCC_ATTR      // developer knob (tools/build_variant.sh): e.g. __attribute__((amdgpu_waves_per_eu(3,3))) - 222 registers give two workgroups per
+#endif                   // CU; capped to 168 / 128 the kernel spills and the headline loses 2 % (r04)
 __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs, const PoVertex* verts, const float* xw,
                                                 const float* obs, const float* inv_sigma2, const uint8_t* valid,
                                                 uint8_t* outlier, double* chi2c, uint8_t* state, double* poses,
