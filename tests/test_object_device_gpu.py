@@ -96,6 +96,25 @@ def test_device_object_chain_equals_the_per_call_chain_and_the_cpu_checker():
     assert ok >= n - 2 and int(obj["reinit"][:, 0].sum()) >= 1
 
 
+def test_device_object_chain_on_an_odd_image_size():
+    """918 x 306: neither the width nor the height is a multiple of the kernels' tile / cell / row-chunk sizes (ob_masks' 256-pixel lane
+    chunks, the detector's 32-pixel tiles and 8-pixel cells, the extractor's 248-column strips) - device chain = per-call chain bit for bit,
+    and the CPU checker behind the same host logic agrees."""
+    n = 4
+    w, h = 918, 306
+    K = (540.0, 540.0, 0.5 * w - 3.5, 0.5 * h + 1.5)
+    seqs = [sequence.generate(n_frames=n, seed=31 + i, w=w, h=h, K=K, bf=290.0) for i in range(2)]
+    tcw, st, obj = _run_device(seqs, n)
+    assert int(st["tracked"][1:].sum()) == 2 * (n - 1) and int((obj["id"] >= 0).sum()) > 0
+    for s, q in enumerate(seqs):
+        be = HipBackend()
+        vo = _run_host(be, q, n)
+        _check_against(vo, tcw, st, obj, s, n, exact=True)
+        be.close()
+    vo = _run_host(OracleBackend(), seqs[0], n)
+    _check_against(vo, tcw, st, obj, 0, n, exact=False)
+
+
 def test_forward_drive_with_yaw_device_chain_host_chain_and_cpu_checker():
     """The KITTI-like scene (sequence.generate_drive: forward motion with yaw, exact ray-cast planes): SearchByProjection(cur, last)
     takes its forward branch, keypoints change octave, local-map points leave the frustum.  Device chain = per-call chain bit for
