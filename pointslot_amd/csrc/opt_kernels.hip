@@ -56,7 +56,7 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
 
 // sums acc[0..N) over the workgroup in a fixed order; the result lands in s.out[0..N) for every thread
 template <int N>
-__device__ void block_sum(double* acc, PoShared& s) {
+__device__ void block_sum(double* acc, PoShared& s, int nthr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (N > 4) {
     // Many values: instead of one 6-step butterfly per value (6 N exchanges), every step halves the number of values a lane
@@ -98,7 +98,7 @@ __device__ void block_sum(double* acc, PoShared& s) {
   if (threadIdx.x < N) {
     double v = 0;
 #pragma unroll
-    for (int w = 0; w < PO_T / 64; w++) v += s.red[w][threadIdx.x];
+    for (int w = 0; w < nthr / 64; w++) v += s.red[w][threadIdx.x];
     s.out[threadIdx.x] = v;
   }
   __syncthreads();
@@ -108,7 +108,7 @@ __device__ void block_sum(double* acc, PoShared& s) {
 // vertices of a CFSE3 graph at the same time (g = the thread's group, tg its index inside it); sums land in s.outg[g][0..N).
 // With G = 1 this is block_sum: same order of additions.
 template <int N>
-__device__ void group_sum(double* acc, PoShared& s, int G, int g, int tg) {
+__device__ void group_sum(double* acc, PoShared& s, int G, int g, int tg, int nthr) {
   static_assert(N > 4 && N <= 32, "group_sum: 5 .. 32 values");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double v[32];
@@ -129,7 +129,7 @@ __device__ void group_sum(double* acc, PoShared& s, int G, int g, int tg) {
   __syncthreads();   // protect s.outg / s.red from the previous use
   if ((lane & 1) == 0 && (lane >> 1) < N) s.red[wave][lane >> 1] = total;
   __syncthreads();
-  const int wpg = (PO_T / 64) / G;
+  const int wpg = (nthr / 64) / G;
   if (tg < N) {
     double sum = 0;
     for (int w = 0; w < wpg; w++) sum += s.red[g * wpg + w][tg];
@@ -211,14 +211,20 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
   const PoProb P = probs[blockIdx.x];
   const int tid = threadIdx.x;
   const int k = P.k;
+  // A CFSE3 graph of one or two objects - a few hundred edges - runs on 128 of the workgroup's threads: the other two waves leave here
+  // (a barrier only counts the waves that are still alive).  With fewer lanes the reductions and the barriers between the short edge
+  // passes weigh less (0.84 -> 0.70 ms per step in the tracker, r04); graphs of more objects keep all four waves (up to four objects
+  // are linearised side by side, one per wave), PoseOptimization its 256 lanes for a frame's ~1000 edges.
+  const int NT = (P.mode == 1 && k <= 2) ? 128 : PO_T;
+  if (tid >= NT) return;
   // CFSE3 graphs: G vertices are linearised side by side, each by a group of GT threads (whole waves)
-  const int G = min(k >= 4 ? 4 : (k >= 2 ? 2 : 1), PO_T / 64), GT = PO_T / G, g = tid / GT, tg = tid - g * GT;
+  const int G = min(k >= 4 ? 4 : (k >= 2 ? 2 : 1), NT / 64), GT = NT / G, g = tid / GT, tg = tid - g * GT;
   const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
   double* tr = trace ? trace + (size_t)blockIdx.x * PS_PO_TRACE * 3 : nullptr;
   int ntr = 0;
 
   // ---- graph construction (Optimizer.cc:262-377 / :506-637) ----
-  for (int i = tid; i < k * 7; i += PO_T) {
+  for (int i = tid; i < k * 7; i += NT) {
     const double v = poses[(size_t)P.v_off * 7 + i];
     (&s.pose[0][0])[i] = v;
     (&s.pose0[0][0])[i] = v;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
   int cnt = 0;
   for (int o = 0; o < k; o++) {
     const PoVertex V = verts[P.v_off + o];
-    for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
+    for (int i = V.e_begin + tid; i < V.e_end; i += NT) {
       uint8_t st = 0;
       if (valid[i]) {
         st = ST_VALID | (obs[3 * i + 2] < 0.f ? ST_MONO : 0);
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
   }
   {
     double c1[1] = {(double)cnt};
-    block_sum<1>(c1, s);
+    block_sum<1>(c1, s, NT);
   }
   const int nInitial = (int)s.out[0];
   const int nTotalEdges = nInitial + (P.mode == 1 ? k : 0);
@@ -263,18 +269,18 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
   for (int it = 0; it < 4; it++) {
     if (P.mode == 0) {   // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)) every round (Optimizer.cc:394)
       __syncthreads();
-      for (int i = tid; i < k * 7; i += PO_T) (&s.pose[0][0])[i] = (&s.pose0[0][0])[i];
+      for (int i = tid; i < k * 7; i += NT) (&s.pose[0][0])[i] = (&s.pose0[0][0])[i];
       __syncthreads();
     }
     // active set = level-0 edges; a vertex without active edges is not optimised
     int nact = 0;
     for (int o = 0; o < k; o++) {
       const PoVertex V = verts[P.v_off + o];
-      for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) nact += ((state[i] & (ST_VALID | ST_LVL1)) == ST_VALID) ? 1 : 0;
+      for (int i = V.e_begin + tid; i < V.e_end; i += NT) nact += ((state[i] & (ST_VALID | ST_LVL1)) == ST_VALID) ? 1 : 0;
     }
     {
       double c1[1] = {(double)nact};
-      block_sum<1>(c1, s);
+      block_sum<1>(c1, s, NT);
     }
     const bool any_active = (int)s.out[0] > 0 || P.mode == 1;
 
@@ -366,12 +372,12 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
             for (int r = 0; r < 6; r++) acc[21 + r] -= wo * (J[0][r] * e[0] + J[1][r] * e[1] + J[2][r] * e[2]);
           }
           if (G == 1) {          // PoseOptimization, or a single object: the plain workgroup reduction
-            block_sum<28>(acc, s);
+            block_sum<28>(acc, s, NT);
             if (tid < 21) s.H[o][tid] = s.out[tid];
             if (tid >= 21 && tid < 27) s.b[o][tid - 21] = s.out[tid];
             if (tid == 27) s.chiv[o] = s.out[27];
           } else {
-            group_sum<28>(acc, s, G, g, tg);
+            group_sum<28>(acc, s, G, g, tg, NT);
             if (have) {
               if (tg < 21) s.H[o][tg] = s.outg[g][tg];
               if (tg >= 21 && tg < 27) s.b[o][tg - 21] = s.outg[g][tg];
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
           bool ok2 = true;
           double scale = 0;
           __syncthreads();
-          for (int i = tid; i < k * 7; i += PO_T) (&s.backup[0][0])[i] = (&s.pose[0][0])[i];
+          for (int i = tid; i < k * 7; i += NT) (&s.backup[0][0])[i] = (&s.pose[0][0])[i];
           __syncthreads();
           if (tid < 64) {   // wave 0: lane o solves vertex o (k <= 16 blocks side by side; PoseOptimization has one)
             bool okv = true;
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
               c1[0] += rho0;
             }
           }
-          block_sum<1>(c1, s);
+          block_sum<1>(c1, s, NT);
           POP_MARK(3);
           double tempChi = s.out[0];
           if (!ok2) tempChi = DBL_MAX;
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
             lambda *= ni;
             ni *= 2;
             __syncthreads();
-            for (int i = tid; i < k * 7; i += PO_T) (&s.pose[0][0])[i] = (&s.backup[0][0])[i];
+            for (int i = tid; i < k * 7; i += NT) (&s.pose[0][0])[i] = (&s.backup[0][0])[i];
             __syncthreads();
           }
           qmax++;
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
     for (int o = 0; o < k; o++) {
       const PoVertex V = verts[P.v_off + o];
       const Se3 T = load_pose(s.pose[o]);
-      for (int i = V.e_begin + tid; i < V.e_end; i += PO_T) {
+      for (int i = V.e_begin + tid; i < V.e_end; i += NT) {
         uint8_t st = state[i];
         if (!(st & ST_VALID)) continue;
         const bool mono = st & ST_MONO;
@@ -574,12 +580,12 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
     }
     if (it == 2) robust = false;   // e->setRobustKernel(0) on the projection edges; the prior keeps its kernel
     double c1[1] = {(double)bad};
-    block_sum<1>(c1, s);
+    block_sum<1>(c1, s, NT);
     nBadTotal = (int)s.out[0];
     POP_MARK(4);
   }
   __syncthreads();
-  for (int i = tid; i < k * 7; i += PO_T) poses[(size_t)P.v_off * 7 + i] = (&s.pose[0][0])[i];
+  for (int i = tid; i < k * 7; i += NT) poses[(size_t)P.v_off * 7 + i] = (&s.pose[0][0])[i];
   if (tid == 0) {
     results[blockIdx.x] = P.mode == 0 ? nInitial - nBadTotal : 1;
     if (tr && ntr < PS_PO_TRACE) tr[3 * ntr + 2] = -1;   // terminator
