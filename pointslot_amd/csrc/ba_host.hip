@@ -47,7 +47,7 @@ int ensure(BaCtx* c, size_t dbytes, size_t hbytes) {
 }
 struct Layout {   // byte offsets in the arena; [0, host_end) is mirrored in pinned host memory
   size_t prob, state, poses, flags, points, e_pose, e_point, e_obs, e_is2, e_state, erase, csr_off, csr_edges, trace, ndone, host_end;
-  size_t poses_bak, pidx, pact, points_bak, lact, chi2c, Hpp, bp, Hll, bl, Dinv, bs, xp, xl, part, W, S, end;
+  size_t poses_bak, pidx, pact, points_bak, lact, chi2c, Hpp, bp, Hll, bl, Dinv, bs, xp, xl, part, W, S, Wd, end;
 };
 }  // namespace
 
@@ -96,7 +96,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   L.points_bak = take(NL * 24); L.lact = take(NL); L.chi2c = take(NE * 8);
   L.Hpp = take(NP * 288); L.bp = take(NP * 48); L.Hll = take(NL * 72); L.bl = take(NL * 24); L.Dinv = take(NL * 72);
   L.bs = take(NP * 48); L.xp = take(NP * 48); L.xl = take(NL * 24); L.part = take(NPART * 8);
-  L.W = take(NW * 8); L.S = take(NS * 8);
+  L.W = take(NW * 8); L.S = take(NS * 8); L.Wd = take(NW * 8);
   L.end = o;
   int rc = ensure(ctx, L.end, L.host_end);
   if (rc != PS_OK) return rc;
@@ -148,6 +148,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   if (const char* fill = getenv("PS_BA_FILL")) PS_HIP(hipMemsetAsync(D + L.host_end, atoi(fill), L.end - L.host_end, st));   // diagnostic: poison the work arrays
   // W must start as zeros: (pose, point) pairs without an edge are never written (see ba_lin_pose)
   PS_HIP(hipMemsetAsync(D + L.W, 0, NW * 8, st));
+  PS_HIP(hipMemsetAsync(D + L.Wd, 0, NW * 8, st));   // (the rows of fixed poses are never written and never read)
   PS_HIP(hipMemsetAsync(D + L.chi2c, 0, NE * 8 + 64, st));
   BaArrays A;
   A.prob = (const BaProb*)(D + L.prob); A.state = (BaState*)(D + L.state);
@@ -160,7 +161,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   A.csr_off = (const int32_t*)(D + L.csr_off); A.csr_edges = (const int32_t*)(D + L.csr_edges);
   A.Hpp = (double*)(D + L.Hpp); A.bp = (double*)(D + L.bp); A.Hll = (double*)(D + L.Hll); A.bl = (double*)(D + L.bl);
   A.Dinv = (double*)(D + L.Dinv); A.bs = (double*)(D + L.bs); A.xp = (double*)(D + L.xp); A.xl = (double*)(D + L.xl);
-  A.W = (double*)(D + L.W); A.S = (double*)(D + L.S); A.part = (double*)(D + L.part); A.trace = (double*)(D + L.trace);
+  A.W = (double*)(D + L.W); A.S = (double*)(D + L.S); A.part = (double*)(D + L.part); A.trace = (double*)(D + L.trace); A.Wd = (double*)(D + L.Wd);
   A.ndone = (int32_t*)(D + L.ndone);
 
   struct EventPair {   // every early return below goes through PS_HIP: the events must not outlive the call

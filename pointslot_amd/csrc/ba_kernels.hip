@@ -471,7 +471,13 @@ __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
   const int i = A.pact[P.pose_base + a];
   double s[6] = {0, 0, 0, 0, 0, 0};
   for (int l = lane; l < P.nl; l += 64) {
-    if (!A.lact[P.point_base + l]) continue;
+    double* Wdb = A.Wd + P.W_base + ((size_t)i * P.nl + l) * 18;
+    if (!A.lact[P.point_base + l]) {
+      // an inactive point takes no part in the Schur complement: its block of W D^-1 is zero (ba_schur multiplies whatever is there)
+#pragma unroll
+      for (int q = 0; q < 9; q++) reinterpret_cast<double2*>(Wdb)[q] = make_double2(0.0, 0.0);
+      continue;
+    }
     double D[9], Di[9];
     const double* H = A.Hll + (size_t)(P.point_base + l) * 9;
 #pragma unroll
@@ -481,8 +487,23 @@ __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
     const double db0 = Di[0] * b[0] + Di[1] * b[1] + Di[2] * b[2], db1 = Di[3] * b[0] + Di[4] * b[1] + Di[5] * b[2],
                  db2 = Di[6] * b[0] + Di[7] * b[1] + Di[8] * b[2];
     const double* Wb = A.W + P.W_base + ((size_t)i * P.nl + l) * 18;
+    double w[18];
 #pragma unroll
-    for (int r = 0; r < 6; r++) s[r] += Wb[r * 3] * db0 + Wb[r * 3 + 1] * db1 + Wb[r * 3 + 2] * db2;
+    for (int q = 0; q < 9; q++) { const double2 v = reinterpret_cast<const double2*>(Wb)[q]; w[2 * q] = v.x; w[2 * q + 1] = v.y; }
+#pragma unroll
+    for (int r = 0; r < 6; r++) s[r] += w[r * 3] * db0 + w[r * 3 + 1] * db1 + w[r * 3 + 2] * db2;
+    // W D^-1 of this trial for ba_schur's A side: written here, where the block and D^-1 are in registers anyway, so that ba_schur
+    // takes both operands with coalesced loads (a thread per block there read 144 bytes at a 144-byte stride: 64 lines per load instruction)
+    double wd[18];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double w0 = w[r * 3], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
+      wd[r * 3] = w0 * Di[0] + w1 * Di[3] + w2 * Di[6];
+      wd[r * 3 + 1] = w0 * Di[1] + w1 * Di[4] + w2 * Di[7];
+      wd[r * 3 + 2] = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) reinterpret_cast<double2*>(Wdb)[q] = make_double2(wd[2 * q], wd[2 * q + 1]);
   }
 #pragma unroll
   for (int r = 0; r < 6; r++) s[r] = wave_sum(s[r]);
@@ -512,11 +533,15 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
   double (*As)[SCH_RS] = reinterpret_cast<double (*)[SCH_RS]>(sch_smem);
   double (*Bs)[SCH_RS] = reinterpret_cast<double (*)[SCH_RS]>(sch_smem + 48 * SCH_RS);
   const int tid = threadIdx.x;
-  // staging role of this thread: TWO (pose, point) pairs of one side per chunk (points lc and lc + 16)
+  // Staging role of this thread: side (A: W D^-1 as ba_prep left it, B: W), pose pl of the side's tile, lane lc of the pose's 16.  A
+  // pose's blocks of a chunk's SCH_LC points are contiguous in memory (18 doubles per point): the 16 lanes read them as 16-byte pieces,
+  // piece j * 16 + lc in step j - coalesced, and no arithmetic (until r04 a thread read its own two blocks, 144 bytes at a 144-byte
+  // stride, and the A side multiplied them by D^-1 here: the load instructions alone were 2.9 of a chunk's 4.4 us on the address unit)
   const int side = tid >> 7, pl = (tid & 127) >> 4, lc = tid & 15;
   const int pc = (side == 0 ? ta : tb) * PS_BA_TILE + pl;               // compact pose index
   const bool pose_ok = pc < npa;
-  const double* Wrow = pose_ok ? A.W + P.W_base + (size_t)A.pact[P.pose_base + pc] * P.nl * 18 : nullptr;
+  const double* Wsrc = side == 0 ? A.Wd : A.W;
+  const double* Wrow = Wsrc + P.W_base + (pose_ok ? (size_t)A.pact[P.pose_base + pc] * P.nl * 18 : 0);
   double (*dstT)[SCH_RS] = side == 0 ? As : Bs;
   // 48 x 48 tile = 3 x 3 tiles of the FP64 matrix cores (v_mfma_f64_16x16x4_f64); wave w (< 3) owns tile row w.  The vector
   // form of this contraction (3 x 3 register blocks, six LDS reads per nine FMAs) was bound by LDS instruction issue.
@@ -526,54 +551,27 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
   for (int a = 0; a < 3; a++)
 #pragma unroll
     for (int c = 0; c < 3; c++) acc[a][c] = sch_d4{0.0, 0.0, 0.0, 0.0};
-  // the chunk's W blocks (and, for the A side, D^-1) of this thread's two (pose, point) pairs: requested one chunk AHEAD, before the
-  // matrix instructions of the current chunk, so that the L2 round trip (two dependent ones: activity flag, then the blocks) runs under them
-  double w[2][18], dv[2][9];
-  bool okv[2];
-  uint8_t lactv[2];
+  // the chunk's pieces are requested one chunk AHEAD, before the matrix instructions of the current chunk: the round trip to L2 runs under them
+  constexpr int NPC = SCH_LC * 18 / 2 / 16;    // 16-byte pieces per lane and chunk (18)
+  static_assert(SCH_LC * 18 % 32 == 0, "ba_schur: a chunk of a pose is a whole number of 16-lane steps");
+  double2 w[NPC];
   auto request = [&](int l0) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int l = l0 + lc + 16 * h;
-      const int lcl = min(l, P.nl - 1);
-      okv[h] = pose_ok && l < P.nl;
-      lactv[h] = A.lact[P.point_base + lcl];   // (looked at when the chunk is used: testing it here would wait for it before the matrix instructions)
-      const double2* src = reinterpret_cast<const double2*>((pose_ok ? Wrow : A.W + P.W_base) + (size_t)lcl * 18);
-#pragma unroll
-      for (int q = 0; q < 9; q++) { const double2 v = src[q]; w[h][2 * q] = v.x; w[h][2 * q + 1] = v.y; }
-      if (side == 0) {
-        const double* Di = A.Dinv + (size_t)(P.point_base + lcl) * 9;
-#pragma unroll
-        for (int q = 0; q < 9; q++) dv[h][q] = Di[q];
-      }
+    for (int j = 0; j < NPC; j++) {
+      const int e = 2 * (j * 16 + lc);          // first of the piece's two doubles inside the pose's chunk; both belong to point e / 18
+      const bool ok = pose_ok && l0 + e / 18 < P.nl;
+      w[j] = ok ? *reinterpret_cast<const double2*>(Wrow + (size_t)l0 * 18 + e) : make_double2(0.0, 0.0);
     }
   };
   request(0);
   for (int l0 = 0; l0 < P.nl; l0 += SCH_LC) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      if (okv[h] && lactv[h]) {
-        if (side == 0) {
-#pragma unroll
-          for (int r = 0; r < 6; r++) {
-            const double w0 = w[h][r * 3], w1 = w[h][r * 3 + 1], w2 = w[h][r * 3 + 2];
-            w[h][r * 3] = w0 * dv[h][0] + w1 * dv[h][3] + w2 * dv[h][6];
-            w[h][r * 3 + 1] = w0 * dv[h][1] + w1 * dv[h][4] + w2 * dv[h][7];
-            w[h][r * 3 + 2] = w0 * dv[h][2] + w1 * dv[h][5] + w2 * dv[h][8];
-          }
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 18; q++) w[h][q] = 0.0;
-      }
-    }
     __syncthreads();   // the previous chunk's tiles are no longer being read
 #pragma unroll
-    for (int h = 0; h < 2; h++)
-#pragma unroll
-      for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) dstT[pl * 6 + r][(lc + 16 * h) * 3 + k] = w[h][r * 3 + k];
+    for (int j = 0; j < NPC; j++) {
+      const int e = 2 * (j * 16 + lc), pt = e / 18, q = e - 18 * pt;     // q even: (r, k) = (q / 3, q % 3) and its successor
+      dstT[pl * 6 + q / 3][pt * 3 + q % 3] = w[j].x;
+      dstT[pl * 6 + (q + 1) / 3][pt * 3 + (q + 1) % 3] = w[j].y;
+    }
     __syncthreads();
     if (l0 + SCH_LC < P.nl) request(l0 + SCH_LC);
     {

@@ -48,6 +48,7 @@ struct BaArrays {
   const int32_t* csr_off; const int32_t* csr_edges;
   double* Hpp; double* bp; double* Hll; double* bl; double* Dinv; double* bs; double* xp; double* xl;
   double* W; double* S; double* part; double* trace;
+  double* Wd;                  // W D^-1 of the current damping trial (the blocks of inactive points: zero), same layout as W: ba_prep writes it, ba_schur's A side reads it
   int32_t* ndone;
 };
 // ba_update: points per 256-thread block (16 lanes per point share the sum over the free poses)
