@@ -1162,10 +1162,27 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P, int nslots) {
   __shared__ float resp[CAP];
   __shared__ int32_t pay[CAP];
   __shared__ int nkeep;
-  // (the launch for the long lists - rare - is a few workgroups that walk over all slots: one workgroup per slot, each with 32 KB of LDS
+  // (the launch for the long lists - rare - is a few workgroups that share all slots: one workgroup per slot, each with 32 KB of LDS
   // to find on a CU before it can start and return, waited 280 us for its turn beside the other lockstep groups' kernels; 5 us alone)
   const int tid = threadIdx.x;
-  for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+  // LO >= 0 (the launch for the long lists): a workgroup looks at the candidate counts of its share of the slots in parallel and keeps
+  // the few it has to work on in `todo`; LO < 0: one workgroup per slot
+  __shared__ int todo[1024];
+  __shared__ int ntodo;
+  int first = blockIdx.x, count = 1;
+  if (LO >= 0) {
+    const int share = (nslots + (int)gridDim.x - 1) / (int)gridDim.x, s0 = blockIdx.x * share, s1 = min(s0 + share, nslots);
+    if (tid == 0) ntodo = 0;
+    __syncthreads();
+    for (int sl = s0 + tid; sl < s1; sl += 256) {
+      const int n = min(P.ncand[sl], CVB_CAND_CAP);
+      if (n > LO && n <= CAP) { const int k = atomicAdd(&ntodo, 1); if (k < 1024) todo[k] = sl; }
+    }
+    __syncthreads();
+    count = min(ntodo, 1024);        // (host check: a workgroup's share is at most 1024 slots)
+  }
+  for (int it = 0; it < count; it++) {
+  const int slot = LO >= 0 ? todo[it] : first;
   const int l = slot % P.nlevels, img = slot / P.nlevels;
   const int total = P.ncand[slot];
   const int n = min(total, CVB_CAND_CAP);
@@ -1371,7 +1388,10 @@ void psk_cvb_run(const CvbPlan* Pin, int nimg, const uint8_t* imgs, int stride, 
   hipLaunchKernelGGL(cvb_detect, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
   hipLaunchKernelGGL(cvb_blur, dim3(grid / 4, NL), dim3(CVB_TT), 0, st, *P);
   hipLaunchKernelGGL((cvb_select<512, -1>), dim3(nimg * NL), dim3(256), 0, st, *P, nimg * NL);
-  hipLaunchKernelGGL((cvb_select<CVB_CAND_CAP, 512>), dim3(nimg * NL < 256 ? nimg * NL : 256), dim3(256), 0, st, *P, nimg * NL);
+  {
+    const int nslots = nimg * NL, g = nslots < 32 ? nslots : (nslots + 1023) / 1024 > 32 ? (nslots + 1023) / 1024 : 32;   // 32 workgroups, more only so that a share stays within 1024 slots
+    hipLaunchKernelGGL((cvb_select<CVB_CAND_CAP, 512>), dim3(g), dim3(256), 0, st, *P, nslots);
+  }
   hipLaunchKernelGGL(cvb_describe, dim3(32, nimg), dim3(256), 0, st, *P);
 }
 }

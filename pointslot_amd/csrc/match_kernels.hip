@@ -351,10 +351,10 @@ extern "C" void psk_bf_launch_dev(const BfBlock* blocks, const int32_t* d_count,
   hipLaunchKernelGGL((bf_topk_small<256, -1>), dim3(grid), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
   // (215 registers: two workgroups per CU - a grid beyond 512 adds waiting workgroups, not parallelism)
   hipLaunchKernelGGL((bf_topk_small<BF_SMALL_NT, 256>), dim3(grid < 512 ? grid : 512), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
-  // (the launch for the problems with more than BF_SMALL_NT trains - none in most steps, the workgroups then return at once - with one
-  // workgroup per CU: each needs 64 KB of LDS before it can start, and 1024 of them waited 220 us for their turn beside the other
+  // (the launch for the problems with more than BF_SMALL_NT trains - none in most steps, the workgroups then return at once - with 32
+  // workgroups: each needs 64 KB of LDS before it can start, and 1024 of them waited 220 us for their turn beside the other
   // lockstep groups' kernels; 5 us alone)
-  hipLaunchKernelGGL(bf_topk, dim3(grid < 256 ? grid : 256), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
+  hipLaunchKernelGGL(bf_topk, dim3(grid < 32 ? grid : 32), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
   hipLaunchKernelGGL(bf_resolve, dim3(nprob), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
                      nmatch, nn_ratio, check_ori);
 }
