@@ -1234,8 +1234,11 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P, int nslots) {
 #ifndef CVB_DESC_OCC
 #define CVB_DESC_OCC 5       // waves per SIMD the register allocation aims at (the LDS admits five workgroups per CU); measured 3 / 4 / 5: 518 / 461 / 435 us
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CVB_DESC_OCC, 8))) void cvb_describe(CvbPlan P) {
-  __shared__ __attribute__((aligned(16))) uint8_t patch_all[16][40 * 48];
+#ifndef CVB_DESC_T
+#define CVB_DESC_T 64        // one wave = four keypoints per workgroup (7.5 KB of LDS): easier to place beside the other lockstep groups' kernels than
+#endif                     // sixteen keypoints and 30 KB (256 / 128 / 64 threads: 40.6 / 40.8 / 40.8 k frames/s)
+__global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_DESC_OCC, 8))) void cvb_describe(CvbPlan P) {
+  __shared__ __attribute__((aligned(16))) uint8_t patch_all[CVB_DESC_T / 16][40 * 48];
   const int img = blockIdx.y, lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   int nsel[CV_MAX_LEVELS];
   int total = 0;
@@ -1245,7 +1248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CVB_DESC_OC
     if (total > P.ocap) atomicAdd(&P.overflow[img], 1);
   }
   total = min(total, P.ocap);
-  for (int k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; k0 < total; k0 += gridDim.x * 16) {
+  for (int k0 = (blockIdx.x * (CVB_DESC_T / 64) + (threadIdx.x >> 6)) * 4; k0 < total; k0 += gridDim.x * (CVB_DESC_T / 16)) {
     const bool live = k0 + grp < total;
     const int k = live ? k0 + grp : total - 1;
     int l = 0, base = 0;
@@ -1392,6 +1395,6 @@ void psk_cvb_run(const CvbPlan* Pin, int nimg, const uint8_t* imgs, int stride, 
     const int nslots = nimg * NL, g = nslots < 32 ? nslots : (nslots + 1023) / 1024 > 32 ? (nslots + 1023) / 1024 : 32;   // 32 workgroups, more only so that a share stays within 1024 slots
     hipLaunchKernelGGL((cvb_select<CVB_CAND_CAP, 512>), dim3(g), dim3(256), 0, st, *P, nslots);
   }
-  hipLaunchKernelGGL(cvb_describe, dim3(32, nimg), dim3(256), 0, st, *P);
+  hipLaunchKernelGGL(cvb_describe, dim3(32 * 256 / CVB_DESC_T, nimg), dim3(CVB_DESC_T), 0, st, *P);
 }
 }
