@@ -118,3 +118,15 @@ def test_batched_device_detector_matches_the_cpu_restatement():
         d_i = torch.from_numpy(np.stack(imgs[::-1])).cuda(); d_m = torch.from_numpy(np.stack(masks[::-1])).cuda()
         imgs, masks = imgs[::-1], masks[::-1]
     det.close()
+
+
+def test_randomised_batched_detector_sweep():
+    """tools/stress_cvorb_batch.py: random crops / flips of the real frame under random masks, several images per batch, image sizes that
+    are no multiple of the kernels' tile / cell sizes - keypoints (order included) and descriptors identical to the CPU restatement"""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_cvorb_batch.py")
+    r = subprocess.run([sys.executable, tool, "7", "10"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "identical to the CPU restatement" in r.stdout
