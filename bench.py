@@ -1128,6 +1128,11 @@ def main():
                         "headline runs %d groups of %d on %d streams - one group's latency-bound kernels (quadtree, pose_lm, glue) under the other's issue-bound ones"
                         % (S, alone["images_per_launch"], alone["ms_per_step"], S / (alone["ms_per_step"] * 1e-3), G, S // G, G),
                 "ms_per_step": alone["ms_per_step"], "stage_ms": {k: round(v, 5) for k, v in alone["stage_ms"].items()},
+                "stage_ms_per_512_sequences": {k: round(v * 512.0 / S, 5) for k, v in alone["stage_ms"].items()},
+                "stage_ms_per_512_sequences_note": "stage_ms x 512 / %d: the stage times of earlier rounds' bench lines were taken on one lockstep group of 512 sequences "
+                                                   "(r03: orb_extract 6.7, object_features 3.5, pose_optimization 1.88 ms).  Linear scaling is right for the throughput-bound "
+                                                   "stages; pose_lm runs two workgroups per CU (768 problems: two rounds, 512: one), so its true 512-sequence time is "
+                                                   "secondary_metrics.lateral_scene.stage_ms_group0 (one group of 512, another scene)" % S,
                 "kernels": [{"kernel": k, "bound": "hbm", "avg_ms_per_step": alone["stage_ms"]["orb/" + k],
                              "achieved": ALGO_BYTES_PER_IMAGE[k] * alone["images_per_launch"] / (alone["stage_ms"]["orb/" + k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ALGO_BYTES_PER_IMAGE[k] * alone["images_per_launch"] / (alone["stage_ms"]["orb/" + k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
