@@ -1214,12 +1214,13 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P, int nslots) {
   __syncthreads();
   const int quota = P.lv[l].quota;
   RbList Lst{resp, pay};
-  if (tid == 0) nkeep = rb_retain_best(Lst, n, 2 * quota);
+  // (wave 0 runs the library's selection with its partition loops spread over the lanes, retain_best.h; the sort's key / index arrays serve as its scratch)
+  if (tid < 64) { const int k = rbw_retain_best(Lst, n, 2 * quota, reinterpret_cast<int*>(key), idx, tid); if (tid == 0) nkeep = k; }
   __syncthreads();
   const int m1 = nkeep;
   for (int i = tid; i < m1; i += 256) resp[i] = C[pay[i]].w;     // HarrisResponses
   __syncthreads();
-  if (tid == 0) nkeep = rb_retain_best(Lst, m1, quota);
+  if (tid < 64) { const int k = rbw_retain_best(Lst, m1, quota, reinterpret_cast<int*>(key), idx, tid); if (tid == 0) nkeep = k; }
   __syncthreads();
   const int m = nkeep;
   CvSel* S = P.sel + (size_t)slot * CVB_CAND_CAP;

@@ -149,3 +149,125 @@ RB_HD int rb_retain_best(const RbList& L, int n, int n_points) {
   }
   return n;
 }
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same algorithms with the two partition loops executed by a whole wave (64 lanes, all of them call these functions together, the
+// lists live in LDS).  The element order after every step is still the library's: a Hoare-style partition is a sequence of swaps
+// whose partners are fixed by the ORIGINAL contents of the range - the k-th element (from the left) at which the left scan stops is
+// swapped with the k-th element (from the right) at which the right scan stops, as long as the former lies left of the latter; the
+// scans never look at a position again once a pointer has passed it.  So: every lane classifies its share of the positions, two prefix
+// sums number the stops from the left and from the right, the pairs with "left stop < right stop" are swapped all at once.
+// (One lane walking a 500-element list through LDS was 125 us; r04.)  lpos / rpos: LDS scratch for one int per element of the range.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rbw_scan_inclusive(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
+  return v;
+}
+__device__ __forceinline__ void rbw_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// swaps of the pairs (lpos[k], rpos[nR - 1 - k]) for k < npairs; rpos holds the right stops in ascending position order
+__device__ __forceinline__ void rbw_swap_pairs(const RbList& L, const int* lpos, const int* rpos, int nR, int npairs, int lane) {
+  for (int k = lane; k < npairs; k += 64) rb_swap(L, lpos[k], rpos[nR - 1 - k]);
+  rbw_fence();
+}
+// std::__unguarded_partition(first, last, pivot) with pivot = first - 1 (std::__unguarded_partition_pivot calls it so): returns the cut
+__device__ inline int rbw_unguarded_partition(const RbList& L, int first, int last, int* lpos, int* rpos, int lane) {
+  const int lo = first - 1, len = last - lo, E = (len + 63) >> 6;        // the pivot's own position is the right scan's last stop
+  const float rp = L.r[lo];
+  const int p0 = lo + lane * E;
+  int cl = 0, cr = 0;
+  for (int e = 0; e < E; e++) {
+    const int p = p0 + e;
+    if (p < last) { const float v = L.r[p]; cl += (p >= first && !(v > rp)) ? 1 : 0; cr += !(rp > v) ? 1 : 0; }
+  }
+  const int il = rbw_scan_inclusive(cl, lane), ir = rbw_scan_inclusive(cr, lane);
+  const int nL = __shfl(il, 63), nR = __shfl(ir, 63);
+  int kl = il - cl, kr = ir - cr;
+  for (int e = 0; e < E; e++) {
+    const int p = p0 + e;
+    if (p < last) {
+      const float v = L.r[p];
+      if (p >= first && !(v > rp)) lpos[kl++] = p;
+      if (!(rp > v)) rpos[kr++] = p;
+    }
+  }
+  rbw_fence();
+  // the number of swaps: the pairs k with (k-th left stop) < (k-th right stop from the right); monotone in k
+  int cnt = 0;
+  const int nk = nL < nR ? nL : nR;
+  for (int k = lane; k < nk; k += 64) cnt += lpos[k] < rpos[nR - 1 - k] ? 1 : 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+  // Where the left scan ends after the last swap: at its next stop in the original contents - or, if that lies further right, at the
+  // position of the last swap's right partner, which by then holds a value the left scan stops at (the only place where a scan meets
+  // a position that was already swapped)
+  int cut = cnt < nL ? lpos[cnt] : 0x7fffffff;
+  if (cnt >= 1) { const int rprev = rpos[nR - cnt]; cut = cut < rprev ? cut : rprev; }
+  rbw_fence();
+  rbw_swap_pairs(L, lpos, rpos, nR, cnt, lane);
+  return cut;
+}
+// std::partition (bidirectional) with the predicate response >= threshold on [first, last): returns the new end
+__device__ inline int rbw_partition_ge(const RbList& L, int first, int last, float threshold, int* lpos, int* rpos, int lane) {
+  const int len = last - first, E = (len + 63) >> 6;
+  const int p0 = first + lane * E;
+  int cl = 0, cr = 0;
+  for (int e = 0; e < E; e++) {
+    const int p = p0 + e;
+    if (p < last) { const bool keep = L.r[p] >= threshold; cl += keep ? 0 : 1; cr += keep ? 1 : 0; }
+  }
+  const int il = rbw_scan_inclusive(cl, lane), ir = rbw_scan_inclusive(cr, lane);
+  const int nL = __shfl(il, 63), nR = __shfl(ir, 63);
+  int kl = il - cl, kr = ir - cr;
+  for (int e = 0; e < E; e++) {
+    const int p = p0 + e;
+    if (p < last) { if (L.r[p] >= threshold) rpos[kr++] = p; else lpos[kl++] = p; }
+  }
+  rbw_fence();
+  int cnt = 0;
+  const int nk = nL < nR ? nL : nR;
+  for (int k = lane; k < nk; k += 64) cnt += lpos[k] < rpos[nR - 1 - k] ? 1 : 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+  rbw_fence();
+  rbw_swap_pairs(L, lpos, rpos, nR, cnt, lane);
+  return first + nR;                   // the elements that satisfy the predicate end up in front, whatever the order of the swaps
+}
+// KeyPointsFilter::retainBest by a wave: the introselect loop's pivot choice, the final insertion sort of at most three elements and
+// the heap-select fallback stay with lane 0
+__device__ inline int rbw_retain_best(const RbList& L, int n, int n_points, int* lpos, int* rpos, int lane) {
+  if (!(n_points >= 0 && n > n_points)) return n;
+  if (n_points == 0) return 0;
+  {
+    int first = 0, last = n;
+    const int nth = n_points - 1;
+    int depth_limit = 0;
+    for (int m = last - first; m > 1; m >>= 1) depth_limit++;
+    depth_limit *= 2;
+    bool done = false;
+    while (last - first > 3) {
+      if (depth_limit == 0) {
+        if (lane == 0) { rb_heap_select(L, first, nth + 1, last); rb_swap(L, first, nth); }
+        rbw_fence();
+        done = true;
+        break;
+      }
+      --depth_limit;
+      const int mid = first + (last - first) / 2;
+      if (lane == 0) rb_move_median_to_first(L, first, first + 1, mid, last - 1);
+      rbw_fence();
+      const int cut = rbw_unguarded_partition(L, first + 1, last, lpos, rpos, lane);
+      if (cut <= nth) first = cut; else last = cut;
+    }
+    if (!done) {
+      if (lane == 0) rb_insertion_sort(L, first, last);
+      rbw_fence();
+    }
+  }
+  const float ambiguous_response = L.r[n_points - 1];
+  return rbw_partition_ge(L, n_points, n, ambiguous_response, lpos, rpos, lane);
+}
+#endif
