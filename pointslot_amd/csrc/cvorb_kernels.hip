@@ -329,7 +329,9 @@ __device__ __forceinline__ void cvb_reflect_range(int lo, int hi, int len, int& 
   rlo = max(rlo, 0); rhi = min(rhi, len - 1);
 }
 
+#ifndef CVB_PLAN_T
 #define CVB_PLAN_T 512
+#endif
 #define CVB_PLAN_MAXCW 1024     // cells per row / per column of a level's padded plane that cvb_plan's row tables hold (host check)
 #define CVB_PLAN_MAXCH 512
 // one workgroup per image: kp cells and needed cells of every level (dynamic LDS: per level a byte per cell for the plane need and
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
   }
   __syncthreads();
   // worklist entries: positions inside the workgroup by LDS counters, then ONE global atomic per list and level
-  constexpr int PER = 8;                                           // tiles per thread (host check: tile_total <= PER * CVB_PLAN_T)
+  constexpr int PER = 8 * 512 / CVB_PLAN_T;                        // tiles per thread (host check: tile_total <= 8 * 512)
   int lpos[PER][3];
   for (int k = 0; k < PER; k++) {
     const int i = tid + k * CVB_PLAN_T;
