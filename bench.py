@@ -39,7 +39,7 @@ ALGO_BYTES_PER_FRAME_POSE_ITER = 2000 * 29 + 224      # pose-opt, 
 ALGO_FLOP_PER_OBJECT_BA_ITER = 103e6                  # object BA, per LM iteration per object (P=50, L=300, E=15000)
 RED_DEV = "cuda"              # device of the tensors used for cross-rank reductions
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r04"   # the committed counter tables the line reads its traffic figures from
 
 
 def _profile_json(name):
@@ -134,7 +134,10 @@ def make_sequences(rank, n_frames, n_distinct, texture, scene="drive", n_objects
         return [_make_one(j) for j in jobs]
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
-    with ProcessPoolExecutor(max_workers=min(n_distinct, max(1, (os.cpu_count() or 8) - 2), 48), mp_context=mp.get_context("spawn")) as pool:
+    # sized from the CPUs this process is GRANTED (affinity cut by the cgroup quota: the GPU boxes show 256 logical CPUs and grant 16),
+    # shared between the ranks of the node
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    with ProcessPoolExecutor(max_workers=min(n_distinct, max(1, _cpu_quota() // max(world, 1)), 48), mp_context=mp.get_context("spawn")) as pool:
         return list(pool.map(_make_one, jobs))
 
 
@@ -169,73 +172,76 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
     del base
     if objects:
         del mbase
-    trks = [LockstepTracker(per_group, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n_frames, device=local_rank, max_objects=MAX_OBJECTS if objects else 0)
-            for _ in range(n_groups)]
+    trks = []
+    try:
+        for _ in range(n_groups):
+            trks.append(LockstepTracker(per_group, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n_frames, device=local_rank, max_objects=MAX_OBJECTS if objects else 0))
 
-    def step(i):
-        for g, t in enumerate(trks):
-            if objects:
-                t.step_slot_device(imgs[g][i].data_ptr(), masks[g][i].data_ptr(), dets[g][i].data_ptr())
-            else:
-                t.step_device(imgs[g][i].data_ptr())
+        def step(i):
+            for g, t in enumerate(trks):
+                if objects:
+                    t.step_slot_device(imgs[g][i].data_ptr(), masks[g][i].data_ptr(), dets[g][i].data_ptr())
+                else:
+                    t.step_device(imgs[g][i].data_ptr())
 
-    def sync():
+        def sync():
+            for t in trks:
+                t.sync()
+
+        for i in range(warmup):
+            step(i)
+        sync()
+        barrier()
         for t in trks:
-            t.sync()
-
-    for i in range(warmup):
-        step(i)
-    sync()
-    barrier()
-    for t in trks:
-        t.enable_stage_timing(True)      # HIP events on the stream the kernels run on
-    t0 = time.perf_counter()
-    for i in range(warmup, n_frames):
-        step(i)
-    sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    stage = trks[0].stage_times()
-    out = {"dt": dt, "stage_ms_group0": stage, "frames_per_step_per_gpu": per_group * n_groups, "images_per_launch": 2 * per_group,
-           "h": h, "w": w, "n_distinct": n_distinct}
-    # every trajectory against the ground truth of the generator, every frame's tracked flag
-    err, untracked, tracked_timed, overflowed = 0.0, 0, 0, 0
-    tcw0 = st0 = obj0 = None
-    ob = {"detections": 0, "with_object": 0, "track_ok": 0, "max_abs_centre_error_m": 0.0, "reinit": 0}
-    for g, t in enumerate(trks):
-        tcw, st = t.fetch()
-        untracked += int((st["tracked"] == 0).sum())
-        # a frame whose search windows overflowed the candidate store is not the reference's result: it does not count as tracked
-        overflowed += int((st["overflowed"] != 0).sum())
-        tracked_timed += int(((st["tracked"][warmup:] != 0) & (st["overflowed"][warmup:] == 0)).sum())
-        if g == 0:
-            tcw0, st0 = tcw, st
-        R = tcw[:, :, :3, :3]
-        twc = -np.einsum("nsji,nsj->nsi", R, tcw[:, :, :3, 3])
-        for j in range(per_group):
-            truth = seqs[(g * per_group + j) % n_distinct]["twc"][:n_frames, :, 3]
-            ok = st["tracked"][:, j] != 0
-            if ok.any():
-                err = max(err, float(np.abs(twc[ok, j] - truth[ok]).max()))
-        if objects:
-            o = t.fetch_objects()
+            t.enable_stage_timing(True)      # HIP events on the stream the kernels run on
+        t0 = time.perf_counter()
+        for i in range(warmup, n_frames):
+            step(i)
+        sync()
+        barrier()
+        dt = time.perf_counter() - t0      # the contract's bracket: barrier + synchronize on both sides of the K steps
+        stage = trks[0].stage_times()
+        out = {"dt": dt, "stage_ms_group0": stage, "frames_per_step_per_gpu": per_group * n_groups, "images_per_launch": 2 * per_group,
+               "h": h, "w": w, "n_distinct": n_distinct}
+        # every trajectory against the ground truth of the generator, every frame's tracked flag
+        err, untracked, tracked_timed, overflowed = 0.0, 0, 0, 0
+        tcw0 = st0 = obj0 = None
+        ob = {"detections": 0, "with_object": 0, "track_ok": 0, "max_abs_centre_error_m": 0.0, "reinit": 0}
+        for g, t in enumerate(trks):
+            tcw, st = t.fetch()
+            untracked += int((st["tracked"] == 0).sum())
+            # a frame whose search windows overflowed the candidate store is not the reference's result: it does not count as tracked
+            overflowed += int((st["overflowed"] != 0).sum())
+            tracked_timed += int(((st["tracked"][warmup:] != 0) & (st["overflowed"][warmup:] == 0)).sum())
             if g == 0:
-                obj0 = o
-            live = o["id"] >= 0
-            ob["detections"] += int(live[2:].sum()); ob["with_object"] += int((o["tracked"][2:] != 0).sum())
-            ob["track_ok"] += int((o["track_ok"][2:] != 0).sum()); ob["reinit"] += int(o["reinit"].sum())
-            for j in range(min(per_group, n_distinct)):                  # the distinct sequences once: cuboid centres against the labels
-                q = seqs[(g * per_group + j) % n_distinct]
-                for i in range(2, n_frames):
-                    for k, d in enumerate(q["dets"][i]):
-                        if o[i, j, k]["track_ok"]:
-                            ob["max_abs_centre_error_m"] = max(ob["max_abs_centre_error_m"], float(np.abs(o[i, j, k]["tco"][:3] - d["pose7"][:3]).max()))
-    out.update(max_abs_position_error_m=err, untracked_frames=untracked, tracked_frames_timed=tracked_timed, overflowed_frames=overflowed, seqs=seqs, tcw_group0=tcw0, stats_group0=st0, obj_group0=obj0,
-               objects=ob if objects else None)
-    for t in trks:
-        t.close()
-    del imgs, masks, dets
-    torch.cuda.empty_cache()
+                tcw0, st0 = tcw, st
+            R = tcw[:, :, :3, :3]
+            twc = -np.einsum("nsji,nsj->nsi", R, tcw[:, :, :3, 3])
+            for j in range(per_group):
+                truth = seqs[(g * per_group + j) % n_distinct]["twc"][:n_frames, :, 3]
+                ok = st["tracked"][:, j] != 0
+                if ok.any():
+                    err = max(err, float(np.abs(twc[ok, j] - truth[ok]).max()))
+            if objects:
+                o = t.fetch_objects()
+                if g == 0:
+                    obj0 = o
+                live = o["id"] >= 0
+                ob["detections"] += int(live[2:].sum()); ob["with_object"] += int((o["tracked"][2:] != 0).sum())
+                ob["track_ok"] += int((o["track_ok"][2:] != 0).sum()); ob["reinit"] += int(o["reinit"].sum())
+                for j in range(min(per_group, n_distinct)):                  # the distinct sequences once: cuboid centres against the labels
+                    q = seqs[(g * per_group + j) % n_distinct]
+                    for i in range(2, n_frames):
+                        for k, d in enumerate(q["dets"][i]):
+                            if o[i, j, k]["track_ok"]:
+                                ob["max_abs_centre_error_m"] = max(ob["max_abs_centre_error_m"], float(np.abs(o[i, j, k]["tco"][:3] - d["pose7"][:3]).max()))
+        out.update(max_abs_position_error_m=err, untracked_frames=untracked, tracked_frames_timed=tracked_timed, overflowed_frames=overflowed, seqs=seqs, tcw_group0=tcw0, stats_group0=st0, obj_group0=obj0,
+                   objects=ob if objects else None)
+    finally:       # a leg abandoned by an exception must not leave its arenas beside the next leg
+        for t in trks:
+            t.close()
+        del imgs, masks, dets
+        torch.cuda.empty_cache()
     return out
 
 
@@ -794,27 +800,32 @@ def pcie_leg(rank, world, local_rank, guard, seqs, n_seq, n_groups, barrier):
             q = seqs[(g * per_group + j) % nd]
             arr[:, g, j, 0] = q["left"][:n]
             arr[:, g, j, 1] = q["right"][:n]
-    trks = [LockstepTracker(per_group, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n, device=local_rank) for _ in range(n_groups)]
-    lists = [[([arr[i, g, j, 0] for j in range(per_group)], [arr[i, g, j, 1] for j in range(per_group)]) for g in range(n_groups)] for i in range(n)]
-    warm = 2
-    for i in range(warm):
-        for g, t in enumerate(trks):
-            t.step(*lists[i][g])
-    for t in trks:
-        t.sync()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(warm, n):
-        for g, t in enumerate(trks):
-            t.step(*lists[i][g])
-    for t in trks:
-        t.sync()
-    barrier()
-    dt = guard.max(time.perf_counter() - t0)
-    untracked = sum(int((t.fetch()[1]["tracked"] == 0).sum()) for t in trks)
-    for t in trks:
-        t.close()
-    pin.close()
+    trks = []
+    try:
+        for _ in range(n_groups):
+            trks.append(LockstepTracker(per_group, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n, device=local_rank))
+        lists = [[([arr[i, g, j, 0] for j in range(per_group)], [arr[i, g, j, 1] for j in range(per_group)]) for g in range(n_groups)] for i in range(n)]
+        warm = 2
+        for i in range(warm):
+            for g, t in enumerate(trks):
+                t.step(*lists[i][g])
+        for t in trks:
+            t.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(warm, n):
+            for g, t in enumerate(trks):
+                t.step(*lists[i][g])
+        for t in trks:
+            t.sync()
+        dt = time.perf_counter() - t0          # before the guarded barrier: its handshake is a host round trip
+        barrier()
+        dt = guard.max(dt)
+        untracked = sum(int((t.fetch()[1]["tracked"] == 0).sum()) for t in trks)
+    finally:
+        for t in trks:
+            t.close()
+        pin.close()
     return {"workload": "the headline loop with the images in pinned host memory: %d sequences per GPU x %d timed frames, one ps_tracker_step per group and frame "
                         "(every image crosses PCIe inside the timed region)" % (per_group * n_groups, n - warm),
             "tracked_frames_per_s": world * per_group * n_groups * (n - warm) / dt, "ms_per_step": dt / (n - warm) * 1e3, "untracked_frames": untracked,
@@ -832,15 +843,17 @@ def config5_leg(rank, world, local_rank, guard, n_frames=154):
     h, w = seq["left"][0].shape
     d = torch.from_numpy(np.stack([seq["left"], seq["right"]], 1)).cuda()
     trk = LockstepTracker(1, seq["K"], seq["bf"], w, h, max_steps=n_frames, device=local_rank)
-    trk.step_device(d[0].data_ptr())
-    trk.sync()
-    t0 = time.perf_counter()
-    for i in range(1, n_frames):
-        trk.step_device(d[i].data_ptr())
-        trk.sync()                                 # one frame in flight: a live sequence delivers its frames one by one
-    dt = time.perf_counter() - t0
-    tcw, st = trk.fetch()
-    trk.close()
+    try:
+        trk.step_device(d[0].data_ptr())
+        trk.sync()
+        t0 = time.perf_counter()
+        for i in range(1, n_frames):
+            trk.step_device(d[i].data_ptr())
+            trk.sync()                                 # one frame in flight: a live sequence delivers its frames one by one
+        dt = time.perf_counter() - t0
+        tcw, st = trk.fetch()
+    finally:
+        trk.close()
     traj = np.zeros((n_frames, 12), np.float32)
     err = 0.0
     for k in range(n_frames):
@@ -870,6 +883,110 @@ def fp64_mfma_peak(local_rank):
     v = ctypes.c_double(0)
     check(lib.ps_debug_mfma_f64_peak(local_rank, ctypes.byref(v)))
     return v.value
+
+
+LINE_LIMIT = 8192             # the driver reads the bench line from a bounded tail of stdout: r04's 28.8 KB line came back unparsed
+
+
+def _num(v, sig=6):
+    """floats to `sig` significant digits, containers recursively (the line is a record, not a log)"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, (float, np.floating)):
+        v = float(v)
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, v))
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, dict):
+        return {k: _num(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_num(x, sig) for x in v]
+    return str(v)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "images_per_launch")
+
+
+def compact_line(full):
+    """The ONE stdout line of the contract, from the full result: the schema keys, `roofline` + `cpu_baseline`, the whole-step
+    roofline, a numeric-only per-stage table, `metric_ba` and the parity spot check - no prose beyond one short `workload` / `sample`
+    string each.  Everything else (notes, secondary legs, the per-kernel tables) is in the side file named by `full`."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype"))
+    line["data"] = "synthetic"
+    cfg = full.get("config", {})
+    line["config"] = dict(_pick(cfg, ("sequences_per_gpu", "lockstep_groups_per_gpu", "images_per_step_per_gpu", "object_chain", "dynamic_static_discrimination", "scene")),
+                          workload="%s lockstep 1242x375 stereo sequences/GPU, one frame of each per step: ORB 2000 kp x2, stereo, SearchByProjection + PoseOptimization x2%s"
+                                   % (cfg.get("sequences_per_gpu"), ", object chain (SLOT.MODE 4)" if cfg.get("object_chain") else ""),
+                          parallelism="sequences sharded over %s GPU(s), no data-path collective" % full.get("n_gpus"))
+    line["roofline"] = _pick(full.get("roofline") or {}, _ROOF_KEYS)
+    if full.get("step_roofline"):
+        line["step_roofline"] = _pick(full["step_roofline"], ("bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_step", "traffic"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = dict(_pick(cb, ("value", "unit", "cores", "kind")), sample=str(cb.get("sample", ""))[:100])
+    for k in ("cpu_baseline_reference_thread_model", "cpu_baseline_all_cores"):
+        if isinstance(full.get(k), dict) and "value" in full[k]:
+            line[k] = _pick(full[k], ("value", "unit", "cores"))
+    # per stage of the timed step: [stage, bound, ms per step of group 0, HBM fraction or null, HBM traffic / algorithmic bytes or null]
+    line["rooflines_columns"] = ["stage", "bound", "ms_per_step", "frac", "traffic_over_algorithmic"]
+    line["rooflines"] = [[r.get("stage"), r.get("bound"), r.get("ms_per_step"), r.get("frac"),
+                          (r["traffic"] / r["algorithmic_bytes_per_step"]) if r.get("traffic") and r.get("algorithmic_bytes_per_step") else None]
+                         for r in full.get("rooflines", [])]
+    alone = full.get("roofline_kernels_alone")
+    if alone:
+        line["kernels_alone"] = {"ms_per_step": alone.get("ms_per_step"),
+                                 "frac": {k["kernel"]: k.get("frac") for k in alone.get("kernels", [])},
+                                 "stage_ms_per_512_sequences": alone.get("stage_ms_per_512_sequences")}
+    tc = full.get("tracking_checks")
+    if tc:
+        line["tracking_checks"] = {k: v for k, v in tc.items() if k != "checked"}
+    mb = full.get("metric_ba")
+    if mb:
+        line["metric_ba"] = dict(_pick(mb, ("metric", "value", "unit", "higher_is_better")),
+                                 roofline=_pick(mb.get("roofline") or {}, ("bound", "achieved", "peak", "unit", "frac", "frac_per_iteration", "traffic")),
+                                 cpu_baseline=_pick(mb.get("cpu_baseline") or {}, ("value", "unit", "cores", "kind")))
+        sec = full.get("secondary_metrics") or {}
+        if "ms_per_iter_1_object" in sec.get("object_ba", {}):
+            line["metric_ba"]["value_1_object"] = sec["object_ba"]["ms_per_iter_1_object"]
+    if "parity_spot" in full:
+        line["parity_spot"] = full["parity_spot"]
+    sec = full.get("secondary_metrics") or {}
+    if sec.get("failed_legs"):
+        line["failed_legs"] = sec["failed_legs"]
+    line["full"] = full.get("full_result_file")
+    line = _num(line, 5)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:      # never hand the driver a line it cannot read: drop the optional tables, largest first
+        for k in ("kernels_alone", "rooflines", "rooflines_columns", "tracking_checks", "cpu_baseline_all_cores", "cpu_baseline_reference_thread_model"):
+            line.pop(k, None)
+            text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    return text
+
+
+def emit(full):
+    """rank 0: the full result to bench_full.json (beside this file; gpurun_out/ too when it exists) and to stderr, then the compact
+    line as the LAST line of stdout"""
+    full["full_result_file"] = "bench_full.json"
+    blob = json.dumps(_num(full, 9), allow_nan=False)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(blob + "\n")
+            except OSError:
+                pass
+    sys.stderr.write(blob + "\n")
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(compact_line(full), flush=True)
 
 
 def main():
@@ -960,10 +1077,16 @@ def main():
     # the kernels of the step on their own: a short single-group pass over the same sequences (one stream: no overlap between kernels)
     alone = None
     if args.groups > 1 and not args.no_alone:
-        a1 = tracking_leg(rank, local_rank, args.texture, min(args.steps, 6), max(args.warmup, 2), args.sequences, 1, barrier, scene=args.scene,
-                          n_distinct=args.distinct, objects=objects, seqs=head["seqs"])
-        alone = {"ms_per_step": parallel.max_over_ranks(dist, a1["dt"], RED_DEV) / min(args.steps, 6) * 1e3, "stage_ms": a1["stage_ms_group0"],
-                 "images_per_launch": a1["images_per_launch"]}
+        # under the guard: a failure here (memory beside the cached sequences, a capacity limit that only shows with every sequence in
+        # one group) must not discard the headline that is already measured, nor leave the peers inside a collective
+        def alone_pass():
+            a1 = tracking_leg(rank, local_rank, args.texture, min(args.steps, 6), max(args.warmup, 2), args.sequences, 1, gbarrier, scene=args.scene,
+                              n_distinct=args.distinct, objects=objects, seqs=head["seqs"])
+            return {"ms_per_step": guard.max(a1["dt"]) / min(args.steps, 6) * 1e3, "stage_ms": a1["stage_ms_group0"], "images_per_launch": a1["images_per_launch"]}
+        alone = guard.run(alone_pass)
+        if "error" in alone and len(alone) == 1:
+            sys.stderr.write("bench.py: single-group pass failed: %s\n" % alone["error"])
+            alone = None
     secondary = None
     if not args.no_secondary:
         secondary = {}
@@ -1093,6 +1216,17 @@ def main():
                                      "the timed region (%d steps, %.3f ms per step): the timed region runs %d lockstep groups on %d streams, where a kernel's event-to-event time includes the other group's "
                                      "kernels (`roofline_timed_region_group0`); profiles/%s_bench_kernel_stats_1group_timed.csv is the rocprofv3 table of this pass's command (--groups 1)"
                                      % (min(args.steps, 6), alone["ms_per_step"], G, G, PROFILE_ROUND)}
+        # the step as a whole against HBM (frames/s "as fraction of HBM roofline"): SURVEY's 8.68 MB per image x the images of
+        # a step (+ image, object mask and id mask read once for the object features) over the wall time of a step on this GPU
+        step_algo = sum(ALGO_BYTES_PER_IMAGE.values()) * 2 * S + ((2 * 465750 * 2 * S + 465750 * S) if objects else 0)
+        step_ms = dt / args.steps * 1e3
+        step_tr = _profile_json(PROFILE_ROUND + "_traffic.json")
+        step_traffic = None
+        if step_tr and step_tr.get("images_per_launch") == nimg_step:
+            step_traffic = sum(v.get("hbm_bytes_per_step", 0.0) for v in step_tr.get("kernels", {}).values()) or None
+        step_rl = {"bound": "hbm", "achieved": step_algo / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": step_algo / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": step_algo, "traffic": step_traffic,
+                   "note": "whole step of one GPU: SURVEY 8d bytes of every image of the step (+ the object-feature inputs) / ms_per_step; traffic = all kernels of the committed counter pass"}
         out = {
             "metric": "tracked frames/sec KITTI stereo 1242x375",
             "value": value,
@@ -1121,6 +1255,7 @@ def main():
                                 "checked": "every frame of every sequence: tracked flag, position against the generator's ground truth; objects: "
                                            "detections with a MapObject / with mbTrackOK, cuboid centres of the distinct sequences against the labels"},
             "roofline": roofline_main,
+            "step_roofline": step_rl,
             "roofline_timed_region_group0": roofline_timed,
             "rooflines": rl,
             "roofline_kernels_alone": None if alone is None else {
@@ -1157,7 +1292,7 @@ def main():
                                     "roofline": ba.get("roofline"),
                                     "cpu_baseline": {"value": ba.get("cpu_port_ms_per_iter_1core_1object"), "unit": "ms/iter (one object)", "cores": 1, "kind": "port",
                                                      "sample": "one object's 5 + 10 iteration schedule through the CPU restatement (oracle/opt_oracle.cpp)"}}
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -84,7 +84,7 @@ def gather_trajectories(dist, local, device="cpu"):
     return [o[:int(c.item())].cpu().numpy() for o, c in zip(outs, counts)]
 
 
-class PeerFailed(RuntimeError):
+class PeerFailed(BaseException):   # not an Exception: a broad `except Exception` inside a leg must not swallow it (the handshakes would fall out of step)
     """another rank reported a failure at the handshake in front of a collective"""
 
 

@@ -1,0 +1,80 @@
+"""The bench line is a record the driver must be able to read: one stdout line, strict JSON, well under 8 KB, carrying the contract's
+keys with `roofline` and `cpu_baseline` (r04's 28.8 KB line came back from the driver unparsed).  Built here from a canned full
+result (the committed profiles/r04_bench.json) - no GPU."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+SCHEMA = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+          "roofline", "cpu_baseline")
+
+
+def _strict(text):
+    def bad(c):
+        raise ValueError("non-finite constant %s in the line" % c)
+    return json.loads(text, parse_constant=bad)
+
+
+def _canned():
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    full["step_roofline"] = {"bound": "hbm", "achieved": 805.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1006, "algorithmic_bytes_per_step": 15.1e9, "traffic": None, "note": "x" * 400}
+    return full
+
+
+def test_line_is_small_strict_json_with_the_contract_keys():
+    text = bench.compact_line(_canned())
+    assert "\n" not in text
+    assert len(text.encode()) < 8192, len(text)
+    line = _strict(text)
+    for k in SCHEMA:
+        assert k in line, k
+    assert line["value"] > 0 and line["unit"] == "frames/s" and line["higher_is_better"] is True
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-4
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["step_roofline"]["frac"] > 0
+    assert line["metric_ba"]["roofline"]["bound"] == "mfma" and "cpu_baseline" in line["metric_ba"]
+    # numeric-only per-stage table: no prose
+    for row in line["rooflines"]:
+        assert len(row) == len(line["rooflines_columns"])
+        assert all(v is None or isinstance(v, (int, float)) for v in row[2:])
+    assert max(len(v) for v in _strings(line)) <= 200
+
+
+def _strings(o):
+    if isinstance(o, str):
+        yield o
+    elif isinstance(o, dict):
+        for v in o.values():
+            yield from _strings(v)
+    elif isinstance(o, list):
+        for v in o:
+            yield from _strings(v)
+
+
+def test_line_survives_nan_and_oversized_input():
+    full = _canned()
+    full["value"] = float("nan")
+    full["rooflines"] = full["rooflines"] * 60            # a table that would blow the limit is dropped, the schema keys stay
+    text = bench.compact_line(full)
+    assert len(text.encode()) < 8192
+    line = _strict(text)
+    assert line["value"] is None and "roofline" in line and "cpu_baseline" in line
+
+
+def test_emit_prints_the_line_last(tmp_path, capsys, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(_canned())
+    cap = capsys.readouterr()
+    lines = cap.out.strip().splitlines()
+    assert len(lines) == 1 and _strict(lines[0])["full"] == "bench_full.json"
+    side = _strict(open(tmp_path / "bench_full.json").read())
+    assert "secondary_metrics" in side and "rooflines" in side
