@@ -362,7 +362,26 @@ int ps_orb_create(const ps_orb_config* cfg, ps_orb** out) {
   ps_orb* h = new ps_orb();
   h->cfg = *cfg;
   build_tables(h);
-  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  hipError_t e;
+  if (const char* part = getenv("PS_CU_PARTITION")) {
+    // experiment: the k-th extractor handle of the process - the k-th lockstep group of a tracker bench - gets its own
+    // share of the compute units instead of competing for all of them: PS_CU_PARTITION=N cuts the CU mask bits into N ranges (the driver
+    // deals consecutive bits round-robin over the 8 XCDs, so a range is a slice of every XCD), PS_CU_SHARE=k gives a handle k consecutive ranges
+    static int created = 0;
+    const int N = atoi(part) > 0 ? atoi(part) : 1, K = getenv("PS_CU_SHARE") ? atoi(getenv("PS_CU_SHARE")) : 1;
+    hipDeviceProp_t prop;
+    PS_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int kk = 0; kk < K; kk++) {
+      const int r = (created + kk) % N;
+      for (int c = r * ncu / N; c < (r + 1) * ncu / N; c++) mask[c >> 5] |= 1u << (c & 31);
+    }
+    created++;
+    e = hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)mask.size(), mask.data());
+  } else {
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  }
   if (e != hipSuccess) { delete h; return ps_set_error(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
   for (int r = 0; r < ps_orb::RING; r++)
     for (int c = 0; c < ps_orb::MAXCHUNK; c++)
