@@ -111,7 +111,43 @@ def pmc_valu_issue(kernel, nimg, ms_per_step=None):
     return None
 
 
+def _seq_cache_path(job):
+    """rendered sequences are kept on disk (PS_SEQ_CACHE, default /tmp/pointslot_seq_cache; empty string = off), keyed by the job and the
+    generator's source: a second run on the same host, the other ranks' identical jobs and the secondary legs do not render again"""
+    root = os.environ.get("PS_SEQ_CACHE", "/tmp/pointslot_seq_cache")
+    if not root:
+        return None
+    import hashlib
+    hsh = hashlib.sha256(repr(tuple(job)).encode())
+    for name in ("sequence.py", "object_tracker.py"):
+        with open(os.path.join(ROOT, "pointslot_amd", name), "rb") as f:
+            hsh.update(f.read())
+    return os.path.join(root, hsh.hexdigest()[:24] + ".pkl")
+
+
 def _make_one(job):
+    import pickle
+    path = _seq_cache_path(job)
+    if path and os.path.exists(path):
+        try:
+            with open(path, "rb") as f:
+                return pickle.load(f)
+        except Exception:   # noqa: BLE001  (a torn or stale file: render again)
+            pass
+    q = _render_one(job)
+    if path:
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            with open(tmp, "wb") as f:
+                pickle.dump(q, f, protocol=4)
+            os.replace(tmp, path)          # atomic: a reader sees the whole file or none
+        except OSError:
+            pass
+    return q
+
+
+def _render_one(job):
     scene, n_frames, seed, k, texture = job[:5]
     n_objects = job[5] if len(job) > 5 else 2
     from pointslot_amd import sequence
@@ -206,7 +242,7 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
         # every trajectory against the ground truth of the generator, every frame's tracked flag
         err, untracked, tracked_timed, overflowed = 0.0, 0, 0, 0
         tcw0 = st0 = obj0 = None
-        ob = {"detections": 0, "with_object": 0, "track_ok": 0, "max_abs_centre_error_m": 0.0, "reinit": 0}
+        ob = {"detections": 0, "with_object": 0, "track_ok": 0, "max_abs_centre_error_m": 0.0, "reinit": 0, "dsd_tested": 0, "dsd_dynamic": 0}
         for g, t in enumerate(trks):
             tcw, st = t.fetch()
             untracked += int((st["tracked"] == 0).sum())
@@ -229,6 +265,8 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
                 live = o["id"] >= 0
                 ob["detections"] += int(live[2:].sum()); ob["with_object"] += int((o["tracked"][2:] != 0).sum())
                 ob["track_ok"] += int((o["track_ok"][2:] != 0).sum()); ob["reinit"] += int(o["reinit"].sum())
+                ran = (o["dyn_n_mono"] + o["dyn_n_stereo"]) > 0          # DynamicStaticDiscrimination's reprojection test ran (depth / centre gates passed)
+                ob["dsd_tested"] += int(ran.sum()); ob["dsd_dynamic"] += int((ran & (o["dynamic"] != 0)).sum())
                 for j in range(min(per_group, n_distinct)):                  # the distinct sequences once: cuboid centres against the labels
                     q = seqs[(g * per_group + j) % n_distinct]
                     for i in range(2, n_frames):
@@ -400,7 +438,8 @@ def cpu_tracking_baseline(seqs, tcw_gpu, obj_gpu, objects, budget_s=10.0):
                     for j, o in enumerate(vo.objects.stats[i]["objects"]):
                         d = obj_gpu[i, k, j]
                         same = (int(d["n"]) == o["n"] and int(d["tracked"]) == int(o["tracked"]) and int(d["bf_matches"]) == o["bf_matches"]
-                                and int(d["lm_matches"]) == o["lm_matches"] and int(d["inliers"]) == o["inliers"])
+                                and int(d["lm_matches"]) == o["lm_matches"] and int(d["inliers"]) == o["inliers"]
+                                and int(d["dynamic"]) == int(o["dynamic"]) and (int(d["dyn_n_mono"]), int(d["dyn_n_stereo"])) == tuple(o["dyn_n"]))
                         obj_checked += 1; obj_bad += 0 if same else 1
         k += 1
     one = {"value": frames / spent, "unit": "frames/s", "cores": 1, "kind": "port",
@@ -1247,8 +1286,8 @@ def main():
                                    "generated drives), one stereo frame of each per step through the whole of Tracking::Track's per-frame work on the device - camera chain (BASELINE configs[1] per "
                                    "image: 8-level ORB, 2000 keypoints + rBRIEF; ComputeStereoMatches; configs[2] per frame: SearchByProjection + PoseOptimization twice)%s - images, instance masks "
                                    "and detections resident in HBM; value counts the frames that came out tracked"
-                                   % (S, head["n_distinct"], " and object chain (cv::ORB object features, object stereo, SearchByBruceMatching, CFSE3 x 2, object SearchByProjection)" if objects else ""),
-                       "sequences_per_gpu": S, "lockstep_groups_per_gpu": args.groups, "images_per_step_per_gpu": 2 * S, "object_chain": objects, "scene": args.scene,
+                                   % (S, head["n_distinct"], " and object chain (cv::ORB object features, object stereo, SearchByBruceMatching, CFSE3 x 2, object SearchByProjection, DynamicStaticDiscrimination)" if objects else ""),
+                       "sequences_per_gpu": S, "lockstep_groups_per_gpu": args.groups, "images_per_step_per_gpu": 2 * S, "object_chain": objects, "dynamic_static_discrimination": objects, "scene": args.scene,
                        "parallelism": "sequences sharded over %d GPU(s), no collective in the data path" % world},
             "tracking_checks": {"untracked_frames": untracked, "frames_with_overflowed_search_windows": overflowed, "max_abs_position_error_m": err, "distinct_sequences_per_gpu": head["n_distinct"],
                                 "objects": head["objects"],

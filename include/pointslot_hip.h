@@ -518,7 +518,11 @@ typedef struct ps_object_stat {
   int32_t lm_matches;     /* SearchByProjection(F, nOrder, MOPs)'s return value                                                */
   int32_t map_points;     /* the frame's MapObjectPoints with observations when the frame was finished                         */
   int32_t reinit;         /* MapObjectReInit ran                                                                               */
+  int32_t dynamic;        /* DetectionObject::GetDynamicFlag() after Tracking::DynamicStaticDiscrimination (Tracking.cc:2058)  */
+  int32_t mo_dynamic;     /* its MapObject's GetDynamicFlag(), -1 without a MapObject                                          */
+  int32_t dyn_n_mono, dyn_n_stereo;   /* points the two averages below were taken over (after the 5 x median rejection)        */
   double tco[7];          /* GetCFInFrameObjState(frame).pose when the frame was finished                                      */
+  double dyn_mono, dyn_stereo;        /* mdMonoDynaVal / mdStereoDynaVal: mean chi2 of "the object did not move" (0: not run)  */
 } ps_object_stat;
 int ps_tracker_step_slot_device(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_pitch, const uint8_t* d_masks, int mask_stride,
                                 size_t mask_pitch, const ps_detection* d_dets);

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(OB_T) void ob_begin(ObArrays A, int step) {
       ObStat o;
       for (int i = 0; i < (int)(sizeof(ObStat) / 4); i++) ((int32_t*)&o)[i] = 0;
       o.id = F.det[(size_t)s * K + j].id; o.n = n; o.stereo = st;
+      o.dynamic = 1; o.mo_dynamic = -1;      // a DetectionObject is born dynamic (DetectionObject.cc:74)
       A.stats[((size_t)step * A.S + s) * K + j] = o;
     }
   }
@@ -628,6 +629,7 @@ __global__ __launch_bounds__(OB_T) void ob_track(ObArrays A, int step) {
         s_pose = P;
         ObMapObject& O = A.mobj[(size_t)s * A.M + slot];
         O.id = det.id; O.first_frame = step; O.tco_frame = step;
+        O.dyn = 3;     // new MapObject(id, candidate_cuboid->GetDynamicFlag() = true, ...): mbFirstObserved, no history (MapObject.cc:20-21)
         for (int k = 0; k < 3; k++) O.scale[k] = det.scale[k];
         ob_store_pose(O.tco, P);
         F.mo[(size_t)s * K + j] = slot;
@@ -969,6 +971,132 @@ __global__ __launch_bounds__(OB_T) void ob_after_lm(ObArrays A, int step) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Tracking::DynamicStaticDiscrimination (Tracking.cc:2058-2202; Track calls it right behind the object tracking functions, :1244) for
+// one detection that was tracked from the last frame; its tail StaticPointRecoveryFromObj is outside the slice.
+//   gates: camera-frame depth of the object outside [7, mThDepth] -> the detection takes its MapObject's flag; the box within
+//   width / 2 + 60 px of the image centre column -> dynamic by prior (a vehicle straight ahead).
+//   test: every MapObjectPoint of the detection moved as if the object stood still (Pc = Tcw_cur Tcw_last^-1 Tco_last Po) against its
+//   observation - the arithmetic of dyn_kernels.hip (a f-4), term by term; per kind (monocular / stereo) the values are sorted, those
+//   above 5 x median dropped and the rest summed IN SORTED ORDER (std::sort + std::accumulate), here by ranking: a value's rank among
+//   its kind is its sorted position (equal values are interchangeable in a sum).
+//   flags: DetectionObject::SetDynamicFlag(mono, stereo) (DetectionObject.cc:169-196), MapObject::DynamicDetection / SetDynamicFlag
+//   (MapObject.cc:414-448) with its queue of the last four verdicts.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ob_mo_dynamic_detection(int d, bool f) {
+  if (d & 4) return d;
+  int len = (d >> 8) & 7, h = (d >> 4) & 15;
+  if (len < 4) { h |= (f ? 1 : 0) << len; len++; }
+  else h = (h >> 1) | ((f ? 1 : 0) << 3);                       // push, then pop the oldest
+  d = (d & ~0x7F0) | (h << 4) | (len << 8);
+  if (len < 4) return d;
+  if (h == (f ? 15 : 0) && (d & 1) != (f ? 1 : 0)) d |= 4;      // four equal verdicts against the current flag: mbDynamicChanged
+  return d;
+}
+__device__ __forceinline__ int ob_mo_set_dynamic(int d, bool f) {
+  if (d & 2) d = (d & ~3) | (f ? 1 : 0);
+  if (d & 4) d = (d & ~5) | (f ? 1 : 0);
+  return d;
+}
+
+__device__ void ob_dsd(const ObArrays& A, const ObFrame& F, const ObFrame& L, int s, int j, int lj, ObMapObject& O, size_t fo, int n, int step,
+                       ObStat* st, ObShared& sh, double* s_avg, int* s_kept) {
+  const ObCam& C = A.cam;
+  const int tid = threadIdx.x, K = A.K;
+  const ObDet det = F.det[(size_t)s * K + j];
+  const int mo_dyn = O.dyn;
+  const double depth = O.tco[2];
+  if (depth < 7 || depth > (double)C.th_depth) {
+    if (tid == 0) st->dynamic = mo_dyn & 1;
+    return;
+  }
+  const double middle_x = (double)(C.w / 2), current_px = (double)(det.bbox[0] + det.bbox[2] / 2);
+  if (fabs(current_px - middle_x) < (double)(det.bbox[2] / 2 + 60)) {
+    if (tid == 0) { st->dynamic = 1; O.dyn = ob_mo_set_dynamic(mo_dyn, true); }
+    return;
+  }
+  // current_pose * last_pose.inverse() on the frames' mSETcw (a frame without a pose keeps the identity)
+  Se3 ident;
+  ident.q[0] = ident.q[1] = ident.q[2] = 0; ident.q[3] = 1; ident.t[0] = ident.t[1] = ident.t[2] = 0;
+  const float* Fc = ob_cam_pose(A, s, step);
+  const float* Lc = ob_cam_pose(A, s, step - 1);
+  const Se3 Tc = Fc ? se3_from_mat4f(Fc) : ident, Tl = Lc ? se3_from_mat4f(Lc) : ident;
+  Se3 Tli;
+  Tli.q[0] = -Tl.q[0]; Tli.q[1] = -Tl.q[1]; Tli.q[2] = -Tl.q[2]; Tli.q[3] = Tl.q[3];
+  const double nt[3] = {Tl.t[0] * -1., Tl.t[1] * -1., Tl.t[2] * -1.};
+  se3_rotate(Tli.q, nt, Tli.t);
+  const Se3 trel = se3_mul(Tc, Tli);
+  const Se3 tco = ob_pose(L.tco + ((size_t)s * K + lj) * 7);
+  double* vals = A.cam_pts + 3 * fo;                                    // [n] values, [n] monocular sorted, [n] stereo sorted
+  uint8_t* kind = reinterpret_cast<uint8_t*>(A.bf_qot + fo);           // 0 no point, 1 monocular, 2 stereo
+  const double fx = (double)C.fx, fy = (double)C.fy, cx = (double)C.cx, cy = (double)C.cy;
+  int cm = 0, cs = 0;
+  for (int i = tid; i < n; i += OB_T) {
+    uint8_t kd = 0;
+    double v = 0;
+    if (F.mp_valid[fo + i]) {
+      const double po[3] = {(double)F.mp_po[3 * (fo + i)], (double)F.mp_po[3 * (fo + i) + 1], (double)F.mp_po[3 * (fo + i) + 2]};
+      double Plc[3], Pc[3];
+      se3_map(tco, po, Plc);
+      se3_map(trel, Plc, Pc);
+      const double invz = 1.0 / Pc[2];
+      const double w = (double)C.inv_sigma2[F.octave[fo + i]];
+      const double z0 = cx + Pc[0] * invz * fx, z1 = cy + Pc[1] * invz * fy;
+      const double e0 = (double)F.x[fo + i] - z0, e1 = (double)F.y[fo + i] - z1;
+      const float ur = F.uright[fo + i];
+      if (ur < 0) { v = e0 * (w * e0) + e1 * (w * e1); kd = 1; cm++; }
+      else {
+        const double z2 = z0 - (double)C.mbf * invz;
+        const double e2 = (double)ur - z2;
+        v = e0 * (w * e0) + e1 * (w * e1) + e2 * (w * e2); kd = 2; cs++;
+      }
+    }
+    vals[i] = v; kind[i] = kd;
+  }
+  cm = ob_block_sum(cm, sh.red);
+  cs = ob_block_sum(cs, sh.red);
+  __syncthreads();
+  for (int i = tid; i < n; i += OB_T) {
+    const int kd = kind[i];
+    if (!kd) continue;
+    const double v = vals[i];
+    int r = 0;
+    for (int k = 0; k < n; k++) {
+      const double vk = vals[k];
+      r += (kind[k] == kd && (vk < v || (vk == v && k < i))) ? 1 : 0;
+    }
+    vals[(size_t)kd * n + r] = v;
+  }
+  __syncthreads();
+  if (tid == 0 || tid == 64) {
+    const int which = tid >> 6, num = which ? cs : cm;
+    const double* v = vals + (size_t)(which + 1) * n;
+    double avg = 0;
+    int kept = num;
+    if (num >= 5) {
+      const double cut = 5 * v[num / 2];                       // int(size / 2 + 0.5) with integer size / 2
+      kept = 0;
+      double sum = 0.0;
+      for (int i = 0; i < num; i++)
+        if (!(v[i] > cut)) { sum += v[i]; kept++; }
+      avg = sum / kept;
+    }
+    s_avg[which] = avg; s_kept[which] = kept;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double mono = s_avg[0], stereo = s_avg[1];
+    st->dyn_n_mono = s_kept[0]; st->dyn_n_stereo = s_kept[1];
+    if (mono > 0 || stereo > 0) {
+      const bool f = mono > 1 || stereo > 2;
+      st->dyn_mono = mono; st->dyn_stereo = stereo; st->dynamic = f ? 1 : 0;
+      O.dyn = ob_mo_set_dynamic(ob_mo_dynamic_detection(mo_dyn, f), f);
+    } else {
+      st->dynamic = mo_dyn & 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The end of the object chain: the second CFSE3's poses and inliers (Tracking.cc:2492-2520), the end of Track for SLOT mode 4
 // (:1443-1478: matches on temporal points dropped, MapObjectReInit for a detection whose tracking failed, :1932-2031), the
 // frame's statistics, and mLastFrame = Frame(mCurrentFrame).  One workgroup per (detection, sequence).
@@ -977,6 +1105,7 @@ __global__ __launch_bounds__(OB_T) void ob_finish(ObArrays A, int step) {
   __shared__ ObShared sh;
   __shared__ Se3 s_pose;
   __shared__ int s_int[2];
+  __shared__ double s_dsd[2];
   const int j = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, K = A.K;
   const ObCam& C = A.cam;
   ObFrame& F = A.cur;
@@ -1010,6 +1139,14 @@ __global__ __launch_bounds__(OB_T) void ob_finish(ObArrays A, int step) {
         if (tid == 0) { st->inliers = inl; A.track_ok[(size_t)s * K + j] = inl > 10 ? 1 : 0; }
       }
       __syncthreads();
+      {
+        // Moving Objects Recognition (Tracking.cc:1244): the detections tracked from the last frame; one tracked from an older frame took
+        // its MapObject's flag in TrackMapObject (:1617)
+        const int lj = A.in_last[(size_t)s * K + j];
+        if (lj >= 0) ob_dsd(A, F, L, s, j, lj, O, fo, n, step, st, sh, s_dsd, s_int);
+        else if (A.tracked[(size_t)s * K + j] && tid == 0) st->dynamic = O.dyn & 1;
+        __syncthreads();
+      }
       if (O.first_frame != step) {
         for (int i = tid; i < n; i += OB_T)
           if (F.mp_valid[fo + i] && !F.mp_observed[fo + i]) { F.mp_valid[fo + i] = 0; F.outlier[fo + i] = 0; }
@@ -1097,7 +1234,7 @@ __global__ __launch_bounds__(OB_T) void ob_finish(ObArrays A, int step) {
       for (int i = tid; i < n; i += OB_T) mpn += (F.mp_valid[fo + i] && F.mp_observed[fo + i]) ? 1 : 0;
       mpn = ob_block_sum(mpn, sh.red);
       if (tid == 0) {
-        st->map_points = mpn; st->track_ok = A.track_ok[(size_t)s * K + j];
+        st->map_points = mpn; st->track_ok = A.track_ok[(size_t)s * K + j]; st->mo_dynamic = O.dyn & 1;
         for (int c = 0; c < 7; c++) { st->tco[c] = O.tco[c]; F.tco[((size_t)s * K + j) * 7 + c] = O.tco[c]; }
       }
     }
@@ -1122,7 +1259,6 @@ __global__ __launch_bounds__(OB_T) void ob_finish(ObArrays A, int step) {
     if (tid <= K) L.off[(size_t)s * (K + 1) + tid] = F.off[(size_t)s * (K + 1) + tid];
     if (tid == 0) L.ndet[s] = nd;
   }
-  (void)s_int;
 }
 
 // ---- brute-force matcher: the block table of bf_topk derived from the problem table on the device ----

@@ -36,7 +36,9 @@ struct ObMapObject {
   int32_t tco_frame;          // latest frame with a camera-frame state
   int32_t local_valid;        // mvLocalObjectKeyFrames holds the keyframe
   int32_t npts;               // points of the keyframe (local map)
-  int32_t pad[2];
+  int32_t dyn;                // bit 0 mbDynamicFlag, bit 1 mbFirstObserved, bit 2 mbDynamicChanged, bits 4-7 mqbHistoricalDynafFlag
+                              // (oldest entry in bit 4), bits 8-10 its length (MapObject.cc:414-448)
+  int32_t pad;
   double scale[3];
   double tco[7];
 };
@@ -44,7 +46,9 @@ struct ObMapObject {
 // per step, sequence and detection (ps_tracker_fetch_objects hands these out as ps_object_stat)
 struct ObStat {
   int32_t id, n, stereo, tracked, is_new, track_ok, inliers, bf_matches, lm_candidates, lm_matches, map_points, reinit;
+  int32_t dynamic, mo_dynamic, dyn_n_mono, dyn_n_stereo;   // DynamicStaticDiscrimination: the detection's / its MapObject's flag (-1: none), points averaged
   double tco[7];
+  double dyn_mono, dyn_stereo;                             // DetectionObject::mdMonoDynaVal / mdStereoDynaVal
 };
 
 struct ObCam { float fx, fy, cx, cy, mbf, mb, th_depth, gw_inv, gh_inv, log_sf, inv_fx, inv_fy; int32_t w, h, nlevels, pad; float sf[8], inv_sigma2[8]; };

@@ -285,7 +285,6 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
     bool need0[LV_HROWS];
 #pragma unroll
     for (int r = 0; r < LV_HROWS; r++) {
-      const int rr = tyq * LV_RPT + half * (LV_HROWS) + r;
       ty[r] = ty_all[half * (LV_HROWS) + r];
       const int prev_s1 = r > 0 ? ty[r - 1].y : hc_row;
       need0[r] = LEVEL0 || ty[r].x != prev_s1;

@@ -7,12 +7,15 @@ by call through the hot-path kernels - the per-call twin of the device-resident 
                             MapObjectInit for a first observation                             src/Tracking.cc:1533-1930
     TrackLastFrameObjectPoint   temporal points, SearchByBruceMatching (a10), CFSE3ObjStateOptimization (a15)   :2288-2466
     TrackObjectLocalMap     isInFrustum(pMP, nOrder), SearchByProjection(F, nOrder, MOPs) (a13), CFSE3 (a15)    :2468-2712
+    DynamicStaticDiscrimination   depth / image-centre gates, reprojection test "the object did not move" (8f-4),
+                            DetectionObject::SetDynamicFlag, MapObject::DynamicDetection / SetDynamicFlag           :1244,2058-2202
     end of Track            temporal matches dropped, MapObjectReInit for an object whose tracking failed       :1443-1478,1932-2031
 
 The slice is the localisation-mode one of tracker.py: an object's local map is the object keyframe of its (re-)initialisation
-(no NeedNewObjectKeyFrame / ObjectLocalMapping), every object keeps the dynamic flag of its detection (no
-DynamicStaticDiscrimination / StaticPointRecoveryFromObj) and its virtual velocity stays zero (MapObject::UpdateVelocity is
-outside the slice; the prediction is Tcl * Tco as the reference has it for an object flagged static).
+(no NeedNewObjectKeyFrame / ObjectLocalMapping); DynamicStaticDiscrimination runs where Track runs it (after TrackObjectLocalMap,
+r05) and keeps the detections' and the MapObjects' dynamic flags, its tail StaticPointRecoveryFromObj (it moves object points into
+the static map) is outside the slice, and an object's virtual velocity stays zero (MapObject::UpdateVelocity is outside the slice;
+the prediction is Tcl * Tco as the reference has it for an object without a velocity).
 
 Arithmetic is written operation by operation in the precision the reference uses (float32 pixel / point arithmetic, FP64 pose
 algebra on g2o::SE3Quat) so that the device-resident chain can repeat it bit for bit.  Where OpenCV's cv::Mat arithmetic decides a
@@ -232,6 +235,9 @@ class ObjectTracker:
             o.mo = None                               # mvMapObjects[j]
             o.track_ok = False
             o.inliers = 0
+            o.dynamic = True                          # DetectionObject::mbDynamicFlag (true from the constructor, DetectionObject.cc:74)
+            o.dyn_mono = 0.0; o.dyn_stereo = 0.0      # mdMonoDynaVal / mdStereoDynaVal
+            o.dyn_n = (0, 0)                          # points the two averages were taken over
             F.obj.append(o)
         F.n_temp = len(x)
         return F
@@ -391,7 +397,9 @@ class ObjectTracker:
         c[1] = 0 + scale[1] / 2
         truth = from_pose7(det["pose7"])
         pose = self._fine_tune(det, (tuple(c), truth[1]), scale)
-        mo = {"id": det["id"], "first_frame": self.frame_id, "scale": scale, "tco": pose, "tco_frame": self.frame_id}
+        # new MapObject(id, candidate_cuboid->GetDynamicFlag(), ...): mbDynamicChanged(false), mbFirstObserved(true), empty history (MapObject.cc:20-21)
+        mo = {"id": det["id"], "first_frame": self.frame_id, "scale": scale, "tco": pose, "tco_frame": self.frame_id,
+              "dynamic": bool(o.dynamic), "dyn_changed": False, "dyn_first": True, "dyn_hist": []}
         self.objects[det["id"]] = mo
         o.mo = mo
         self._keyframe_points(o, mo, pose, inl, pts, idx, fmax, True)
@@ -462,6 +470,8 @@ class ObjectTracker:
                 lj = next((k for k, d in enumerate(self.last.dets) if d["id"] == det["id"]), -1)
                 assert lj >= 0
                 F.in_last.append((lj, j))
+            else:
+                o.dynamic = mo["dynamic"]            # candidate_cuboid->SetDynamicFlag(object_temp->GetDynamicFlag()) (Tracking.cc:1617)
             F.tracked.append(j)
 
     def _cfse3(self, F, orders):
@@ -614,6 +624,63 @@ class ObjectTracker:
             o.mp_valid[o.mp_valid & (o.outlier != 0)] = False
             o.track_ok = o.inliers > 10
 
+    # ---- MapObject::DynamicDetection + SetDynamicFlag (MapObject.cc:414-448) ----
+    @staticmethod
+    def _mo_dynamic_detection(mo, flag):
+        if not mo["dyn_changed"]:
+            h = mo["dyn_hist"]
+            h.append(bool(flag))
+            if len(h) >= 4:
+                if len(h) > 4:
+                    h.pop(0)
+                if all(v == bool(flag) for v in h) and mo["dynamic"] != bool(flag):
+                    mo["dyn_changed"] = True
+
+    @staticmethod
+    def _mo_set_dynamic(mo, flag):
+        if mo["dyn_first"]:
+            mo["dynamic"] = bool(flag); mo["dyn_first"] = False
+        if mo["dyn_changed"]:
+            mo["dynamic"] = bool(flag); mo["dyn_changed"] = False
+
+    # ---- Tracking::DynamicStaticDiscrimination (Tracking.cc:2058-2202) without its tail StaticPointRecoveryFromObj ----
+    def _dynamic_static_discrimination(self, F, tcw_cur, tcw_last):
+        ident = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0))
+        # mCurrentFrame.mSETcw / mLastFrame.mSETcw = Converter::toSE3Quat(mTcw) (Frame.cc:1669); a frame without a pose keeps the
+        # default-constructed SE3Quat (identity)
+        cur = se3_from_mat4f(tcw_cur) if tcw_cur is not None else ident
+        last = se3_from_mat4f(tcw_last) if tcw_last is not None else ident
+        jobs, who = [], []
+        for lj, j in F.in_last:
+            o, det, mo = F.obj[j], F.dets[j], F.obj[j].mo
+            depth = mo["tco"][0][2]
+            if depth < 7 or depth > float(self.th_depth):
+                o.dynamic = mo["dynamic"]
+                continue
+            bx, by, bw, bh = det["bbox"]
+            middle_x = float(self.w // 2)                       # double middle_x = mImGray.size[1] / 2  (int / int)
+            current_px = float(bx + int(bw / 2))                # cv::Rect members are int
+            if abs(current_px - middle_x) < int(bw / 2) + 60:   # image prior: a vehicle straight ahead moves
+                o.dynamic = True
+                self._mo_set_dynamic(mo, True)
+                continue
+            jobs.append({"valid": o.mp_valid.astype(np.uint8), "po": o.mp_po.astype(np.float64),
+                         "obs": np.stack([o.x, o.y, o.uright], 1).astype(np.float32) if o.n else np.zeros((0, 3), np.float32),
+                         "inv_sigma2": self.is2[o.octave], "last_tco": pose7(self.last.obj[lj].tco_at_frame), "last_tcw": pose7(last),
+                         "cur_tcw": pose7(cur), "K": (float(self.fx), float(self.fy), float(self.cx), float(self.cy)), "mbf": self.bf})
+            who.append(j)
+        res = self.be.dynamic_discrimination(jobs) if jobs else []
+        for (mono, stereo, n_mono, n_stereo), j in zip(res, who):
+            o, mo = F.obj[j], F.obj[j].mo
+            o.dyn_n = (int(n_mono), int(n_stereo))
+            if mono > 0 or stereo > 0:                          # DetectionObject::SetDynamicFlag(mono, stereo) (DetectionObject.cc:169-196)
+                o.dyn_mono, o.dyn_stereo = float(mono), float(stereo)
+                o.dynamic = bool(mono > 1 or stereo > 2)
+                self._mo_dynamic_detection(mo, o.dynamic)
+                self._mo_set_dynamic(mo, o.dynamic)
+            else:
+                o.dynamic = mo["dynamic"]
+
     # ---- the object part of Tracking::Track for one frame (camera poses of the last and the current frame: 4x4 float or None) ----
     def track(self, left, right, mask, detections, tcw_cur, tcw_last, camera_initialized):
         self.frame_id += 1
@@ -633,6 +700,7 @@ class ObjectTracker:
             self._track_last_frame(F)
         if F.tracked:
             self._track_local_map(F)
+        self._dynamic_static_discrimination(F, tcw_cur, tcw_last)      # Moving Objects Recognition (Tracking.cc:1244)
         # end of Track, SLOT mode 4 (Tracking.cc:1443-1478)
         for j, o in enumerate(F.obj):
             if o.mo is None or o.mo["first_frame"] == self.frame_id:
@@ -652,6 +720,8 @@ class ObjectTracker:
                                   "new": bool(getattr(o, "new", False)), "track_ok": bool(o.track_ok), "inliers": int(o.inliers),
                                   "bf_matches": int(getattr(o, "bf_matches", 0)), "lm_candidates": int(getattr(o, "lm_candidates", 0)),
                                   "lm_matches": int(getattr(o, "lm_matches", 0)), "map_points": int((o.mp_valid & o.mp_observed).sum()),
-                                  "tco": None if o.mo is None else pose7(o.mo["tco"])})
+                                  "tco": None if o.mo is None else pose7(o.mo["tco"]),
+                                  "dynamic": bool(o.dynamic), "mo_dynamic": None if o.mo is None else bool(o.mo["dynamic"]),
+                                  "dyn_mono": float(o.dyn_mono), "dyn_stereo": float(o.dyn_stereo), "dyn_n": tuple(o.dyn_n)})
         self.last = F
         self.stats.append(st)

@@ -82,6 +82,9 @@ class HipBackend:
     def cfse3(self, objs, K):
         return self.optimizer.CFSE3ObjStateOptimization([{"objs": objs, "K": K}])[0]
 
+    def dynamic_discrimination(self, objs):
+        return self.optimizer.DynamicStaticDiscrimination(objs)        # the reprojection test of Tracking::DynamicStaticDiscrimination
+
     def close(self):
         for o in (self.left, self.right, self.matcher_mm, self.matcher_lm, self.optimizer, self.cv_left, self.cv_right):
             if o is not None:

@@ -24,8 +24,10 @@ assert STAT_DTYPE.itemsize == 48
 # ps_detection / ps_object_stat (include/pointslot_hip.h)
 DETECTION_DTYPE = np.dtype([("id", "<i4"), ("bbox", "<i4", 4), ("reserved", "<i4", 3), ("scale", "<f8", 3), ("pose7", "<f8", 7)])
 OBJECT_STAT_DTYPE = np.dtype([("id", "<i4"), ("n", "<i4"), ("stereo", "<i4"), ("tracked", "<i4"), ("is_new", "<i4"), ("track_ok", "<i4"), ("inliers", "<i4"),
-                              ("bf_matches", "<i4"), ("lm_candidates", "<i4"), ("lm_matches", "<i4"), ("map_points", "<i4"), ("reinit", "<i4"), ("tco", "<f8", 7)])
-assert DETECTION_DTYPE.itemsize == 112 and OBJECT_STAT_DTYPE.itemsize == 104
+                              ("bf_matches", "<i4"), ("lm_candidates", "<i4"), ("lm_matches", "<i4"), ("map_points", "<i4"), ("reinit", "<i4"),
+                              ("dynamic", "<i4"), ("mo_dynamic", "<i4"), ("dyn_n_mono", "<i4"), ("dyn_n_stereo", "<i4"), ("tco", "<f8", 7),
+                              ("dyn_mono", "<f8"), ("dyn_stereo", "<f8")])
+assert DETECTION_DTYPE.itemsize == 112 and OBJECT_STAT_DTYPE.itemsize == 136
 
 
 def pack_detections(dets_per_sequence, max_objects):

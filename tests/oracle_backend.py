@@ -48,5 +48,8 @@ class OracleBackend:
     def cfse3(self, objs, K):
         return oracle_lib.cfse3_optimize(objs, K)
 
+    def dynamic_discrimination(self, objs):
+        return [oracle_lib.dynamic_discrimination(o) for o in objs]
+
     def close(self):
         pass

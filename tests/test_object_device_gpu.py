@@ -58,6 +58,17 @@ def _check_against(vo, tcw, st, obj, s, n, exact):
                     "inliers": o["inliers"], "bf_matches": o["bf_matches"], "lm_candidates": o["lm_candidates"], "lm_matches": o["lm_matches"],
                     "map_points": o["map_points"]}
             assert got == want, (k, j, got, want)
+            # Tracking::DynamicStaticDiscrimination: the flags, the points behind the two averages, the averages themselves (bit for bit
+            # against the per-call chain - same arithmetic, sums in sorted order -, to the optimiser's tolerance against the CPU checker,
+            # whose object poses differ in the last digits)
+            gdyn = (int(d["dynamic"]), int(d["mo_dynamic"]), int(d["dyn_n_mono"]), int(d["dyn_n_stereo"]))
+            wdyn = (int(o["dynamic"]), -1 if o["mo_dynamic"] is None else int(o["mo_dynamic"]), o["dyn_n"][0], o["dyn_n"][1])
+            assert gdyn == wdyn, (k, j, gdyn, wdyn)
+            for f in ("dyn_mono", "dyn_stereo"):
+                if exact:
+                    assert float(d[f]) == o[f], (k, j, f, float(d[f]), o[f])
+                else:
+                    assert abs(float(d[f]) - o[f]) <= 1e-5 * max(1.0, abs(o[f])), (k, j, f, float(d[f]), o[f])
             if o["tco"] is not None:
                 if exact:
                     assert np.array_equal(d["tco"], o["tco"]), (k, j, d["tco"], o["tco"])
@@ -94,6 +105,25 @@ def test_device_object_chain_equals_the_per_call_chain_and_the_cpu_checker():
             assert np.abs(obj[k, 0, b]["tco"][:3] - truth).max() < 0.35
             ok += 1
     assert ok >= n - 2 and int(obj["reinit"][:, 0].sum()) >= 1
+
+
+def test_dynamic_static_discrimination_in_the_device_chain():
+    """Ten frames of a drive whose first object leaves the image-centre prior after a few frames: the reprojection test of
+    Tracking::DynamicStaticDiscrimination runs inside the device chain (ob_finish) - flags, point counts and the two averages equal
+    the per-call chain's (ps_dynamic_discrimination_batch behind the host logic) bit for bit and the CPU checker's."""
+    n = 10
+    seqs = [sequence.generate_drive(n_frames=n, seed=40, texture=sequence.kitti_texture())]
+    tcw, st, obj = _run_device(seqs, n)
+    be = HipBackend()
+    vo = _run_host(be, seqs[0], n)
+    _check_against(vo, tcw, st, obj, 0, n, exact=True)
+    be.close()
+    vo = _run_host(OracleBackend(), seqs[0], n)
+    _check_against(vo, tcw, st, obj, 0, n, exact=False)
+    ran = (obj["dyn_n_mono"][:, 0] + obj["dyn_n_stereo"][:, 0]) > 0
+    assert int(ran.sum()) >= 3, "the reprojection test never ran"
+    # the generator's objects move: where the test ran it says so
+    assert (obj["dynamic"][:, 0][ran] == 1).all() and (obj["dyn_stereo"][:, 0][ran] > 2).all()
 
 
 def test_device_object_chain_on_an_odd_image_size():

@@ -140,3 +140,55 @@ def test_154_frames_against_the_cpu_restatement():
     assert first is None or first >= 20, first        # identical counts for the first frames at least
     print("154 frames: max |Tcw diff| %.3g, max frame-to-frame motion diff %.3g, %d tracked, %d frames with a differing match count (first: %s), final position error %.3f m" % (
         worst, worst_rel, int(st["tracked"].sum()), differ, first, float(np.abs(-(tcw[-1, 0, :3, :3].T @ tcw[-1, 0, :3, 3]) - seq["twc"][-1][:, 3]).max())))
+
+
+@pytest.mark.gpu
+def test_full_size_frames_of_the_headline_chain_against_the_cpu_restatement():
+    """The bench line's `parity_spot` as a test: 112 full-size frames - 8 generated 1242 x 375 drives x 14 frames with
+    instance masks and detections, the headline's scene, BASELINE config 5's image size - through the device-resident camera + object chain
+    (ps_tracker_step_slot_device, images / masks / detections resident in HBM) and through the CPU restatement of the same loop: every
+    frame's pose within 1e-4 (float32 poses of an FP64 LM chained over the frames), every object record equal (feature counts, MapObject,
+    match counts, inliers, the DynamicStaticDiscrimination flags and point counts)."""
+    import os
+    import sys
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle_backend import OracleBackend
+    from pointslot_amd.tracker import StereoOdometry
+    from pointslot_amd.tracker_device import LockstepTracker, pack_detections
+    S, n = 8, 14
+    seqs = bench.make_sequences(0, n, S, "kitti", "drive")
+    h, w = seqs[0]["left"][0].shape
+    assert (w, h) == (1242, 375)
+    imgs = torch.from_numpy(np.stack([np.stack([q["left"][:n], q["right"][:n]], 1) for q in seqs], 1)).cuda()        # [n, S, 2, h, w]
+    masks = torch.from_numpy(np.stack([q["masks"][:n] for q in seqs], 1)).cuda()
+    dets = [torch.from_numpy(np.ascontiguousarray(pack_detections([q["dets"][i] for q in seqs], bench.MAX_OBJECTS)).view(np.uint8)).cuda() for i in range(n)]
+    trk = LockstepTracker(S, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n, max_objects=bench.MAX_OBJECTS)
+    for i in range(n):
+        trk.step_slot_device(imgs[i].data_ptr(), masks[i].data_ptr(), dets[i].data_ptr())
+    tcw, st = trk.fetch()
+    obj = trk.fetch_objects()
+    trk.close()
+    assert int((st["overflowed"] != 0).sum()) == 0
+    worst, records, dsd = 0.0, 0, 0
+    for s, q in enumerate(seqs):
+        vo, _ = bench._cpu_chain(q, n, OracleBackend(), True)
+        for i in range(n):
+            a = vo.trajectory[i]
+            assert (a is not None) == bool(st["tracked"][i, s]), (s, i)
+            if a is not None:
+                worst = max(worst, float(np.abs(a - tcw[i, s]).max()))
+            for j, o in enumerate(vo.objects.stats[i]["objects"]):
+                d = obj[i, s, j]
+                got = (int(d["id"]), int(d["n"]), int(d["stereo"]), int(d["tracked"]), int(d["track_ok"]), int(d["bf_matches"]), int(d["lm_matches"]), int(d["inliers"]),
+                       int(d["dynamic"]), int(d["dyn_n_mono"]), int(d["dyn_n_stereo"]))
+                want = (o["id"], o["n"], o["stereo"], int(o["tracked"]), int(o["track_ok"]), o["bf_matches"], o["lm_matches"], o["inliers"],
+                        int(o["dynamic"]), o["dyn_n"][0], o["dyn_n"][1])
+                assert got == want, (s, i, j, got, want)
+                records += 1
+                dsd += 1 if o["dyn_n"][0] + o["dyn_n"][1] > 0 else 0
+    assert worst < 1e-4, worst
+    assert records >= S * (n - 1) and int(st["tracked"].sum()) == S * n
+    assert dsd > 0, "DynamicStaticDiscrimination's reprojection test never ran in 112 frames"
