@@ -379,10 +379,10 @@ int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out) {
   if (cfg->max_objects > 0) {
     // the object half: its own cv::ORB detector (Frame.cc:2625: cv::ORB::create(1000, 1.2, 8, 19)) and the arrays of objtrack_plan.h
     if (cfg->max_objects > OB_MAXK) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_INVALID, "max_objects: at most %d detections per frame", OB_MAXK); }
-    // ob_masks keeps 8 rows x 3 planes of the padded width in LDS (at most the 64 KB a kernel gets without asking for more)
-    if (8 * 3 * (size_t)((cfg->width + 255) & ~255) + 2 * (size_t)(cfg->width / 8 + 8) + 64 > 64 * 1024) {
+    // ob_masks keeps one row x 3 planes of the padded width in LDS (psk_ob_masks: 3 WP + 64 bytes; at most the 64 KB a kernel gets without asking for more)
+    if (3 * (size_t)((cfg->width + 255) & ~255) + 64 > 64 * 1024) {
       ps_tracker_destroy(t);
-      return ps_set_error(PS_ERR_CAPACITY, "ps_tracker_create: the object chain serves images up to 2560 pixels wide (%d asked)", cfg->width);
+      return ps_set_error(PS_ERR_CAPACITY, "ps_tracker_create: the object chain serves images up to 21760 pixels wide (%d asked)", cfg->width);
     }
     rc = ps_cvorb_create(1000, 1.2f, 8, 19, 20, cfg->device, &t->cvorb);
     if (rc == PS_OK) {
