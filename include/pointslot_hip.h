@@ -459,7 +459,10 @@ typedef struct ps_tracker_config {
   int32_t nfeatures; float scale_factor; int32_t nlevels, ini_th_fast, min_th_fast;   /* ORBextractor.*      */
   int32_t max_steps;                 /* frames per sequence the handle keeps results for                       */
   int32_t device;
-  int32_t max_objects;               /* detections per frame (SLOT.MODE 4 object chain; 0 = camera only, <= 8)  */
+  int32_t max_objects;               /* detections per frame (SLOT.MODE 4 object chain; 0 = camera only, <= 16) */
+  int32_t max_map_objects;           /* MapObjects a sequence can hold over its life (Tracking's AllObjects; the reference's list is
+                                        unbounded, the device table is not): 0 = 8, <= 64.  A detection that would need one more is
+                                        ignored and ps_tracker_fetch_objects reports PS_ERR_CAPACITY                            */
 } ps_tracker_config;
 /* what Tracking::Track leaves per frame and sequence */
 typedef struct ps_track_stat {

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(OB_T) void ob_begin(ObArrays A, int step) {
   if (tid == 0 && (A.cv_overflow[2 * s] | A.cv_overflow[2 * s + 1])) A.det_overflow[s]++;
   if (tid == 0 && init) {
     ObMapObject* T = A.mobj + (size_t)s * A.M;
-    uint32_t reserved = 0;
+    unsigned long long reserved = 0;
     for (int j = 0; j < ndet; j++) {
       const int id = F.det[(size_t)s * K + j].id;
       int slot = -1;
@@ -292,9 +292,9 @@ __global__ __launch_bounds__(OB_T) void ob_begin(ObArrays A, int step) {
       for (int m = 0; m < A.M; m++) if (T[m].id == id) { slot = m; break; }
       if (slot < 0) {
         int fr = -1;
-        for (int m = 0; m < A.M; m++) if (T[m].id < 0 && !((reserved >> m) & 1u)) { fr = m; break; }
+        for (int m = 0; m < A.M; m++) if (T[m].id < 0 && !((reserved >> m) & 1ull)) { fr = m; break; }
         if (fr < 0) { A.dropped[s]++; slot = -1; }
-        else { reserved |= 1u << fr; slot = -2 - fr; }     // reserved for MapObjectInit
+        else { reserved |= 1ull << fr; slot = -2 - fr; }     // reserved for MapObjectInit
       }
       F.mo[(size_t)s * K + j] = slot;
     }

@@ -8,8 +8,8 @@
 #include "match_plan.h"
 #include "opt_plan.h"
 
-#define OB_MAXK 8        // detections per frame and sequence
-#define OB_MAXM 8        // MapObjects per sequence (AllObjects)
+#define OB_MAXK 16       // detections per frame and sequence (PS_PO_MAX_K: one CFSE3 graph holds them all)
+#define OB_MAXM 64       // MapObjects per sequence (AllObjects): upper bound of ps_tracker_config.max_map_objects (default 8)
 #define OB_NCELL (PS_GRID_COLS * PS_GRID_ROWS)
 
 // = ps_detection of pointslot_hip.h

@@ -379,6 +379,7 @@ int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out) {
   if (cfg->max_objects > 0) {
     // the object half: its own cv::ORB detector (Frame.cc:2625: cv::ORB::create(1000, 1.2, 8, 19)) and the arrays of objtrack_plan.h
     if (cfg->max_objects > OB_MAXK) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_INVALID, "max_objects: at most %d detections per frame", OB_MAXK); }
+    if (cfg->max_map_objects < 0 || cfg->max_map_objects > OB_MAXM) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_INVALID, "max_map_objects: 0 (= 8) .. %d", OB_MAXM); }
     // ob_masks keeps one row x 3 planes of the padded width in LDS (psk_ob_masks: 3 WP + 64 bytes; at most the 64 KB a kernel gets without asking for more)
     if (3 * (size_t)((cfg->width + 255) & ~255) + 64 > 64 * 1024) {
       ps_tracker_destroy(t);
@@ -400,7 +401,7 @@ int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out) {
     if (rc != PS_OK) { ps_tracker_destroy(t); return rc; }
     ObArrays& O = t->OA;
     memset(&O, 0, sizeof(O));
-    O.S = A.S; O.K = cfg->max_objects; O.M = OB_MAXM; O.max_steps = cfg->max_steps;
+    O.S = A.S; O.K = cfg->max_objects; O.M = cfg->max_map_objects > 0 ? cfg->max_map_objects : 8; O.max_steps = cfg->max_steps;
     int32_t ccap = 0;
     ps_cvorb_batch_device_outputs(t->cvorb, nullptr, nullptr, nullptr, nullptr, &ccap);
     O.OC = ccap; O.LC = 1024;
@@ -501,7 +502,7 @@ int ps_tracker_fetch_objects(ps_tracker* t, int first_step, int nsteps, ps_objec
   for (size_t i = 0; i < sov.size(); i++)
     if (sov[i]) return ps_set_error(PS_ERR_CAPACITY, "sequence %zu: %d object search windows held more than %d candidates since the last reset", i, sov[i], PS_PJ_CAP);
   for (size_t i = 0; i < drop.size(); i++)
-    if (drop[i]) return ps_set_error(PS_ERR_CAPACITY, "sequence %zu: more than %d objects over the sequence (%d detections ignored)", i, OB_MAXM, drop[i]);
+    if (drop[i]) return ps_set_error(PS_ERR_CAPACITY, "sequence %zu: more than %d objects over the sequence (%d detections ignored; ps_tracker_config.max_map_objects)", i, t->OA.M, drop[i]);
   return PS_OK;
 }
 

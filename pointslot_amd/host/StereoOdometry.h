@@ -601,9 +601,9 @@ class StereoOdometryDevice {
  public:
   // maxObjects > 0 (at most 8): the handle also carries the object half of Tracking::Track in SLOT.MODE 4 (TrackAllSlotDevice)
   StereoOdometryDevice(int nSequences, float fx, float fy, float cx, float cy, float bf, int width, int height, int maxFrames, float thDepth = 35.f,
-                       int nFeatures = 2000, float scale = 1.2f, int nLevels = 8, int iniTh = 20, int minTh = 5, int device = 0, int maxObjects = 0)
+                       int nFeatures = 2000, float scale = 1.2f, int nLevels = 8, int iniTh = 20, int minTh = 5, int device = 0, int maxObjects = 0, int maxMapObjects = 0)
       : nseq(nSequences), nobj(maxObjects) {
-    ps_tracker_config cfg{nSequences, width, height, fx, fy, cx, cy, bf, thDepth, nFeatures, scale, nLevels, iniTh, minTh, maxFrames, device, maxObjects};
+    ps_tracker_config cfg{nSequences, width, height, fx, fy, cx, cy, bf, thDepth, nFeatures, scale, nLevels, iniTh, minTh, maxFrames, device, maxObjects, maxMapObjects};
     if (ps_tracker_create(&cfg, &trk) != PS_OK) throw std::runtime_error(std::string("ps_tracker_create: ") + ps_last_error());
   }
   ~StereoOdometryDevice() { ps_tracker_destroy(trk); }

@@ -15,7 +15,7 @@ class _Config(ctypes.Structure):
                 ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float), ("bf", ctypes.c_float),
                 ("th_depth", ctypes.c_float), ("nfeatures", ctypes.c_int32), ("scale_factor", ctypes.c_float), ("nlevels", ctypes.c_int32),
                 ("ini_th_fast", ctypes.c_int32), ("min_th_fast", ctypes.c_int32), ("max_steps", ctypes.c_int32), ("device", ctypes.c_int32),
-                ("max_objects", ctypes.c_int32)]
+                ("max_objects", ctypes.c_int32), ("max_map_objects", ctypes.c_int32)]
 
 
 STAT_DTYPE = np.dtype([("state", "<i4"), ("tracked", "<i4"), ("n", "<i4"), ("mm_matches", "<i4"), ("retried", "<i4"), ("matches", "<i4"),
@@ -60,10 +60,10 @@ lib.ps_tracker_orb.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
 
 class LockstepTracker:
     def __init__(self, n_sequences, K, bf, width, height, max_steps, th_depth=35.0, nfeatures=2000, scale=1.2, nlevels=8, ini_th=20, min_th=5,
-                 device=0, max_objects=0):
+                 device=0, max_objects=0, max_map_objects=0):
         fx, fy, cx, cy = [float(v) for v in K]
         cfg = _Config(n_sequences, width, height, fx, fy, cx, cy, float(bf), float(th_depth), nfeatures, scale, nlevels, ini_th, min_th,
-                      max_steps, device, max_objects)
+                      max_steps, device, max_objects, max_map_objects)
         self._h = ctypes.c_void_p()
         check(lib.ps_tracker_create(ctypes.byref(cfg), ctypes.byref(self._h)))
         self.n_sequences, self.width, self.height, self.max_objects = n_sequences, width, height, max_objects

@@ -22,22 +22,24 @@ def _run_host(backend, seq, n):
     return vo
 
 
-def _run_device(seqs, n, max_objects=4):
+def _run_device(seqs, n, max_objects=4, max_map_objects=0):
     import torch
     from pointslot_amd.tracker_device import LockstepTracker, pack_detections
     h, w = seqs[0]["left"][0].shape
     S = len(seqs)
-    trk = LockstepTracker(S, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n, max_objects=max_objects)
+    trk = LockstepTracker(S, seqs[0]["K"], seqs[0]["bf"], w, h, max_steps=n, max_objects=max_objects, max_map_objects=max_map_objects)
     imgs = torch.from_numpy(np.stack([np.stack([q["left"][:n], q["right"][:n]], 1) for q in seqs], 1)).cuda()      # [n, S, 2, h, w]
     masks = torch.from_numpy(np.stack([np.stack([sequence.frame_mask(q, k) for q in seqs]) for k in range(n)])).cuda()   # [n, S, h, w]
     keep = []
-    for k in range(n):
-        d = torch.from_numpy(pack_detections([sequence.frame_detections(q, k) for q in seqs], max_objects).view(np.uint8)).cuda()
-        keep.append(d)
-        trk.step_slot_device(imgs[k].data_ptr(), masks[k].data_ptr(), d.data_ptr())
-    tcw, st = trk.fetch()
-    obj = trk.fetch_objects()
-    trk.close()
+    try:
+        for k in range(n):
+            d = torch.from_numpy(pack_detections([sequence.frame_detections(q, k) for q in seqs], max_objects).view(np.uint8)).cuda()
+            keep.append(d)
+            trk.step_slot_device(imgs[k].data_ptr(), masks[k].data_ptr(), d.data_ptr())
+        tcw, st = trk.fetch()
+        obj = trk.fetch_objects()
+    finally:
+        trk.close()
     return tcw, st, obj
 
 
@@ -124,6 +126,23 @@ def test_dynamic_static_discrimination_in_the_device_chain():
     assert int(ran.sum()) >= 3, "the reprojection test never ran"
     # the generator's objects move: where the test ran it says so
     assert (obj["dynamic"][:, 0][ran] == 1).all() and (obj["dyn_stereo"][:, 0][ran] > 2).all()
+
+
+def test_twelve_detections_per_frame_and_the_map_object_table():
+    """KITTI tracking frames carry up to ~15 detections (the chain served 8): a drive with 12 objects through a tracker created
+    for 16 detections per frame and 16 MapObjects per sequence equals the per-call chain bit for bit; the same drive through a tracker whose
+    MapObject table holds 4 ignores the detections that would need a fifth slot and says so (PS_ERR_CAPACITY from ps_tracker_fetch_objects)."""
+    n = 5
+    seqs = [sequence.generate_drive(n_frames=n, seed=71, n_objects=12, texture=sequence.kitti_texture())]
+    assert max(len(sequence.frame_detections(seqs[0], k)) for k in range(n)) > 8
+    tcw, st, obj = _run_device(seqs, n, max_objects=16, max_map_objects=16)
+    be = HipBackend()
+    vo = _run_host(be, seqs[0], n)
+    _check_against(vo, tcw, st, obj, 0, n, exact=True)
+    be.close()
+    assert int((obj["id"][n - 1, 0] >= 0).sum()) > 8 and int((obj["tracked"][n - 1, 0] != 0).sum()) >= 7
+    with pytest.raises(RuntimeError, match="max_map_objects"):
+        _run_device(seqs, n, max_objects=16, max_map_objects=4)
 
 
 def test_device_object_chain_on_an_odd_image_size():
