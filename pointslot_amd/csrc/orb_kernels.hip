@@ -315,19 +315,40 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
       } else {
         const uint32_t bz = (uint32_t)ty[r].z << 16, bw = (uint32_t)ty[r].w << 16;
         pk = 0;
+        uint32_t skv[4], h0[4], h1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) skv[k] = fast ? sel[k] : ((uint32_t)k | (0x0cu << 8) | ((uint32_t)(4 + k) << 16) | (0x0cu << 24));
+        // The upper source row is the previous output row's lower one four times out of five: its interpolated values were carried
+        // over.  need0 is wave-uniform, and the empty asm statement keeps the compiler from turning the block into "compute anyway, then
+        // select" (r05: it did - three vector instructions and a v_cndmask per pixel on every row).  The four dot products of a row are
+        // issued together and consumed afterwards: v_dot2 needs wait states before its result can be read (the compiler filled them with s_nop).
+        if (need0[r]) {
+          asm volatile("");
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint32_t p0 = __builtin_amdgcn_perm(wh[r][0], wl[r][0], skv[k]);
+            h0[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, p0), __builtin_bit_cast(lv_us2, coef[k]), 0u, false);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) h0[k] >>= 4;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) h0[k] = hc[k];
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const uint32_t sk = fast ? sel[k] : ((uint32_t)k | (0x0cu << 8) | ((uint32_t)(4 + k) << 16) | (0x0cu << 24));
-          uint32_t h0 = hc[k];
-          if (need0[r]) {
-            const uint32_t p0 = __builtin_amdgcn_perm(wh[r][0], wl[r][0], sk);
-            h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, p0), __builtin_bit_cast(lv_us2, coef[k]), 0u, false) >> 4;
-          }
-          const uint32_t p1 = __builtin_amdgcn_perm(wh[r][1], wl[r][1], sk);
-          const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, p1), __builtin_bit_cast(lv_us2, coef[k]), 0u, false) >> 4;
-          hc[k] = h1;
+          const uint32_t p1 = __builtin_amdgcn_perm(wh[r][1], wl[r][1], skv[k]);
+          h1[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, p1), __builtin_bit_cast(lv_us2, coef[k]), 0u, false);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          h1[k] >>= 4;
+          hc[k] = h1[k];
           // ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2, weights pre-shifted by 16 for mul_hi
-          const uint32_t o = (__umulhi(h0, bz) + __umulhi(h1, bw) + 2u) >> 2;
+          uint32_t o = (__umulhi(h0[k], bz) + __umulhi(h1[k], bw) + 2u) >> 2;
+          // (the value fits a byte; without the opaque copy the compiler rewrites (x >> 2) << 8k as ((x << (8k - 2)) + c) & mask and
+          // rematerialises the two literals into vector registers for every pixel: four instructions where add3 / shift / shift-or are three)
+          asm("" : "+v"(o));
           pk |= o << (8 * k);
         }
       }
