@@ -1067,8 +1067,11 @@ __device__ void ob_dsd(const ObArrays& A, const ObFrame& F, const ObFrame& L, in
     vals[(size_t)kd * n + r] = v;
   }
   __syncthreads();
-  if (tid == 0 || tid == 64) {
-    const int which = tid >> 6, num = which ? cs : cm;
+  if (tid < 128) {
+    // wave 0: the monocular list, wave 1: the stereo one.  The sum runs in sorted order as std::accumulate does; the values come 64 at a
+    // time into the lanes' registers and are added one by one out of them (v_readlane: a dependent global load per element would cost
+    // a cache round trip each - 90 us for 300 points).  A sorted list keeps a PREFIX (what is above 5 x median sits at the end).
+    const int which = tid >> 6, lane = tid & 63, num = which ? cs : cm;
     const double* v = vals + (size_t)(which + 1) * n;
     double avg = 0;
     int kept = num;
@@ -1076,11 +1079,18 @@ __device__ void ob_dsd(const ObArrays& A, const ObFrame& F, const ObFrame& L, in
       const double cut = 5 * v[num / 2];                       // int(size / 2 + 0.5) with integer size / 2
       kept = 0;
       double sum = 0.0;
-      for (int i = 0; i < num; i++)
-        if (!(v[i] > cut)) { sum += v[i]; kept++; }
+      for (int base = 0; base < num; base += 64) {
+        const bool in = base + lane < num;
+        const double x = in ? v[base + lane] : 0.0;
+        const int c = __popcll(__ballot(in && !(x > cut)));
+        const int xlo = __double2loint(x), xhi = __double2hiint(x);
+        for (int i = 0; i < c; i++) sum += __hiloint2double(__builtin_amdgcn_readlane(xhi, i), __builtin_amdgcn_readlane(xlo, i));
+        kept += c;
+        if (c < 64) break;
+      }
       avg = sum / kept;
     }
-    s_avg[which] = avg; s_kept[which] = kept;
+    if (lane == 0) { s_avg[which] = avg; s_kept[which] = kept; }
   }
   __syncthreads();
   if (tid == 0) {
