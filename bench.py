@@ -125,7 +125,7 @@ def _seq_cache_path(job):
     return os.path.join(root, hsh.hexdigest()[:24] + ".pkl")
 
 
-def _make_one(job):
+def _load_cached(job):
     import pickle
     path = _seq_cache_path(job)
     if path and os.path.exists(path):
@@ -134,6 +134,15 @@ def _make_one(job):
                 return pickle.load(f)
         except Exception:   # noqa: BLE001  (a torn or stale file: render again)
             pass
+    return None
+
+
+def _make_one(job):
+    import pickle
+    path = _seq_cache_path(job)
+    q = _load_cached(job)
+    if q is not None:
+        return q
     q = _render_one(job)
     if path:
         try:
@@ -168,13 +177,20 @@ def make_sequences(rank, n_frames, n_distinct, texture, scene="drive", n_objects
     jobs = [(scene, n_frames, 40 + 64 * rank + k, k, texture, n_objects) for k in range(n_distinct)]
     if n_distinct <= 2:
         return [_make_one(j) for j in jobs]
+    # what an earlier run on this host left in the cache is read here, in this process: a run under rocprofv3 --pmc (the profiler has the
+    # GPU open before python starts, so it may not start child processes) then needs no pool at all
+    have = [_load_cached(j) for j in jobs]
+    if all(q is not None for q in have):
+        return have
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     # sized from the CPUs this process is GRANTED (affinity cut by the cgroup quota: the GPU boxes show 256 logical CPUs and grant 16),
     # shared between the ranks of the node
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    with ProcessPoolExecutor(max_workers=min(n_distinct, max(1, _cpu_quota() // max(world, 1)), 48), mp_context=mp.get_context("spawn")) as pool:
-        return list(pool.map(_make_one, jobs))
+    todo = [j for j, q in zip(jobs, have) if q is None]
+    with ProcessPoolExecutor(max_workers=min(len(todo), max(1, _cpu_quota() // max(world, 1)), 48), mp_context=mp.get_context("spawn")) as pool:
+        made = iter(list(pool.map(_make_one, todo)))
+    return [q if q is not None else next(made) for q in have]
 
 
 MAX_OBJECTS = 8     # detections per frame the tracker is created for (KITTI tracking frames carry up to ~15; the device chain serves 8)

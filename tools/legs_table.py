@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the passes of tools/prof_legs.sh into gpurun_out/<name>_<leg>_kernel_stats.csv (rocprofv3 --stats table of the leg) and
+"""Turns the passes of tools/reproduce_profiles.sh into gpurun_out/<name>_<leg>_kernel_stats.csv (rocprofv3 --stats table of the leg) and
 gpurun_out/<name>_legs_pmc.json (per leg and kernel: launches, mean duration, HBM read / write bytes per launch from the request
 size classes, VALU / SALU instructions per wave, matrix-core busy cycles per launch).  bench.py reads the committed copy
 (profiles/<round>_legs_pmc.json) into metric_ba.roofline.traffic and the a10 / a14 / a15 rooflines."""
@@ -69,6 +69,6 @@ for leg in legs:
         print("%-28s n=%5d mean %9.1f us  %5.1f%%  rd %9.1f KB wr %9.1f KB  valu/wave %s  mfma busy %s" % (
             k[:28], x["launches"], x["mean_us"], 100 * x["total_ms"] / tot, x.get("read_bytes_per_launch", 0) / 1e3,
             x.get("write_bytes_per_launch", 0) / 1e3, x.get("valu_per_wave"), x.get("mfma_busy_cycles_per_launch")))
-json.dump({"method": "tools/prof_legs.sh: rocprofv3 --kernel-trace (durations) and three separate --pmc passes (TCC_EA0_RDREQ size classes, "
+json.dump({"method": "tools/reproduce_profiles.sh: rocprofv3 --kernel-trace (durations) and three separate --pmc passes (TCC_EA0_RDREQ size classes, "
            "TCC_EA0_WRREQ(_64B), SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAVES / SQ_VALU_MFMA_BUSY_CYCLES) of the leg's tool script; every launch of "
            "the process, means per launch", "legs": out}, open("gpurun_out/%s_legs_pmc.json" % name, "w"), indent=1)

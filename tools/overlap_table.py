@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Developer tool: what the lockstep groups' overlap does to every kernel of the headline loop.
 
-Reads the two kernel traces tools/profile.sh leaves (gpurun_out/<name>/orb_kernel_trace.csv: the default run, several lockstep groups on
-their own streams; gpurun_out/<name>_1group/...: the same sequences in ONE group, the kernels alone) and prints, over the timed steps of
+Reads the two kernel traces tools/reproduce_profiles.sh leaves (<dir>/orb_kernel_trace.csv: the default run, several lockstep groups on
+their own streams; <dir>_1group/...: the same sequences in ONE group, the kernels alone) and prints, over the timed steps of
 each run: how much of the wall time 0 / 1 / 2 / 3 ... kernels were running at once, and per kernel its share of the wall time summed over
 the streams, its mean duration under the overlap and the mean duration of the single-group launch divided by the number of groups (what a
 launch of one group's size would take alone if the kernel scaled with its batch - latency-bound kernels do not, their ratio overstates).
-  python tools/overlap_table.py <name> <groups>  >  profiles/rNN_overlap_table.txt"""
+  python tools/overlap_table.py <dir> <groups> [steps warmup]  >  profiles/rNN_overlap_table.txt"""
 import collections
 import csv
 import sys
@@ -43,8 +43,9 @@ def load(path, steps=20, warmup=3):
 
 def main():
     name, groups = sys.argv[1], int(sys.argv[2])
-    a3, c3, w3, h3 = load("gpurun_out/%s/orb_kernel_trace.csv" % name)
-    a1, c1, w1, _ = load("gpurun_out/%s_1group/orb_kernel_trace.csv" % name)
+    steps, warmup = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (20, 3)
+    a3, c3, w3, h3 = load("%s/orb_kernel_trace.csv" % name, steps, warmup)
+    a1, c1, w1, _ = load("%s_1group/orb_kernel_trace.csv" % name, steps, warmup)
     tot = sum(h3.values())
     print("%d lockstep groups: share of the wall time with k kernels running: %s" % (groups, {k: round(v / tot, 3) for k, v in sorted(h3.items())}))
     print("kernel time summed over the streams / wall time: %.2f   (one group: %.2f)" % (sum(a3.values()) / w3, sum(a1.values()) / w1))

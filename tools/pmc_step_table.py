@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the three counter passes of tools/pmc_step.sh into gpurun_out/<name>_traffic.json and <name>_valu_issue.json (per kernel,
+"""Turns the three counter passes of tools/reproduce_profiles.sh into gpurun_out/<name>_traffic.json and <name>_valu_issue.json (per kernel,
 summed over the kernel's launches of one timed step and averaged over the timed steps)."""
 import collections
 import csv
@@ -71,7 +71,7 @@ for k, c in wr.items():
     out[k]["write_bytes_per_step"] = 64 * n64 + 32 * (n - n64)
 for k, e in out.items():
     e["hbm_bytes_per_step"] = e.get("read_bytes_per_step", 0.0) + e.get("write_bytes_per_step", 0.0)
-json.dump({"images_per_launch": IMAGES, "images_per_launch_note": "images per STEP (all lockstep groups of the run); a launch of one of G groups handles 1 / G of it", "method": "tools/pmc_step.sh: TCC_EA0_RDREQ size classes (32 / 64 / 128 B) and TCC_EA0_WRREQ(_64B), separate passes, "
+json.dump({"images_per_launch": IMAGES, "images_per_launch_note": "images per STEP (all lockstep groups of the run); a launch of one of G groups handles 1 / G of it", "method": "tools/reproduce_profiles.sh: TCC_EA0_RDREQ size classes (32 / 64 / 128 B) and TCC_EA0_WRREQ(_64B), separate passes, "
            "bench.py --no-cpu --no-secondary --distinct 2; per kernel summed over its launches of one step, mean of %d timed steps" % steps,
            "kernels": out}, open("gpurun_out/%s_traffic.json" % name, "w"), indent=1)
 iss = collections.OrderedDict()
@@ -83,7 +83,7 @@ for k, c in sq.items():
     w = per_step(c.get("SQ_WAVES", []))[0] or 0.0
     iss[k] = {"launches_per_step": lps, "waves_per_step": w, "valu_per_wave": v / w if w else None, "salu_per_wave": s / w if w else None,
               "valu_issue_ms_per_step": v * 4 / SIMDS / CLOCK_HZ * 1e3}
-json.dump({"images_per_launch": IMAGES, "method": "tools/pmc_step.sh: SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAVES; valu_issue_ms = instructions x 4 cycles / 1024 SIMDs / 2.4 GHz "
+json.dump({"images_per_launch": IMAGES, "method": "tools/reproduce_profiles.sh: SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAVES; valu_issue_ms = instructions x 4 cycles / 1024 SIMDs / 2.4 GHz "
            "(the time the launch would take if VALU issue were the only limit)", "kernels": iss}, open("gpurun_out/%s_valu_issue.json" % name, "w"), indent=1)
 for k, e in out.items():
     i = iss.get(k, {})
