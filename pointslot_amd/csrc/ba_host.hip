@@ -13,7 +13,7 @@
 #include "ps_common.h"
 
 
-extern "C" void psk_ba_global_step(const BaArrays*, int, int, int, int, int, int, int, hipStream_t);
+extern "C" void psk_ba_global_step(const BaArrays*, int, int, int, int, int, int, int, int, hipStream_t);
 
 struct ps_optimizer;   // defined in opt_host.hip; BA keeps its own arena inside this small side struct
 struct BaCtx {
@@ -60,7 +60,12 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   BaCtx* ctx = psi_optimizer_ba_ctx(m);
   size_t NP = 0, NL = 0, NE = 0, NW = 0, NS = 0, NPART = 0;
   int max_np = 0, max_nl = 0, max_ne = 0, max_free = 0;
-  for (int p = 0; p < nprob; p++) {
+  // Speculative twins (ba_kernels.hip, ba_decide): every problem is in the batch twice - the twin runs the damping trial g2o would run
+  // next if the current one is rejected, so that "first trial rejected, second accepted" costs one round of kernels.  PS_BA_TWINS=0: off.
+  static const bool twins_on = !(getenv("PS_BA_TWINS") && getenv("PS_BA_TWINS")[0] == '0');
+  const int twins = twins_on ? 1 : 0;
+  const int user_nprob = nprob;
+  for (int p = 0; p < user_nprob; p++) {
     const ps_ba_problem& P = probs[p];
     if (P.np < 1 || P.nl < 0 || P.ne < 0 || !P.poses7 || !P.pose_flags || (P.nl > 0 && !P.points) ||
         (P.ne > 0 && (!P.e_pose || !P.e_point || !P.e_obs || !P.e_inv_sigma2 || !P.erase)))
@@ -77,6 +82,8 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
     NW += (size_t)P.np * P.nl * 18;
     NS += (size_t)36 * P.np * P.np;
   }
+  if (twins) { NP *= 2; NL *= 2; NE *= 2; NW *= 2; NS *= 2; nprob *= 2; }
+  auto user = [&](int p) -> ps_ba_problem& { return probs[twins ? p / 2 : p]; };
   const int nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
   const int part_cap = max_np + (max_nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB + nbp + nbe + 8;
   NPART = (size_t)part_cap * nprob;
@@ -109,7 +116,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   int32_t* csr_edges = (int32_t*)(H + L.csr_edges);
   size_t pb = 0, lb = 0, eb = 0, cb = 0, ceb = 0, wb = 0, sb = 0;
   for (int p = 0; p < nprob; p++) {
-    const ps_ba_problem& P = probs[p];
+    const ps_ba_problem& P = user(p);
     BaProb& d = hp[p];
     d.np = P.np; d.nl = P.nl; d.ne = P.ne;
     d.pose_base = (int32_t)pb; d.point_base = (int32_t)lb; d.edge_base = (int32_t)eb;
@@ -140,7 +147,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
       csr_edges[ceb + cur_p[P.e_pose[e]]++] = e;
       csr_edges[ceb + P.ne + cur_l[P.e_point[e]]++] = e;
     }
-    hs[p].stage = 0; hs[p].phase = BA_PH_BEGIN;
+    hs[p].stage = 0; hs[p].phase = BA_PH_BEGIN; hs[p].spec = twins ? (p & 1) : 0;
     pb += P.np; lb += P.nl; eb += P.ne; cb += P.np + P.nl + 2; ceb += 2 * (size_t)P.ne;
     wb += (size_t)P.np * P.nl * 18; sb += (size_t)36 * P.np * P.np;
   }
@@ -181,7 +188,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   // stream drain + PCIe round trip.
   const int steps_per_sync = 3;
   for (;;) {
-    for (int k = 0; k < steps_per_sync; k++) psk_ba_global_step(&A, nprob, max_np, max_nl, max_ne, max_tilepairs, max_free, steps + k == 0, st);
+    for (int k = 0; k < steps_per_sync; k++) psk_ba_global_step(&A, nprob, max_np, max_nl, max_ne, max_tilepairs, max_free, steps + k == 0, twins, st);
     PS_HIP(hipGetLastError());
     PS_HIP(hipMemcpyAsync(h_done, A.ndone, 4, hipMemcpyDeviceToHost, st));
     PS_HIP(hipStreamSynchronize(st));
@@ -197,7 +204,8 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   psi_optimizer_set_ms(m, ms);
   pb = lb = eb = 0;
   for (int p = 0; p < nprob; p++) {
-    ps_ba_problem& P = probs[p];
+    ps_ba_problem& P = user(p);
+    if (twins && (p & 1)) { pb += P.np; lb += P.nl; eb += P.ne; continue; }   // the results are the primaries'
     memcpy(P.poses7, H + L.poses + pb * 56, (size_t)P.np * 56);
     if (P.nl) memcpy(P.points, H + L.points + lb * 24, (size_t)P.nl * 24);
     int ner = 0;

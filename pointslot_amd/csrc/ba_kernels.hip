@@ -180,9 +180,9 @@ __device__ __forceinline__ bool inv3(const double M[9], double O[9]) {
 // stage 1: chi2 > 5.991|7.815 or depth <= 0 -> level 1, Huber off, 10 iterations (:959-986).
 // stage 2: the same test fills the erase list (:988-1012) and the problem is DONE.
 // -------------------------------------------------------------------------------------------------------
-__device__ void ba_stage_entry(const BaArrays& A) {
-  const BaProb P = A.prob[blockIdx.x];
-  BaState& S = A.state[blockIdx.x];
+__device__ void ba_stage_entry(const BaArrays& A, int prob) {
+  const BaProb P = A.prob[prob];
+  BaState& S = A.state[prob];
   const int tid = threadIdx.x;
   __shared__ int s_stage;
   for (;;) {
@@ -266,7 +266,7 @@ __device__ void ba_stage_entry(const BaArrays& A) {
 }
 
 // the first global step's stage entry; later ones run at the end of ba_decide, in the workgroup that made the stage change
-__global__ __launch_bounds__(256) void ba_begin(BaArrays A) { ba_stage_entry(A); }
+__global__ __launch_bounds__(256) void ba_begin(BaArrays A) { ba_stage_entry(A, blockIdx.x); }
 
 // -------------------------------------------------------------------------------------------------------
 // computeActiveErrors + buildSystem, pose-major: one wave per pose, lanes over the pose's edges.
@@ -446,12 +446,19 @@ __device__ __forceinline__ double ba_post_lin(const BaArrays& A, const BaProb& P
   return lambda;
 }
 
+// The damping a problem's trial runs with.  A speculative twin (BaState::spec, see ba_decide) runs the trial its primary would run NEXT if the
+// current one is rejected: g2o's retry is lambda *= ni (levenberg.cpp:139-141) on the same linearisation - this very product.
+__device__ __forceinline__ double ba_trial_lambda(const BaState& S, double lambda, double ni) { return S.spec ? lambda * ni : lambda; }
+
 // D^-1 per point; b_s per active pose (block_solver.hpp:367-439)
 __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
   const BaProb P = A.prob[blockIdx.y];
   BaState& S = A.state[blockIdx.y];
   if (S.phase != BA_PH_TRIAL && S.phase != BA_PH_LINEARIZE) return;
-  const double lambda = S.phase == BA_PH_LINEARIZE ? ba_post_lin(A, P, S, blockIdx.x == 0) : S.lambda;
+  const bool lin = S.phase == BA_PH_LINEARIZE;
+  const double lambda0 = lin ? ba_post_lin(A, P, S, blockIdx.x == 0) : S.lambda;
+  // (on the first iteration of a stage ba_post_lin's record sets ni = 2 - possibly after this workgroup has read the state)
+  const double lambda = ba_trial_lambda(S, lambda0, (lin && S.iter == 0) ? 2.0 : S.ni);
   const int nbl = (P.nl + 255) / 256;
   if ((int)blockIdx.x < nbl) {
     const int l = blockIdx.x * 256 + threadIdx.x;
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
     double h = 0;
     if (gr / 6 == gc / 6) {
       h = A.Hpp[(size_t)(P.pose_base + A.pact[P.pose_base + gr / 6]) * 36 + (gr % 6) * 6 + (gc % 6)];
-      if (gr == gc) h += St.lambda;
+      if (gr == gc) h += ba_trial_lambda(St, St.lambda, St.ni);
     }
     Sm[(size_t)gr * lda + gc] = h - v;
   }
@@ -1067,7 +1074,7 @@ __global__ __launch_bounds__(256) void ba_update(BaArrays A) {
   __shared__ double red[4];
   const int tid = threadIdx.x;
   const int nbl = (P.nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB;
-  const double lambda = S.lambda;
+  const double lambda = ba_trial_lambda(S, S.lambda, S.ni);
   double sc = 0;
   if ((int)blockIdx.x < nbl) {
     // 16 lanes per point: each takes every 16th free pose of c = b_l - sum_a W_a^T x_a, then the group adds up (the thread-per-
@@ -1160,50 +1167,73 @@ __global__ __launch_bounds__(256) void ba_error_k(BaArrays A, int err_part_off) 
 }
 
 // gain ratio, lambda schedule, accept / pop, iteration and stage control (levenberg.cpp:121-161)
-__global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
-  const BaProb P = A.prob[blockIdx.x];
-  BaState& S = A.state[blockIdx.x];
+// `twins`: the batch holds every problem twice, primary 2 b and speculative twin 2 b + 1, and this workgroup decides for the pair.
+// Both start a trial round from the same estimate and the same linearisation (each computes its own copy with the same code on the
+// same data); the primary runs the trial g2o would run now, the twin the one g2o would run next if this one is rejected
+// (lambda *= ni: the retry sequence is fixed before the first trial ends).  In BASELINE config 4 every second iteration is
+// "first trial rejected, second accepted" (profiles/r05_trial_histogram.txt): the pair finishes it in one round of kernels instead of
+// two, for the price of a batch twice as large (+17 % per round at 8 objects).  The decision below replays the two trials in
+// sequence order with g2o's bookkeeping (trial counts, lambda / ni, the stop rules), then makes the twins identical again: the
+// estimate the sequence ends with, the increments and - when a stage ends here - the cached chi2 of the LAST trial g2o ran.
+// A twin whose factorisation failed is ignored (its "whatever x holds" update would need the primary's x of this same round): the
+// primary runs that lambda itself in the next round.
+__global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off, int twins) {
+  const int pa = twins ? 2 * blockIdx.x : blockIdx.x, pb = pa + 1;
+  const BaProb P = A.prob[pa];
+  BaState& S = A.state[pa];
   if (S.phase != BA_PH_TRIAL && S.phase != BA_PH_LINEARIZE) return;
-  __shared__ int s_restore;
-  __shared__ double s_part[1024];
+  __shared__ int s_acc, s_last;
+  __shared__ double s_part[2][1024];
   const int tid = threadIdx.x;
   // the partial sums of the trial (scale: one per block of ba_update, chi2: one per block of ba_error_k) come in with one round trip for
   // all of them; thread 0 then adds them in the order it always did (it used to fetch them one dependent load after the other: 15 us)
   const int nbl = (P.nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB, nbp = (P.np + 255) / 256, nbe = (P.ne + 255) / 256;
   const int ns = nbl + nbp, staged = ns + nbe <= 1024;
+  const int part_b = twins ? A.prob[pb].part_base : 0;
   if (staged)
-    for (int b = tid; b < ns + nbe; b += 256) s_part[b] = b < ns ? A.part[P.part_base + P.np + b] : A.part[P.part_base + err_part_off + (b - ns)];
+    for (int b = tid; b < ns + nbe; b += 256) {
+      s_part[0][b] = b < ns ? A.part[P.part_base + P.np + b] : A.part[P.part_base + err_part_off + (b - ns)];
+      if (twins) s_part[1][b] = b < ns ? A.part[part_b + P.np + b] : A.part[part_b + err_part_off + (b - ns)];
+    }
   __syncthreads();
   if (tid == 0) {
-    double scale = 0, temp = 0;
-    if (staged) {
-      for (int b = 0; b < ns; b++) scale += s_part[b];
-      for (int b = 0; b < nbe; b++) temp += s_part[ns + b];
-    } else {
-      for (int b = 0; b < ns; b++) scale += A.part[P.part_base + P.np + b];
-      for (int b = 0; b < nbe; b++) temp += A.part[P.part_base + err_part_off + b];
-    }
-    if (!S.ok2) temp = DBL_MAX;
-    double rho = (S.current_chi - temp) / (scale + 1e-3);
-    int restore = 0;
-    if (rho > 0 && isfinite(temp)) {
-      double alpha = 1. - se3_cube(2 * rho - 1);
-      alpha = fmin(alpha, 2. / 3.);
-      S.lambda *= fmax(1. / 3., alpha);
-      S.ni = 2;
-      S.current_chi = temp;
-    } else {
-      S.lambda *= S.ni;
-      S.ni *= 2;
-      restore = 1;
+    int accepted = -1, last = 0;
+    double rho = 0;
+    for (int w = 0; w < (twins ? 2 : 1); w++) {
+      const BaState& T = A.state[pa + w];
+      if (w == 1 && !T.ok2) break;                       // the twin's trial is void: the primary repeats it
+      const int pbase = w ? part_b : P.part_base;
+      double scale = 0, temp = 0;
+      if (staged) {
+        for (int b = 0; b < ns; b++) scale += s_part[w][b];
+        for (int b = 0; b < nbe; b++) temp += s_part[w][ns + b];
+      } else {
+        for (int b = 0; b < ns; b++) scale += A.part[pbase + P.np + b];
+        for (int b = 0; b < nbe; b++) temp += A.part[pbase + err_part_off + b];
+      }
+      if (!T.ok2) temp = DBL_MAX;
+      rho = (S.current_chi - temp) / (scale + 1e-3);
+      last = w;
+      if (rho > 0 && isfinite(temp)) {
+        double alpha = 1. - se3_cube(2 * rho - 1);
+        alpha = fmin(alpha, 2. / 3.);
+        S.lambda *= fmax(1. / 3., alpha);
+        S.ni = 2;
+        S.current_chi = temp;
+        accepted = w;
+      } else {
+        S.lambda *= S.ni;
+        S.ni *= 2;
+      }
+      S.trial++;
+      S.trials_done++;
+      if (!(rho < 0 && S.trial < 10)) break;             // the iteration is over
     }
     S.rho = rho;
-    S.trial++;
-    S.trials_done++;
-    s_restore = restore;
+    s_acc = accepted; s_last = last;
     if (!(rho < 0 && S.trial < 10)) {   // the iteration is over
       if (S.ntrace < PS_BA_TRACE) {
-        double* tr = A.trace + ((size_t)blockIdx.x * PS_BA_TRACE + S.ntrace) * 3;
+        double* tr = A.trace + ((size_t)pa * PS_BA_TRACE + S.ntrace) * 3;
         tr[0] = S.current_chi; tr[1] = S.lambda; tr[2] = S.trial;
       }
       S.ntrace++;
@@ -1219,13 +1249,42 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
     } else S.phase = BA_PH_TRIAL;   // another damping trial on the same linearisation
   }
   __syncthreads();
-  if (s_restore) {   // _optimizer->pop()
-    for (int q = tid; q < P.np * 7; q += 256) A.poses[(size_t)P.pose_base * 7 + q] = A.poses_bak[(size_t)P.pose_base * 7 + q];
-    for (int q = tid; q < P.nl * 3; q += 256) A.points[(size_t)P.point_base * 3 + q] = A.points_bak[(size_t)P.point_base * 3 + q];
+  const int acc = s_acc, last = s_last;
+  if (!twins) {
+    if (acc < 0) {   // _optimizer->pop()
+      for (int q = tid; q < P.np * 7; q += 256) A.poses[(size_t)P.pose_base * 7 + q] = A.poses_bak[(size_t)P.pose_base * 7 + q];
+      for (int q = tid; q < P.nl * 3; q += 256) A.points[(size_t)P.point_base * 3 + q] = A.points_bak[(size_t)P.point_base * 3 + q];
+    }
+  } else {
+    const BaProb Q = A.prob[pb];
+    // the estimate the sequence ends with: the accepted trial's, or the one before the trials (pop) - into both twins
+    const double* ps = acc == 0 ? A.poses + (size_t)P.pose_base * 7 : (acc == 1 ? A.poses + (size_t)Q.pose_base * 7 : A.poses_bak + (size_t)P.pose_base * 7);
+    const double* xs = acc == 0 ? A.points + (size_t)P.point_base * 3 : (acc == 1 ? A.points + (size_t)Q.point_base * 3 : A.points_bak + (size_t)P.point_base * 3);
+    for (int q = tid; q < P.np * 7; q += 256) { const double v = ps[q]; A.poses[(size_t)P.pose_base * 7 + q] = v; A.poses[(size_t)Q.pose_base * 7 + q] = v; }
+    for (int q = tid; q < P.nl * 3; q += 256) { const double v = xs[q]; A.points[(size_t)P.point_base * 3 + q] = v; A.points[(size_t)Q.point_base * 3 + q] = v; }
+    // g2o's increment vectors persist between trials (a failed factorisation updates with what they hold): those of the last trial that ran
+    const BaProb& F = last ? Q : P;
+    const BaProb& G = last ? P : Q;
+    for (int q = tid; q < P.np * 6; q += 256) A.xp[(size_t)G.pose_base * 6 + q] = A.xp[(size_t)F.pose_base * 6 + q];
+    for (int q = tid; q < P.nl * 3; q += 256) A.xl[(size_t)G.point_base * 3 + q] = A.xl[(size_t)F.point_base * 3 + q];
+    // the edge errors g2o has cached are those of the last trial it ran; they are read when a stage ends (classification / erase list) -
+    // the next linearisation overwrites them otherwise
+    if (S.phase == BA_PH_BEGIN)
+      for (int e = tid; e < P.ne; e += 256) A.chi2c[G.edge_base + e] = A.chi2c[F.edge_base + e];
+    __syncthreads();
+    if (tid == 0) {   // the twin continues from the primary's state
+      BaState& T = A.state[pb];
+      const int ok2 = T.ok2;
+      T = S;
+      T.spec = 1; T.ok2 = ok2;
+    }
   }
   // a stage ended: its successor's entry (classification, active sets) right here instead of in a launch of its own per global step
   __syncthreads();
-  if (S.phase == BA_PH_BEGIN) ba_stage_entry(A);
+  if (S.phase == BA_PH_BEGIN) {
+    ba_stage_entry(A, pa);
+    if (twins) { __syncthreads(); ba_stage_entry(A, pb); }
+  }
 }
 
 }  // namespace
@@ -1233,7 +1292,7 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off) {
 // one "global step": every unfinished problem advances by one LM trial (plus linearisation / stage entry
 // when it is due).  max_* are maxima over the batch.
 extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int max_nl, int max_ne, int max_tilepairs,
-                                   int max_free, int first, hipStream_t st) {
+                                   int max_free, int first, int twins, hipStream_t st) {
   const int nbl = (max_nl + 255) / 256, nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
   const int nblu = (max_nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB;   // ba_update's point blocks
   const int err_off = max_np + nblu + nbp;   // layout of `part`: [np chi partials][update partials][error partials]
@@ -1267,7 +1326,7 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   }
   hipLaunchKernelGGL(ba_update, dim3(nblu + nbp, nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_error_k, dim3(nbe, nprob), dim3(256), 0, st, *A, err_off);
-  hipLaunchKernelGGL(ba_decide, dim3(nprob), dim3(256), 0, st, *A, err_off);
+  hipLaunchKernelGGL(ba_decide, dim3(twins ? nprob / 2 : nprob), dim3(256), 0, st, *A, err_off, twins);
 }
 // the stage-2 pass of ba_begin (erase list) needs one more launch once every problem left its last trial
 extern "C" void psk_ba_finalize(const BaArrays* A, int nprob, hipStream_t st) {

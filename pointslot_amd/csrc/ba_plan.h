@@ -33,7 +33,8 @@ struct BaState {
   int32_t ntrace;
   int32_t iters_done;   // LM iterations executed over both stages (for ms/iter reporting)
   int32_t trials_done;
-  int32_t pad;
+  int32_t spec;         // 1: the speculative twin of the problem in front of it (ba_decide): its damping trial runs with lambda * ni, the value
+                        // the primary's next trial would use if this one is rejected
   double lambda, ni, current_chi, ini_chi, rho;
 };
 
