@@ -28,6 +28,10 @@ namespace {
 #ifndef PO_T
 #define PO_T 256
 #endif
+#ifndef PO_JMAX
+#define PO_JMAX 9      // damping trials whose solves are done side by side once a first trial was rejected (g2o stops after 10 trials: 1 + 9)
+#endif
+static_assert(PO_T % 64 == 0, "only whole waves may leave the kernel early (see NT below)");
 
 struct PoShared {
   double red[PO_T / 64][28];
@@ -41,6 +45,9 @@ struct PoShared {
   double b[PS_PO_MAX_K][6];
   double x[PS_PO_MAX_K][6];
   double xnew[PS_PO_MAX_K][6];      // candidate step of the current solve (committed to x only when every block factorises)
+  double cpose[64][7];              // estimates of the damping trials solved ahead (index j k + o: trial j of the batch, vertex o) ...
+  double cx[64][6];                 // ... and the increment vector g2o would hold after each of them
+  unsigned cok;                     // bit j: every block of trial j factorised
   double prior_obs[PS_PO_MAX_K][3];
   double prior_err[PS_PO_MAX_K][3];
   uint8_t prior_robust[PS_PO_MAX_K];
@@ -403,6 +410,14 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
         }
         double rho = 0;
         int qmax = 0;
+        // Solves ahead.  After a rejected trial g2o restores the estimate and retries with lambda *= ni, ni *= 2 on the SAME H and b
+        // (levenberg.cpp:139-149), and rejections come in runs (BASELINE config 3: 221 of 1 281 iterations need 2 - 10 trials, 1 486 trials
+        // between them; the tracker's frames likewise - profiles/r05_trial_histogram.txt): the whole retry sequence is known when the
+        // first trial fails.  The solve is the serial part of a trial (one lane per 6 x 6 block, ~2 us, half of a trial on a frame with
+        // 700 edges), so from the second trial on the J trials that are left are solved side by side - lane j k + o of wave 0 takes block o
+        // of trial j - and every later trial of the run only takes its estimate out of LDS.  Each trial is still evaluated and decided
+        // on its own, in order: same values, same counts.
+        int sp_n = 0, sp_i = 0;       // trials solved by the last batch / the next one to use
         do {
           // ---- solve (H + lambda I) x = b per vertex block; x only changes when every block succeeds ----
           bool ok2 = true;
@@ -410,81 +425,107 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
           __syncthreads();
           for (int i = tid; i < k * 7; i += NT) (&s.backup[0][0])[i] = (&s.pose[0][0])[i];
           __syncthreads();
-          if (tid < 64) {   // wave 0: lane o solves vertex o (k <= 16 blocks side by side; PoseOptimization has one)
-            bool okv = true;
-            const int o = tid < k ? tid : 0;
-            {
-              // unpivoted LDL^T of the 6x6 block (LinearSolverDense uses Eigen::LDLT + isPositive()).  Every loop has
-              // compile-time bounds and there is no early exit, so A / D / y live in registers (a `break` or a data-dependent
-              // bound sends them to scratch memory, one L2 round trip per access); a failed pivot only clears ok2.
-              double A[6][6], D[6];
+          if (sp_i == sp_n) {
+            const int J = qmax == 0 ? 1 : min(min(10 - qmax, PO_JMAX), 64 / k);
+            if (tid < 64) {
+              const int j = tid / k, o = tid - j * k;
+              const bool act = j < J;
+              double lam = lambda, nn = ni;
+              for (int t = 0; t < j && t < J; t++) { lam *= nn; nn *= 2; }      // what the rejections before trial j will have made of lambda
+              bool okv = true;
+              double xv[6];
               {
-                int a = 0;
+                // unpivoted LDL^T of the 6x6 block (LinearSolverDense uses Eigen::LDLT + isPositive()).  Every loop has
+                // compile-time bounds and there is no early exit, so A / D / y live in registers (a `break` or a data-dependent
+                // bound sends them to scratch memory, one L2 round trip per access); a failed pivot only clears okv.
+                double A[6][6], D[6];
+                {
+                  int a = 0;
 #pragma unroll
-                for (int r = 0; r < 6; r++)
+                  for (int r = 0; r < 6; r++)
 #pragma unroll
-                  for (int c = r; c < 6; c++) { A[r][c] = s.H[o][a]; A[c][r] = s.H[o][a]; a++; }
-              }
+                    for (int c = r; c < 6; c++) { A[r][c] = s.H[o][a]; A[c][r] = s.H[o][a]; a++; }
+                }
 #pragma unroll
-              for (int j = 0; j < 6; j++) A[j][j] += lambda;
-              // (the 21 divisions by a pivot go through one reciprocal per pivot - hardware estimate + two Newton steps, full
-              // double precision - like the LDL^T of the BA solver: a division sequence is a dozen dependent instructions)
-              double rD[6];
+                for (int q = 0; q < 6; q++) A[q][q] += lam;
+                // (the 21 divisions by a pivot go through one reciprocal per pivot - hardware estimate + two Newton steps, full
+                // double precision - like the LDL^T of the BA solver: a division sequence is a dozen dependent instructions)
+                double rD[6];
 #pragma unroll
-              for (int j = 0; j < 6; j++) {
-                double d = A[j][j];
+                for (int q = 0; q < 6; q++) {
+                  double d = A[q][q];
 #pragma unroll
-                for (int q = 0; q < j; q++) d -= A[j][q] * A[j][q] * D[q];
-                if (!(d > 0)) okv = false;
-                D[j] = d;
-                double r = __builtin_amdgcn_rcp(d);
-                double e = __builtin_fma(-d, r, 1.0);
-                r = __builtin_fma(r, e, r);
-                e = __builtin_fma(-d, r, 1.0);
-                rD[j] = __builtin_fma(r, e, r);
+                  for (int u = 0; u < q; u++) d -= A[q][u] * A[q][u] * D[u];
+                  if (!(d > 0)) okv = false;
+                  D[q] = d;
+                  double r = __builtin_amdgcn_rcp(d);
+                  double e = __builtin_fma(-d, r, 1.0);
+                  r = __builtin_fma(r, e, r);
+                  e = __builtin_fma(-d, r, 1.0);
+                  rD[q] = __builtin_fma(r, e, r);
 #pragma unroll
-                for (int i = j + 1; i < 6; i++) {
-                  double v = A[i][j];
+                  for (int i = q + 1; i < 6; i++) {
+                    double v = A[i][q];
 #pragma unroll
-                  for (int q = 0; q < j; q++) v -= A[i][q] * A[j][q] * D[q];
-                  A[i][j] = v * rD[j];
+                    for (int u = 0; u < q; u++) v -= A[i][u] * A[q][u] * D[u];
+                    A[i][q] = v * rD[q];
+                  }
+                }
+                double y[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                  double v = s.b[o][i];
+#pragma unroll
+                  for (int u = 0; u < i; u++) v -= A[i][u] * y[u];
+                  y[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) y[i] *= rD[i];
+#pragma unroll
+                for (int i = 5; i >= 0; i--) {
+                  double v = y[i];
+#pragma unroll
+                  for (int u = i + 1; u < 6; u++) v -= A[u][i] * xv[u];
+                  xv[i] = v;
                 }
               }
-              double y[6];
-#pragma unroll
-              for (int i = 0; i < 6; i++) {
-                double v = s.b[o][i];
-#pragma unroll
-                for (int q = 0; q < i; q++) v -= A[i][q] * y[q];
-                y[i] = v;
+              // g2o's increment only changes when every block of a trial factorises, and a trial that fails updates with whatever the
+              // vector holds: trial j moves by the solution of the last trial <= j that factorised, or by the vector as it was
+              const unsigned long long bad = __ballot(act && !okv);
+              const unsigned long long vmask = (1ull << k) - 1;
+              int src = -1;
+              unsigned okmask = 0;
+              for (int t = 0; t < J; t++) {
+                const bool okt = ((bad >> (t * k)) & vmask) == 0;
+                if (okt) okmask |= 1u << t;
+                if (okt && t <= j) src = t;
               }
+              const int srcl = (src >= 0 && act) ? src * k + o : tid;
+              double xj[6];
 #pragma unroll
-              for (int i = 0; i < 6; i++) y[i] *= rD[i];
-              double xv[6];
-#pragma unroll
-              for (int i = 5; i >= 0; i--) {
-                double v = y[i];
-#pragma unroll
-                for (int q = i + 1; q < 6; q++) v -= A[q][i] * xv[q];
-                xv[i] = v;
+              for (int c = 0; c < 6; c++) {
+                const int lo = __shfl(__double2loint(xv[c]), srcl), hi = __shfl(__double2hiint(xv[c]), srcl);
+                xj[c] = src >= 0 ? __hiloint2double(hi, lo) : s.x[o][c];
               }
-              if (tid < k) {
+              if (act) {
+                // update: estimate <- exp(x) * estimate (VertexSE3Expmap::oplusImpl), with whatever x holds
+                const Se3 Tn = se3_mul(se3_exp(xj, false), load_pose(s.pose[o]));
+                store_pose(s.cpose[tid], Tn);
 #pragma unroll
-                for (int i = 0; i < 6; i++) s.xnew[o][i] = xv[i];
+                for (int c = 0; c < 6; c++) s.cx[tid][c] = xj[c];
               }
+              if (tid == 0) s.cok = okmask;
             }
-            const bool ok_all = !__any(tid < k && !okv);                 // x only changes when every block factorises
-            if (tid < k) {
-              if (ok_all)
-                for (int j = 0; j < 6; j++) s.x[o][j] = s.xnew[o][j];
-              // update: estimate <- exp(x) * estimate (VertexSE3Expmap::oplusImpl), with whatever x holds
-              const Se3 Tn = se3_mul(se3_exp(s.x[o], false), load_pose(s.pose[o]));
-              store_pose(s.pose[o], Tn);
-            }
-            if (tid == 0) s.icount = ok_all ? 1 : 0;
+            sp_n = J; sp_i = 0;
+            __syncthreads();
           }
+          // the trial in turn: its estimate and increment out of the batch
+          if (tid < k * 7) (&s.pose[0][0])[tid] = (&s.cpose[sp_i * k][0])[tid];
+          if (tid < k * 6) (&s.x[0][0])[tid] = (&s.cx[sp_i * k][0])[tid];
           __syncthreads();
-          ok2 = s.icount != 0;
+          ok2 = (s.cok >> sp_i) & 1u;
+          sp_i++;
+          POP_MARK(2);
           for (int o = 0; o < k; o++)
             for (int j = 0; j < 6; j++) scale += s.x[o][j] * (lambda * s.x[o][j] + s.b[o][j]);
           // ---- computeActiveErrors at the trial estimate ----

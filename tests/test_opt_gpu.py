@@ -60,7 +60,17 @@ def test_pose_optimization_batch(opt):
         assert np.array_equal(outl, oo), "frame %d: outlier masks differ at %d edges" % (i, (outl != oo).sum())
         assert _pose_err(tcw, to) <= POSE_TOL, (i, _pose_err(tcw, to))
         trg = opt.get_trace(i)
-        assert len(trg) == len(tro), (i, len(trg), len(tro))
+        if len(trg) != len(tro):
+            # A round ends when a trial leaves chi2 EXACTLY unchanged (rho == 0, levenberg.cpp:151) or after ten rejections.  In an
+            # iteration that has converged the difference of the two chi2 is rounding noise of sums the GPU adds in another order: one
+            # side can see 0 where the other sees 1e-13 and runs one more iteration that changes nothing.  Allowed only there: every
+            # iteration one side has more must leave chi2 where it was; the estimate is compared above either way.
+            longer, shorter = (trg, tro) if len(trg) > len(tro) else (tro, trg)
+            assert len(longer) - len(shorter) <= 2, (i, len(trg), len(tro))
+            for r in longer:
+                assert (np.abs(shorter[:, 0] - r[0]) <= 1e-10 * r[0]).any(), (i, r)      # no chi2 level the other run does not have
+            noise_only.append(i)
+            continue
         if len(tro):
             # The number of damping trials of an iteration is decided by the sign of rho = (chi2 - chi2_new) / scale.  In an
             # iteration that has already converged (its chi2 equals the previous one to ~1e-12) that difference is rounding noise
