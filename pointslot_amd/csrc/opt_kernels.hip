@@ -40,11 +40,8 @@ struct PoShared {
   double chiv[PS_PO_MAX_K];         // robust chi2 per vertex of the last linearisation
   double pose[PS_PO_MAX_K][7];      // current estimates
   double pose0[PS_PO_MAX_K][7];     // estimates at entry (PoseOptimization restarts every round from them)
-  double backup[PS_PO_MAX_K][7];
   double H[PS_PO_MAX_K][21];
   double b[PS_PO_MAX_K][6];
-  double x[PS_PO_MAX_K][6];
-  double xnew[PS_PO_MAX_K][6];      // candidate step of the current solve (committed to x only when every block factorises)
   double cpose[64][7];              // estimates of the damping trials solved ahead (index j k + o: trial j of the batch, vertex o) ...
   double cx[64][6];                 // ... and the increment vector g2o would hold after each of them
   unsigned cok;                     // bit j: every block of trial j factorised
@@ -241,7 +238,6 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
     for (int c = 0; c < 3; c++) s.prior_obs[tid][c] = poses[(size_t)(P.v_off + tid) * 7 + c];
     // g2o keeps the increment in a zero-initialised vector: when the very first factorisation of a problem fails the
     // update is exp(0) (and rho = -inf: the damping is raised and the trial repeated) - never leftover LDS contents
-    for (int c = 0; c < 6; c++) { s.x[tid][c] = 0.0; s.xnew[tid][c] = 0.0; }
   }
   int cnt = 0;
   for (int o = 0; o < k; o++) {
@@ -272,6 +268,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
   }
   bool robust = true;
   int nBadTotal = 0;
+  int last_c = -1;     // where in s.cx the increment vector of the last trial that ran lives (g2o's vector persists over trials, iterations and rounds); -1: still zero
 
   for (int it = 0; it < 4; it++) {
     if (P.mode == 0) {   // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)) every round (Optimizer.cc:394)
@@ -422,10 +419,8 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
           // ---- solve (H + lambda I) x = b per vertex block; x only changes when every block succeeds ----
           bool ok2 = true;
           double scale = 0;
-          __syncthreads();
-          for (int i = tid; i < k * 7; i += NT) (&s.backup[0][0])[i] = (&s.pose[0][0])[i];
-          __syncthreads();
           if (sp_i == sp_n) {
+            __syncthreads();      // everybody is done with the batch before (s.cpose / s.cx / s.out of the last trial)
             const int J = qmax == 0 ? 1 : min(min(10 - qmax, PO_JMAX), 64 / k);
             if (tid < 64) {
               const int j = tid / k, o = tid - j * k;
@@ -501,11 +496,13 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
                 if (okt && t <= j) src = t;
               }
               const int srcl = (src >= 0 && act) ? src * k + o : tid;
-              double xj[6];
+              double xj[6], xprev[6];
+#pragma unroll
+              for (int c = 0; c < 6; c++) xprev[c] = last_c >= 0 ? s.cx[last_c * k + o][c] : 0.0;     // (read before this batch overwrites s.cx: one wave, in order)
 #pragma unroll
               for (int c = 0; c < 6; c++) {
                 const int lo = __shfl(__double2loint(xv[c]), srcl), hi = __shfl(__double2hiint(xv[c]), srcl);
-                xj[c] = src >= 0 ? __hiloint2double(hi, lo) : s.x[o][c];
+                xj[c] = src >= 0 ? __hiloint2double(hi, lo) : xprev[c];
               }
               if (act) {
                 // update: estimate <- exp(x) * estimate (VertexSE3Expmap::oplusImpl), with whatever x holds
@@ -519,15 +516,15 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
             sp_n = J; sp_i = 0;
             __syncthreads();
           }
-          // the trial in turn: its estimate and increment out of the batch
-          if (tid < k * 7) (&s.pose[0][0])[tid] = (&s.cpose[sp_i * k][0])[tid];
-          if (tid < k * 6) (&s.x[0][0])[tid] = (&s.cx[sp_i * k][0])[tid];
-          __syncthreads();
+          // the trial in turn: its estimate and increment stay where the batch left them (s.pose keeps the estimate the trials start from:
+          // a rejected trial has nothing to restore)
+          const int ci = sp_i * k;
           ok2 = (s.cok >> sp_i) & 1u;
+          last_c = sp_i;
           sp_i++;
           POP_MARK(2);
           for (int o = 0; o < k; o++)
-            for (int j = 0; j < 6; j++) scale += s.x[o][j] * (lambda * s.x[o][j] + s.b[o][j]);
+            for (int j = 0; j < 6; j++) scale += s.cx[ci + o][j] * (lambda * s.cx[ci + o][j] + s.b[o][j]);
           // ---- computeActiveErrors at the trial estimate ----
           POP_MARK(2);
           double c1[1] = {0};
@@ -535,7 +532,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
             const int o = min(o0 + g, k - 1);
             const bool have = o0 + g < k;
             const PoVertex V = have ? verts[P.v_off + o] : PoVertex{0, 0};
-            const Se3 T = load_pose(s.pose[o]);
+            const Se3 T = load_pose(s.cpose[ci + o]);
             // four edges per step, all loads issued before the first use: the pass is short (an error and a Huber weight per
             // edge), so the memory round trip would otherwise be paid once per edge
             for (int i0 = V.e_begin + tg; i0 < V.e_end; i0 += 4 * GT) {
@@ -581,12 +578,12 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
             lambda *= fmax(1. / 3., alpha);
             ni = 2;
             currentChi = tempChi;
+            __syncthreads();
+            if (tid < k * 7) (&s.pose[0][0])[tid] = (&s.cpose[ci][0])[tid];       // the accepted estimate
+            __syncthreads();
           } else {
             lambda *= ni;
             ni *= 2;
-            __syncthreads();
-            for (int i = tid; i < k * 7; i += NT) (&s.pose[0][0])[i] = (&s.backup[0][0])[i];
-            __syncthreads();
           }
           qmax++;
         } while (rho < 0 && qmax < 10);
