@@ -337,14 +337,27 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
               J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - bf * invz_2;
             }
             const double wo = rho1 * w;
+            // J^T W J and J^T W e without the products whose factor is a structural zero of the projection Jacobian (the u and uR rows have
+            // no entry in column 4, the v row none in column 3): 18 of the 63 + 3 of the 18 products, and entry (3, 4) altogether.  A product
+            // with an exact zero adds nothing to a sum, so the values are the ones the dense expression gives.
             int a = 0;
 #pragma unroll
             for (int r = 0; r < 6; r++) {
 #pragma unroll
-              for (int c = r; c < 6; c++) { acc[a] += wo * (J[0][r] * J[0][c] + J[1][r] * J[1][c] + J[2][r] * J[2][c]); a++; }
+              for (int c = r; c < 6; c++) {
+                const bool u02 = r != 4 && c != 4, u1 = r != 3 && c != 3;      // compile-time after unrolling
+                if (u02 && u1) acc[a] += wo * (J[0][r] * J[0][c] + J[1][r] * J[1][c] + J[2][r] * J[2][c]);
+                else if (u02) acc[a] += wo * (J[0][r] * J[0][c] + J[2][r] * J[2][c]);
+                else if (u1) acc[a] += wo * (J[1][r] * J[1][c]);
+                a++;
+              }
             }
 #pragma unroll
-            for (int r = 0; r < 6; r++) acc[21 + r] -= wo * (J[0][r] * e[0] + J[1][r] * e[1] + J[2][r] * e[2]);
+            for (int r = 0; r < 6; r++) {
+              if (r == 3) acc[21 + r] -= wo * (J[0][r] * e[0] + J[2][r] * e[2]);
+              else if (r == 4) acc[21 + r] -= wo * (J[1][r] * e[1]);
+              else acc[21 + r] -= wo * (J[0][r] * e[0] + J[1][r] * e[1] + J[2][r] * e[2]);
+            }
           }
           if (P.mode == 1 && tg == 0 && have) {
             // EdgeTransConstraintFromDetction: error = obs - t, information 50 I, Huber(sqrt 5.991) that is never
