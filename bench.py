@@ -39,7 +39,7 @@ ALGO_BYTES_PER_FRAME_POSE_ITER = 2000 * 29 + 224      # pose-opt, 
 ALGO_FLOP_PER_OBJECT_BA_ITER = 103e6                  # object BA, per LM iteration per object (P=50, L=300, E=15000)
 RED_DEV = "cuda"              # device of the tensors used for cross-rank reductions
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r04"   # the committed counter tables the line reads its traffic figures from
+PROFILE_ROUND = "r05"   # the committed counter tables the line reads its traffic figures from (tools/reproduce_profiles.sh)
 
 
 def _profile_json(name):
