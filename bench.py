@@ -1049,7 +1049,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sequences", type=int, default=768, help="independent stereo sequences tracked in lockstep per GPU")
+    ap.add_argument("--sequences", type=int, default=1536, help="independent stereo sequences tracked in lockstep per GPU (r05: 768 -> 1536 = three groups of 512: 40.1 -> 41.2 k frames/s on one box; 2304 / 3072: 41.6 / 41.4 k, profiles/r05_group_sweep.txt)")
     ap.add_argument("--groups", type=int, default=3, help="lockstep groups per GPU (one tracker handle and stream each: a group's latency-bound kernels run under the others' issue-bound ones; measured 1 / 2 / 3 / 4 / 6 groups of 256: 30.5 / 37.7 / 40.5 / 37.6 / 40.2 k frames/s, profiles/r04_group_sweep.txt)")
     ap.add_argument("--texture", choices=["kitti", "synthetic"], default="kitti", help="texture of the generated sequences of the headline run")
     ap.add_argument("--scene", choices=["drive", "lateral"], default="drive", help="generator of the headline sequences: forward drive with yaw / lateral translation")

@@ -35,7 +35,7 @@ cp bench_full.json $OUT/${ROUND}_bench_full.json
   for i in 1 2 3 4 5; do python3 bench.py $HEAD 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3))"; done
 } > $OUT/${ROUND}_headline_runs.txt
 { echo "# python3 bench.py --no-cpu --no-secondary --no-alone --sequences S --groups G: tracked frames/s, ms per step"
-  for C in "256 1" "512 1" "768 1" "512 2" "768 3" "1024 4" "1536 3"; do set -- $C
+  for C in "256 1" "512 1" "768 1" "512 2" "768 3" "1024 4" "1536 3" "1536 2" "2304 3" "3072 3"; do set -- $C
     python3 bench.py --no-cpu --no-secondary --no-alone --sequences $1 --groups $2 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('sequences=$1 groups=$2', round(d['value']), 'ms/step', round(d['ms_per_step'],2))"
   done
 } > $OUT/${ROUND}_group_sweep.txt
