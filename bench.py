@@ -283,6 +283,11 @@ def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barr
                 ob["track_ok"] += int((o["track_ok"][2:] != 0).sum()); ob["reinit"] += int(o["reinit"].sum())
                 ran = (o["dyn_n_mono"] + o["dyn_n_stereo"]) > 0          # DynamicStaticDiscrimination's reprojection test ran (depth / centre gates passed)
                 ob["dsd_tested"] += int(ran.sum()); ob["dsd_dynamic"] += int((ran & (o["dynamic"] != 0)).sum())
+                if scene == "drive":
+                    # the generator's even-numbered objects drive ahead, the odd ones stand at the roadside (sequence.generate_drive): where the test
+                    # ran, its verdict against that
+                    moving = (o["id"] % 2 == 0)
+                    ob["dsd_agrees_with_generator"] = ob.get("dsd_agrees_with_generator", 0) + int((ran & ((o["dynamic"] != 0) == moving)).sum())
                 for j in range(min(per_group, n_distinct)):                  # the distinct sequences once: cuboid centres against the labels
                     q = seqs[(g * per_group + j) % n_distinct]
                     for i in range(2, n_frames):

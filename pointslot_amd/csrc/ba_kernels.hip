@@ -119,6 +119,11 @@ __device__ __forceinline__ void huber(double e, double delta, double& rho0, doub
 #define DELTA_STEREO ((double)(float)2.7955321496988727)  /* (float)sqrt(7.815) */
 
 // EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ::computeError (types_six_dof_expmap.h:87-139, .cpp:141-158)
+// chi2 of an edge from its error: ONE statement with the operation order spelled out, used by both halves of the linearisation and by the
+// trial's error pass - the pose-major and the point-major half must give an edge the same Huber weight whatever the compiler contracts around them
+__device__ __forceinline__ double ba_edge_chi2(const double er[3], double w) {
+  return __builtin_fma(er[2], er[2], __builtin_fma(er[1], er[1], er[0] * er[0])) * w;
+}
 __device__ __forceinline__ void ba_error(const Se3& T, const BaProb& P, const double X[3], const float* ob, bool mono,
                                          double p[3], double e[3]) {
   se3_map(T, X, p);
@@ -301,7 +306,7 @@ __device__ __forceinline__ void ba_lin_pose(const BaArrays& A, int bx) {
     double p[3], er[3];
     ba_error(T, P, X, A.e_obs + (size_t)ge * 3, mono, p, er);
     const double w = (double)A.e_is2[ge];
-    const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * w;
+    const double chi2 = ba_edge_chi2(er, w);
     A.chi2c[ge] = chi2;
     double rho0 = chi2, rho1 = 1.0;
     if (robust) huber(chi2, mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
@@ -384,7 +389,7 @@ __device__ __forceinline__ void ba_lin_point(const BaArrays& A, int bx) {
       const double w = (double)A.e_is2[ge];
       double rho0, rho1 = 1.0;
       // (the edge's chi2 evaluated here as ba_lin_pose evaluates it: the two halves run in one launch, the cache is not written yet)
-      if (robust) huber((er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * w, mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
+      if (robust) huber(ba_edge_chi2(er, w), mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
       const double wo = rho1 * w;
       acc[0] += wo * (Jx[0][0] * Jx[0][0] + Jx[1][0] * Jx[1][0] + Jx[2][0] * Jx[2][0]);
       acc[1] += wo * (Jx[0][0] * Jx[0][1] + Jx[1][0] * Jx[1][1] + Jx[2][0] * Jx[2][1]);
@@ -1153,7 +1158,7 @@ __global__ __launch_bounds__(256) void ba_error_k(BaArrays A, int err_part_off) 
       const Se3 T = load_pose(A.poses + (size_t)(P.pose_base + A.e_pose[ge]) * 7);
       double p[3], er[3];
       ba_error(T, P, A.points + (size_t)(P.point_base + A.e_point[ge]) * 3, A.e_obs + (size_t)ge * 3, mono, p, er);
-      const double chi2 = (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]) * (double)A.e_is2[ge];
+      const double chi2 = ba_edge_chi2(er, (double)A.e_is2[ge]);
       A.chi2c[ge] = chi2;
       double rho0 = chi2, rho1;
       if (S.robust) huber(chi2, mono ? DELTA_MONO : DELTA_STEREO, rho0, rho1);
