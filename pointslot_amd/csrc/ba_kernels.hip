@@ -746,6 +746,45 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
           d = dn; rd = rdn;
         }
       }
+    } else if (NB == 24) {
+      // r05: the 24 rows over TWO DPP rows - rows 0..15 on lanes 0..15, rows 16..23 on lanes 16..23.  The update of column k is one
+      // v_fmac_f64_dpp row_newbcast as in the 16-row form: for k < 16 the multiplier of row k must also be reachable from DPP row 1, so
+      // every step copies the lanes' (negated) multipliers 16 lanes up once (v_permlane16_swap: DPP row 1 <- DPP row 0); for k >= 16 the
+      // multiplier sits in DPP row 1 itself and only rows >= 16 need it.  The pivot still travels by v_readlane (one per step).
+      // tools/ubench/ldlt_diag24.hip: 4 300 against 7 600 cycles per block, same bits.  (v_permlane16_swap -> DPP read needs more than the
+      // two wait states of VALU -> DPP: with s_nop 1 the lanes of DPP row 1 read the OLD register - hence the s_nop 4.)
+      double d = shfl_d(a[0], 0), rd = recip_d(d);
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        if (j < jb) {
+          if (d == 0) bad = true;
+          myrd = lane == j ? rd : myrd;
+          mydiag = lane == j ? d : mydiag;
+          const double l = a[j] * rd, nl = -l;
+          double m = nl;
+          if (j < 15) {
+            const int lo = __double2loint(nl), hi = __double2hiint(nl);
+            const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            m = __hiloint2double(sh[0], sl[0]);
+            asm volatile("s_nop 4" : "+v"(m));
+          }
+          double dn = 1.0, rdn = 1.0;
+          if (j + 1 < NB) {
+            if (j + 1 < 16) fmac_row_bcast(a[j + 1], m, a[j], j + 1, true);
+            else fmac_row_bcast(a[j + 1], nl, a[j], j + 1 - 16, true);
+            dn = shfl_d(a[j + 1], j + 1);
+            rdn = recip_d(dn);
+          }
+#pragma unroll
+          for (int k = j + 2; k < NB; k++) {
+            if (k < 16) fmac_row_bcast(a[k], m, a[j], k, false);
+            else fmac_row_bcast(a[k], nl, a[j], k - 16, false);
+          }
+          a[j] = lane > j ? l : a[j];
+          d = dn; rd = rdn;
+        }
+      }
     } else {
     double d = shfl_d(a[0], 0), rd = recip_d(d);
 #pragma unroll
