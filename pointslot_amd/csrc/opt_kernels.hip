@@ -58,6 +58,22 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
   return __hiloint2double(hi, lo);
 }
 
+// One value-halving step of the reductions below between the lanes l and l ^ 32 (W = 32) or l ^ 16 (W = 16): the lower lane of a pair keeps a and
+// adds its partner's a, the upper lane keeps b and adds its partner's b.  v_permlane32_swap / v_permlane16_swap exchange the upper half (odd
+// rows) of one register with the lower half (even rows) of the other: after the swap a' = [a.lo, b.lo], b' = [a.hi, b.hi], and a' + b' is that sum
+// on every lane - two swaps and an add per double where select / select / shuffle / add were seven instructions.  Same operands, same order.
+template <int W>
+__device__ __forceinline__ double swap_add_d(double a, double b) {
+  int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  if (W == 32) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false), hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+  } else {
+    const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false), hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+  }
+}
+
 // sums acc[0..N) over the workgroup in a fixed order; the result lands in s.out[0..N) for every thread
 template <int N>
 __device__ void block_sum(double* acc, PoShared& s, int nthr) {
@@ -72,7 +88,11 @@ __device__ void block_sum(double* acc, PoShared& s, int nthr) {
 #pragma unroll
     for (int i = 0; i < 32; i++) v[i] = i < N ? acc[i] : 0.0;
 #pragma unroll
-    for (int step = 0; step < 5; step++) {
+    for (int i = 0; i < 16; i++) v[i] = swap_add_d<32>(v[i], v[i + 16]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = swap_add_d<16>(v[i], v[i + 8]);
+#pragma unroll
+    for (int step = 2; step < 5; step++) {
       const int d = 32 >> step, half = 16 >> step;
       const bool upper = (lane & d) != 0;
 #pragma unroll
@@ -119,7 +139,11 @@ __device__ void group_sum(double* acc, PoShared& s, int G, int g, int tg, int nt
 #pragma unroll
   for (int i = 0; i < 32; i++) v[i] = i < N ? acc[i] : 0.0;
 #pragma unroll
-  for (int step = 0; step < 5; step++) {
+  for (int i = 0; i < 16; i++) v[i] = swap_add_d<32>(v[i], v[i + 16]);
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = swap_add_d<16>(v[i], v[i + 8]);
+#pragma unroll
+  for (int step = 2; step < 5; step++) {
     const int d = 32 >> step, half = 16 >> step;
     const bool upper = (lane & d) != 0;
 #pragma unroll
