@@ -78,3 +78,17 @@ def test_emit_prints_the_line_last(tmp_path, capsys, monkeypatch):
     assert len(lines) == 1 and _strict(lines[0])["full"] == "bench_full.json"
     side = _strict(open(tmp_path / "bench_full.json").read())
     assert "secondary_metrics" in side and "rooflines" in side
+
+
+def test_rendered_sequences_are_cached_and_read_back(tmp_path, monkeypatch):
+    """bench.make_sequences: a rendered sequence is written once (atomically) under PS_SEQ_CACHE and the second request reads it in this process -
+    what lets a run under the counter tool (no child processes) and the other ranks skip the rendering."""
+    import numpy as np
+    monkeypatch.setenv("PS_SEQ_CACHE", str(tmp_path))
+    job = ("lateral", 2, 41, 0, "synthetic", 2)
+    assert bench._load_cached(job) is None
+    a = bench._make_one(job)
+    assert len(list(tmp_path.iterdir())) == 1 and not any(p.name.endswith(".tmp") for p in tmp_path.iterdir())
+    b = bench._load_cached(job)
+    assert b is not None and np.array_equal(a["left"], b["left"]) and np.array_equal(a["masks"], b["masks"])
+    assert bench._seq_cache_path(("lateral", 2, 42, 0, "synthetic", 2)) != bench._seq_cache_path(job)

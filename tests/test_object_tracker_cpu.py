@@ -158,3 +158,77 @@ def test_cpp_make_detection_equals_the_python_twin(tmp_path):
         d = detection_from_label(*r)
         want = [d["id"], *d["bbox"], *d["scale"], *d["pose7"]]
         assert [float(x) for x in line.split()] == [float(x) for x in want]
+
+
+def test_map_object_dynamic_flag_state_machine_against_a_literal_transcription():
+    """MapObject::DynamicDetection / SetDynamicFlag (src/MapObject.cc:414-448) as ObjectTracker keeps them (and ob_finish on the device, with the
+    same packed history) against a line-by-line transcription with a std::queue: random verdict sequences."""
+    import collections
+    import random
+    from pointslot_amd.object_tracker import ObjectTracker
+
+    class Literal:
+        def __init__(self, flag):
+            self.mbDynamicFlag, self.mbDynamicChanged, self.mbFirstObserved, self.q = flag, False, True, collections.deque()
+
+        def DynamicDetection(self, b):
+            if not self.mbDynamicChanged:
+                self.q.append(b)
+                if len(self.q) < 4:
+                    return
+                if len(self.q) > 4:
+                    self.q.popleft()
+                for v in list(self.q):
+                    if v != b:
+                        return
+                if self.mbDynamicFlag != b:
+                    self.mbDynamicChanged = True
+
+        def SetDynamicFlag(self, b):
+            if self.mbFirstObserved:
+                self.mbDynamicFlag = b
+                self.mbFirstObserved = False
+            if self.mbDynamicChanged:
+                self.mbDynamicFlag = b
+                self.mbDynamicChanged = False
+
+    def packed_detection(d, f):      # objtrack_kernels.hip: ob_mo_dynamic_detection / ob_mo_set_dynamic on ObMapObject::dyn
+        if d & 4:
+            return d
+        ln, h = (d >> 8) & 7, (d >> 4) & 15
+        if ln < 4:
+            h |= (1 if f else 0) << ln
+            ln += 1
+        else:
+            h = (h >> 1) | ((1 if f else 0) << 3)
+        d = (d & ~0x7F0) | (h << 4) | (ln << 8)
+        if ln < 4:
+            return d
+        if h == (15 if f else 0) and (d & 1) != (1 if f else 0):
+            d |= 4
+        return d
+
+    def packed_set(d, f):
+        if d & 2:
+            d = (d & ~3) | (1 if f else 0)
+        if d & 4:
+            d = (d & ~5) | (1 if f else 0)
+        return d
+
+    rnd = random.Random(5)
+    for trial in range(200):
+        lit = Literal(True)
+        mo = {"dynamic": True, "dyn_changed": False, "dyn_first": True, "dyn_hist": []}
+        packed = 3
+        for step in range(rnd.randint(1, 30)):
+            kind = rnd.random()
+            b = rnd.random() < (0.8 if trial % 2 else 0.3)
+            if kind < 0.15:                       # the image-centre prior: SetDynamicFlag(true) without a verdict
+                lit.SetDynamicFlag(True); ObjectTracker._mo_set_dynamic(mo, True); packed = packed_set(packed, True)
+            else:
+                lit.DynamicDetection(b); lit.SetDynamicFlag(b)
+                ObjectTracker._mo_dynamic_detection(mo, b); ObjectTracker._mo_set_dynamic(mo, b)
+                packed = packed_set(packed_detection(packed, b), b)
+            assert (mo["dynamic"], mo["dyn_changed"], mo["dyn_first"]) == (lit.mbDynamicFlag, lit.mbDynamicChanged, lit.mbFirstObserved), (trial, step)
+            assert (bool(packed & 1), bool(packed & 4), bool(packed & 2)) == (lit.mbDynamicFlag, lit.mbDynamicChanged, lit.mbFirstObserved), (trial, step)
+            assert [bool((packed >> (4 + i)) & 1) for i in range((packed >> 8) & 7)] == list(lit.q), (trial, step)
