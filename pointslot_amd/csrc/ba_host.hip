@@ -126,6 +126,8 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
     d.csr_pose_edges_base = (int32_t)ceb; d.csr_point_edges_base = (int32_t)(ceb + P.ne);
     d.W_base = (int64_t)wb; d.S_base = (int64_t)sb;
     d.part_base = p * part_cap; d.part_cap = part_cap;
+    if (twins && (p & 1)) { const BaProb& q = hp[p - 1]; d.lin_pose_base = q.pose_base; d.lin_point_base = q.point_base; d.lin_part_base = q.part_base; d.lin_W_base = q.W_base; }
+    else { d.lin_pose_base = d.pose_base; d.lin_point_base = d.point_base; d.lin_part_base = d.part_base; d.lin_W_base = d.W_base; }
     d.fx = P.fx; d.fy = P.fy; d.cx = P.cx; d.cy = P.cy; d.bf = P.bf;
     memcpy(H + L.poses + pb * 56, P.poses7, (size_t)P.np * 56);
     memcpy(H + L.flags + pb, P.pose_flags, P.np);

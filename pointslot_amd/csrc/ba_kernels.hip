@@ -414,6 +414,7 @@ __device__ __forceinline__ void ba_lin_point(const BaArrays& A, int bx) {
 
 // both halves of buildSystem in one launch: blocks [0, nbpose) linearise pose-major, the others point-major
 __global__ __launch_bounds__(256) void ba_linearize(BaArrays A, int nbpose) {
+  if (A.state[blockIdx.y].spec) return;      // a speculative twin reads its primary's linearisation (BaProb::lin_*)
   if ((int)blockIdx.x < nbpose) ba_lin_pose(A, blockIdx.x);
   else ba_lin_point(A, blockIdx.x - nbpose);
 }
@@ -427,12 +428,12 @@ __device__ __forceinline__ double ba_post_lin(const BaArrays& A, const BaProb& P
   double m = 0;
   if (S.iter == 0) {
     for (int a = tid; a < S.npa; a += 256) {
-      const double* H = A.Hpp + (size_t)(P.pose_base + A.pact[P.pose_base + a]) * 36;
+      const double* H = A.Hpp + (size_t)(P.lin_pose_base + A.pact[P.pose_base + a]) * 36;
       for (int j = 0; j < 6; j++) m = fmax(m, fabs(H[j * 7]));
     }
     for (int l = tid; l < P.nl; l += 256)
       if (A.lact[P.point_base + l]) {
-        const double* H = A.Hll + (size_t)(P.point_base + l) * 9;
+        const double* H = A.Hll + (size_t)(P.lin_point_base + l) * 9;
         m = fmax(m, fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8]))));
       }
   }
@@ -442,7 +443,7 @@ __device__ __forceinline__ double ba_post_lin(const BaArrays& A, const BaProb& P
   const double lambda = S.iter == 0 ? 1e-5 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) : S.lambda;
   if (record && tid == 0) {
     double chi = 0;
-    for (int i = 0; i < P.np; i++) chi += A.part[P.part_base + i];   // fixed order
+    for (int i = 0; i < P.np; i++) chi += A.part[P.lin_part_base + i];   // fixed order
     S.current_chi = chi;
     S.ini_chi = chi;
     if (S.iter == 0) { S.lambda = lambda; S.ni = 2; S.n_bad = 0; }
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= P.nl || !A.lact[P.point_base + l]) return;
     double D[9], Di[9];
-    const double* H = A.Hll + (size_t)(P.point_base + l) * 9;
+    const double* H = A.Hll + (size_t)(P.lin_point_base + l) * 9;
 #pragma unroll
     for (int q = 0; q < 9; q++) D[q] = H[q] + ((q % 4 == 0) ? lambda : 0.0);
     inv3(D, Di);
@@ -491,14 +492,14 @@ __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
       continue;
     }
     double D[9], Di[9];
-    const double* H = A.Hll + (size_t)(P.point_base + l) * 9;
+    const double* H = A.Hll + (size_t)(P.lin_point_base + l) * 9;
 #pragma unroll
     for (int q = 0; q < 9; q++) D[q] = H[q] + ((q % 4 == 0) ? lambda : 0.0);
     inv3(D, Di);
-    const double* b = A.bl + (size_t)(P.point_base + l) * 3;
+    const double* b = A.bl + (size_t)(P.lin_point_base + l) * 3;
     const double db0 = Di[0] * b[0] + Di[1] * b[1] + Di[2] * b[2], db1 = Di[3] * b[0] + Di[4] * b[1] + Di[5] * b[2],
                  db2 = Di[6] * b[0] + Di[7] * b[1] + Di[8] * b[2];
-    const double* Wb = A.W + P.W_base + ((size_t)i * P.nl + l) * 18;
+    const double* Wb = A.W + P.lin_W_base + ((size_t)i * P.nl + l) * 18;
     double w[18];
 #pragma unroll
     for (int q = 0; q < 9; q++) { const double2 v = reinterpret_cast<const double2*>(Wb)[q]; w[2 * q] = v.x; w[2 * q + 1] = v.y; }
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
 #pragma unroll
   for (int r = 0; r < 6; r++) s[r] = wave_sum(s[r]);
   if (lane == 0)
-    for (int r = 0; r < 6; r++) A.bs[(size_t)P.pose_base * 6 + a * 6 + r] = A.bp[(size_t)(P.pose_base + i) * 6 + r] - s[r];
+    for (int r = 0; r < 6; r++) A.bs[(size_t)P.pose_base * 6 + a * 6 + r] = A.bp[(size_t)(P.lin_pose_base + i) * 6 + r] - s[r];
 }
 
 // S(ta, tb) = [ta == tb] (H_pp + lambda I) - sum_l (W_a D_l^-1) W_b^T, lower-triangular tile pairs only.
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
   const int pc = (side == 0 ? ta : tb) * PS_BA_TILE + pl;               // compact pose index
   const bool pose_ok = pc < npa;
   const double* Wsrc = side == 0 ? A.Wd : A.W;
-  const double* Wrow = Wsrc + P.W_base + (pose_ok ? (size_t)A.pact[P.pose_base + pc] * P.nl * 18 : 0);
+  const double* Wrow = Wsrc + (side == 0 ? P.W_base : P.lin_W_base) + (pose_ok ? (size_t)A.pact[P.pose_base + pc] * P.nl * 18 : 0);
   double (*dstT)[SCH_RS] = side == 0 ? As : Bs;
   // 48 x 48 tile = 3 x 3 tiles of the FP64 matrix cores (v_mfma_f64_16x16x4_f64); wave w (< 3) owns tile row w.  The vector
   // form of this contraction (3 x 3 register blocks, six LDS reads per nine FMAs) was bound by LDS instruction issue.
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
     if (gr >= n || gc >= n) continue;
     double h = 0;
     if (gr / 6 == gc / 6) {
-      h = A.Hpp[(size_t)(P.pose_base + A.pact[P.pose_base + gr / 6]) * 36 + (gr % 6) * 6 + (gc % 6)];
+      h = A.Hpp[(size_t)(P.lin_pose_base + A.pact[P.pose_base + gr / 6]) * 36 + (gr % 6) * 6 + (gc % 6)];
       if (gr == gc) h += ba_trial_lambda(St, St.lambda, St.ni);
     }
     Sm[(size_t)gr * lda + gc] = h - v;
@@ -1129,7 +1130,7 @@ __global__ __launch_bounds__(256) void ba_update(BaArrays A) {
     double c[3] = {0, 0, 0};
     if (act && S.ok2) {
       for (int a = sub; a < S.npa; a += 16) {
-        const double* Wb = A.W + P.W_base + ((size_t)A.pact[P.pose_base + a] * P.nl + l) * 18;
+        const double* Wb = A.W + P.lin_W_base + ((size_t)A.pact[P.pose_base + a] * P.nl + l) * 18;
         const double* xp = A.xp + (size_t)P.pose_base * 6 + a * 6;
 #pragma unroll
         for (int r = 0; r < 6; r++) { c[0] -= Wb[r * 3] * xp[r]; c[1] -= Wb[r * 3 + 1] * xp[r]; c[2] -= Wb[r * 3 + 2] * xp[r]; }
@@ -1145,7 +1146,7 @@ __global__ __launch_bounds__(256) void ba_update(BaArrays A) {
       Xb[0] = X[0]; Xb[1] = X[1]; Xb[2] = X[2];
       if (act) {
         double* xl = A.xl + (size_t)(P.point_base + l) * 3;
-        const double* b = A.bl + (size_t)(P.point_base + l) * 3;
+        const double* b = A.bl + (size_t)(P.lin_point_base + l) * 3;
         if (S.ok2) {
           c[0] += b[0]; c[1] += b[1]; c[2] += b[2];
           const double* Di = A.Dinv + (size_t)(P.point_base + l) * 9;
@@ -1166,7 +1167,7 @@ __global__ __launch_bounds__(256) void ba_update(BaArrays A) {
       const int a = A.pidx[P.pose_base + i];
       if (a >= 0) {
         const double* xp = A.xp + (size_t)P.pose_base * 6 + a * 6;
-        const double* b = A.bp + (size_t)(P.pose_base + i) * 6;
+        const double* b = A.bp + (size_t)(P.lin_pose_base + i) * 6;
         double u[6] = {xp[0], xp[1], xp[2], xp[3], xp[4], xp[5]};
         for (int r = 0; r < 6; r++) sc += u[r] * (lambda * u[r] + b[r]);
         const bool nrp = (A.pose_flags[P.pose_base + i] >> 1) & 1;

@@ -21,6 +21,10 @@ struct BaProb {
   int32_t part_base;                // doubles: per-block partial sums, `part_cap` entries
   int32_t part_cap;
   float fx, fy, cx, cy, bf;
+  // where the problem READS its linearisation (H_pp, b_p / H_ll, b_l / W / the chi2 partials): its own arrays - or, for a speculative twin, the
+  // primary's: both twins stand at the same estimate when an iteration starts, so the twin does not linearise at all
+  int32_t lin_pose_base, lin_point_base, lin_part_base;
+  int64_t lin_W_base;
 };
 
 struct BaState {
