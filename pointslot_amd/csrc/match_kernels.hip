@@ -451,12 +451,17 @@ __device__ __forceinline__ int row_scan_inclusive(int v) {          // Kogge-Sto
 // prefix sums through ds_bpermute) and filters / measures it: bounds, feature index, feature fields, descriptor - four dependent
 // memory round trips for a whole window, where a wave per query walking column after column paid four per column.
 template <int IDXB>
-__global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
+__global__ __launch_bounds__(256) void pj_gather(PjArrays A, int nprob) {
   constexpr int CAP = 1 << (23 - IDXB);
-  const PjProb& P = A.prob[blockIdx.y];
+  // r05: one problem per XCD at a time (workgroup b runs on XCD b % 8, every XCD has its own L2): the launch is (8 x blocks per problem,
+  // ceil(problems / 8)) and problem = 8 y + x % 8, so the workgroups that walk one frame's grid, candidate records and descriptors
+  // (~110 KB) share an L2 instead of fetching them eight times
+  const int pb = (int)blockIdx.y * 8 + ((int)blockIdx.x & 7), bxq = (int)blockIdx.x >> 3;
+  if (pb >= nprob) return;
+  const PjProb& P = A.prob[pb];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   const int nq = P.nq;
-  const int qi0 = blockIdx.x * 16 + wave * 4;
+  const int qi0 = bxq * 16 + wave * 4;
   if (qi0 >= nq) return;
   const int qi = qi0 + grp;
   const bool live = qi < nq;
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A) {
     prev = top[rr];
   }
   if (l16 == 0 && live) {
-    if (count > CAP) { atomicAdd(&A.overflow[blockIdx.y], 1); count = CAP; }
+    if (count > CAP) { atomicAdd(&A.overflow[pb], 1); count = CAP; }
     A.ncand[q] = count;
     A.ttop[q] = make_uint4(top[0], top[1], top[2], top[3]);
   }
@@ -815,10 +820,10 @@ extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int
   const size_t lds = (size_t)((max_nt < 1 ? 1 : max_nt > 32768 ? 32768 : max_nt) + 15) & ~(size_t)15;
   if (any_frame_mode) hipLaunchKernelGGL(pj_project, dim3((max_nq + 255) / 256, nprob), dim3(256), 0, st, A);
   if (wide) {
-    hipLaunchKernelGGL(pj_gather<13>, dim3((max_nq + 15) / 16, nprob), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(pj_gather<13>, dim3(8 * ((max_nq + 15) / 16), (nprob + 7) / 8), dim3(256), 0, st, A, nprob);
     hipLaunchKernelGGL(pj_resolve<13>, dim3(nprob), dim3(64), lds, st, A);
   } else {
-    hipLaunchKernelGGL(pj_gather<15>, dim3((max_nq + 15) / 16, nprob), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(pj_gather<15>, dim3(8 * ((max_nq + 15) / 16), (nprob + 7) / 8), dim3(256), 0, st, A, nprob);
     hipLaunchKernelGGL(pj_resolve<15>, dim3(nprob), dim3(64), lds, st, A);
   }
 }
