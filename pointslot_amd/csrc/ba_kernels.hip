@@ -533,12 +533,16 @@ __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
 #define SCH_LDS_BYTES (2 * 48 * SCH_RS * 8)
 typedef double sch_d4 __attribute__((ext_vector_type(4)));
 typedef double sch_d2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void ba_schur(BaArrays A) {
-  const BaProb P = A.prob[blockIdx.y];
-  const BaState& St = A.state[blockIdx.y];
+__global__ __launch_bounds__(256) void ba_schur(BaArrays A, int nprob) {
+  // r05: one problem per XCD at a time (workgroup b runs on XCD b % 8, every XCD has its own L2): the launch is (8 x tile pairs,
+  // ceil(problems / 8)) and problem = 8 y + x % 8 - a pose tile's rows of W / W D^-1 (345 KB) are read by seven and more tile pairs
+  const int prob = (int)blockIdx.y * 8 + ((int)blockIdx.x & 7);
+  if (prob >= nprob) return;
+  const BaProb P = A.prob[prob];
+  const BaState& St = A.state[prob];
   if (St.phase != BA_PH_TRIAL && St.phase != BA_PH_LINEARIZE) return;
   const int npa = St.npa, nt = (npa + PS_BA_TILE - 1) / PS_BA_TILE;
-  int ta = 0, rem = blockIdx.x;   // blockIdx.x -> (ta, tb), tb <= ta
+  int ta = 0, rem = (int)blockIdx.x >> 3;   // -> (ta, tb), tb <= ta
   while (ta < nt && rem > ta) { rem -= ta + 1; ta++; }
   if (ta >= nt) return;
   const int tb = rem;
@@ -1361,7 +1365,7 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   hipLaunchKernelGGL(ba_linearize, dim3((max_np + 3) / 4 + (max_nl + 15) / 16, nprob), dim3(256), 0, st, *A, (max_np + 3) / 4);
   hipLaunchKernelGGL(ba_prep, dim3(nbl + (max_np + 3) / 4, nprob), dim3(256), 0, st, *A);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_schur), hipFuncAttributeMaxDynamicSharedMemorySize, SCH_LDS_BYTES);
-  hipLaunchKernelGGL(ba_schur, dim3(max_tilepairs, nprob), dim3(256), SCH_LDS_BYTES, st, *A);
+  hipLaunchKernelGGL(ba_schur, dim3(8 * max_tilepairs, (nprob + 7) / 8), dim3(256), SCH_LDS_BYTES, st, *A, nprob);
   {
     const int n_max = 6 * max_free;
     auto lds = [&](int nb, bool pb) { return (size_t)(2 * nb * (nb + 1) + 4 * nb + 2 * nb * nb + 12 * PS_BA_MAX_POSES + (size_t)(pb ? 2 * (nb + 2) : nb + 1) * (n_max > nb ? n_max - nb + 4 : 4) + 8) * sizeof(double); };
