@@ -1271,12 +1271,11 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P, int nslots) {
 #endif                     // sixteen keypoints and 30 KB (256 / 128 / 64 threads: 40.6 / 40.8 / 40.8 k frames/s)
 __global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_DESC_OCC, 8))) void cvb_describe(CvbPlan P, int nimg) {
   __shared__ __attribute__((aligned(16))) uint8_t patch_all[CVB_DESC_T / 16][40 * 48];
-  // r05: one image per XCD at a time.  Workgroup b runs on XCD b % 8 and every XCD has its own L2; the launch is (8 x blocks per image,
-  // ceil(images / 8)) and image = 8 y + x % 8, so all workgroups of an image share one L2.  The keypoints of an object sit within a few dozen
-  // pixels of each other and their 32 x 48 / 40 x 48 byte windows overlap many times over: with the image's workgroups dealt over all eight XCDs
-  // every L2 fetched the windows for itself - 6.5 GB per 3072 images, 5.5 TB/s, the kernel was bound by HBM (profiles/r05_traffic.json).
-  const int img = (int)blockIdx.y * 8 + ((int)blockIdx.x & 7), bx = (int)blockIdx.x >> 3, nbx = (int)gridDim.x >> 3;
-  if (img >= nimg) return;
+  // (r05: one image per XCD at a time - the launch as (8 x blocks per image, images / 8) - cut this kernel's read requests from 11.3 M to 2.8 M per
+  // 1024 images and made it SLOWER in the tracker's batches, 1.22 -> 1.45 ms per 3072 images: an object's keypoints crowd a few dozen lines, and 128
+  // waves asking one L2 for them at once queue where eight L2s served them side by side.  The image's workgroups stay dealt over all XCDs.)
+  const int img = blockIdx.y, bx = (int)blockIdx.x, nbx = (int)gridDim.x;
+  (void)nimg;
   const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   int nsel[CV_MAX_LEVELS];
   int total = 0;
@@ -1433,6 +1432,6 @@ void psk_cvb_run(const CvbPlan* Pin, int nimg, const uint8_t* imgs, int stride, 
     const int nslots = nimg * NL, g = nslots < 32 ? nslots : (nslots + 1023) / 1024 > 32 ? (nslots + 1023) / 1024 : 32;   // 32 workgroups, more only so that a share stays within 1024 slots
     hipLaunchKernelGGL((cvb_select<CVB_CAND_CAP, 512>), dim3(g), dim3(256), 0, st, *P, nslots);
   }
-  hipLaunchKernelGGL(cvb_describe, dim3(8 * (32 * 256 / CVB_DESC_T), (nimg + 7) / 8), dim3(CVB_DESC_T), 0, st, *P, nimg);
+  hipLaunchKernelGGL(cvb_describe, dim3(32 * 256 / CVB_DESC_T, nimg), dim3(CVB_DESC_T), 0, st, *P, nimg);
 }
 }

@@ -456,7 +456,9 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A, int nprob) {
   // r05: one problem per XCD at a time (workgroup b runs on XCD b % 8, every XCD has its own L2): the launch is (8 x blocks per problem,
   // ceil(problems / 8)) and problem = 8 y + x % 8, so the workgroups that walk one frame's grid, candidate records and descriptors
   // (~110 KB) share an L2 instead of fetching them eight times
-  const int pb = (int)blockIdx.y * 8 + ((int)blockIdx.x & 7), bxq = (int)blockIdx.x >> 3;
+  // (the XCD a problem lands on rotates with y: the object search has its live problems at p % 8 in {0, 1} - two detections per sequence of eight
+  // slots - and would otherwise use two of the eight XCDs)
+  const int pb = (int)blockIdx.y * 8 + (((int)blockIdx.x + (int)blockIdx.y) & 7), bxq = (int)blockIdx.x >> 3;
   if (pb >= nprob) return;
   const PjProb& P = A.prob[pb];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
