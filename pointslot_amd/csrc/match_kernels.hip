@@ -138,17 +138,21 @@ __global__ __launch_bounds__(TOPK_T) void bf_topk(const BfBlock* blocks, const B
 __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint8_t* qdesc, const float* qang,
                                                   const uint8_t* qvalid, const uint8_t* tdesc, const float* tang,
                                                   const uint32_t* topk, int32_t* query_of_train, int32_t* nmatch,
-                                                  float nn_ratio, int check_ori) {
+                                                  float nn_ratio, int check_ori, int nprob_total) {
   __shared__ uint32_t taken[PS_BF_MAX_TRAIN / 32];
   __shared__ uint8_t bin_of[PS_BF_MAX_TRAIN];
   __shared__ int hist[32];
   __shared__ float tang_s[BF_RES_TANG];
   __shared__ uint32_t claim[BF_CLAIM];   // hashed train -> earliest pending lane of the chunk whose best it is
-  const BfProb P = probs[blockIdx.x];
+  // (r05) problem <-> workgroup rotated inside every group of eight: workgroup b runs on XCD b % 8, and the tracker's problems are
+  // (sequence, detection slot) with eight slots of which the first two are live - unrotated, they all ran on XCDs 0 and 1
+  const int pbi = ((int)blockIdx.x & ~7) | (((int)blockIdx.x + ((int)blockIdx.x >> 3)) & 7);
+  if (pbi >= nprob_total) return;
+  const BfProb P = probs[pbi];
   const int lane = threadIdx.x;
   if (P.nt == 0 || P.nq == 0) {   // nothing to match (bf_topk was not run for this problem)
     for (int j = lane; j < P.nt; j += 64) query_of_train[P.t_off + j] = -1;
-    if (lane == 0) nmatch[blockIdx.x] = 0;
+    if (lane == 0) nmatch[pbi] = 0;
     return;
   }
   int32_t* out = query_of_train + P.t_off;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(64) void bf_resolve(const BfProb* probs, const uint
     for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
     nm -= removed;
   }
-  if (lane == 0) nmatch[blockIdx.x] = nm;
+  if (lane == 0) nmatch[pbi] = nm;
 }
 
 __global__ __launch_bounds__(256) void hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out) {
@@ -341,8 +345,8 @@ extern "C" void psk_bf_launch(const BfBlock* blocks, int nblocks, const BfProb* 
     hipLaunchKernelGGL((bf_topk_small<BF_SMALL_NT, 256>), dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
     hipLaunchKernelGGL(bf_topk, dim3(nblocks), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, (const int32_t*)nullptr);
   }
-  hipLaunchKernelGGL(bf_resolve, dim3(nprob), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
-                     nmatch, nn_ratio, check_ori);
+  hipLaunchKernelGGL(bf_resolve, dim3((nprob + 7) & ~7), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
+                     nmatch, nn_ratio, check_ori, nprob);
 }
 // the same with a block table that was built on the device: `d_count` entries, `grid` workgroups loop over them
 extern "C" void psk_bf_launch_dev(const BfBlock* blocks, const int32_t* d_count, int grid, const BfProb* probs, int nprob, const uint8_t* qdesc,
@@ -355,8 +359,8 @@ extern "C" void psk_bf_launch_dev(const BfBlock* blocks, const int32_t* d_count,
   // workgroups: each needs 64 KB of LDS before it can start, and 1024 of them waited 220 us for their turn beside the other
   // lockstep groups' kernels; 5 us alone)
   hipLaunchKernelGGL(bf_topk, dim3(grid < 32 ? grid : 32), dim3(TOPK_T), 0, st, blocks, probs, qdesc, tdesc, topk, d_count);
-  hipLaunchKernelGGL(bf_resolve, dim3(nprob), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
-                     nmatch, nn_ratio, check_ori);
+  hipLaunchKernelGGL(bf_resolve, dim3((nprob + 7) & ~7), dim3(64), 0, st, probs, qdesc, qang, qvalid, tdesc, tang, topk, out,
+                     nmatch, nn_ratio, check_ori, nprob);
 }
 extern "C" void psk_hamming_matrix_launch(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out, hipStream_t st) {
   hipLaunchKernelGGL(hamming_matrix, dim3((nt + 255) / 256, nq), dim3(256), 0, st, q, nq, t, nt, out);
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A, int nprob) {
 #define PJ_TBL 4096   // (8192: 3 % fewer lanes lose the parallel path to a hash collision, but 16 KB more LDS per problem - measured slower)
 #endif
 template <int IDXB>
-__global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
+__global__ __launch_bounds__(64) void pj_resolve(PjArrays A, int nprob_total) {
   constexpr int CAP = 1 << (23 - IDXB);
   constexpr uint32_t IDXM = (1u << IDXB) - 1u;
   __shared__ uint32_t blocked[1024];   // up to 32768 train features
@@ -575,7 +579,9 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
   extern __shared__ uint8_t loct[];    // train octaves (ratio test), staged once: no global load inside the serial loop; sized by the launch
                                        // for the call's largest train set (with room for all 32768 the workgroup took 72 KB: two per CU)
   __shared__ uint32_t first_lane[PJ_TBL];   // hashed train -> earliest lane of the current block that lists it among its four keys
-  const PjProb P = A.prob[blockIdx.x];
+  const int pbi = ((int)blockIdx.x & ~7) | (((int)blockIdx.x + ((int)blockIdx.x >> 3)) & 7);      // (rotated inside every group of eight: see bf_resolve)
+  if (pbi >= nprob_total) return;
+  const PjProb P = A.prob[pbi];
   const int lane = threadIdx.x;
   int32_t* match = A.match + P.t_off;
   for (int w = lane; w < (P.nt + 31) / 32; w += 64) {
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A) {
     for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
     nm -= removed;
   }
-  if (lane == 0) A.nmatch[blockIdx.x] = nm;
+  if (lane == 0) A.nmatch[pbi] = nm;
 #ifdef PS_PJ_PROFILE
   if (lane == 0 && blockIdx.x == 0) printf("pj_resolve nq %d nt %d: loop %lld ticks, tail %lld ticks, matches %d, decided in parallel %d, sequentially %d, blocks with a scanning query %d\n", P.nq, P.nt, pj_t1 - pj_t0, wall_clock64() - pj_t1, nm, pj_clean, pj_dirty, pj_serial_blocks);
 #endif
@@ -823,10 +829,10 @@ extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int
   if (any_frame_mode) hipLaunchKernelGGL(pj_project, dim3((max_nq + 255) / 256, nprob), dim3(256), 0, st, A);
   if (wide) {
     hipLaunchKernelGGL(pj_gather<13>, dim3(8 * ((max_nq + 15) / 16), (nprob + 7) / 8), dim3(256), 0, st, A, nprob);
-    hipLaunchKernelGGL(pj_resolve<13>, dim3(nprob), dim3(64), lds, st, A);
+    hipLaunchKernelGGL(pj_resolve<13>, dim3((nprob + 7) & ~7), dim3(64), lds, st, A, nprob);
   } else {
     hipLaunchKernelGGL(pj_gather<15>, dim3(8 * ((max_nq + 15) / 16), (nprob + 7) / 8), dim3(256), 0, st, A, nprob);
-    hipLaunchKernelGGL(pj_resolve<15>, dim3(nprob), dim3(64), lds, st, A);
+    hipLaunchKernelGGL(pj_resolve<15>, dim3((nprob + 7) & ~7), dim3(64), lds, st, A, nprob);
   }
 }
 

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(OB_T) void ob_track(ObArrays A, int step) {
   __shared__ Se3 s_pose;
   __shared__ int s_flag[4];
   __shared__ unsigned long long s_stop[OB_T / 64];
-  const int j = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, K = A.K;
+  const int s = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, K = A.K;   // sequence-major launch: see psk_ob_track
   const ObCam& C = A.cam;
   ObFrame& F = A.cur;
   BfProb* bp = A.bf_prob + (size_t)s * K + j;
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(OB_T) void ob_after_bf(ObArrays A, int step) {
 __global__ __launch_bounds__(OB_T) void ob_after_cf1(ObArrays A, int step) {
   __shared__ int red[OB_T / 64];
   extern __shared__ uint8_t seen[];
-  const int j = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, K = A.K;
+  const int s = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, K = A.K;   // sequence-major launch: see psk_ob_track
   const ObCam& C = A.cam;
   ObFrame& F = A.cur;
   PjProb* pp = A.pj_prob + (size_t)s * K + j;
@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(OB_T) void ob_finish(ObArrays A, int step) {
   __shared__ Se3 s_pose;
   __shared__ int s_int[2];
   __shared__ double s_dsd[2];
-  const int j = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, K = A.K;
+  const int s = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, K = A.K;   // sequence-major launch: see psk_ob_track
   const ObCam& C = A.cam;
   ObFrame& F = A.cur;
   ObFrame& L = A.last;
@@ -1293,13 +1293,15 @@ void psk_ob_masks(const ObArrays* A, uint8_t* objmask, int W, int H, int ostride
   hipLaunchKernelGGL(ob_masks, dim3(H, A->S), dim3(OB_MASK_T), lds, st, *A, objmask, W, H, ostride, occ, ocw, och);
 }
 void psk_ob_begin(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_begin, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
-void psk_ob_track(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_track, dim3(A->K, A->S), dim3(OB_T), 0, st, *A, step); }
+// (r05) the per-detection kernels are launched sequence-major, (S, K): workgroup b runs on XCD b % 8, and with the detection slot as the fast index -
+// (K, S), K = 8 - slot j of EVERY sequence ran on XCD j: two live detections per sequence kept two of the eight XCDs busy and the other six idle
+void psk_ob_track(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_track, dim3(A->S, A->K), dim3(OB_T), 0, st, *A, step); }
 void psk_ob_bf_blocks(const BfProb* probs, BfBlock* blocks, int32_t* count, int nprob, int blocks_per_prob, hipStream_t st) {
   hipMemsetAsync(count, 0, 8, st);
   hipLaunchKernelGGL(ob_bf_blocks, dim3((nprob * blocks_per_prob + 63) / 64), dim3(64), 0, st, probs, blocks, count, nprob, blocks_per_prob);
 }
 void psk_ob_after_bf(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_bf, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
-void psk_ob_after_cf1(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_cf1, dim3(A->K, A->S), dim3(OB_T), (size_t)A->LC, st, *A, step); }
+void psk_ob_after_cf1(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_cf1, dim3(A->S, A->K), dim3(OB_T), (size_t)A->LC, st, *A, step); }
 void psk_ob_after_lm(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_after_lm, dim3(A->S), dim3(OB_T), 0, st, *A, step); }
-void psk_ob_finish(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_finish, dim3(A->K, A->S), dim3(OB_T), 0, st, *A, step); }
+void psk_ob_finish(const ObArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(ob_finish, dim3(A->S, A->K), dim3(OB_T), 0, st, *A, step); }
 }
