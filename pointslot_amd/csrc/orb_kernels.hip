@@ -508,6 +508,9 @@ __device__ __forceinline__ int wave_scan_inclusive(int v) {
 }
 
 #define FAST_T 256
+#ifndef FAST_STOP
+#define FAST_STOP 0      // developer switch (instruction counts per phase: the kernel returns after phase A / B / C / D; results are wrong)
+#endif
 typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
 typedef short fs_s2 __attribute__((ext_vector_type(2)));
 
@@ -596,6 +599,10 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
     }
   }
   wave_sync();
+#if FAST_STOP == 1
+  if (lane == 0) cellcnt[cell] = 0;
+  return;
+#endif
   int total = 0;
   // Two passes at most: first with iniThFAST - a keypoint at threshold t only competes with neighbours that are corners
   // at t, so when the cell has a keypoint at iniThFAST (the common case) the many weak corners between minThFAST and
@@ -666,6 +673,10 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
         }
       }
       wave_sync();
+#if FAST_STOP == 2
+      if (lane == 0) cellcnt[cell] = 0;
+      return;
+#endif
       // ---- C: exact scores, two entries per lane: entry k of the concatenation [dark entries, bright entries] ----
       const int ntot = nd + nb;
       for (int i0 = 0; i0 < ntot; i0 += 128) {
@@ -703,6 +714,10 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
         if ((int)sc.x > th && i0 + lane < ntot) smap[p[0] + (SS + 1)] = (uint8_t)sc.x;
         if ((int)sc.y > th && i0 + 64 + lane < ntot) smap[p[1] + (SS + 1)] = (uint8_t)sc.y;
       }
+#if FAST_STOP == 3
+      if (lane == 0) cellcnt[cell] = 0;
+      return;
+#endif
       if (!full) break;
       wave_sync();
       nd = nb = 0;
@@ -737,6 +752,13 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
       }
     }
     if (flushed) anykp = __builtin_amdgcn_ballot_w64(rowbits != 0);
+#if FAST_STOP == 4
+    if (lane == 0) cellcnt[cell] = 0;
+    return;
+#endif
+#if FAST_STOP == 5
+    if (!anykp && pass == 0) { if (lane == 0) cellcnt[cell] = 0; return; }
+#endif
     if (!anykp && pass == 0) continue;   // no keypoint at iniThFAST: run the cell again at minThFAST
     // ---- emission in raster order: bitmap of the kept pixels, one row per lane; the row counts' prefix is the rank ----
     const int mx0 = ci_x * L.w_cell + 3, my0 = ci_y * L.h_cell + 3;   // cell pixel (0, 0) relative to (minBorderX, minBorderY)
