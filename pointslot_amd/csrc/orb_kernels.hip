@@ -180,6 +180,14 @@ __global__ __launch_bounds__(256) void orb_pyramid_level(OrbPlan plan, int level
 //     v_dot2_u32_u16 forms b0*a0 + b1*a1 in one instruction; the vertical step is two v_mul_hi_u32 (the
 //     weights are pre-shifted by 16) and one add3.  No saturation is needed: a0 + a1 = 2048 bounds the result by 255.
 // ------------------------------------------------------------------------------------------------
+// bytes {sat8(a >> 16), sat8(b >> 16), sat8(c >> 16), sat8(d >> 16)} of four sums below 2^31 (sat8: values above 255 become 255)
+__device__ __forceinline__ uint32_t ps_sat_pack4_hi16(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x07060302u), cd = __builtin_amdgcn_perm(d, c, 0x07060302u);   // {a.hi16, b.hi16}, {c.hi16, d.hi16}
+  uint32_t lo, hi;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(lo) : "v"(ab));
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi) : "v"(cd));
+  return lo | (hi << 16);
+}
 #define LV_RPT 10                 // region rows per thread
 #ifndef LV_WAVES
 #define LV_WAVES 4                // waves per workgroup: each takes LV_RPT region rows
@@ -209,7 +217,7 @@ typedef unsigned short lv_us2 __attribute__((ext_vector_type(2)));
 template <bool LEVEL0>
 __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(PS_LV_WAVES, 8))) void orb_level_fused(OrbPlan plan, int level, uint8_t* arena, const uint8_t* imgs,
                                                       int img_stride, size_t img_pitch, const int4* tabs, int nimg, int tiles_x) {
-  __shared__ uint32_t tile[LV_R][64];
+  __shared__ uint32_t tile[LV_R + 2][64];   // (+ 2: the last blur chunk reads two rows past the region for outputs it never stores - no clamp, the rows are immediate offsets)
   LVP_DECL;
   const OrbLevel L = plan.lv[level];
   // one image per XCD at a time, its tiles in row-major order: tiles that share halo rows and 128-byte lines meet in one L2
@@ -373,51 +381,56 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
   const int nrows = min(LV_BLUR_ROWS, LV_OWN_R - o0);
   const int y0 = Q0 + 3 + o0 - PS_EDGE;                    // level row of the chunk's first output
   if (y0 >= L.h || y0 + nrows <= 0) return;
-  // horizontal 7-tap sums (exact in 16 bits: the taps add up to 257) with two v_dot4_u32_u8 per pixel; two consecutive
-  // rows are packed into one register so that the vertical pass is four v_dot2_u32_u16 per pixel
-  const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24), KHI = 49u | (34u << 8) | (18u << 16);
+  // horizontal 7-tap sums (exact in 16 bits: the taps add up to 257); two consecutive rows are packed into one register so that the
+  // vertical pass is four v_dot2_u32_u16 per pixel.  The four pixels of a group read bytes j .. j + 6 of the 12-byte window
+  // (a0, a1, a2): instead of shifting the window to every pixel (v_alignbyte x 6) the TAPS are shifted - constants - and every
+  // aligned dword that holds one of the pixel's bytes gets its own v_dot4_u32_u8: 2 + 2 + 3 + 3 dot products, nothing else (r05).
+  constexpr uint32_t T0 = 18, T1 = 34, T2 = 49, T3 = 55, T4 = 49, T5 = 34, T6 = 18;
+#define LV_K4(b0, b1, b2, b3) ((uint32_t)(b0) | ((uint32_t)(b1) << 8) | ((uint32_t)(b2) << 16) | ((uint32_t)(b3) << 24))
   uint32_t E[(LV_BLUR_ROWS + 7) / 2][4];     // E[i][j] = hs(row 2i)[j] | hs(row 2i + 1)[j] << 16
 #pragma unroll
   for (int r = 0; r < LV_BLUR_ROWS + 6; r++) {
-    const int rr = min(o0 + r, LV_R - 1);
+    const int rr = o0 + r;
     const uint32_t a0 = tile[rr][c], a1 = tile[rr][c + 1], a2 = tile[rr][c + 2];
-    uint32_t w[8];
-    w[0] = a0; w[4] = a1;
-#pragma unroll
-    for (int k = 1; k < 4; k++) { w[k] = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)k); w[4 + k] = __builtin_amdgcn_alignbyte(a2, a1, (uint32_t)k); }
+    uint32_t hs[4];
+    hs[0] = __builtin_amdgcn_udot4(a1, LV_K4(T4, T5, T6, 0), __builtin_amdgcn_udot4(a0, LV_K4(T0, T1, T2, T3), 0u, false), false);
+    hs[1] = __builtin_amdgcn_udot4(a1, LV_K4(T3, T4, T5, T6), __builtin_amdgcn_udot4(a0, LV_K4(0, T0, T1, T2), 0u, false), false);
+    hs[2] = __builtin_amdgcn_udot4(a2, LV_K4(T6, 0, 0, 0), __builtin_amdgcn_udot4(a1, LV_K4(T2, T3, T4, T5), __builtin_amdgcn_udot4(a0, LV_K4(0, 0, T0, T1), 0u, false), false), false);
+    hs[3] = __builtin_amdgcn_udot4(a2, LV_K4(T5, T6, 0, 0), __builtin_amdgcn_udot4(a1, LV_K4(T1, T2, T3, T4), __builtin_amdgcn_udot4(a0, LV_K4(0, 0, 0, T0), 0u, false), false), false);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const uint32_t hsum = __builtin_amdgcn_udot4(w[j + 4], KHI, __builtin_amdgcn_udot4(w[j], KLO, 0u, false), false);
-      if (r & 1) E[r >> 1][j] |= hsum << 16; else E[r >> 1][j] = hsum;
+      if (r & 1) E[r >> 1][j] |= hs[j] << 16; else E[r >> 1][j] = hs[j];
     }
   }
+#undef LV_K4
   const uint32_t C01 = 18u | (34u << 16), C23 = 49u | (55u << 16), C45 = 49u | (34u << 16), C6 = 18u;           // even output rows
   const uint32_t D0 = 18u << 16, D12 = 34u | (49u << 16), D34 = 55u | (49u << 16), D56 = 34u | (18u << 16);      // odd output rows
-  uint8_t* dst = base + L.blur_off + x0;
+  // (32-bit offset from the image's wave-uniform arena base: one vector add per row; a 64-bit row address was two v_mad_u64_u32)
+  uint32_t doff = L.blur_off + (uint32_t)x0 + (uint32_t)y0 * (uint32_t)L.bstride;
 #pragma unroll
-  for (int o = 0; o < LV_BLUR_ROWS; o++) {
+  for (int o = 0; o < LV_BLUR_ROWS; o++, doff += (uint32_t)L.bstride) {
     const int y = y0 + o;
     if (o >= nrows || y < 0 || y >= L.h) continue;
     const int m = o >> 1;
-    uint32_t pk = 0;
+    uint32_t v[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      uint32_t v = 32768u;
+      v[j] = 32768u;
       if (o & 1) {
-        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m][j]), __builtin_bit_cast(lv_us2, D0), v, false);
-        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 1][j]), __builtin_bit_cast(lv_us2, D12), v, false);
-        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 2][j]), __builtin_bit_cast(lv_us2, D34), v, false);
-        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 3][j]), __builtin_bit_cast(lv_us2, D56), v, false);
+        v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m][j]), __builtin_bit_cast(lv_us2, D0), v[j], false);
+        v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 1][j]), __builtin_bit_cast(lv_us2, D12), v[j], false);
+        v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 2][j]), __builtin_bit_cast(lv_us2, D34), v[j], false);
+        v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 3][j]), __builtin_bit_cast(lv_us2, D56), v[j], false);
       } else {
-        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m][j]), __builtin_bit_cast(lv_us2, C01), v, false);
-        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 1][j]), __builtin_bit_cast(lv_us2, C23), v, false);
-        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 2][j]), __builtin_bit_cast(lv_us2, C45), v, false);
-        v = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 3][j]), __builtin_bit_cast(lv_us2, C6), v, false);
+        v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m][j]), __builtin_bit_cast(lv_us2, C01), v[j], false);
+        v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 1][j]), __builtin_bit_cast(lv_us2, C23), v[j], false);
+        v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 2][j]), __builtin_bit_cast(lv_us2, C45), v[j], false);
+        v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(lv_us2, E[m + 3][j]), __builtin_bit_cast(lv_us2, C6), v[j], false);
       }
-      const uint32_t qv = v >> 16;
-      pk |= (qv > 255u ? 255u : qv) << (8 * j);
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.bstride) = pk;
+    // the four results are v >> 16 (at most 257), saturated to a byte: the upper halves of two sums side by side (v_perm_b32) are a
+    // packed i16 pair that v_sat_pk_u8_i16 turns into two bytes - five instructions per dword where shift / min / shift-or were twelve
+    *reinterpret_cast<uint32_t*>(base + doff) = ps_sat_pack4_hi16(v[0], v[1], v[2], v[3]);
   }
   LVP_PRINT();
 }
