@@ -266,6 +266,7 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
     sbase = base; srel = S.plane_off + (uint32_t)(PS_EDGE * S.stride + PS_EDGE); src_stride = (uint32_t)S.stride;
   }
   const uint32_t sbase_lo = (uint32_t)reinterpret_cast<uintptr_t>(sbase);
+  const bool fast_wave = __all(fast);
   const bool own_x = lane >= 1 && lane <= 62 && P0 + 4 * lane < PW;
   uint8_t* plane = base + L.plane_off;
   // Consecutive output rows share a source row four times out of five at scale 1.2 (s0 of row r is s1 of row r - 1), so
@@ -296,11 +297,29 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
       ty[r] = ty_all[half * (LV_HROWS) + r];
       const int prev_s1 = r > 0 ? ty[r - 1].y : hc_row;
       need0[r] = LEVEL0 || ty[r].x != prev_s1;
+    }
+    if (fast_wave) {
+      // every lane's eight source bytes are one window (all of levels >= 1, level 0 away from the image's left / right edge): ONE
+      // 8-byte load per lane and row at the byte address itself (global loads take any alignment), all the half's rows requested
+      // before the first is looked at.  (r05: three aligned dwords + v_alignbyte inside the lane-dependent `fast` test made the
+      // compiler close every row's block with s_waitcnt vmcnt(0) - six or seven memory round trips per half, one after the other.)
+#pragma unroll
+      for (int r = 0; r < LV_HROWS; r++)
+#pragma unroll
+        for (int v = 0; v < (LEVEL0 ? 1 : 2); v++) {
+          if (v == 0 && !need0[r]) continue;
+          const uint32_t roff = srel + (uint32_t)(v == 0 ? ty[r].x : ty[r].y) * src_stride;   // wave-uniform
+          uint2 w;
+          __builtin_memcpy(&w, sbase + (roff + (uint32_t)sb), 8);
+          wl[r][v] = w.x; wh[r][v] = w.y;
+        }
+    } else {
+#pragma unroll
+    for (int r = 0; r < LV_HROWS; r++) {
 #pragma unroll
       for (int v = 0; v < (LEVEL0 ? 1 : 2); v++) {
         if (v == 0 && !need0[r]) continue;
         const uint32_t roff = srel + (uint32_t)(v == 0 ? ty[r].x : ty[r].y) * src_stride;   // wave-uniform
-        const uint8_t* row = sbase + roff;
         if (fast) {
           const uint32_t sh = (sbase_lo + roff + (uint32_t)sb) & 3u;
           const uint32_t* q = reinterpret_cast<const uint32_t*>(sbase + (roff + (uint32_t)sb - sh));
@@ -309,10 +328,14 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
           wh[r][v] = __builtin_amdgcn_alignbyte(d2, d1, sh);
         } else {
           // generic gather (image edges of level 0, scale factors above 2): byte k <- s0[k], byte 4 + k <- s1[k]
-          wl[r][v] = (uint32_t)row[s0[0]] | ((uint32_t)row[s0[1]] << 8) | ((uint32_t)row[s0[2]] << 16) | ((uint32_t)row[s0[3]] << 24);
-          wh[r][v] = (uint32_t)row[s1[0]] | ((uint32_t)row[s1[1]] << 8) | ((uint32_t)row[s1[2]] << 16) | ((uint32_t)row[s1[3]] << 24);
+          // (32-bit offsets from the wave-uniform base: as 64-bit lane addresses the eight sign-extended indices held 16 registers for the whole phase)
+#define LV_SB(i) ((uint32_t)sbase[roff + (uint32_t)(i)])
+          wl[r][v] = LV_SB(s0[0]) | (LV_SB(s0[1]) << 8) | (LV_SB(s0[2]) << 16) | (LV_SB(s0[3]) << 24);
+          wh[r][v] = LV_SB(s1[0]) | (LV_SB(s1[1]) << 8) | (LV_SB(s1[2]) << 16) | (LV_SB(s1[3]) << 24);
+#undef LV_SB
         }
       }
+    }
     }
 #pragma unroll
     for (int r = 0; r < LV_HROWS; r++) {
@@ -368,6 +391,9 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
     hc_row = ty[LV_HROWS - 1].y;
     LVP_MARK();
   }
+#ifdef LV_STOP      // developer switch (instruction counts): the kernel ends after the resize phase
+  return;
+#endif
   __syncthreads();
   LVP_MARK();
 
