@@ -603,16 +603,29 @@ __global__ __launch_bounds__(CVB_TT) void cvb_level0(CvbPlan P) {
     const int px0 = CVB_TILE * tx + (tid & 7) * 4;
     int xs[4];
     for (int j = 0; j < 4; j++) xs[j] = reflect101(min(px0 + j, L.w + 2 * CV_BORDER - 1) - CV_BORDER, L.w);
+    // (the sixteen byte loads of the lane's four rows first, then the stores: row by row every row was a memory round trip)
+    uint32_t v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int py = min(CVB_TILE * ty + (tid >> 3) + 8 * r, L.h + 2 * CV_BORDER - 1);
+      const uint8_t* row = I + (size_t)reflect101(py - CV_BORDER, L.h) * P.img_stride;
+      v[r] = (uint32_t)row[xs[0]] | ((uint32_t)row[xs[1]] << 8) | ((uint32_t)row[xs[2]] << 16) | ((uint32_t)row[xs[3]] << 24);
+    }
+#pragma unroll
     for (int r = 0; r < 4; r++) {
       const int py = CVB_TILE * ty + (tid >> 3) + 8 * r;
-      if (py >= L.h + 2 * CV_BORDER) continue;
-      const uint8_t* row = I + (size_t)reflect101(py - CV_BORDER, L.h) * P.img_stride;
-      const uint32_t v = (uint32_t)row[xs[0]] | ((uint32_t)row[xs[1]] << 8) | ((uint32_t)row[xs[2]] << 16) | ((uint32_t)row[xs[3]] << 24);
-      if (px0 < L.stride) *reinterpret_cast<uint32_t*>(L.pad + (size_t)py * L.stride + px0) = v;
+      if (py < L.h + 2 * CV_BORDER && px0 < L.stride) *reinterpret_cast<uint32_t*>(L.pad + (size_t)py * L.stride + px0) = v[r];
     }
   }
 }
 
+// 16 aligned bytes of GLOBAL memory at an integer address (as a generic pointer the compiler emits flat_load: it counts on the LDS
+// counter as well, and every wait for it becomes vmcnt(0) lgkmcnt(0))
+typedef uint32_t cvb_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 cvb_gload16(uintptr_t a) {
+  const cvb_u4v x = *(const __attribute__((address_space(1))) cvb_u4v*)a;
+  return make_uint4(x.x, x.y, x.z, x.w);
+}
 // level l >= 1 from level l - 1 (level 1 from the image): the tile's table rows and its source patch are staged in LDS, every thread
 // interpolates four consecutive pixels of four rows and stores each quad as one dword; the mask likewise on the tiles of the mask chain
 __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
@@ -624,6 +637,12 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
   __shared__ int4 xt[CVB_TILE], yt[CVB_TILE];     // table entries of the tile's columns / rows, source offsets resolved
   const int tid = threadIdx.x;
   const CvbLevel& Sb = P.lv[l - 1];
+  // (the level's constants pinned in scalar registers: left to itself the compiler selects between the two ADDRESSES inside the kernel
+  // arguments - the x or the y field - and loads the winner per lane: vector loads, and with them a vmcnt(0) wait in every tile's
+  // table step, which also drains the previous tile's stores)
+  int dmaxx = P.lv[l].dmaxx, dmaxy = P.lv[l].dmaxy, dminx = P.lv[l].dminx, dminy = P.lv[l].dminy, lvw = P.lv[l].w, lvh = P.lv[l].h, srw = Sb.w, srh = Sb.h;
+  double scx = P.lv[l].sx, scy = P.lv[l].sy;
+  asm volatile("" : "+s"(dmaxx), "+s"(dmaxy), "+s"(dminx), "+s"(dminy), "+s"(lvw), "+s"(lvh), "+s"(srw), "+s"(srh), "+s"(scx), "+s"(scy));
   CVB_TILE_LOOP(P, 0, l) {
     const bool with_mask = (e >> 31) != 0;
     const int img = (int)((e >> 12) & 0x7FFFFu), t = (int)(e & 4095u), tx = t % B.tw, ty = t / B.tw;
@@ -640,9 +659,9 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
       // lanes 0..31: the columns' table entries, lanes 32..63: the rows'; .x = the first source index of the entry
       const int k = tid & 31;
       const bool isx = tid < 32;
-      const int len = isx ? L.w : L.h, slen = isx ? Sb.w : Sb.h;
+      const int len = isx ? lvw : lvh, slen = isx ? srw : srh;
       const int p = min(CVB_TILE * (isx ? tx : ty) + k, len + 2 * CV_BORDER - 1);
-      const int4 v = cvb_tab_entry(reflect101(p - CV_BORDER, len), isx ? B.sx : B.sy, slen, isx ? B.dminx : B.dminy, isx ? B.dmaxx : B.dmaxy);
+      const int4 v = cvb_tab_entry(reflect101(p - CV_BORDER, len), isx ? scx : scy, slen, isx ? dminx : dminy, isx ? dmaxx : dmaxy);
       (isx ? xt : yt)[k] = v;
     }
     cvb_wave_sync();
@@ -675,10 +694,10 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
         v[ry] = make_uint4(0, 0, 0, 0); mv[ry] = make_uint4(0, 0, 0, 0);
         if (yy < ny) {
           const uintptr_t a = sb + so;
-          if (16 * q < (int)(a & 15) + nx) v[ry] = *reinterpret_cast<const uint4*>((a & ~(uintptr_t)15) + 16 * q);
+          if (16 * q < (int)(a & 15) + nx) v[ry] = cvb_gload16((a & ~(uintptr_t)15) + 16 * q);
           if (with_mask) {
             const uintptr_t ma = mb + mo;
-            if (16 * q < (int)(ma & 15) + nx) { mv[ry] = *reinterpret_cast<const uint4*>((ma & ~(uintptr_t)15) + 16 * q); mloaded |= 1u << ry; }
+            if (16 * q < (int)(ma & 15) + nx) { mv[ry] = cvb_gload16((ma & ~(uintptr_t)15) + 16 * q); mloaded |= 1u << ry; }
           }
         }
       }

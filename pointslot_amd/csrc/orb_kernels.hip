@@ -196,7 +196,7 @@ __device__ __forceinline__ uint32_t ps_sat_pack4_hi16(uint32_t a, uint32_t b, ui
 #define LV_OWN_R (LV_R - 6)       // owned rows
 #define LV_OWN_C 248              // owned columns (62 dword groups; lanes 0 and 63 are halo)
 #ifndef LV_HALVES
-#define LV_HALVES 2            // the region rows of a thread are loaded and resized in this many groups
+#define LV_HALVES 1            // the region rows of a thread are loaded and resized in this many groups (r05: 1 - with two registers per row load all ten rows' loads fit; 2: 43.6, 1: 43.85, 5: 43.4 k frames/s)
 #endif
 #define LV_HROWS (LV_RPT / LV_HALVES)
 #define LV_BLUR_ROWS ((LV_OWN_R + LV_WAVES - 1) / LV_WAVES)   // LV_WAVES row chunks cover the owned rows (9 of 34 with 4 waves)
@@ -1405,36 +1405,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_DESC_WAV
   // the two lane-indexed tables go to LDS once per workgroup (from the vector cache they would be two thirds of the bytes a wave loads)
   __shared__ uint4 s_pat[4][16];
   __shared__ uint2 s_icm[8][16];
-  reinterpret_cast<uint32_t*>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&c_pattab)[threadIdx.x];
-  reinterpret_cast<uint32_t*>(s_icm)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&c_ictab)[threadIdx.x];
-  __syncthreads();
   int img, lb;
-  if (!xcd_image_block(nimg, img, lb)) return;
+  if (!xcd_image_block(nimg, img, lb)) return;         // (the whole workgroup)
+  // Everything the keypoint's patch address depends on is requested HERE, in front of the barrier, in one go: the tables' words,
+  // the wave's slot and the eight per-level counts (two scalar loads).  r05: the counts were read level by level inside
+  // `if (l < nlevels)` - eight scalar round trips one after the other, behind the tables' round trip and the barrier, in front of
+  // the slot's - which is why the kernel issued on half of its cycles.
+  const uint32_t t_pat = reinterpret_cast<const uint32_t*>(&c_pattab)[threadIdx.x], t_icm = reinterpret_cast<const uint32_t*>(&c_ictab)[threadIdx.x];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int slot0 = (lb * 4 + wv) * 4;
   const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
-  const int32_t* selcnt = reinterpret_cast<const int32_t*>(base + plan.selcnt_off);
-  if (slot0 >= plan.sel_total) return;
   int level = 0;
 #pragma unroll
   for (int l = 1; l < PS_ORB_MAX_LEVELS; l++)
     if (l < plan.nlevels && slot0 >= plan.lv[l].sel_off) level = l;
   const OrbLevel& L = plan.lv[level];
   const int k0 = slot0 - L.sel_off, k = k0 + grp;
-  // the slot is read before the counts are known (it always exists), so the two round trips overlap
+  // (the slot always exists; a wave beyond the last slot reads the level's last one and leaves below)
   uint32_t e = (reinterpret_cast<const uint32_t*>(base + plan.sel_base) + L.sel_off)[min(k, L.sel_cap - 1)];
-  int offset = 0, total = 0;
+  static_assert(PS_ORB_MAX_LEVELS == 8, "the per-level counts are read as two int4");
+  typedef const int32_t __attribute__((address_space(4))) * sel_scalar_ptr;     // wave-uniform address, written by the kernel before this one
+  const sel_scalar_ptr scp = (sel_scalar_ptr)(uintptr_t)(base + plan.selcnt_off);
+  int selc[8];
+#pragma unroll
+  for (int l = 0; l < 8; l++) selc[l] = scp[l];
+  asm volatile("" :: "s"(selc[0]), "s"(selc[7]));   // (keeps the scalar loads on this side of the barrier: the compiler sinks them to their first use)
+  reinterpret_cast<uint32_t*>(s_pat)[threadIdx.x] = t_pat;
+  reinterpret_cast<uint32_t*>(s_icm)[threadIdx.x] = t_icm;
+  __syncthreads();
+  if (slot0 >= plan.sel_total) return;
+  int offset = 0, total = 0, cnt = 0;
 #pragma unroll
   for (int l = 0; l < PS_ORB_MAX_LEVELS; l++) {
     if (l < plan.nlevels) {
-      const int c = selcnt[l];
+      const int c = selc[l];
       if (l < level) offset += c;
+      if (l == level) cnt = c;
       total += c;
     }
   }
   if (slot0 == 0 && lane == 0) out_counts[img] = min(total, plan.kp_cap);
-  const int cnt = selcnt[level];
   if (k0 >= cnt) return;
   const int oi = offset + k;
   const bool valid = k < cnt && oi < plan.kp_cap;
