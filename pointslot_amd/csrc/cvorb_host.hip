@@ -284,6 +284,10 @@ int build_batch_plan(ps_cvorb* h, int w, int hgt, int cap) {
     int v, v0, vmax = cv_floor(hp * sqrtf(2.f) / 2 + 1), vmin = cv_ceil(hp * sqrtf(2.f) / 2);
     for (v = 0; v <= vmax; ++v) P.umax[v] = cv_round(sqrt((double)hp * hp - v * v));
     for (v = hp, v0 = 0; v >= vmin; --v) { while (P.umax[v0] == P.umax[v0 + 1]) ++v0; P.umax[v] = v0; ++v0; }
+    // cvb_describe reads the disc through the byte masks of describe_common.h (make_ictab), which are built from these sixteen numbers
+    static const int disc[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (v = 0; v <= hp; ++v)
+      if (P.umax[v] != disc[v]) return ps_set_error(PS_ERR_INVALID, "the intensity-centroid disc differs from the kernels' mask table");
   }
   for (int i = 0; i < 4; i++) P.kq[i] = h->kq[i];
   std::vector<int> quota(h->nlevels, 0);

@@ -15,6 +15,8 @@
 
 namespace {
 
+#include "describe_common.h"
+
 __constant__ __attribute__((aligned(16))) int8_t cv_pattern[1024] = {
 #include "orb_pattern.inc"
 };
@@ -1289,7 +1291,17 @@ __global__ __launch_bounds__(256) void cvb_select(CvbPlan P, int nslots) {
 #define CVB_DESC_T 64        // one wave = four keypoints per workgroup (7.5 KB of LDS): easier to place beside the other lockstep groups' kernels than
 #endif                     // sixteen keypoints and 30 KB (256 / 128 / 64 threads: 40.6 / 40.8 / 40.8 k frames/s)
 __global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_DESC_OCC, 8))) void cvb_describe(CvbPlan P, int nimg) {
-  __shared__ __attribute__((aligned(16))) uint8_t patch_all[CVB_DESC_T / 16][40 * 48];
+  // (r05: the body is orb_describe's - describe_common.h - on this detector's planes: the disc's moments from eight unaligned 8-byte loads
+  // per lane under byte masks with v_dot4, sin / cos by the [0, 2 pi] routine, the steered pattern on packed floats; before, the moments
+  // were 31 byte pairs per lane out of an LDS copy of the disc and sin / cos the general-purpose double routines: 1270 -> see DESIGN.md)
+  __shared__ uint4 s_pat[4][16];
+  __shared__ uint2 s_icm[8][16];
+  __shared__ uint32_t patch_all[CVB_DESC_T / 16][39 * 10];
+  for (int i = threadIdx.x; i < 256; i += CVB_DESC_T) {
+    reinterpret_cast<uint32_t*>(s_pat)[i] = reinterpret_cast<const uint32_t*>(&c_pattab)[i];
+    reinterpret_cast<uint32_t*>(s_icm)[i] = reinterpret_cast<const uint32_t*>(&c_ictab)[i];
+  }
+  __syncthreads();
   // (r05: one image per XCD at a time - the launch as (8 x blocks per image, images / 8) - cut this kernel's read requests from 11.3 M to 2.8 M per
   // 1024 images and made it SLOWER in the tracker's batches, 1.22 -> 1.45 ms per 3072 images: an object's keypoints crowd a few dozen lines, and 128
   // waves asking one L2 for them at once queue where eight L2s served them side by side.  The image's workgroups stay dealt over all XCDs.)
@@ -1304,6 +1316,8 @@ __global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_
     if (total > P.ocap) atomicAdd(&P.overflow[img], 1);
   }
   total = min(total, P.ocap);
+  uint32_t* patch = patch_all[(threadIdx.x >> 6) * 4 + grp];
+  const int r4 = l16 >> 2, c4 = l16 & 3;
   for (int k0 = (bx * (CVB_DESC_T / 64) + (threadIdx.x >> 6)) * 4; k0 < total; k0 += nbx * (CVB_DESC_T / 16)) {
     const bool live = k0 + grp < total;
     const int k = live ? k0 + grp : total - 1;
@@ -1318,62 +1332,61 @@ __global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_
     const CvSel S = P.sel[(size_t)(img * P.nlevels + l) * CVB_CAND_CAP + (k - base)];
     const CvLevelDev L = cvb_level(P, img, l);
     const int x0 = S.x, y0 = S.y;
-    // Both neighbourhoods of the keypoint go to LDS with row-coalesced loads (4 lanes x 12 bytes per row, aligned down: the rows' common
-    // byte shift is added at the reads): the 31 x 31 disc of the level plane for the intensity centroid, and the
-    // 39 x 39 neighbourhood of the blurred plane for the steered pattern (its taps stay within 19 pixels of the keypoint) - the byte
-    // gathers they replace (62 + 32 per lane) touch some 60 cache lines per load instruction.
-    uint8_t* patch = patch_all[(threadIdx.x >> 6) * 4 + grp];
     const float px = __fmul_rn((float)x0, L.scale), py = __fmul_rn((float)y0, L.scale);
     const float inv = __fdiv_rn(1.f, L.scale);
-    const int r4 = l16 >> 2, c4 = l16 & 3;
-    const uint32_t sd = (uint32_t)L.stride >> 2;     // row stride in dwords (the planes' strides are multiples of 64)
-    const uint8_t* ca = L.pad + (size_t)(CV_BORDER + y0 - 15) * L.stride + CV_BORDER + x0 - 15;
-    const uint32_t ashift = (uint32_t)(reinterpret_cast<uintptr_t>(ca) & 3);
+    // ---- the 39 x 39 neighbourhood of the blurred plane that the steered pattern can reach goes to LDS with row-coalesced loads (four
+    // lanes x 12 bytes per row, four rows per step, ten steps; issued first, consumed last), shifted to the patch's own first column ----
     const uint8_t* cb = L.blur + (size_t)(CV_BORDER + __float2int_rn(__fmul_rn(py, inv)) - 19) * L.stride + CV_BORDER + __float2int_rn(__fmul_rn(px, inv)) - 19;
     const uint32_t pshift = (uint32_t)(reinterpret_cast<uintptr_t>(cb) & 3);
+    const uint32_t sd = (uint32_t)L.stride >> 2;     // row stride in dwords (the planes' strides are multiples of 64)
     uint32_t tmp[10][3];
     {
-      uint32_t ta[8][3];
-      const uint32_t* qa = reinterpret_cast<const uint32_t*>(ca - ashift) + 3 * c4;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const uint32_t* r = qa + (uint32_t)(4 * i + r4) * sd;
-        ta[i][0] = r[0]; ta[i][1] = r[1]; ta[i][2] = r[2];
-      }
-      cvb_wave_sync();                               // the previous round's taps are read
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        uint32_t* d = reinterpret_cast<uint32_t*>(patch + (4 * i + r4) * 48) + 3 * c4;
-        d[0] = ta[i][0]; d[1] = ta[i][1]; d[2] = ta[i][2];
-      }
-      // the blurred neighbourhood is requested now (the disc's staging registers are free again) and arrives under the moments
       const uint32_t* q = reinterpret_cast<const uint32_t*>(cb - pshift) + 3 * c4;
 #pragma unroll
       for (int i = 0; i < 10; i++) {
-        const uint32_t* r = q + (uint32_t)(4 * i + r4) * sd;
+        // row 39 (i = 9, r4 = 3) does not exist in the neighbourhood: that lane repeats row 38 (never read)
+        const uint32_t* r = q + (uint32_t)(i < 9 || r4 < 3 ? 4 * i + r4 : 38) * sd;
         tmp[i][0] = r[0]; tmp[i][1] = r[1]; tmp[i][2] = r[2];
       }
     }
-    cvb_wave_sync();
-    int m10 = 0, m01 = 0;
+    // ---- ICAngles: m10 = sum u I, m01 = sum v I over the disc of the UNBLURRED plane: 32 rows x 4 groups of 8 columns = 128 items, 8 per lane,
+    // one unaligned 8-byte load each; disc mask and column weights (u + 15, as bytes) from a table:  m10 = sum (u + 15) I - 15 sum I ----
+    int m10, m01 = 0;
     {
-      // row +v and row -v of the disc on lane v of the keypoint's 16 lanes (lane 0: the centre row, counted once); the whole 31-column
-      // span is read, the disc mask picks the pixels that count
-      const int v = l16, d = P.umax[v];
-      const uint8_t* rp = patch + (15 + v) * 48 + 15 + ashift;
-      const uint8_t* rm = patch + (15 - v) * 48 + 15 + ashift;
-      int v_sum = 0;
+      const uint8_t* ca = L.pad + (size_t)(CV_BORDER + y0 - 15 + r4) * L.stride + CV_BORDER + x0 - 15 + 8 * c4;
+      uint2 pix[8];
 #pragma unroll
-      for (int u = -15; u <= 15; ++u) {
-        const int vp = rp[u], vm = rm[u];
-        const int in = (u >= -d && u <= d) ? 1 : 0;
-        v_sum += in * (vp - vm);
-        m10 += in * u * (v == 0 ? vp : vp + vm);
+      for (int j = 0; j < 8; j++) __builtin_memcpy(&pix[j], ca + (size_t)(4 * j) * L.stride, 8);
+      cvb_wave_sync();                               // the previous round's taps are read
+#pragma unroll
+      for (int i = 0; i < 10; i++) {
+        // the dword after the lane's three comes from the next lane of the quad
+        const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tmp[i][0], 0xF9 /* quad_perm [1,2,3,3] */, 0xF, 0xF, false);
+        const uint32_t o0 = __builtin_amdgcn_alignbyte(tmp[i][1], tmp[i][0], pshift), o1 = __builtin_amdgcn_alignbyte(tmp[i][2], tmp[i][1], pshift),
+                       o2 = __builtin_amdgcn_alignbyte(nxt, tmp[i][2], pshift);
+        uint32_t* d = patch + (4 * i + r4) * 10 + 3 * c4;
+        if (i < 9 || r4 < 3) {                     // row 39 does not exist
+          d[0] = o0;
+          if (c4 < 3) { d[1] = o1; d[2] = o2; }    // ten dwords per row: the fourth lane only has the last one
+        }
       }
-      m01 = v * v_sum;
-    }
+      int s0 = 0;
+      uint32_t acc = 0;
+      const int v0 = r4 - 15;
+      const uint32_t wlo = 0x03020100u + 0x08080808u * (uint32_t)c4, whi = wlo + 0x04040404u;   // u + 15 of the lane's eight columns
 #pragma unroll
-    for (int dd = 8; dd >= 1; dd >>= 1) { m10 += __shfl_xor(m10, dd); m01 += __shfl_xor(m01, dd); }
+      for (int j = 0; j < 8; j++) {
+        const uint2 mk = s_icm[j][l16];
+        const uint32_t qx = pix[j].x & mk.x, qy = pix[j].y & mk.y;
+        const uint32_t sr = __builtin_amdgcn_udot4(qy, 0x01010101u, __builtin_amdgcn_udot4(qx, 0x01010101u, 0u, false), false);
+        acc = __builtin_amdgcn_udot4(qy, whi, __builtin_amdgcn_udot4(qx, wlo, acc, false), false);
+        s0 += (int)sr;
+        m01 += (v0 + 4 * j) * (int)sr;
+      }
+      m10 = (int)acc - 15 * s0;
+    }
+    m10 = row_sum_i32(m10);
+    m01 = row_sum_i32(m01);
     const float angle_deg = cv_fast_atan2_deg((float)m01, (float)m10);
     if (live && l16 == 0) {
       ps_keypoint_pod o;
@@ -1381,30 +1394,49 @@ __global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_
       P.kps[(size_t)img * P.ocap + k] = o;
     }
     const float angle = __fmul_rn(angle_deg, (float)(3.14159265358979323846 / 180.f));
-    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
-    cvb_wave_sync();                                 // the disc is read
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-      uint32_t* d = reinterpret_cast<uint32_t*>(patch + (4 * i + r4) * 48) + 3 * c4;
-      d[0] = tmp[i][0]; d[1] = tmp[i][1]; d[2] = tmp[i][2];
-    }
+    double sn_d, cs_d;
+    sincos_0_2pi((double)angle, sn_d, cs_d, c_sincos);
+    const float a = (float)cs_d, b = (float)sn_d;
     cvb_wave_sync();
-    const uint8_t* c = patch + 19 * 48 + 19 + pshift;
-    for (int half = 0; half < 2; half++) {
-      const int byte = l16 + 16 * half;
-      const int8_t* pat = cv_pattern + byte * 32;
-      int tv[16];
+    // A pattern point (x, y) samples the blurred patch at row cvRound(x b + y a), column cvRound(x a - y b), every product and sum rounded to
+    // float (orb.cpp computeOrbDescriptors): two floats per instruction, cvRound by adding 1.5 * 2^23 (see orb_describe)
+    const ds_f2 ba = {b, a}, anb = {a, -b};
+    const unsigned long long ba64 = __builtin_bit_cast(unsigned long long, ba), anb64 = __builtin_bit_cast(unsigned long long, anb);
+    const unsigned long long magic64 = 0x4B4000004B400000ull;  // {1.5 * 2^23, 1.5 * 2^23}
+    typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+    const uint32_t kall = (uint32_t)(uintptr_t)(lds_u8*)reinterpret_cast<const uint8_t*>(patch) + (uint32_t)(19 * 40 + 19) - (0x400000u * 40u + 0x4B400000u);
+    uint32_t bits = 0;
+#pragma unroll 1
+    for (int t4 = 0; t4 < 4; t4++) {
+      const uint4 pw4 = s_pat[t4][l16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float fx = (float)pat[2 * i], fy = (float)pat[2 * i + 1];
-        const float rx = __fsub_rn(__fmul_rn(fx, a), __fmul_rn(fy, b)), ry = __fadd_rn(__fmul_rn(fx, b), __fmul_rn(fy, a));
-        tv[i] = c[__float2int_rn(ry) * 48 + __float2int_rn(rx)];
+      for (int tq = 0; tq < 4; tq++) {
+        const int tst = 4 * t4 + tq;
+        const uint32_t pw = tq == 0 ? pw4.x : tq == 1 ? pw4.y : tq == 2 ? pw4.z : pw4.w;
+        float4 pt;
+        pt.x = (float)(int8_t)(pw & 0xFF); pt.y = (float)(int8_t)((pw >> 8) & 0xFF); pt.z = (float)(int8_t)((pw >> 16) & 0xFF); pt.w = (float)(int8_t)(pw >> 24);
+        const unsigned long long xy0 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.x, pt.y}), xy1 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.z, pt.w});
+        unsigned long long T0, T1, Q0, Q1;
+        asm("v_pk_mul_f32 %0, %4, %6 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 %1, %5, %6 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 %2, %4, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+            "v_pk_mul_f32 %3, %5, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %8\n\t"
+            "v_pk_add_f32 %1, %1, %8\n\t"
+            "s_nop 0"
+            : "=&v"(T0), "=&v"(T1), "=&v"(Q0), "=&v"(Q1)
+            : "v"(xy0), "v"(xy1), "v"(ba64), "v"(anb64), "v"(magic64));
+        const uint32_t i0 = (uint32_t)__mul24((int)(uint32_t)T0, 40) + ((uint32_t)(T0 >> 32) + kall);
+        const uint32_t i1 = (uint32_t)__mul24((int)(uint32_t)T1, 40) + ((uint32_t)(T1 >> 32) + kall);
+        const int t0 = *(lds_u8*)(uintptr_t)i0, t1 = *(lds_u8*)(uintptr_t)i1;
+        bits |= (uint32_t)(t0 < t1) << tst;
       }
-      int val = 0;
-#pragma unroll
-      for (int tt = 0; tt < 8; tt++) val |= (tv[2 * tt] < tv[2 * tt + 1]) << tt;
-      if (live) P.desc[((size_t)img * P.ocap + k) * 32 + byte] = (uint8_t)val;
     }
+    if (live) reinterpret_cast<uint16_t*>(P.desc + ((size_t)img * P.ocap + k) * 32)[l16] = (uint16_t)bits;
   }
 }
 
