@@ -716,6 +716,9 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
       if (lane == 0) cellcnt[cell] = 0;
       return;
 #endif
+#if FAST_STOP == 6      // second pass only: return after its compass test
+      if (pass == 1) { if (lane == 0) cellcnt[cell] = nd + nb; return; }
+#endif
       // ---- C: exact scores, two entries per lane: entry k of the concatenation [dark entries, bright entries] ----
       const int ntot = nd + nb;
       for (int i0 = 0; i0 < ntot; i0 += 128) {
@@ -756,6 +759,9 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
 #if FAST_STOP == 3
       if (lane == 0) cellcnt[cell] = 0;
       return;
+#endif
+#if FAST_STOP == 7      // second pass only: return after its scores
+      if (pass == 1) { if (lane == 0) cellcnt[cell] = 0; return; }
 #endif
       if (!full) break;
       wave_sync();
