@@ -111,6 +111,15 @@ __global__ __launch_bounds__(OB_MASK_T) void ob_masks(ObArrays A, uint8_t* objma
         if (vv[u]) local = x + 3 - (__builtin_clz(vv[u]) >> 3);
       }
     }
+    // a row without a labelled pixel (most rows: the objects cover a few percent of the image) leaves two rows of zeros and no cell
+    // (r05: the kernel is bound by vector instruction issue - 1.0 busy in tools/valu_busy.sh - and nine tenths of them are the
+    // per-pixel passes below)
+    if (!__any(local >= 0)) {
+      uint8_t* L0 = objmask + ((size_t)(2 * s) * H + y) * ostride;
+      uint8_t* R0 = objmask + ((size_t)(2 * s + 1) * H + y) * ostride;
+      for (int x4 = lane * 4; x4 < ostride; x4 += 256) { *reinterpret_cast<uint32_t*>(L0 + x4) = 0u; *reinterpret_cast<uint32_t*>(R0 + x4) = 0u; }
+      return;
+    }
     // run[c] = rightmost labelled column <= c (-1: none): the exclusive prefix maximum over the lanes, then the lane's own pixels
     int incl = local;
 #pragma unroll

@@ -1,0 +1,34 @@
+#!/bin/bash
+# developer tool: how busy the vector ALUs / the LDS are per kernel of the step: one lockstep group of 512 sequences (kernels one after the other).
+# A plain run first: the counter passes read the rendered sequences from the cache it leaves.
+A="--no-cpu --no-secondary --no-alone --groups 1 --sequences 512 --steps 3 --warmup 2"
+python3 bench.py $A > /dev/null 2>&1
+R=$PWD; export TMPDIR=/tmp
+pass() {
+  cd /tmp; rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $R/gpurun_out/$1 -o pmc -- python3 $R/bench.py $A > $R/gpurun_out/$1.log 2>&1; cd $R
+}
+pass vb1 "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+pass vb2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+python3 - <<'PY'
+import csv,glob,collections
+tab=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
+for d in ('vb1','vb2'):
+    f=glob.glob('gpurun_out/%s/*counter_collection.csv'%d)
+    if not f: print('no csv for',d); continue
+    seen=collections.Counter()
+    for r in csv.DictReader(open(f[0])):
+        k=r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','')[:34]
+        tab[k][d+':'+r['Counter_Name']]+=float(r['Counter_Value'])
+print('%-36s %9s %8s %8s %8s %8s %8s' % ('kernel (all launches of the run)', 'VALU busy', 'waves/SIMD', 'wait', 'LDS busy', 'conflict', 'VALU/wave'))
+for k,v in sorted(tab.items(), key=lambda kv: -kv[1].get('vb1:GRBM_GUI_ACTIVE',0)):
+    gui=v.get('vb1:GRBM_GUI_ACTIVE',0)/8.0            # cycles of the launch(es): the counter is summed over the 8 XCDs
+    if gui<=0: continue
+    simd=gui*1024.0
+    valu=4*v.get('vb1:SQ_ACTIVE_INST_VALU',0)/simd
+    occ=4*v.get('vb1:SQ_WAVE_CYCLES',0)/simd
+    wait=v.get('vb1:SQ_WAIT_INST_ANY',0)/max(v.get('vb1:SQ_WAVE_CYCLES',1),1)
+    gui2=v.get('vb2:GRBM_GUI_ACTIVE',0)/8.0
+    lds=v.get('vb2:SQ_LDS_IDX_ACTIVE',0)/(gui2*256.0) if gui2 else 0
+    conf=v.get('vb2:SQ_LDS_BANK_CONFLICT',0)/max(v.get('vb2:SQ_LDS_IDX_ACTIVE',1),1)
+    print('%-36s %8.2f %9.1f %8.2f %8.2f %8.2f %9.0f' % (k, valu, occ, wait, lds, conf, v.get('vb1:SQ_INSTS_VALU',0)/max(v.get('vb1:SQ_WAVES',1),1)))
+PY
