@@ -739,10 +739,34 @@ __global__ __launch_bounds__(CVB_TT) void cvb_resize(CvbPlan P, int l) {
     int cx[4]; cvb_us2 xw[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { const int4 v = xt[c4 + j]; cx[j] = v.x - ox; xw[j] = __builtin_bit_cast(cvb_us2, (uint32_t)v.y | ((uint32_t)v.z << 16)); }
+    // r05 (tools/valu_busy.sh: the LDS busy 0.57 of the kernel's time, half of it bank conflicts, the vector ALUs 0.46): the eight source
+    // bytes a lane's four pixels can touch - taps min cx .. max cx + 1, at most 8 apart for scale factors up to 2 - come as THREE ALIGNED
+    // dwords per source row + v_alignbyte, and v_perm_b32 picks each pixel's (b0, b1) pair as packed u16 (orb_level_fused's form): 4 LDS
+    // reads per output row where the byte reads were 16.  (Wider spans - scale factors above 2 - keep the byte reads.)
+    // (the columns of a tile are not monotonic where the border reflects: the window starts at the smallest tap)
+    const int cmin = min(min(cx[0], cx[1]), min(cx[2], cx[3])), cmax = max(max(cx[0], cx[1]), max(cx[2], cx[3]));
+    const bool narrow = __all(cmax - cmin <= 6);
+    uint32_t psel[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const uint32_t dj = (uint32_t)(cx[j] - cmin); psel[j] = dj | 0x0c000c00u | ((dj + 1u) << 16); }
     auto interp4 = [&](const uint8_t* rowa, const uint8_t* rowb, cvb_us2 yw, uint32_t* o) {
-      // (one unaligned 8-byte LDS read per source row + v_perm_b32 per pixel instead of the byte reads: 16 % fewer instructions, 3 %
-      // slower - a misaligned ds_read_b64 takes several passes; r05: the two taps as ONE ds_read_u16 at the byte address: the stage
-      // 2.5 -> 3.9 ms per 512 sequences - LDS reads that are not naturally aligned are to be avoided at every size)
+      if (narrow) {
+        const uint8_t* pa = rowa + cmin;
+        const uint8_t* pb = rowb + cmin;
+        const uint32_t sa = (uint32_t)(uintptr_t)pa & 3u, sb = (uint32_t)(uintptr_t)pb & 3u;
+        const uint32_t* qa = reinterpret_cast<const uint32_t*>(pa - sa);
+        const uint32_t* qb = reinterpret_cast<const uint32_t*>(pb - sb);
+        const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
+        const uint32_t al = __builtin_amdgcn_alignbyte(a1, a0, sa), ah = __builtin_amdgcn_alignbyte(a2, a1, sa);
+        const uint32_t bl = __builtin_amdgcn_alignbyte(b1, b0, sb), bh = __builtin_amdgcn_alignbyte(b2, b1, sb);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(cvb_us2, __builtin_amdgcn_perm(ah, al, psel[j])), xw[j], 0u, false);
+          const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(cvb_us2, __builtin_amdgcn_perm(bh, bl, psel[j])), xw[j], 0u, false);
+          o[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(cvb_us2, h0 | (h1 << 16)), yw, 32768u, false) >> 16;
+        }
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const uint32_t wa = (uint32_t)rowa[cx[j]] | ((uint32_t)rowa[cx[j] + 1] << 8), wb = (uint32_t)rowb[cx[j]] | ((uint32_t)rowb[cx[j] + 1] << 8);
