@@ -244,9 +244,12 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
       s0[k] = t.x; s1[k] = t.y; coef[k] = (uint32_t)t.z | ((uint32_t)t.w << 16);
     }
   }
-  const int sb = min(min(s0[0], s0[1]), min(s0[2], s0[3]));
+  // first byte of the lane's 8-byte source window: the smallest tap; at level 0 - whose rows are the caller's, with nothing behind the
+  // last one - pulled back so that the window ends inside the row (r05: lanes at the image's left / right edge took the byte gather
+  // before, and with them, since the window test is per wave, every wave of the two edge tiles of a tile row)
+  const int sb = LEVEL0 ? min(min(min(s0[0], s0[1]), min(s0[2], s0[3])), L.w - 8) : min(min(s0[0], s0[1]), min(s0[2], s0[3]));
   uint32_t sel[4];
-  bool fast = true;
+  bool fast = !LEVEL0 || L.w >= 8;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int i0 = s0[k] - sb, i1 = s1[k] - sb;
@@ -260,12 +263,10 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
   uint32_t srel, src_stride;
   if (LEVEL0) {
     sbase = imgs + (size_t)img * img_pitch; srel = 0; src_stride = (uint32_t)img_stride;
-    fast = fast && sb >= 4 && sb + 12 <= L.w;        // the aligned 12-byte window must stay inside the caller's row
   } else {
     const OrbLevel S = plan.lv[level - 1];
     sbase = base; srel = S.plane_off + (uint32_t)(PS_EDGE * S.stride + PS_EDGE); src_stride = (uint32_t)S.stride;
   }
-  const uint32_t sbase_lo = (uint32_t)reinterpret_cast<uintptr_t>(sbase);
   const bool fast_wave = __all(fast);
   const bool own_x = lane >= 1 && lane <= 62 && P0 + 4 * lane < PW;
   uint8_t* plane = base + L.plane_off;
@@ -321,11 +322,9 @@ __global__ __launch_bounds__(64 * LV_WAVES) __attribute__((amdgpu_waves_per_eu(P
         if (v == 0 && !need0[r]) continue;
         const uint32_t roff = srel + (uint32_t)(v == 0 ? ty[r].x : ty[r].y) * src_stride;   // wave-uniform
         if (fast) {
-          const uint32_t sh = (sbase_lo + roff + (uint32_t)sb) & 3u;
-          const uint32_t* q = reinterpret_cast<const uint32_t*>(sbase + (roff + (uint32_t)sb - sh));
-          const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-          wl[r][v] = __builtin_amdgcn_alignbyte(d1, d0, sh);
-          wh[r][v] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+          uint2 w;
+          __builtin_memcpy(&w, sbase + (roff + (uint32_t)sb), 8);
+          wl[r][v] = w.x; wh[r][v] = w.y;
         } else {
           // generic gather (image edges of level 0, scale factors above 2): byte k <- s0[k], byte 4 + k <- s1[k]
           // (32-bit offsets from the wave-uniform base: as 64-bit lane addresses the eight sign-extended indices held 16 registers for the whole phase)
