@@ -1406,9 +1406,9 @@ __global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_
         const uint32_t sr = __builtin_amdgcn_udot4(qy, 0x01010101u, __builtin_amdgcn_udot4(qx, 0x01010101u, 0u, false), false);
         acc = __builtin_amdgcn_udot4(qy, whi, __builtin_amdgcn_udot4(qx, wlo, acc, false), false);
         s0 += (int)sr;
-        m01 += (v0 + 4 * j) * (int)sr;
+        m01 += __mul24(v0 + 4 * j, (int)sr);            // (24-bit: a full 32-bit multiply issues at a quarter of the rate)
       }
-      m10 = (int)acc - 15 * s0;
+      m10 = (int)acc - __mul24(15, s0);
     }
     m10 = row_sum_i32(m10);
     m01 = row_sum_i32(m01);
@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_
     }
     const float angle = __fmul_rn(angle_deg, (float)(3.14159265358979323846 / 180.f));
     double sn_d, cs_d;
-    sincos_0_2pi((double)angle, sn_d, cs_d, c_sincos);
+    sincos_0_2pi((double)angle, sn_d, cs_d, sincos_table());
     const float a = (float)cs_d, b = (float)sn_d;
     cvb_wave_sync();
     // A pattern point (x, y) samples the blurred patch at row cvRound(x b + y a), column cvRound(x a - y b), every product and sum rounded to

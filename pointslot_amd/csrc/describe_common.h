@@ -82,6 +82,14 @@ __constant__ double c_sincos[16] = {0.63661977236758134308, 1.570796326734125614
                                     -1.13585365213876817300e-11, 2.08757008419747316778e-9, -2.75573141792967388112e-7,
                                     2.48015872888517045348e-5, -1.38888888888730564116e-3, 4.16666666666665929218e-2, 0.0};
 
+// the table's address behind an empty asm statement: seen through, the compiler replaces every coefficient by a 64-bit literal - two
+// vector moves per use (24 in all) - where a scalar load brings it once
+__device__ __forceinline__ const double* sincos_table() {
+  const double* t = c_sincos;
+  asm volatile("" : "+s"(t));
+  return t;
+}
+
 // sum over the 16 lanes of a DPP row, left in every lane of the row: xor-1, xor-2, half-row mirror, row mirror
 __device__ __forceinline__ int row_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]

@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_DESC_WAV
   const int r4 = l16 >> 2, c4 = l16 & 3;
   uint32_t tmp[10][3];
   {
-    const uint32_t loff = L.blur_off + (uint32_t)((ky - 19 + r4) * L.bstride + (kx - 19 - pshift) + 12 * c4);
+    const uint32_t loff = L.blur_off + (uint32_t)(__mul24(ky - 19 + r4, L.bstride) + (kx - 19 - pshift) + 12 * c4);
     const uint32_t s4 = 4u * (uint32_t)L.bstride;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_DESC_WAV
   // v_dot4_u32_u8 and a multiply-add:  m10 = sum (u + 15) I - 15 sum I,   m01 = sum_rows v * (row sum) ----
   int m10, m01 = 0;
   {
-    const uint32_t coff = L.plane_off + (uint32_t)((PS_EDGE + ky - 15 + r4) * L.stride + PS_EDGE + kx - 15 + 8 * c4);
+    const uint32_t coff = L.plane_off + (uint32_t)(__mul24(PS_EDGE + ky - 15 + r4, L.stride) + PS_EDGE + kx - 15 + 8 * c4);
     const uint32_t s4 = 4u * (uint32_t)L.stride;
     uint2 pix[8];
 #pragma unroll
@@ -1424,9 +1424,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_DESC_WAV
       const uint32_t sr = __builtin_amdgcn_udot4(py, 0x01010101u, __builtin_amdgcn_udot4(px, 0x01010101u, 0u, false), false);
       acc = __builtin_amdgcn_udot4(py, whi, __builtin_amdgcn_udot4(px, wlo, acc, false), false);
       s0 += (int)sr;
-      m01 += (v0 + 4 * j) * (int)sr;
+      m01 += __mul24(v0 + 4 * j, (int)sr);            // (24-bit: a full 32-bit multiply issues at a quarter of the rate)
     }
-    m10 = (int)acc - 15 * s0;
+    m10 = (int)acc - __mul24(15, s0);
   }
   m10 = row_sum_i32(m10);
   m01 = row_sum_i32(m01);
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_DESC_WAV
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float arad = __fmul_rn(angle, factorPI);
   double sn_d, cs_d;
-  sincos_0_2pi((double)arad, sn_d, cs_d, c_sincos);
+  sincos_0_2pi((double)arad, sn_d, cs_d, sincos_table());
   const float a = (float)cs_d, b = (float)sn_d;
   wave_sync();
   // A point (x, y) of the pattern samples the blurred patch at row cvRound(x b + y a), column cvRound(x a - y b)
