@@ -188,7 +188,9 @@ __device__ __forceinline__ uint32_t ps_sat_pack4_hi16(uint32_t a, uint32_t b, ui
   asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi) : "v"(cd));
   return lo | (hi << 16);
 }
+#ifndef LV_RPT
 #define LV_RPT 10                 // region rows per thread
+#endif
 #ifndef LV_WAVES
 #define LV_WAVES 4                // waves per workgroup: each takes LV_RPT region rows
 #endif
