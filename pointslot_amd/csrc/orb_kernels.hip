@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void orb_pyramid_level(OrbPlan plan, int level
 // level's GaussianBlur plane (ORBextractor.cc:1107-1132 + :1085-1086), replacing orb_pyramid_level + orb_border + orb_blur.
 //   * The output domain is the padded plane; a padded pixel (px, py) is the level pixel (reflect101(px - 19),
 //     reflect101(py - 19)), so the border is just more resize evaluations - no second pass, no read-back.
-//   * A workgroup owns 248 x 34 padded pixels and evaluates a 256 x 40 region (4 / 3 pixels of halo) into LDS;
+//   * A workgroup owns 248 x 50 padded pixels and evaluates a 256 x 56 region (4 / 3 pixels of halo) into LDS;
 //     the 7x7 blur of the owned in-image pixels is then taken from LDS, so the plane is never re-read from HBM.
 //   * Arithmetic: the 8 source bytes that the 4 pixels of a lane can touch are brought into two registers
 //     (3 aligned dword loads + v_alignbyte); v_perm_b32 extracts each pixel's (b0, b1) pair as packed u16 and
@@ -189,8 +189,8 @@ __device__ __forceinline__ uint32_t ps_sat_pack4_hi16(uint32_t a, uint32_t b, ui
   return lo | (hi << 16);
 }
 #ifndef LV_RPT
-#define LV_RPT 10                 // region rows per thread
-#endif
+#define LV_RPT 14                 // region rows per thread (r05: 14 rows in two groups of 7 - 56-row regions, 50 owned: less halo and 13 + 6 instead of
+#endif                            // 9 + 6 rows in a thread's blur chunk; ORB 6.36 -> 6.27 ms per 512 sequences; 12: 6.35, 8: 6.49, 16 spills)
 #ifndef LV_WAVES
 #define LV_WAVES 4                // waves per workgroup: each takes LV_RPT region rows
 #endif
@@ -198,10 +198,10 @@ __device__ __forceinline__ uint32_t ps_sat_pack4_hi16(uint32_t a, uint32_t b, ui
 #define LV_OWN_R (LV_R - 6)       // owned rows
 #define LV_OWN_C 248              // owned columns (62 dword groups; lanes 0 and 63 are halo)
 #ifndef LV_HALVES
-#define LV_HALVES 1            // the region rows of a thread are loaded and resized in this many groups (r05: 1 - with two registers per row load all ten rows' loads fit; 2: 43.6, 1: 43.85, 5: 43.4 k frames/s)
+#define LV_HALVES 2            // the region rows of a thread are loaded and resized in this many groups (with LV_RPT 10: 1 -> 43.85, 2 -> 43.6, 5 -> 43.4 k frames/s)
 #endif
 #define LV_HROWS (LV_RPT / LV_HALVES)
-#define LV_BLUR_ROWS ((LV_OWN_R + LV_WAVES - 1) / LV_WAVES)   // LV_WAVES row chunks cover the owned rows (9 of 34 with 4 waves)
+#define LV_BLUR_ROWS ((LV_OWN_R + LV_WAVES - 1) / LV_WAVES)   // LV_WAVES row chunks cover the owned rows (13 of 50 with 4 waves)
 typedef unsigned short lv_us2 __attribute__((ext_vector_type(2)));
 
 #ifdef PS_LV_PROFILE   // developer build: 100 MHz ticks of one workgroup in the middle of the launch
