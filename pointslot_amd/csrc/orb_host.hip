@@ -14,7 +14,7 @@
 
 extern "C" {
 void psk_orb_launch_pyramid(const OrbPlan*, int, uint8_t*, const uint8_t*, int, size_t, const int4*, int, hipStream_t);
-void psk_orb_launch_fast(const OrbPlan*, uint8_t*, int, const uint8_t*, int, size_t, hipStream_t);
+void psk_orb_launch_fast(const OrbPlan*, uint8_t*, int, const uint8_t*, int, size_t, const int4*, hipStream_t);
 void psk_orb_launch_quadtree(const OrbPlan*, uint8_t*, int, hipStream_t);
 void psk_orb_launch_blur(const OrbPlan*, uint8_t*, int, hipStream_t);
 void psk_orb_launch_border(const OrbPlan*, uint8_t*, int, hipStream_t);
@@ -266,6 +266,15 @@ int build_plan(ps_orb* h, int w, int hgt) {
     P.border_blocks = nb;
   }
   P.n_cells = cells;
+  {   // per cell: its level and its position in the level's cell grid (orb_fast_cells reads the word with one scalar load instead of
+      // searching the level and dividing by the grid width on the scalar unit)
+    P.celltab_off = (uint32_t)h->tabs_host.size();
+    std::vector<uint32_t> ct((size_t)((cells + 3) & ~3), 0u);
+    for (int l = 0; l < nl; l++)
+      for (int c = 0; c < P.lv[l].n_cols * P.lv[l].n_rows; c++)
+        ct[(size_t)P.lv[l].cell_base + c] = (uint32_t)l | ((uint32_t)(c % P.lv[l].n_cols) << 4) | ((uint32_t)(c / P.lv[l].n_cols) << 18);
+    for (size_t i = 0; i < ct.size(); i += 4) h->tabs_host.push_back(make_int4((int)ct[i], (int)ct[i + 1], (int)ct[i + 2], (int)ct[i + 3]));
+  }
   P.sel_total = sel;
   P.kp_cap = (int)align_up(sel, 64);
   off = align_up(off, 256); P.cellcnt_off = off; off += (size_t)cells * 4;
@@ -328,7 +337,7 @@ int run_batch(ps_orb* h, const uint8_t* d_imgs, int nimg, int stride, size_t pit
       h->input_read_pending = true;
     }
     if (tm) PS_HIP(hipEventRecord(ev[1], st));
-    psk_orb_launch_fast(P, arena, n, h->d_mask ? h->d_mask + (size_t)i0 * h->mask_pitch : nullptr, h->mask_stride, h->mask_pitch, st);
+    psk_orb_launch_fast(P, arena, n, h->d_mask ? h->d_mask + (size_t)i0 * h->mask_pitch : nullptr, h->mask_stride, h->mask_pitch, h->d_tabs, st);
     if (tm) PS_HIP(hipEventRecord(ev[2], st));
     psk_orb_launch_quadtree(P, arena, n, st);
     if (tm) PS_HIP(hipEventRecord(ev[3], st));

@@ -577,8 +577,8 @@ __host__ __device__ __forceinline__ FastLds fast_lds(int TS, int TR, int LCAP) {
 #define PS_FAST_WAVES 8        // waves per SIMD the register allocation aims at (the LDS of the usual cells admits 8 workgroups per CU)
 #endif
 template <int TS, int LG, int MAXROWS>
-__global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_WAVES, 8))) void orb_fast_cells(OrbPlan plan, uint8_t* arena, int TR, int LCAP, int nimg, int bpi,
-                                                         const uint8_t* masks, int mask_stride, size_t mask_pitch) {
+__global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_WAVES, 8))) void orb_fast_cells(OrbPlan plan, uint8_t* arena, FastLds F, int nimg, int bpi,
+                                                         const uint8_t* masks, int mask_stride, size_t mask_pitch, const uint32_t* celltab) {
   constexpr int NG = 1 << LG, RPS = 64 >> LG;          // groups per row = loader lanes per row; rows per 64-lane step
   constexpr int NPASS = (MAXROWS + RPS - 1) / RPS;
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
@@ -588,20 +588,20 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
   const int cell = lb * 4 + wave;
   if (cell >= plan.n_cells) return;
   constexpr int SS = TS;                               // score-map row stride = window row stride
-  const FastLds F = fast_lds(TS, TR, LCAP);
+  // (r05: the scalar unit is the busiest unit of this kernel - 0.79 against 0.75 for the vector ALUs, tools/valu_busy.sh - : the LDS
+  // layout comes from the host, and the cell's level and grid position from a table, one scalar load, where the level was searched and
+  // the cell index divided by the grid width)
   uint8_t* tile = fast_smem + (size_t)wave * F.total;
   uint8_t* smap = tile + F.smap;
   unsigned long long* bmp = reinterpret_cast<unsigned long long*>(tile + F.bmp);
   uint16_t* list = reinterpret_cast<uint16_t*>(tile + F.list);
   const int CAP = F.cap;
   uint8_t* base = arena + (size_t)img * plan.arena_bytes;
-  int level = 0;
-#pragma unroll
-  for (int l = 1; l < PS_ORB_MAX_LEVELS; l++)
-    if (l < plan.nlevels && cell >= plan.lv[l].cell_base) level = l;
+  typedef const uint32_t __attribute__((address_space(4))) * celltab_ptr;          // wave-uniform address, written once when the plan was made
+  const uint32_t crec = ((celltab_ptr)(uintptr_t)celltab)[cell];
+  const int level = (int)(crec & 15u), ci_x = (int)((crec >> 4) & 0x3FFFu), ci_y = (int)(crec >> 18);
   const OrbLevel& L = plan.lv[level];
   const int ci = cell - L.cell_base;
-  const int ci_y = ci / L.n_cols, ci_x = ci - ci_y * L.n_cols;
   int32_t* cellcnt = reinterpret_cast<int32_t*>(base + plan.cellcnt_off);
   const int maxBX = L.w - PS_MINB, maxBY = L.h - PS_MINB;
   const int iniX = PS_MINB + ci_x * L.w_cell, iniY = PS_MINB + ci_y * L.h_cell;
@@ -686,15 +686,23 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
           const fs_us2 m = __builtin_elementwise_min(__builtin_elementwise_max(pN, pS), __builtin_elementwise_max(pE, pW));
           const fs_s2 dd = cv - __builtin_bit_cast(fs_s2, M);         // > th: two adjacent compass points darker than v - th
           const fs_s2 bb = __builtin_bit_cast(fs_s2, m) - cv;         // > th: two adjacent compass points brighter than v + th
-          DK[2 * pq] = __builtin_amdgcn_ballot_w64(dd.x > thv[pq].x) & rv;
-          DK[2 * pq + 1] = __builtin_amdgcn_ballot_w64(dd.y > thv[pq].y) & rv;
-          BR[2 * pq] = __builtin_amdgcn_ballot_w64(bb.x > thv[pq].x) & rv;
-          BR[2 * pq + 1] = __builtin_amdgcn_ballot_w64(bb.y > thv[pq].y) & rv;
+          DK[2 * pq] = __builtin_amdgcn_ballot_w64(dd.x > thv[pq].x);
+          DK[2 * pq + 1] = __builtin_amdgcn_ballot_w64(dd.y > thv[pq].y);
+          BR[2 * pq] = __builtin_amdgcn_ballot_w64(bb.x > thv[pq].x);
+          BR[2 * pq + 1] = __builtin_amdgcn_ballot_w64(bb.y > thv[pq].y);
         }
-        int nstep = 0;
+        // (scalar-unit diet, r05: the row mask only where a step is partial - the cell's last one -, and the step's survivor count only
+        // where the region could overflow at all: a step adds at most 512 entries)
+        if (nl < 64) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) nstep += __popcll(DK[i]) + __popcll(BR[i]);
-        if (nd + nb + nstep > CAP) { full = true; break; }   // (a step adds at most 512 entries <= CAP: an empty region always takes it)
+          for (int i = 0; i < 4; i++) { DK[i] &= rv; BR[i] &= rv; }
+        }
+        if (nd + nb + 512 > CAP) {
+          int nstep = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) nstep += __popcll(DK[i]) + __popcll(BR[i]);
+          if (nd + nb + nstep > CAP) { full = true; break; }   // (512 <= CAP: an empty region always takes a step)
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           if (DK[i]) {                                   // wave-uniform
@@ -1532,7 +1540,7 @@ extern "C" void psk_orb_launch_level_fused(const OrbPlan* plan, int level, uint8
 extern "C" void psk_orb_launch_border(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {
   hipLaunchKernelGGL(orb_border, dim3(plan->border_blocks, nimg), dim3(256), 0, st, *plan, arena);
 }
-extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nimg, const uint8_t* masks, int mask_stride, size_t mask_pitch, hipStream_t st) {
+extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nimg, const uint8_t* masks, int mask_stride, size_t mask_pitch, const int4* tabs, hipStream_t st) {
   // LDS geometry from the largest cell window of the plan
   int mw = 0, mh = 0;
   for (int l = 0; l < plan->nlevels; l++) {
@@ -1542,14 +1550,15 @@ extern "C" void psk_orb_launch_fast(const OrbPlan* plan, uint8_t* arena, int nim
   const int TR = mh;
   const int LCAP = (mw - 6) * (mh - 6);
   const int bpi = (plan->n_cells + 3) / 4;
+  const uint32_t* celltab = reinterpret_cast<const uint32_t*>(tabs + plan->celltab_off);
   if (mw <= 38 && mh <= 48) {      // cells up to 32 px wide (30-px cells of the usual image sizes): 8 groups per row, 8 rows per step
     const FastLds F = fast_lds(40, TR, LCAP);
-    hipLaunchKernelGGL((orb_fast_cells<40, 3, 48>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, TR, LCAP,
-                       nimg, bpi, masks, mask_stride, mask_pitch);
+    hipLaunchKernelGGL((orb_fast_cells<40, 3, 48>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, F,
+                       nimg, bpi, masks, mask_stride, mask_pitch, celltab);
   } else {                         // up to PS_FAST_WIN: 16 groups per row, 4 rows per step
     const FastLds F = fast_lds(72, TR, LCAP);
-    hipLaunchKernelGGL((orb_fast_cells<72, 4, 68>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, TR, LCAP,
-                       nimg, bpi, masks, mask_stride, mask_pitch);
+    hipLaunchKernelGGL((orb_fast_cells<72, 4, 68>), PS_XCD_GRID(bpi, nimg), dim3(FAST_T), (size_t)F.total * 4, st, *plan, arena, F,
+                       nimg, bpi, masks, mask_stride, mask_pitch, celltab);
   }
 }
 extern "C" void psk_orb_launch_quadtree(const OrbPlan* plan, uint8_t* arena, int nimg, hipStream_t st) {

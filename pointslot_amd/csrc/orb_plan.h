@@ -53,6 +53,7 @@ struct OrbPlan {
   uint64_t sel_base;        // u32[sel_total]
   uint64_t selcnt_off;      // int32[PS_ORB_MAX_LEVELS]
   uint64_t ncand_off;       // int32[PS_ORB_MAX_LEVELS] (diagnostic: candidates per level)
+  uint32_t celltab_off;     // in int4 units into the plan's table buffer: u32[n_cells] = level | cell column << 4 | cell row << 18 (orb_fast_cells)
 };
 
 // one stereo pair for the stereo matcher (orb_stereo.hip): raw device pointers so that the left and the right image may
