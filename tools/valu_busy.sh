@@ -19,7 +19,7 @@ for d in ('vb1','vb2'):
     for r in csv.DictReader(open(f[0])):
         k=r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','')[:34]
         tab[k][d+':'+r['Counter_Name']]+=float(r['Counter_Value'])
-print('%-36s %9s %8s %8s %8s %8s %8s' % ('kernel (all launches of the run)', 'VALU busy', 'waves/SIMD', 'wait', 'LDS busy', 'conflict', 'VALU/wave'))
+print('%-36s %9s %9s %9s %8s %8s %8s %8s' % ('kernel (all launches of the run)', 'VALU busy', 'SALU busy', 'waves/SIMD', 'wait', 'LDS busy', 'conflict', 'VALU/wave'))
 for k,v in sorted(tab.items(), key=lambda kv: -kv[1].get('vb1:GRBM_GUI_ACTIVE',0)):
     gui=v.get('vb1:GRBM_GUI_ACTIVE',0)/8.0            # cycles of the launch(es): the counter is summed over the 8 XCDs
     if gui<=0: continue
@@ -30,5 +30,6 @@ for k,v in sorted(tab.items(), key=lambda kv: -kv[1].get('vb1:GRBM_GUI_ACTIVE',0
     gui2=v.get('vb2:GRBM_GUI_ACTIVE',0)/8.0
     lds=v.get('vb2:SQ_LDS_IDX_ACTIVE',0)/(gui2*256.0) if gui2 else 0
     conf=v.get('vb2:SQ_LDS_BANK_CONFLICT',0)/max(v.get('vb2:SQ_LDS_IDX_ACTIVE',1),1)
-    print('%-36s %8.2f %9.1f %8.2f %8.2f %8.2f %9.0f' % (k, valu, occ, wait, lds, conf, v.get('vb1:SQ_INSTS_VALU',0)/max(v.get('vb1:SQ_WAVES',1),1)))
+    sca=4*v.get('vb2:SQ_ACTIVE_INST_SCA',0)/(gui2*1024.0) if gui2 else 0      # one scalar unit per CU, one instruction per cycle
+    print('%-36s %8.2f %9.2f %9.1f %8.2f %8.2f %8.2f %9.0f' % (k, valu, sca, occ, wait, lds, conf, v.get('vb1:SQ_INSTS_VALU',0)/max(v.get('vb1:SQ_WAVES',1),1)))
 PY
