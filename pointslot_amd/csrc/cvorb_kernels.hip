@@ -1438,9 +1438,9 @@ __global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_
       for (int tq = 0; tq < 4; tq++) {
         const int tst = 4 * t4 + tq;
         const uint32_t pw = tq == 0 ? pw4.x : tq == 1 ? pw4.y : tq == 2 ? pw4.z : pw4.w;
-        float4 pt;
-        pt.x = (float)(int8_t)(pw & 0xFF); pt.y = (float)(int8_t)((pw >> 8) & 0xFF); pt.z = (float)(int8_t)((pw >> 16) & 0xFF); pt.w = (float)(int8_t)(pw >> 24);
-        const unsigned long long xy0 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.x, pt.y}), xy1 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.z, pt.w});
+        // (one packed conversion per point: FP8 bytes -> {x, y} as a float pair; operands as 64-bit integers: register pairs)
+        const unsigned long long xy0 = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_cvt_pk_f32_fp8((int)pw, false)),
+                                 xy1 = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_cvt_pk_f32_fp8((int)pw, true));
         unsigned long long T0, T1, Q0, Q1;
         asm("v_pk_mul_f32 %0, %4, %6 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
             "v_pk_mul_f32 %1, %5, %6 op_sel:[0,0] op_sel_hi:[0,1]\n\t"

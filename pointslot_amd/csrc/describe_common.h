@@ -7,18 +7,35 @@ constexpr int8_t k_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 // the pattern for orb_describe's lane layout: lane l of a 16-lane group owns tests 16 l .. 16 l + 15 (two descriptor bytes);
-// word [jj][l][t] = test 16 l + 4 jj + t as four signed bytes (x0, y0, x1, y1).  The workgroup copies it to LDS, where lane l
+// word [jj][l][t] = test 16 l + 4 jj + t as four bytes (x0, y0, x1, y1).  The workgroup copies it to LDS, where lane l
 // reads four 16-byte rows (consecutive lanes, consecutive rows: no bank conflicts).
+// r05: the four coordinates are stored as FP8 (OCP E4M3: every integer up to 15 in magnitude is exact; the pattern's are -13 .. 12), so
+// that ONE v_cvt_pk_f32_fp8 turns a point's (x, y) into the packed float pair the steering arithmetic takes - it was a sign-extending
+// byte conversion per coordinate.
 struct PatTab { uint32_t w[4][16][4]; };
+constexpr uint32_t fp8_e4m3_of_small_int(int v) {
+  const uint32_t sgn = v < 0 ? 0x80u : 0u;
+  const int a = v < 0 ? -v : v;
+  if (a == 0) return 0u;
+  int e = 0;
+  while ((a >> (e + 1)) != 0) e++;                 // floor(log2 a), a <= 15
+  const uint32_t m = ((uint32_t)a << 3 >> e) & 7u; // the three bits behind the leading one (a has at most four significant bits)
+  return sgn | ((uint32_t)(e + 7) << 3) | m;
+}
 constexpr PatTab make_pattab() {
   PatTab t{};
   for (int l = 0; l < 16; l++)
     for (int j = 0; j < 16; j++) {
       const int8_t* p = k_pattern + 4 * (16 * l + j);
-      t.w[j >> 2][l][j & 3] = (uint32_t)(uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8) | ((uint32_t)(uint8_t)p[2] << 16) | ((uint32_t)(uint8_t)p[3] << 24);
+      t.w[j >> 2][l][j & 3] = fp8_e4m3_of_small_int(p[0]) | (fp8_e4m3_of_small_int(p[1]) << 8) | (fp8_e4m3_of_small_int(p[2]) << 16) | (fp8_e4m3_of_small_int(p[3]) << 24);
     }
   return t;
 }
+constexpr bool pattern_fits_fp8() {
+  for (int i = 0; i < 1024; i++) if (k_pattern[i] > 15 || k_pattern[i] < -15) return false;
+  return true;
+}
+static_assert(pattern_fits_fp8(), "the pattern table stores coordinates as E4M3: integers beyond 15 are not exact");
 __constant__ PatTab c_pattab = make_pattab();
 
 

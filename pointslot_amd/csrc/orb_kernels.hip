@@ -1468,10 +1468,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_DESC_WAV
   for (int tq = 0; tq < 4; tq++) {
     const int tst = 4 * t4 + tq;
     const uint32_t pw = tq == 0 ? pw4.x : tq == 1 ? pw4.y : tq == 2 ? pw4.z : pw4.w;
-    float4 pt;
-    pt.x = (float)(int8_t)(pw & 0xFF); pt.y = (float)(int8_t)((pw >> 8) & 0xFF); pt.z = (float)(int8_t)((pw >> 16) & 0xFF); pt.w = (float)(int8_t)(pw >> 24);
-    // (operands as 64-bit integers: register pairs; a vector-typed asm output comes back with both lanes reading the low register)
-    const unsigned long long xy0 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.x, pt.y}), xy1 = __builtin_bit_cast(unsigned long long, (ds_f2){pt.z, pt.w});
+    // (one packed conversion per point: FP8 bytes -> {x, y} as a float pair; operands as 64-bit integers: register pairs)
+    const unsigned long long xy0 = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_cvt_pk_f32_fp8((int)pw, false)),
+                             xy1 = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_cvt_pk_f32_fp8((int)pw, true));
     unsigned long long T0, T1, Q0, Q1;
     // packed FP32 with the operand halves chosen by op_sel (the compiler scalarises this form): P = {x b, x a}, Q = {y a, -(y b)},
     // T = (P + Q) + magic - each instruction rounds on its own, as the separate float operations of the reference do.  The two
