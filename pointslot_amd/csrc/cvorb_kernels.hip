@@ -1494,7 +1494,10 @@ void psk_cvb_run(const CvbPlan* Pin, int nimg, const uint8_t* imgs, int stride, 
   const CvbPlan* P = &Q;
   const int NL = P->nlevels;
   static const int grid_env = getenv("PS_CVB_GRID") ? atoi(getenv("PS_CVB_GRID")) : 0;   // developer knob (a multiple of 32)
-  const int grid = grid_env > 0 ? grid_env : 16384;            // persistent loops over the worklists, one wave per tile
+  // persistent loops over the worklists, one wave per tile at a time: 32 waves per image, at least 16384, at most 65536 (r05, ms per call of
+  // tools/cvorb_batch_bench.py for 4096 / 16384 / 32768 / 65536 waves: 128 images 0.472 / 0.470 / 0.473 / 0.531, 1024 images - a lockstep
+  // group of 512 sequences - 2.65 (5632) / 2.48 / 2.31 / 2.29, 2048 images 4.78 / 4.70 / 4.58 / 4.46)
+  const int grid = grid_env > 0 ? grid_env : (nimg * 32 < 16384 ? 16384 : nimg * 32 > 65536 ? 65536 : (nimg * 32 + 31) & ~31);
   if (!occupancy_given) hipLaunchKernelGGL(cvb_occupancy, dim3((P->h0 + 31) / 32, nimg), dim3(256), 0, st, *P, masks, mask_stride, mask_pitch);
   const size_t plan_lds = (size_t)((P->cell_total + 3) & ~3) + 2 * (size_t)((P->cell_max + 3) & ~3) + 2 * (size_t)(P->ocw + 1) * (P->och + 1) + (size_t)P->tile_total + 16;
   if (plan_lds > 48 * 1024) hipFuncSetAttribute((const void*)cvb_plan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds);
