@@ -889,7 +889,7 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
                                   // workgroups share a CU: the kernel is latency-bound and its duration is rounds x workgroup latency
 #endif
 template <int NCAP, int NT, int KCAP>
-struct QtShared {
+struct __attribute__((aligned(16))) QtShared {     // (16: `ord` is read as uint4 in the careful rounds)
   uint32_t boxa[2][NCAP];   // x0 | y0 << 16
   uint32_t boxb[2][NCAP];   // x1 | y1 << 16
   uint32_t cnt[2][NCAP];    // key count | QT_INV (member of vSizeAndPointerToNode)
@@ -1074,6 +1074,31 @@ __global__ __launch_bounds__(NT) void orb_quadtree(OrbPlan plan, uint8_t* arena,
     } else {
       // descending (count, seq): rank = number of candidates that sort after this one
       int local = 0;
+      if (n < 65535 && seq_base < 65536u) {
+        // (r05) the pair as ONE word, count << 16 | creation order (+ 1; 0 = not a candidate), in `ord` - free until the ranks are known -
+        // and four of them per LDS read: the comparison of two fields per node and an LDS word per field was a fifth of a level-0
+        // workgroup's time (-DPS_QT_PROFILE)
+        uint32_t* key = reinterpret_cast<uint32_t*>(s.ord);
+        const int A4 = (A + 3) & ~3;
+        for (int i = t; i < A4; i += NT) {
+          const uint32_t ci = i < A ? cnt[i] : 0u;
+          key[i] = (ci & QT_INV) ? (((ci & ~QT_INV) << 16) | sq[i]) + 1u : 0u;
+        }
+        __syncthreads();
+        for (int i = t; i < A; i += NT) {
+          int r = -1;
+          const uint32_t ki = key[i];
+          if (ki) {
+            r = 0;
+            for (int j = 0; j < A4; j += 4) {
+              const uint4 k = *reinterpret_cast<const uint4*>(key + j);
+              r += (k.x > ki ? 1 : 0) + (k.y > ki ? 1 : 0) + (k.z > ki ? 1 : 0) + (k.w > ki ? 1 : 0);
+            }
+            local++;
+          }
+          s.rank[i] = r;
+        }
+      } else
       for (int i = t; i < A; i += NT) {
         int r = -1;
         const uint32_t ci = cnt[i];
