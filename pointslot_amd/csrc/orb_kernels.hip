@@ -880,6 +880,10 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
 #define QT_T 512
 #endif
 #define QT_INV 0x80000000u
+#ifndef QT_GB
+#define QT_GB 4                  // keys per thread and step of the gather (r05: 8 / 12 keys - two / one step for a level-0 workgroup's 4 400 keys - made the
+                                  // whole kernel slower, 0.089 -> 0.098 ms per 128 images: registers)
+#endif
 
 #ifndef QT_KCAP512
 #define QT_KCAP512 2048          // ... of the 512-node configuration
@@ -998,10 +1002,10 @@ __global__ __launch_bounds__(NT) void orb_quadtree(OrbPlan plan, uint8_t* arena,
   auto passes = [&](auto kxy, auto kns) {
   if (t == 0) coff[ncell] = n;
   __syncthreads();
-  for (int j0 = t; j0 < n; j0 += 4 * NT) {       // four keys per thread and step: their slot loads are in flight together
-    uint32_t ev[4];
+  for (int j0 = t; j0 < n; j0 += QT_GB * NT) {       // QT_GB keys per thread and step: their slot loads are in flight together
+    uint32_t ev[QT_GB];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < QT_GB; u++) {
       const int j = min(j0 + u * NT, n - 1);
       int lo = 0, hi = ncell;          // invariant: off[lo] <= j < off[hi]
       while (hi - lo > 1) {
@@ -1011,7 +1015,7 @@ __global__ __launch_bounds__(NT) void orb_quadtree(OrbPlan plan, uint8_t* arena,
       ev[u] = slots[(size_t)lo * L.cell_cap + (j - coff[lo])];
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < QT_GB; u++) {
       const int j = j0 + u * NT;
       if (j >= n) continue;
       const uint32_t e = ev[u];
@@ -1052,11 +1056,20 @@ __global__ __launch_bounds__(NT) void orb_quadtree(OrbPlan plan, uint8_t* arena,
     __syncthreads();
     QTP_MARK(1);
     // B: count keys per child of every candidate node
-    for (int k = t; k < n; k += NT) {
-      const int i = kns[k] & 0xFFFF;
-      const uint32_t c = cnt[i];
-      const bool cand = careful ? (c & QT_INV) != 0 : (c & ~QT_INV) > 1;
-      if (cand) atomicAdd(&s.child[i * 4 + qt_quadrant(kxy[k], boxa[i], boxb[i])], 1u);
+    // (four keys per thread and step, their words requested together: the keys of the large levels live in global memory - r05:
+    // one dependent round trip per key and pass before)
+    for (int k0 = t; k0 < n; k0 += 4 * NT) {
+      uint32_t kv[4], kp[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = min(k0 + u * NT, n - 1); kv[u] = kns[k]; kp[u] = kxy[k]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (k0 + u * NT >= n) continue;
+        const int i = kv[u] & 0xFFFF;
+        const uint32_t c = cnt[i];
+        const bool cand = careful ? (c & QT_INV) != 0 : (c & ~QT_INV) > 1;
+        if (cand) atomicAdd(&s.child[i * 4 + qt_quadrant(kp[u], boxa[i], boxb[i])], 1u);
+      }
     }
     __syncthreads();
     QTP_MARK(2);
@@ -1203,21 +1216,29 @@ __global__ __launch_bounds__(NT) void orb_quadtree(OrbPlan plan, uint8_t* arena,
     }
     QTP_MARK(5);
     // F: re-home the keys
-    for (int k = t; k < n; k += NT) {
-      const uint32_t kv = kns[k];
-      const int i = kv & 0xFFFF;
-      const int r = s.rank[i];
-      int ni;
-      if (r >= 0 && r <= m) {
-        const int q = qt_quadrant(kxy[k], boxa[i], boxb[i]);
-        const int cr = s.cpre[r + 1] - s.cpre[r];
-        int before = 0;
-        for (int qq = 0; qq < q; qq++) before += s.child[i * 4 + qq] > 0 ? 1 : 0;
-        ni = TC - s.cpre[r] - cr + (cr - before - 1);
-      } else {
-        ni = TC + s.surv[i];
+    for (int k0 = t; k0 < n; k0 += 4 * NT) {
+      uint32_t kv4[4], kp4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = min(k0 + u * NT, n - 1); kv4[u] = kns[k]; kp4[u] = kxy[k]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u * NT;
+        if (k >= n) continue;
+        const uint32_t kv = kv4[u];
+        const int i = kv & 0xFFFF;
+        const int r = s.rank[i];
+        int ni;
+        if (r >= 0 && r <= m) {
+          const int q = qt_quadrant(kp4[u], boxa[i], boxb[i]);
+          const int cr = s.cpre[r + 1] - s.cpre[r];
+          int before = 0;
+          for (int qq = 0; qq < q; qq++) before += s.child[i * 4 + qq] > 0 ? 1 : 0;
+          ni = TC - s.cpre[r] - cr + (cr - before - 1);
+        } else {
+          ni = TC + s.surv[i];
+        }
+        kns[k] = (kv & 0xFFFF0000u) | (uint32_t)ni;
       }
-      kns[k] = (kv & 0xFFFF0000u) | (uint32_t)ni;
     }
     __syncthreads();
     const int n_expand = s.n_expand;
