@@ -340,9 +340,19 @@ __device__ __forceinline__ void cvb_reflect_range(int lo, int hi, int len, int& 
 // one for the mask need, two scratch planes of the largest level, the summed-area table of the occupancy), the three tile
 // worklists per level (0 planes, 1 FAST, 2 blur).  An entry of worklist 0 carries bit 31 when the tile also holds cells of the
 // mask chain (kp cells and, downwards, the cells that hold their source pixels).  Loops run rows by waves, columns by lanes.
+#ifdef PS_CVP_PROFILE   // developer build: 100 MHz ticks per phase of image 0's plan
+#define CPP_DECL long long cp_t = wall_clock64(), cp_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CPP_MARK(k) do { const long long _n = wall_clock64(); cp_ph[k] += _n - cp_t; cp_t = _n; } while (0)
+#define CPP_PRINT() do { if (threadIdx.x == 0 && blockIdx.x == 0) printf("cvb_plan ticks: sat %lld | cells %lld fast+rowdil %lld coldil %lld blurtiles %lld | down %lld wl0 %lld entries %lld\n", cp_ph[0], cp_ph[1], cp_ph[2], cp_ph[3], cp_ph[4], cp_ph[5], cp_ph[6], cp_ph[7]); } while (0)
+#else
+#define CPP_DECL
+#define CPP_MARK(k)
+#define CPP_PRINT()
+#endif
 __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
   extern __shared__ uint8_t sm[];          // per cell of every level: bit 0 = the plane is needed, bit 1 = the mask is needed (4-byte aligned per level)
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = CVB_PLAN_T / 64;
+  CPP_DECL;
   const int cmax4 = (P.cell_max + 3) & ~3;
   uint8_t* kp = sm + ((P.cell_total + 3) & ~3);
   uint8_t* tmp = kp + cmax4;
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
   __syncthreads();
   for (int x = 1 + tid; x <= P.ocw; x += CVB_PLAN_T) { uint16_t acc = 0; for (int y = 1; y <= P.och; y++) { acc += sat[y * SW + x]; sat[y * SW + x] = acc; } }
   __syncthreads();
+  CPP_MARK(0);
   // Per level: the cells are walked as rows by waves; a row band without an occupied level-0 cell (most rows: the objects cover a part
   // of the image) is cleared with dword stores and skipped by the passes behind it.  The dilations work on four cells per lane.
   for (int l = 0; l < P.nlevels; l++) {
@@ -416,6 +427,7 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
       if (lane == 0) s_kprow[cy] = anyrow ? 1 : 0;
     }
     __syncthreads();
+    CPP_MARK(1);
     // FAST + NMS tiles: a tile with a kp cell in its 4 x 4 cells or one cell around them
     for (int ty = wave; ty < B.th; ty += NW) {
       bool rows = false;
@@ -443,6 +455,7 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
       }
     }
     __syncthreads();
+    CPP_MARK(2);
     // ... and along the columns; kp now holds the dilated set, whose cells also need the plane (bit 0 of need)
     for (int cy = wave; cy < B.ch; cy += NW) {
       bool rows = false;
@@ -457,6 +470,7 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
       }
     }
     __syncthreads();
+    CPP_MARK(3);
     // blur tiles: the tiles with a cell of the dilated set (level 0: also the tiles of its padded plane, which is only read around
     // its own keypoints - level 1 reads the image)
     for (int ty = wave; ty < B.th; ty += NW) {
@@ -471,6 +485,7 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
     }
     __syncthreads();
   }
+  CPP_MARK(4);
   // a level's needed cells need their source pixels one level down (level 1's come from the image itself)
   for (int l = P.nlevels - 1; l >= 2; l--) {
     const CvbLevel& B = P.lv[l];
@@ -498,6 +513,7 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
     }
     __syncthreads();
   }
+  CPP_MARK(5);
   for (int l = 1; l < P.nlevels; l++) {
     // worklist 0 of the levels above 0: the tiles with a needed cell; bit 3 when one of them is of the mask chain
     const CvbLevel& B = P.lv[l];
@@ -513,6 +529,7 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
       }
   }
   __syncthreads();
+  CPP_MARK(6);
   // worklist entries: positions inside the workgroup by LDS counters, then ONE global atomic per list and level
   constexpr int PER = 8 * 512 / CVB_PLAN_T;                        // tiles per thread (host check: tile_total <= 8 * 512)
   int lpos[PER][3];
@@ -540,6 +557,8 @@ __global__ __launch_bounds__(CVB_PLAN_T) void cvb_plan(CvbPlan P) {
         if (pos < P.wl_cap) P.wl[((size_t)w * CV_MAX_LEVELS + l) * P.wl_cap + pos] = ((uint32_t)img << 12) | (uint32_t)(i - P.lv[l].tile_off) | ((w == 0 && (f & 8)) ? 0x80000000u : 0u);
       }
   }
+  CPP_MARK(7);
+  CPP_PRINT();
 }
 
 // the next worklist entry is requested while the current tile is worked on (a tile is a chain of dependent round trips: every one
