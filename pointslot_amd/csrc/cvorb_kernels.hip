@@ -1439,7 +1439,7 @@ __global__ __launch_bounds__(CVB_DESC_T) __attribute__((amdgpu_waves_per_eu(CVB_
     }
     const float angle = __fmul_rn(angle_deg, (float)(3.14159265358979323846 / 180.f));
     double sn_d, cs_d;
-    sincos_0_2pi((double)angle, sn_d, cs_d, sincos_table());
+    sincos_0_2pi((double)angle, sn_d, cs_d, c_sincos);
     const float a = (float)cs_d, b = (float)sn_d;
     cvb_wave_sync();
     // A pattern point (x, y) samples the blurred patch at row cvRound(x b + y a), column cvRound(x a - y b), every product and sum rounded to

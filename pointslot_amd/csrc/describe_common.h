@@ -92,20 +92,14 @@ constexpr IcTab make_ictab() {
 }
 __constant__ IcTab c_ictab = make_ictab();
 
-// coefficients of sincos_0_2pi, read with scalar loads (a 64-bit literal would cost two vector moves per use)
+// coefficients of sincos_0_2pi.  (The compiler turns them into 64-bit literals - two vector moves per use, 24 in all.  r05: behind an
+// opaque pointer they become scalar loads AT their use - a scalar-memory round trip in the middle of the keypoint's dependent chain:
+// orb_describe 0.139 -> 0.149 ms per 128 images; requested early and pinned, they push the kernel into scratch: 0.246 ms.)
 __constant__ double c_sincos[16] = {0.63661977236758134308, 1.57079632673412561417e+00, 6.07710050650619224932e-11,
                                     1.58962301576546568060e-10, -2.50507477628578072866e-8, 2.75573136213857245213e-6,
                                     -1.98412698295895385996e-4, 8.33333333332211858878e-3, -1.66666666666666307295e-1,
                                     -1.13585365213876817300e-11, 2.08757008419747316778e-9, -2.75573141792967388112e-7,
                                     2.48015872888517045348e-5, -1.38888888888730564116e-3, 4.16666666666665929218e-2, 0.0};
-
-// the table's address behind an empty asm statement: seen through, the compiler replaces every coefficient by a 64-bit literal - two
-// vector moves per use (24 in all) - where a scalar load brings it once
-__device__ __forceinline__ const double* sincos_table() {
-  const double* t = c_sincos;
-  asm volatile("" : "+s"(t));
-  return t;
-}
 
 // sum over the 16 lanes of a DPP row, left in every lane of the row: xor-1, xor-2, half-row mirror, row mirror
 __device__ __forceinline__ int row_sum_i32(int v) {

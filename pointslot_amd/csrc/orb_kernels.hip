@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_DESC_WAV
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float arad = __fmul_rn(angle, factorPI);
   double sn_d, cs_d;
-  sincos_0_2pi((double)arad, sn_d, cs_d, sincos_table());
+  sincos_0_2pi((double)arad, sn_d, cs_d, c_sincos);
   const float a = (float)cs_d, b = (float)sn_d;
   wave_sync();
   // A point (x, y) of the pattern samples the blurred patch at row cvRound(x b + y a), column cvRound(x a - y b)
