@@ -554,6 +554,27 @@ __device__ __forceinline__ int wave_scan_inclusive(int v) {
 typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
 typedef short fs_s2 __attribute__((ext_vector_type(2)));
 
+// the corner score of two pixels at once on packed u16 halves from their 16 ring values x and centres cv.  BRIGHT = false: v - (min over
+// the 16 nine-pixel arcs of the arc's maximum) - a dark corner's score, or a bright one's on complemented values; BRIGHT = true: (max over
+// the arcs of the arc's minimum) - v on the values as they are.  The arc extremes come from running extremes of the ring's two 8-blocks
+// (suffix S, prefix P): the arc that starts at i < 8 is the block-0 suffix from i and the block-1 prefix up to i, the arc that starts
+// at i + 8 wraps the other way (59 packed operations).
+template <bool BRIGHT>
+__device__ __forceinline__ fs_s2 fast_arc_score(const fs_us2* x, fs_s2 cv) {
+  auto inner = [](fs_us2 a, fs_us2 b) { return BRIGHT ? __builtin_elementwise_min(a, b) : __builtin_elementwise_max(a, b); };
+  auto outer = [](fs_us2 a, fs_us2 b) { return BRIGHT ? __builtin_elementwise_max(a, b) : __builtin_elementwise_min(a, b); };
+  fs_us2 S0[8], P0[8], S1[8], P1[8];
+  S0[7] = x[7]; P0[0] = x[0]; S1[7] = x[15]; P1[0] = x[8];
+#pragma unroll
+  for (int i = 6; i >= 0; i--) { S0[i] = inner(x[i], S0[i + 1]); S1[i] = inner(x[8 + i], S1[i + 1]); }
+#pragma unroll
+  for (int i = 1; i < 8; i++) { P0[i] = inner(x[i], P0[i - 1]); P1[i] = inner(x[8 + i], P1[i - 1]); }
+  fs_us2 best = outer(inner(S0[0], P1[0]), inner(S1[0], P0[0]));
+#pragma unroll
+  for (int i = 1; i < 8; i++) best = outer(best, outer(inner(S0[i], P1[i]), inner(S1[i], P0[i])));
+  return BRIGHT ? __builtin_bit_cast(fs_s2, best) - cv : cv - __builtin_bit_cast(fs_s2, best);
+}
+
 // LDS layout of one cell-wave (bytes; every region 16-byte aligned).  TR = window rows of the plan's tallest cell.
 struct FastLds { int smap, bmp, list, cap, total; };
 __host__ __device__ __forceinline__ FastLds fast_lds(int TS, int TR, int LCAP) {
@@ -744,24 +765,26 @@ __global__ __launch_bounds__(FAST_T) __attribute__((amdgpu_waves_per_eu(PS_FAST_
         // ring offsets from q (centre at (3, 3)): position 0 is (dx, dy) = (0, +3), then as OpenCV's table
         constexpr int RO[16] = {6 * TS + 3, 6 * TS + 4, 5 * TS + 5, 4 * TS + 6, 3 * TS + 6, 2 * TS + 6, 1 * TS + 5, 0 * TS + 4,
                                 0 * TS + 3, 0 * TS + 2, 1 * TS + 1, 2 * TS + 0, 3 * TS + 0, 4 * TS + 0, 5 * TS + 1, 6 * TS + 2};
+        // r05: a round whose 128 entries are all dark (or all bright) - wave-uniform - needs no per-lane complement: dark rounds take the
+        // ring as it is, bright rounds run the same recurrences with minimum and maximum exchanged; only the round that holds the
+        // boundary between the two lists complements per lane (the exclusive-or was 18 of a round's ~120 vector instructions)
+        const int klast = min(i0 + 127, ntot - 1);
         fs_us2 x[16];
+        fs_s2 sc;
+        if (klast < nd) {
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-          x[i] = __builtin_bit_cast(fs_us2, ((uint32_t)q[0][RO[i]] | ((uint32_t)q[1][RO[i]] << 16)) ^ polm);
-        const fs_s2 cv = __builtin_bit_cast(fs_s2, ((uint32_t)q[0][3 * TS + 3] | ((uint32_t)q[1][3 * TS + 3] << 16)) ^ polm);
-        // max of each of the 16 nine-pixel arcs from running maxima of the two 8-blocks (suffix S, prefix P): the arc that starts
-        // at i < 8 is the block-0 suffix from i and the block-1 prefix up to i; the arc that starts at i + 8 wraps the other way
-        fs_us2 S0[8], P0[8], S1[8], P1[8];
-        S0[7] = x[7]; P0[0] = x[0]; S1[7] = x[15]; P1[0] = x[8];
+          for (int i = 0; i < 16; i++) x[i] = __builtin_bit_cast(fs_us2, (uint32_t)q[0][RO[i]] | ((uint32_t)q[1][RO[i]] << 16));
+          sc = fast_arc_score<false>(x, __builtin_bit_cast(fs_s2, (uint32_t)q[0][3 * TS + 3] | ((uint32_t)q[1][3 * TS + 3] << 16)));
+        } else if (i0 >= nd) {
 #pragma unroll
-        for (int i = 6; i >= 0; i--) { S0[i] = __builtin_elementwise_max(x[i], S0[i + 1]); S1[i] = __builtin_elementwise_max(x[8 + i], S1[i + 1]); }
+          for (int i = 0; i < 16; i++) x[i] = __builtin_bit_cast(fs_us2, (uint32_t)q[0][RO[i]] | ((uint32_t)q[1][RO[i]] << 16));
+          sc = fast_arc_score<true>(x, __builtin_bit_cast(fs_s2, (uint32_t)q[0][3 * TS + 3] | ((uint32_t)q[1][3 * TS + 3] << 16)));
+        } else {
 #pragma unroll
-        for (int i = 1; i < 8; i++) { P0[i] = __builtin_elementwise_max(x[i], P0[i - 1]); P1[i] = __builtin_elementwise_max(x[8 + i], P1[i - 1]); }
-        fs_us2 best = __builtin_elementwise_min(__builtin_elementwise_max(S0[0], P1[0]), __builtin_elementwise_max(S1[0], P0[0]));
-#pragma unroll
-        for (int i = 1; i < 8; i++)
-          best = __builtin_elementwise_min(best, __builtin_elementwise_min(__builtin_elementwise_max(S0[i], P1[i]), __builtin_elementwise_max(S1[i], P0[i])));
-        const fs_s2 sc = cv - __builtin_bit_cast(fs_s2, best);
+          for (int i = 0; i < 16; i++)
+            x[i] = __builtin_bit_cast(fs_us2, ((uint32_t)q[0][RO[i]] | ((uint32_t)q[1][RO[i]] << 16)) ^ polm);
+          sc = fast_arc_score<false>(x, __builtin_bit_cast(fs_s2, ((uint32_t)q[0][3 * TS + 3] | ((uint32_t)q[1][3 * TS + 3] << 16)) ^ polm));
+        }
         if ((int)sc.x > th && i0 + lane < ntot) smap[p[0] + (SS + 1)] = (uint8_t)sc.x;
         if ((int)sc.y > th && i0 + 64 + lane < ntot) smap[p[1] + (SS + 1)] = (uint8_t)sc.y;
       }
