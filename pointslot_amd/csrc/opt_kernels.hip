@@ -49,6 +49,7 @@ struct PoShared {
   double prior_err[PS_PO_MAX_K][3];
   uint8_t prior_robust[PS_PO_MAX_K];
   int icount;
+  double red1[2][PO_T / 64];        // block_sum1: the waves' partial sums, two buffers used in turn
 };
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) {
@@ -126,6 +127,54 @@ __device__ void block_sum(double* acc, PoShared& s, int nthr) {
     s.out[threadIdx.x] = v;
   }
   __syncthreads();
+}
+
+// ONE value summed over the workgroup, returned to every thread (r05: the damping trials end in this reduction - 25 to 50 of them per
+// call - and it cost as much as the trial's edge pass: six ds_bpermute pairs and three workgroup barriers).  Inside the wave the same
+// butterfly (partners 32, 16, 8, 4, 2, 1 lanes away, the same sums in the same order) on the vector ALUs alone - v_permlane32/16_swap,
+// then DPP row rotate / shifts / quad permutes -, across the waves ONE barrier: the partial sums go to one of two buffers used in turn
+// (`turn`, the same in every thread: a thread that is still reading a buffer cannot be overtaken by the write after next - the
+// barrier of the call in between holds it back), and every thread adds them itself, wave 0 first.
+__device__ __forceinline__ double wave_sum_d(double v) {
+  v = swap_add_d<32>(v, v);
+  v = swap_add_d<16>(v, v);
+  {   // 8 lanes away: rotate the 16-lane row by 8
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128 /* row_ror:8 */, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, false);
+    v += __hiloint2double(hi, lo);
+  }
+  {   // 4 lanes away: lanes 0-3 / 8-11 of a row take from 4 above (row_shl:4, banks 0 and 2), lanes 4-7 / 12-15 from 4 below (row_shr:4, banks 1 and 3)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int tl = __builtin_amdgcn_update_dpp(lo, lo, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+    tl = __builtin_amdgcn_update_dpp(tl, lo, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+    int th = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xF, 0x5, false);
+    th = __builtin_amdgcn_update_dpp(th, hi, 0x114, 0xF, 0xA, false);
+    v += __hiloint2double(th, tl);
+  }
+  {   // 2 lanes away
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
+    v += __hiloint2double(hi, lo);
+  }
+  {   // the neighbour
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+    v += __hiloint2double(hi, lo);
+  }
+  return v;
+}
+__device__ __forceinline__ double block_sum1(double v, PoShared& s, int nthr, int& turn) {
+  v = wave_sum_d(v);
+  if ((threadIdx.x & 63) == 0) s.red1[turn][threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0;
+#pragma unroll
+  for (int w = 0; w < PO_T / 64; w++) if (w < nthr / 64) t += s.red1[turn][w];
+  turn ^= 1;
+  return t;
 }
 
 // The same reduction per GROUP of waves: the workgroup is split into G = 1, 2 or 4 groups of PO_T / G threads that work on different
@@ -277,11 +326,8 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
       chi2c[i] = 0.0;
     }
   }
-  {
-    double c1[1] = {(double)cnt};
-    block_sum<1>(c1, s, NT);
-  }
-  const int nInitial = (int)s.out[0];
+  int turn = 0;                                     // block_sum1's buffer in use
+  const int nInitial = (int)block_sum1((double)cnt, s, NT, turn);
   const int nTotalEdges = nInitial + (P.mode == 1 ? k : 0);
   if (nTotalEdges < 15) {   // Optimizer.cc:376-377 / :638-639
     if (tid == 0) {
@@ -306,11 +352,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
       const PoVertex V = verts[P.v_off + o];
       for (int i = V.e_begin + tid; i < V.e_end; i += NT) nact += ((state[i] & (ST_VALID | ST_LVL1)) == ST_VALID) ? 1 : 0;
     }
-    {
-      double c1[1] = {(double)nact};
-      block_sum<1>(c1, s, NT);
-    }
-    const bool any_active = (int)s.out[0] > 0 || P.mode == 1;
+    const bool any_active = (int)block_sum1((double)nact, s, NT, turn) > 0 || P.mode == 1;
 
     if (any_active) {
       double lambda = 0, ni = 2;
@@ -604,9 +646,8 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
               c1[0] += rho0;
             }
           }
-          block_sum<1>(c1, s, NT);
+          double tempChi = block_sum1(c1[0], s, NT, turn);
           POP_MARK(3);
-          double tempChi = s.out[0];
           if (!ok2) tempChi = DBL_MAX;
           rho = (currentChi - tempChi) / (scale + 1e-3);
           if (rho > 0 && isfinite(tempChi)) {
@@ -654,9 +695,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
       }
     }
     if (it == 2) robust = false;   // e->setRobustKernel(0) on the projection edges; the prior keeps its kernel
-    double c1[1] = {(double)bad};
-    block_sum<1>(c1, s, NT);
-    nBadTotal = (int)s.out[0];
+    nBadTotal = (int)block_sum1((double)bad, s, NT, turn);
     POP_MARK(4);
   }
   __syncthreads();
