@@ -707,6 +707,7 @@ __global__ __launch_bounds__(OB_T) void ob_track(ObArrays A, int step) {
           for (int k = 0; k < nl; k++) if (A.last.det[(size_t)s * K + k].id == det.id) { lj = k; break; }
         }
         A.in_last[(size_t)s * K + j] = lj;
+        if (lj >= 0) for (int c = 0; c < 7; c++) A.last_tco[((size_t)s * K + j) * 7 + c] = A.last.tco[((size_t)s * K + lj) * 7 + c];
         s_flag[0] = lj;
       }
     }
@@ -1034,7 +1035,7 @@ __device__ void ob_dsd(const ObArrays& A, const ObFrame& F, const ObFrame& L, in
   const double nt[3] = {Tl.t[0] * -1., Tl.t[1] * -1., Tl.t[2] * -1.};
   se3_rotate(Tli.q, nt, Tli.t);
   const Se3 trel = se3_mul(Tc, Tli);
-  const Se3 tco = ob_pose(L.tco + ((size_t)s * K + lj) * 7);
+  const Se3 tco = ob_pose(A.last_tco + ((size_t)s * K + j) * 7);   // ob_track's copy: block (s, lj) of this launch may already have replaced L.tco[lj]
   double* vals = A.cam_pts + 3 * fo;                                    // [n] values, [n] monocular sorted, [n] stereo sorted
   uint8_t* kind = reinterpret_cast<uint8_t*>(A.bf_qot + fo);           // 0 no point, 1 monocular, 2 stereo
   const double fx = (double)C.fx, fy = (double)C.fy, cx = (double)C.cx, cy = (double)C.cy;

@@ -69,6 +69,8 @@ struct ObArrays {
   int8_t* owner;                                                     // [S][cv_cap]
   int32_t* in_last; int32_t* tracked; int32_t* need; int32_t* track_ok; int32_t* inl_flag;   // [S][K]; inl_flag [S][OC]
   double* cam_pts;                                                   // [S][OC][3] camera-frame points of a detection (RANSAC)
+  double* last_tco;                                                  // [S][K][7] the last frame's Tco of the detection's track (slot in_last), copied by ob_track:
+                                                                     // ob_finish's blocks overwrite last.tco while others still run the discrimination test
   // brute-force matcher
   BfProb* bf_prob; uint32_t* bf_topk; uint8_t* bf_qvalid; int32_t* bf_qot; int32_t* bf_nmatch;
   // windowed matcher (queries: the local map of the detection's MapObject, [S][M][LC])

@@ -173,7 +173,7 @@ size_t carve_obj(ps_tracker* t, uint8_t* base) {
   A.lm_po = c.take<float>(3 * nl); A.lm_normal = c.take<float>(3 * nl); A.lm_maxd = c.take<float>(nl); A.lm_mind = c.take<float>(nl); A.lm_desc = c.take<uint8_t>(32 * nl);
   A.owner = c.take<int8_t>(n);
   A.in_last = c.take<int32_t>(S * K); A.tracked = c.take<int32_t>(S * K); A.need = c.take<int32_t>(S * K); A.track_ok = c.take<int32_t>(S * K);
-  A.inl_flag = c.take<int32_t>(n); A.cam_pts = c.take<double>(3 * n);
+  A.inl_flag = c.take<int32_t>(n); A.cam_pts = c.take<double>(3 * n); A.last_tco = c.take<double>(S * K * 7);
   A.bf_prob = c.take<BfProb>(S * K); A.bf_topk = c.take<uint32_t>(n * PS_BF_TOPK); A.bf_qvalid = c.take<uint8_t>(n); A.bf_qot = c.take<int32_t>(n);
   A.bf_nmatch = c.take<int32_t>(S * K);
   A.pj_prob = c.take<PjProb>(S * K);
