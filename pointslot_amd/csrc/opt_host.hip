@@ -13,7 +13,7 @@
 #include "dyn_plan.h"
 
 extern "C" void psk_pose_lm_launch(const PoProb*, int, const PoVertex*, const float*, const float*, const float*,
-                                   const uint8_t*, uint8_t*, double*, uint8_t*, double*, int32_t*, double*, hipStream_t);
+                                   const uint8_t*, uint8_t*, double*, uint8_t*, void*, double*, int32_t*, double*, hipStream_t);
 
 struct BaCtx { uint8_t* d_buf = nullptr; size_t d_bytes = 0; uint8_t* h_buf = nullptr; size_t h_bytes = 0; };
 
@@ -84,6 +84,7 @@ int run_pose_only(ps_optimizer* m, const std::vector<PoView>& pv, std::vector<Se
   const size_t io_end = off;
   const size_t o_chi = off;  off += al(ne * 8 + 16);
   const size_t o_st = off;   off += al(ne + 16);
+  const size_t o_ce = off;   off += al(ne * 32 + 16);     // pose_lm's compacted edge records
   int rc = ensure(m, off);
   if (rc != PS_OK) return rc;
   uint8_t* H = m->h_buf;
@@ -115,7 +116,7 @@ int run_pose_only(ps_optimizer* m, const std::vector<PoView>& pv, std::vector<Se
   PS_HIP(hipEventRecord(m->ev0, m->stream));
   psk_pose_lm_launch((const PoProb*)(D + o_prob), nprob, (const PoVertex*)(D + o_vert), (const float*)(D + o_x),
                      (const float*)(D + o_obs), (const float*)(D + o_is2), D + o_val, D + o_out, (double*)(D + o_chi),
-                     D + o_st, (double*)(D + o_pose), (int32_t*)(D + o_res), m->trace ? (double*)(D + o_tr) : nullptr,
+                     D + o_st, D + o_ce, (double*)(D + o_pose), (int32_t*)(D + o_res), m->trace ? (double*)(D + o_tr) : nullptr,
                      m->stream);
   PS_HIP(hipGetLastError());
   PS_HIP(hipEventRecord(m->ev1, m->stream));

@@ -50,6 +50,8 @@ struct PoShared {
   uint8_t prior_robust[PS_PO_MAX_K];
   int icount;
   double red1[2][PO_T / 64];        // block_sum1: the waves' partial sums, two buffers used in turn
+  int nv[PS_PO_MAX_K];              // valid edges per vertex = the length of its compacted edge list
+  int wcnt[PO_T / 64];              // compaction: valid slots in each wave's share of a vertex's range
 };
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) {
@@ -255,12 +257,16 @@ __device__ __forceinline__ void edge_error(const Se3& T, const PoProb& P, const 
 // state byte per edge: bit0 valid, bit1 level 1 (outlier, inactive), bit2 mono
 // one edge's inputs; the edge loops fetch the NEXT edge before they work on the current one, so a pass pays one L2 round trip
 // instead of one per edge (a thread owns n / PO_T edges, PO_T apart)
+// (r06) The edges a thread walks are the COMPACTED list of its vertex: at entry the valid slots of [e_begin, e_end) are gathered, in slot
+// order, into 32-byte records at the front of the range (`cedge`: {Xw, 1 / sigma^2 | observation, slot index}; state and cached chi2 live at the
+// same compact positions).  The tracker hands over a frame's ~2000 feature slots of which 400 - 800 carry a map point: a wave stepped
+// through every slot it owned and paid an edge's full cost wherever ANY of its 64 lanes had one - eight steps for two to three edges.
 struct PoEdge { float x0, x1, x2, o0, o1, o2, is2; uint8_t st; };
-__device__ __forceinline__ PoEdge po_load(const float* xw, const float* obs, const float* inv_sigma2, const uint8_t* state, int i) {
+__device__ __forceinline__ PoEdge po_load(const float4* cedge, const uint8_t* state, int i) {
+  const float4 a = cedge[2 * (size_t)i], b = cedge[2 * (size_t)i + 1];
   PoEdge e;
-  e.x0 = xw[3 * i]; e.x1 = xw[3 * i + 1]; e.x2 = xw[3 * i + 2];
-  e.o0 = obs[3 * i]; e.o1 = obs[3 * i + 1]; e.o2 = obs[3 * i + 2];
-  e.is2 = inv_sigma2[i]; e.st = state[i];
+  e.x0 = a.x; e.x1 = a.y; e.x2 = a.z; e.is2 = a.w;
+  e.o0 = b.x; e.o1 = b.y; e.o2 = b.z; e.st = state[i];
   return e;
 }
 #define ST_VALID 1
@@ -281,7 +287,7 @@ __device__ __forceinline__ PoEdge po_load(const float* xw, const float* obs, con
 #endif                   // CU; capped to 168 / 128 the kernel spills and the headline loses 2 % (r04)
 __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs, const PoVertex* verts, const float* xw,
                                                 const float* obs, const float* inv_sigma2, const uint8_t* valid,
-                                                uint8_t* outlier, double* chi2c, uint8_t* state, double* poses,
+                                                uint8_t* outlier, double* chi2c, uint8_t* state, float4* cedge, double* poses,
                                                 int32_t* results, double* trace) {
   __shared__ PoShared s;
   POP_DECL;
@@ -312,22 +318,61 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
     // g2o keeps the increment in a zero-initialised vector: when the very first factorisation of a problem fails the
     // update is exp(0) (and rho = -inf: the damping is raised and the trial repeated) - never leftover LDS contents
   }
-  int cnt = 0;
-  for (int o = 0; o < k; o++) {
-    const PoVertex V = verts[P.v_off + o];
-    for (int i = V.e_begin + tid; i < V.e_end; i += NT) {
-      uint8_t st = 0;
-      if (valid[i]) {
-        st = ST_VALID | (obs[3 * i + 2] < 0.f ? ST_MONO : 0);
-        outlier[i] = 0;          // mvbOutlier[i] = false (Optimizer.cc:299,335)
-        cnt++;
+  // the edge lists: every vertex's valid slots, in slot order, compacted to the front of its range.  Wave w takes the w-th share of the
+  // range (whole 64-slot rows), counts its valid slots, and after one barrier writes them behind the shares before it.
+  int turn = 0;                                     // block_sum1's buffer in use
+  int nInitial = 0;
+  {
+    const int lane = tid & 63, wave = tid >> 6, nw = NT / 64;
+    for (int o = 0; o < k; o++) {
+      const PoVertex V = verts[P.v_off + o];
+      const int n = V.e_end - V.e_begin;
+      const int per = (((n + nw - 1) / nw) + 63) & ~63;
+      const int wb = V.e_begin + wave * per, we = min(wb + per, V.e_end);
+      int c = 0;
+      for (int i0 = wb; i0 < we; i0 += 512) {
+        uint8_t f[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + lane; f[u] = i < we ? valid[i] : (uint8_t)0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) c += __popcll(__ballot(f[u] != 0));
       }
-      state[i] = st;
-      chi2c[i] = 0.0;
+      if (lane == 0) s.wcnt[wave] = c;
+      __syncthreads();
+      int run = V.e_begin, tot = 0;
+      for (int w = 0; w < nw; w++) { const int cw = s.wcnt[w]; if (w < wave) run += cw; tot += cw; }
+      for (int i0 = wb; i0 < we; i0 += 256) {
+        uint8_t f[4];
+        float e[4][7];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * 64 + lane;
+          f[u] = i < we ? valid[i] : (uint8_t)0;
+          const int ic = i < we ? i : wb;
+          e[u][0] = xw[3 * (size_t)ic]; e[u][1] = xw[3 * (size_t)ic + 1]; e[u][2] = xw[3 * (size_t)ic + 2];
+          e[u][3] = obs[3 * (size_t)ic]; e[u][4] = obs[3 * (size_t)ic + 1]; e[u][5] = obs[3 * (size_t)ic + 2];
+          e[u][6] = inv_sigma2[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * 64 + lane;
+          const unsigned long long bal = __ballot(f[u] != 0);
+          if (f[u]) {
+            const int pos = run + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+            cedge[2 * (size_t)pos] = make_float4(e[u][0], e[u][1], e[u][2], e[u][6]);
+            cedge[2 * (size_t)pos + 1] = make_float4(e[u][3], e[u][4], e[u][5], __int_as_float(i));
+            state[pos] = ST_VALID | (e[u][5] < 0.f ? ST_MONO : 0);
+            chi2c[pos] = 0.0;
+            outlier[i] = 0;          // mvbOutlier[i] = false (Optimizer.cc:299,335)
+          }
+          run += __popcll(bal);
+        }
+      }
+      if (tid == 0) s.nv[o] = tot;
+      nInitial += tot;
+      __syncthreads();               // s.wcnt is free again; the records are visible to the whole workgroup
     }
   }
-  int turn = 0;                                     // block_sum1's buffer in use
-  const int nInitial = (int)block_sum1((double)cnt, s, NT, turn);
   const int nTotalEdges = nInitial + (P.mode == 1 ? k : 0);
   if (nTotalEdges < 15) {   // Optimizer.cc:376-377 / :638-639
     if (tid == 0) {
@@ -349,8 +394,8 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
     // active set = level-0 edges; a vertex without active edges is not optimised
     int nact = 0;
     for (int o = 0; o < k; o++) {
-      const PoVertex V = verts[P.v_off + o];
-      for (int i = V.e_begin + tid; i < V.e_end; i += NT) nact += ((state[i] & (ST_VALID | ST_LVL1)) == ST_VALID) ? 1 : 0;
+      const int eb = verts[P.v_off + o].e_begin, ee = eb + s.nv[o];
+      for (int i = eb + tid; i < ee; i += NT) nact += ((state[i] & (ST_VALID | ST_LVL1)) == ST_VALID) ? 1 : 0;
     }
     const bool any_active = (int)block_sum1((double)nact, s, NT, turn) > 0 || P.mode == 1;
 
@@ -365,16 +410,17 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
           // G vertices at a time, each by its group of GT threads (PoseOptimization: one vertex, the whole workgroup)
           const int o = min(o0 + g, k - 1);
           const bool have = o0 + g < k;
-          const PoVertex V = have ? verts[P.v_off + o] : PoVertex{0, 0};
+          PoVertex V = have ? verts[P.v_off + o] : PoVertex{0, 0};
+          if (have) V.e_end = V.e_begin + s.nv[o];
           const Se3 T = load_pose(s.pose[o]);
           double acc[28];
 #pragma unroll
           for (int a = 0; a < 28; a++) acc[a] = 0;
           PoEdge nx = {};
-          if (V.e_begin + tg < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, V.e_begin + tg);
+          if (V.e_begin + tg < V.e_end) nx = po_load(cedge, state, V.e_begin + tg);
           for (int i = V.e_begin + tg; i < V.e_end; i += GT) {
             const PoEdge ed = nx;
-            if (i + GT < V.e_end) nx = po_load(xw, obs, inv_sigma2, state, i + GT);
+            if (i + GT < V.e_end) nx = po_load(cedge, state, i + GT);
             const uint8_t st = ed.st;
             if ((st & (ST_VALID | ST_LVL1)) != ST_VALID) continue;
             const bool mono = st & ST_MONO;
@@ -610,7 +656,8 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
           for (int o0 = 0; o0 < k; o0 += G) {
             const int o = min(o0 + g, k - 1);
             const bool have = o0 + g < k;
-            const PoVertex V = have ? verts[P.v_off + o] : PoVertex{0, 0};
+            PoVertex V = have ? verts[P.v_off + o] : PoVertex{0, 0};
+            if (have) V.e_end = V.e_begin + s.nv[o];
             const Se3 T = load_pose(s.cpose[ci + o]);
             // four edges per step, all loads issued before the first use: the pass is short (an error and a Huber weight per
             // edge), so the memory round trip would otherwise be paid once per edge
@@ -619,7 +666,7 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
 #pragma unroll
               for (int u = 0; u < 4; u++) {
                 const int i = i0 + u * GT;
-                eds[u] = po_load(xw, obs, inv_sigma2, state, i < V.e_end ? i : i0);
+                eds[u] = po_load(cedge, state, i < V.e_end ? i : i0);
               }
 #pragma unroll
               for (int u = 0; u < 4; u++) {
@@ -677,20 +724,22 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
     POP_MARK(0);
     int bad = 0;
     for (int o = 0; o < k; o++) {
-      const PoVertex V = verts[P.v_off + o];
+      const int eb = verts[P.v_off + o].e_begin, ee = eb + s.nv[o];
       const Se3 T = load_pose(s.pose[o]);
-      for (int i = V.e_begin + tid; i < V.e_end; i += NT) {
-        uint8_t st = state[i];
-        if (!(st & ST_VALID)) continue;
+      for (int i = eb + tid; i < ee; i += NT) {
+        const PoEdge ed = po_load(cedge, state, i);
+        const int slot = __float_as_int(cedge[2 * (size_t)i + 1].w);
+        uint8_t st = ed.st;
         const bool mono = st & ST_MONO;
-        if (outlier[i]) {   // e->computeError() for edges that sat out the round
+        if (st & ST_LVL1) {   // e->computeError() for edges that sat out the round (mvbOutlier[slot] is set exactly when the edge is at level 1)
           double p[3], e[3];
-          edge_error(T, P, &xw[3 * i], &obs[3 * i], mono, p, e);
-          chi2c[i] = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * (double)inv_sigma2[i];
+          const float exw[3] = {ed.x0, ed.x1, ed.x2}, eob[3] = {ed.o0, ed.o1, ed.o2};
+          edge_error(T, P, exw, eob, mono, p, e);
+          chi2c[i] = (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) * (double)ed.is2;
         }
         const float chi2 = (float)chi2c[i];
-        if (chi2 > (mono ? 5.991f : 7.815f)) { outlier[i] = 1; st |= ST_LVL1; bad++; }
-        else { outlier[i] = 0; st &= ~ST_LVL1; }
+        if (chi2 > (mono ? 5.991f : 7.815f)) { outlier[slot] = 1; st |= ST_LVL1; bad++; }
+        else { outlier[slot] = 0; st &= ~ST_LVL1; }
         state[i] = st;
       }
     }
@@ -711,8 +760,9 @@ __global__ __launch_bounds__(PO_T) PO_OCC_ATTR void pose_lm(const PoProb* probs,
 
 extern "C" void psk_pose_lm_launch(const PoProb* probs, int nprob, const PoVertex* verts, const float* xw,
                                    const float* obs, const float* inv_sigma2, const uint8_t* valid, uint8_t* outlier,
-                                   double* chi2c, uint8_t* state, double* poses, int32_t* results, double* trace,
+                                   double* chi2c, uint8_t* state, void* cedge, double* poses, int32_t* results, double* trace,
                                    hipStream_t st) {
+  // cedge: 32 bytes of scratch per edge slot (the compacted edge records), 16-byte aligned
   hipLaunchKernelGGL(pose_lm, dim3(nprob), dim3(PO_T), 0, st, probs, verts, xw, obs, inv_sigma2, valid, outlier, chi2c,
-                     state, poses, results, trace);
+                     state, (float4*)cedge, poses, results, trace);
 }

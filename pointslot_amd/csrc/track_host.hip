@@ -21,7 +21,7 @@ const OrbPlan* psi_orb_plan(ps_orb*);
 int psi_orb_prepare(ps_orb*, int, int);
 void psk_pj_launch(const PjArrays*, int, int, int, int, int, hipStream_t);
 void psk_pose_lm_launch(const PoProb*, int, const PoVertex*, const float*, const float*, const float*, const uint8_t*, uint8_t*,
-                        double*, uint8_t*, double*, int32_t*, double*, hipStream_t);
+                        double*, uint8_t*, void*, double*, int32_t*, double*, hipStream_t);
 void psk_trk_begin(const TrkArrays*, int, hipStream_t);
 void psk_trk_after_mm1(const TrkArrays*, hipStream_t);
 void psk_trk_after_mm(const TrkArrays*, int, hipStream_t);
@@ -64,7 +64,7 @@ struct ps_tracker {
   TrkArrays A;
   PjArrays pj_mm1, pj_mm2, pj_lm;
   // pose optimiser work arrays
-  double* po_chi2 = nullptr; uint8_t* po_state = nullptr;
+  double* po_chi2 = nullptr; uint8_t* po_state = nullptr; float* po_cedge = nullptr;   // cedge: pose_lm's compacted edge records, 32 B per slot
   int32_t* d_overflow = nullptr;
   int step = 0;
   float mb = 0, mbf = 0;
@@ -76,7 +76,7 @@ struct ps_tracker {
   StPair* d_obj_pairs = nullptr;
   BfBlock* d_bf_blocks = nullptr; int32_t* d_bf_count = nullptr; int bf_blocks_per_prob = 0;
   PjArrays pj_obj;
-  double* ob_chi2 = nullptr; uint8_t* ob_state = nullptr;
+  double* ob_chi2 = nullptr; uint8_t* ob_state = nullptr; float* ob_cedge = nullptr;
   // ExtractObjORB does not depend on the camera chain of its frame: with PS_TRK_OVERLAP=1 it runs on a second (low-priority) stream
   // beside the stereo matching, the searches and PoseOptimization and joins before ComputeObjStereoMatches.  Measured (r03, 512
   // sequences): 16.16 against 16.34 ms per step - the kernels of both streams slow each other down by what the overlap saves - so
@@ -128,7 +128,7 @@ size_t carve(ps_tracker* t, uint8_t* base) {
   A.po_pose = c.take<double>(7 * S); A.po_result = c.take<int32_t>(S);
   A.traj = c.take<float>((size_t)A.max_steps * S * 16);
   A.stats = c.take<TrkStat>((size_t)A.max_steps * S);
-  t->po_chi2 = c.take<double>(n); t->po_state = c.take<uint8_t>(n);
+  t->po_chi2 = c.take<double>(n); t->po_state = c.take<uint8_t>(n); t->po_cedge = c.take<float>(8 * n);
   t->d_overflow = c.take<int32_t>(S);   // per sequence, accumulated over the searches of all steps
   // windowed-matcher work arrays (one set: the three searches of a step run one after the other)
   uint8_t* ones = c.take<uint8_t>(n);
@@ -185,7 +185,7 @@ size_t carve_obj(ps_tracker* t, uint8_t* base) {
   A.stats = c.take<ObStat>((size_t)A.max_steps * S * K);
   A.dropped = c.take<int32_t>(S);
   A.det_overflow = c.take<int32_t>(S); A.search_overflow = c.take<int32_t>(S);
-  t->ob_chi2 = c.take<double>(n); t->ob_state = c.take<uint8_t>(n);
+  t->ob_chi2 = c.take<double>(n); t->ob_state = c.take<uint8_t>(n); t->ob_cedge = c.take<float>(8 * n);
   t->d_objmask = c.take<uint8_t>(2 * S * (size_t)((t->cfg.width + 15) & ~15) * t->cfg.height);
   t->d_obj_pairs = c.take<StPair>(S);
   t->bf_blocks_per_prob = (int)((OC + PS_BF_QPB - 1) / PS_BF_QPB);
@@ -283,13 +283,13 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
   psk_pj_launch(&t->pj_mm2, S, cap, cap, 1, 0, st); mark(TS_SEARCH);   // the 2 * th retry; empty problems where it is not needed
   psk_trk_after_mm(A, t->step, st); mark(TS_GLUE);
   psk_pose_lm_launch(A->po_prob, S, A->po_vert, A->cur.xw, A->po_obs, A->po_is2, A->cur.mp_valid, A->cur.outlier, t->po_chi2, t->po_state,
-                     A->po_pose, A->po_result, nullptr, st);
+                     t->po_cedge, A->po_pose, A->po_result, nullptr, st);
   mark(TS_POSE);
   psk_trk_after_pose1(A, t->step, st); mark(TS_GLUE);
   psk_pj_launch(&t->pj_lm, S, cap, cap, 0, 0, st); mark(TS_SEARCH);
   psk_trk_after_lm(A, st); mark(TS_GLUE);
   psk_pose_lm_launch(A->po_prob, S, A->po_vert, A->cur.xw, A->po_obs, A->po_is2, A->cur.mp_valid, A->cur.outlier, t->po_chi2, t->po_state,
-                     A->po_pose, A->po_result, nullptr, st);
+                     t->po_cedge, A->po_pose, A->po_result, nullptr, st);
   mark(TS_POSE);
   psk_trk_finish(A, t->step, st);
   psk_trk_stamp_overflow(A, t->d_overflow, t->step, st); mark(TS_GLUE);
@@ -312,13 +312,13 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
     mark(TS_OBJ_BRUTEFORCE);
     psk_ob_after_bf(O, t->step, st); mark(TS_OBJ_GLUE);
     psk_pose_lm_launch(O->po_prob, S, O->po_vert, O->cur.mp_po, O->po_obs, O->po_is2, O->cur.mp_valid, O->cur.outlier, t->ob_chi2, t->ob_state,
-                       O->po_pose, O->po_result, nullptr, st);
+                       t->ob_cedge, O->po_pose, O->po_result, nullptr, st);
     mark(TS_OBJ_CFSE3);
     psk_ob_after_cf1(O, t->step, st); mark(TS_OBJ_GLUE);
     psk_pj_launch(&t->pj_obj, S * K, O->LC, O->OC, 0, 0, st); mark(TS_OBJ_SEARCH);
     psk_ob_after_lm(O, t->step, st); mark(TS_OBJ_GLUE);
     psk_pose_lm_launch(O->po_prob, S, O->po_vert, O->cur.mp_po, O->po_obs, O->po_is2, O->cur.mp_valid, O->cur.outlier, t->ob_chi2, t->ob_state,
-                       O->po_pose, O->po_result, nullptr, st);
+                       t->ob_cedge, O->po_pose, O->po_result, nullptr, st);
     mark(TS_OBJ_CFSE3);
     psk_ob_finish(O, t->step, st); mark(TS_OBJ_GLUE);
   }
