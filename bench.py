@@ -111,17 +111,38 @@ def pmc_valu_issue(kernel, nimg, ms_per_step=None):
     return None
 
 
+def _seq_cache_dir():
+    """PS_SEQ_CACHE, default a per-user directory under /tmp (mode 0700, owned by this uid: the files are pickles, and a directory another
+    user could have prepared is not read from); empty string = off"""
+    root = os.environ.get("PS_SEQ_CACHE")
+    if root == "":
+        return None
+    if root is None:
+        root = os.path.join(os.environ.get("XDG_CACHE_HOME") or "/tmp", "pointslot_seq_cache_%d" % os.getuid())
+    try:
+        os.makedirs(root, mode=0o700, exist_ok=True)
+        st = os.stat(root)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            return None
+    except OSError:
+        return None
+    return root
+
+
 def _seq_cache_path(job):
-    """rendered sequences are kept on disk (PS_SEQ_CACHE, default /tmp/pointslot_seq_cache; empty string = off), keyed by the job and the
-    generator's source: a second run on the same host, the other ranks' identical jobs and the secondary legs do not render again"""
-    root = os.environ.get("PS_SEQ_CACHE", "/tmp/pointslot_seq_cache")
+    """rendered sequences are kept on disk, keyed by the job, the generator's source and this file's render parameters: a second run on the
+    same host, the other ranks' identical jobs and the secondary legs do not render again"""
+    root = _seq_cache_dir()
     if not root:
         return None
     import hashlib
+    import inspect
     hsh = hashlib.sha256(repr(tuple(job)).encode())
     for name in ("sequence.py", "object_tracker.py"):
         with open(os.path.join(ROOT, "pointslot_amd", name), "rb") as f:
             hsh.update(f.read())
+    hsh.update(inspect.getsource(_render_one).encode())
+    hsh.update(inspect.getsource(_config5_sequence).encode())
     return os.path.join(root, hsh.hexdigest()[:24] + ".pkl")
 
 
@@ -193,7 +214,7 @@ def make_sequences(rank, n_frames, n_distinct, texture, scene="drive", n_objects
     return [q if q is not None else next(made) for q in have]
 
 
-MAX_OBJECTS = 8     # detections per frame the tracker is created for (KITTI tracking frames carry up to ~15; the device chain serves 8)
+MAX_OBJECTS = 8     # detections per frame the bench's trackers are created for (the generated scenes carry 2 or 6; the device chain serves up to 16)
 
 
 def tracking_leg(rank, local_rank, texture, steps, warmup, n_seq, n_groups, barrier, scene="drive", n_distinct=32, objects=True, seqs=None, n_objects=2):
@@ -892,28 +913,63 @@ def pcie_leg(rank, world, local_rank, guard, seqs, n_seq, n_groups, barrier):
             "host_to_device_GBps_per_gpu": per_group * n_groups * (n - warm) * 2 * pitch / dt / 1e9}
 
 
+def _config5_sequence(rank, n_frames):
+    """the config-1 generator (two moving boxes, MOTS ids, KITTI-format labels), seed = rank, with the SLOT.MODE 4
+    inputs of every frame (instance-id mask, offline detections)"""
+    from pointslot_amd import sequence
+    job = ("config5", n_frames, rank)
+    q = _load_cached(job)
+    if q is None:
+        q = sequence.generate(n_frames=n_frames, seed=rank)
+        q["masks"] = np.stack([sequence.frame_mask(q, i) for i in range(n_frames)])
+        q["dets"] = [sequence.frame_detections(q, i) for i in range(n_frames)]
+        path = _seq_cache_path(job)
+        if path:
+            try:
+                import pickle
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                with open(tmp, "wb") as f:
+                    pickle.dump(q, f, protocol=4)
+                os.replace(tmp, path)
+            except OSError:
+                pass
+    return q
+
+
 def config5_leg(rank, world, local_rank, guard, n_frames=154):
-    """BASELINE configs[4]: one generated 154-frame stereo sequence per GPU (seed = rank) through the
-    tracking chain with a single frame in flight (ps_tracker with one sequence: the latency of the chain, not its throughput),
-    then ONE gather of the [154][12] float32 trajectories — the only collective of the workflow, timed separately."""
+    """BASELINE configs[4] as written: one generated 154-frame SLOT.MODE-4 stereo sequence per GPU (seed = rank) through
+    the WHOLE per-frame chain - camera chain + object chain, ps_tracker_step_slot_device with one sequence - with a single frame in flight
+    (the latency of the chain, not its throughput), then ONE gather of the [154][12] float32 trajectories - the only collective of the
+    workflow, timed separately.  The camera chain alone (r05's number for this leg) is timed on the same sequence beside it."""
     import torch
-    from pointslot_amd import parallel, sequence
-    from pointslot_amd.tracker_device import LockstepTracker
-    seq = sequence.generate(n_frames=n_frames, seed=rank)
+    from pointslot_amd import parallel
+    from pointslot_amd.tracker_device import LockstepTracker, pack_detections
+    seq = _config5_sequence(rank, n_frames)
     h, w = seq["left"][0].shape
     d = torch.from_numpy(np.stack([seq["left"], seq["right"]], 1)).cuda()
-    trk = LockstepTracker(1, seq["K"], seq["bf"], w, h, max_steps=n_frames, device=local_rank)
-    try:
-        trk.step_device(d[0].data_ptr())
-        trk.sync()
-        t0 = time.perf_counter()
-        for i in range(1, n_frames):
-            trk.step_device(d[i].data_ptr())
-            trk.sync()                                 # one frame in flight: a live sequence delivers its frames one by one
-        dt = time.perf_counter() - t0
-        tcw, st = trk.fetch()
-    finally:
-        trk.close()
+    dm = torch.from_numpy(seq["masks"]).cuda()
+    dd = torch.from_numpy(np.stack([pack_detections([seq["dets"][i]], MAX_OBJECTS) for i in range(n_frames)]).view(np.uint8)).cuda()
+    res = {}
+    for name, objects in (("camera_chain", False), ("slot_chain", True)):
+        trk = LockstepTracker(1, seq["K"], seq["bf"], w, h, max_steps=n_frames, device=local_rank, max_objects=MAX_OBJECTS if objects else 0)
+        try:
+            per = []
+            for i in range(n_frames):
+                t0 = time.perf_counter()
+                if objects:
+                    trk.step_slot_device(d[i].data_ptr(), dm[i].data_ptr(), dd[i].data_ptr())
+                else:
+                    trk.step_device(d[i].data_ptr())
+                trk.sync()                                 # one frame in flight: a live sequence delivers its frames one by one
+                per.append(time.perf_counter() - t0)
+            tcw, st = trk.fetch()
+            obj = trk.fetch_objects() if objects else None
+        finally:
+            trk.close()
+        per = np.array(per[1:]) * 1e3                      # the first frame initialises (and pays the first launches)
+        res[name] = {"ms_per_frame": float(per.mean()), "median_ms_per_frame": float(np.median(per)), "tcw": tcw, "st": st, "obj": obj}
+    tcw, st, obj = res["slot_chain"]["tcw"], res["slot_chain"]["st"], res["slot_chain"]["obj"]
     traj = np.zeros((n_frames, 12), np.float32)
     err = 0.0
     for k in range(n_frames):
@@ -928,11 +984,124 @@ def config5_leg(rank, world, local_rank, guard, n_frames=154):
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t0) * 1e3
-    ms = guard.max(dt / (n_frames - 1) * 1e3)
-    return {"workload": "BASELINE configs[4]: %d generated 1242x375 stereo sequence(s) x %d frames, one per GPU, one frame in flight per sequence" % (world, n_frames),
-            "ms_per_frame": ms, "frames_per_s_all_sequences": world * 1e3 / ms, "tracked": int(st["tracked"].sum()),
+    ms = guard.max(res["slot_chain"]["ms_per_frame"])
+    live = obj["id"] >= 0
+    return {"workload": "BASELINE configs[4]: %d generated 1242x375 SLOT.MODE-4 stereo sequence(s) x %d frames, one per GPU, camera chain + object chain "
+                        "(ps_tracker_step_slot_device, one sequence per handle), one frame in flight per sequence" % (world, n_frames),
+            "ms_per_frame": ms, "median_ms_per_frame": guard.max(res["slot_chain"]["median_ms_per_frame"]), "frames_per_s_all_sequences": world * 1e3 / ms,
+            "camera_chain_only_ms_per_frame": guard.max(res["camera_chain"]["ms_per_frame"]),
+            "tracked": int(st["tracked"].sum()), "detections": int(live.sum()), "detections_with_object": int((obj["tracked"] != 0).sum()),
+            "detections_track_ok": int((obj["track_ok"] != 0).sum()),
             "max_abs_position_error_m": guard.max(err), "trajectory_gather_ms": gather_ms,
             "gathered": [list(a.shape) for a in allt]}
+
+
+class _CAbiTimer:
+    """wall time spent inside the C-ABI (every ps_* export the python mirror calls), by entry point: the ctypes function objects of
+    `_lib.lib` are replaced by timing wrappers for the life of the context (the mirror looks them up per call)"""
+
+    def __init__(self):
+        import re
+        from pointslot_amd._lib import lib
+        with open(os.path.join(ROOT, "include", "pointslot_hip.h")) as f:
+            self.names = sorted(set(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", f.read())))
+        self.lib, self.acc, self.cnt, self.saved = lib, {}, {}, {}
+
+    def __enter__(self):
+        for n in self.names:
+            try:
+                orig = getattr(self.lib, n)
+            except AttributeError:
+                continue
+            self.saved[n] = orig
+
+            def w(*a, _o=orig, _n=n):
+                t0 = time.perf_counter()
+                r = _o(*a)
+                self.acc[_n] = self.acc.get(_n, 0.0) + time.perf_counter() - t0
+                self.cnt[_n] = self.cnt.get(_n, 0) + 1
+                return r
+            setattr(self.lib, n, w)
+        return self
+
+    def __exit__(self, *exc):
+        for n, o in self.saved.items():
+            setattr(self.lib, n, o)
+
+    def reset(self):
+        self.acc.clear(); self.cnt.clear()
+
+
+def drop_in_api_leg(rank, local_rank, n_frames=154, py_frames=40):
+    """The drop-in boundary itself (/root/reference/Examples/Stereo/stereo_kitti.cc:108-160 prints exactly this: the
+    median / mean tracking time per frame through the classes).  (a) build/stereo_kitti = examples/stereo_kitti.cpp: the reference driver's
+    loop on the shim classes - ORB_SLAM2::ORBextractor x 2 on two threads, ComputeStereoMatches, ORBmatcher::SearchByProjection,
+    Optimizer::PoseOptimization, one C-ABI call per reference call, HOST images (every frame crosses PCIe, every result comes back) - over the
+    config-5 sequence written to disk; it prints where a frame's time goes.  (b) the same frames WITH masks and detections through the
+    per-call chain of SLOT.MODE 4 (adds OpencvORBDetector x 2, ComputeObjStereoMatches, SearchByBruceMatching, CFSE3 x 2, object
+    SearchByProjection, DynamicStaticDiscrimination): the host side of that chain exists in python only (pointslot_amd/object_tracker.py - the
+    tracking harness is frozen), so it reports the wall time INSIDE the C-ABI calls per frame - kernels, PCIe, sync, the
+    library's own packing: what any host language pays - beside the python host time, which a C++ caller would not pay."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from pointslot_amd import sequence
+    seq = _config5_sequence(rank, n_frames)
+    h, w = seq["left"][0].shape
+    out = {"workload": "the config-5 sequence (%d frames, 1242x375) through the reference-signature classes, host images, one C-ABI call per reference call" % n_frames}
+    exe = os.path.join(ROOT, "build", "stereo_kitti")
+    tmp = tempfile.mkdtemp(prefix="ps_dropin_")
+    try:
+        sequence.write_pgm(tmp, seq)
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(local_rank)) if "HIP_VISIBLE_DEVICES" not in os.environ and local_rank else None
+        r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode != 0:
+            raise RuntimeError("build/stereo_kitti failed: " + (r.stderr or r.stdout)[-300:])
+        med = re.search(r"median tracking time: ([0-9.eE+-]+) ms", r.stdout)
+        mean = re.search(r"mean tracking time: ([0-9.eE+-]+) ms", r.stdout)
+        sp = re.search(r"split_json: (\{.*\})", r.stdout)
+        ok = sum(1 for l in r.stdout.splitlines() if l.startswith("frame ") and ": ok " in l)
+        cpp = {"median_ms_per_frame": float(med.group(1)), "mean_ms_per_frame": float(mean.group(1)), "frames_with_pose": ok}
+        if sp:
+            d = json.loads(sp.group(1))
+            cpp["split_ms_per_frame"] = d
+            # PCIe volume of a frame at this boundary: two images up, two key / descriptor sets + the stereo result down, then the problems
+            kern = d["extract_kernels_ms"] + d["search_kernels_ms"] + d["pose_kernels_ms"]
+            cpp["kernels_ms_per_frame_excl_stereo"] = kern
+            cpp["calls_minus_kernels_ms"] = d["extract_call_ms"] + d["search_call_ms"] + d["pose_call_ms"] - kern
+        out["cpp_shim_camera_chain"] = cpp
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # (b) the SLOT.MODE-4 chain call by call
+    from pointslot_amd.tracker import HipBackend, StereoOdometry
+    from pointslot_amd import extractor, matcher, optimizer, object_orb  # noqa: F401  (argtypes are set at import: before the wrappers go in)
+    n = min(py_frames, n_frames)
+    be = HipBackend(device=local_rank)
+    try:
+        vo = StereoOdometry(be, seq["K"], seq["bf"], w, h)
+        per, inside = [], []
+        with _CAbiTimer() as tm:
+            for k in range(n):
+                tm.reset()
+                t0 = time.perf_counter()
+                vo.track(seq["left"][k], seq["right"][k], seq["masks"][k], seq["dets"][k])
+                per.append(time.perf_counter() - t0)
+                inside.append((sum(tm.acc.values()), sum(tm.cnt.values()), dict(tm.acc)))
+        per = np.array(per[2:]) * 1e3
+        ins = np.array([x[0] for x in inside[2:]]) * 1e3
+        by = {}
+        for _, _, acc in inside[2:]:
+            for kname, v in acc.items():
+                by[kname] = by.get(kname, 0.0) + v * 1e3 / len(per)
+        out["per_call_slot_chain"] = {"frames": int(len(per)), "c_abi_ms_per_frame": float(np.median(ins)), "c_abi_mean_ms_per_frame": float(ins.mean()),
+                                      "c_abi_calls_per_frame": float(np.mean([x[1] for x in inside[2:]])),
+                                      "python_host_ms_per_frame": float(np.median(per - ins)), "wall_ms_per_frame_python_driver": float(np.median(per)),
+                                      "c_abi_ms_per_frame_by_entry_point": {k: round(v, 4) for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:12]},
+                                      "tracked": int(sum(1 for t in vo.trajectory if t is not None))}
+    finally:
+        be.close()
+    return out
 
 
 def fp64_mfma_peak(local_rank):
@@ -1017,13 +1186,24 @@ def compact_line(full):
     if "parity_spot" in full:
         line["parity_spot"] = full["parity_spot"]
     sec = full.get("secondary_metrics") or {}
+    # BASELINE configs[4] as written (one SLOT.MODE-4 sequence per GPU, one frame in flight) and the drop-in boundary (the reference driver's loop
+    # on the shim classes, host images): ms per frame; the split is wall time inside the C-ABI calls by kind / the kernels' own time / host marshalling
+    st = sec.get("sequence_tracking")
+    if isinstance(st, dict) and "ms_per_frame" in st:
+        line["config5_one_sequence_per_gpu"] = _pick(st, ("ms_per_frame", "median_ms_per_frame", "camera_chain_only_ms_per_frame", "frames_per_s_all_sequences", "tracked",
+                                                          "detections_track_ok", "trajectory_gather_ms"))
+    di = sec.get("drop_in_api")
+    if isinstance(di, dict) and ("cpp_shim_camera_chain" in di or "per_call_slot_chain" in di):
+        c, pc = di.get("cpp_shim_camera_chain") or {}, di.get("per_call_slot_chain") or {}
+        line["drop_in_api"] = {"cpp_shim_camera_chain": dict(_pick(c, ("median_ms_per_frame", "mean_ms_per_frame", "frames_with_pose")), split_ms=c.get("split_ms_per_frame")),
+                               "per_call_slot_chain": _pick(pc, ("c_abi_ms_per_frame", "c_abi_calls_per_frame", "python_host_ms_per_frame", "frames", "tracked"))}
     if sec.get("failed_legs"):
         line["failed_legs"] = sec["failed_legs"]
     line["full"] = full.get("full_result_file")
     line = _num(line, 5)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     if len(text) >= LINE_LIMIT:      # never hand the driver a line it cannot read: drop the optional tables, largest first
-        for k in ("kernels_alone", "rooflines", "rooflines_columns", "tracking_checks", "cpu_baseline_all_cores", "cpu_baseline_reference_thread_model"):
+        for k in ("kernels_alone", "rooflines", "rooflines_columns", "tracking_checks", "cpu_baseline_all_cores", "cpu_baseline_reference_thread_model", "drop_in_api"):
             line.pop(k, None)
             text = json.dumps(line, allow_nan=False, separators=(",", ":"))
             if len(text) < LINE_LIMIT:
@@ -1194,7 +1374,8 @@ def main():
                          ("orb_extraction", lambda: orb_leg(rank, local_rank, gbarrier, with_cpu)),
                          ("optimizers", lambda: optimizer_legs(rank, world, local_rank, guard, with_cpu, fp64_peak)),
                          ("lockstep_tracking_host_images", lambda: pcie_leg(rank, world, local_rank, guard, head["seqs"], sseq, 1, gbarrier)),
-                         ("sequence_tracking", lambda: config5_leg(rank, world, local_rank, guard))):
+                         ("sequence_tracking", lambda: config5_leg(rank, world, local_rank, guard)),
+                         ("drop_in_api", lambda: (drop_in_api_leg(rank, local_rank) if rank == 0 else {}))):
             r = guard.run(fn)
             if isinstance(r, dict) and "error" in r and len(r) == 1:
                 failed_legs.append(name)

@@ -46,6 +46,12 @@ struct ps_cvorb {
   // last call (for ps_cvorb_debug_read)
   std::vector<std::vector<float>> last_cand;   // per level: rows of 4 floats
   bool last_had_mask = false;
+  // r06: a masked single image goes through the batched, device-resident form (a batch of one): no host round trips around retainBest,
+  // work proportional to the masked area.  Results land in one page-locked block (count, overflow, keypoints, descriptors: one wait).
+  uint8_t* h_out = nullptr; size_t h_out_bytes = 0;
+  uint8_t* h_in = nullptr; size_t h_in_bytes = 0;   // page-locked staging of image + mask (a 2-D copy from pageable memory goes row by row: 3 ms per image)
+  bool fast = true;                            // PS_CVORB_FAST=0: always the per-level host-selected form below
+  bool last_fast = false;                      // the staged inputs of the last call have not been through that form (ps_cvorb_debug_read runs it)
 };
 
 namespace {
@@ -173,6 +179,7 @@ int ps_cvorb_create(int nfeatures, float scale_factor, int nlevels, int edge_thr
     for (int i = 0; i < 7; i++) { const double x = i - 3; v[i] = exp(-0.5 * x * x / 4.0); sum += v[i]; }
     for (int i = 0; i < 7; i++) h->kq[i] = cv_round(v[i] / sum * 256.0);
   }
+  if (const char* f = getenv("PS_CVORB_FAST")) h->fast = atoi(f) != 0;
   *out = h;
   return PS_OK;
 }
@@ -183,28 +190,26 @@ void ps_cvorb_destroy(ps_cvorb* h) {
   if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
   if (h->d_buf) hipFree(h->d_buf);
   if (h->b_buf) hipFree(h->b_buf);
+  if (h->h_out) hipHostFree(h->h_out);
+  if (h->h_in) hipHostFree(h->h_in);
   delete h;
 }
 
-int ps_cvorb_detect_and_compute(ps_cvorb* h, const uint8_t* img, const uint8_t* mask, int w, int hgt, int stride, int mask_stride, ps_keypoint* kps,
-                                uint8_t* desc, int cap, int* n) {
-  if (!h || !n) return ps_set_error(PS_ERR_INVALID, "ps_cvorb_detect_and_compute: null argument");
-  *n = 0;
-  if (!img || w <= 0 || hgt <= 0) return PS_OK;
-  if (stride < w || (mask && mask_stride < w)) return ps_set_error(PS_ERR_INVALID, "stride < width");
-  PS_HIP(hipSetDevice(h->device));
-  if (!h->planned || h->w != w || h->h != hgt) {
-    int rc = build_plan(h, w, hgt);
-    if (rc != PS_OK) return rc;
-  }
+}  // extern "C"
+
+extern "C" int psi_cvorb_batch_begin(ps_cvorb* h, int nimg, int w, int hgt, hipStream_t st, uint8_t** occ, int* ocw, int* och);
+extern "C" int psi_cvorb_batch_run(ps_cvorb* h, const uint8_t* d_imgs, const uint8_t* d_masks, int nimg, int stride, size_t image_pitch, int mask_stride,
+                                   size_t mask_pitch, int occupancy_given, hipStream_t st);
+
+namespace {
+// The per-level form on the inputs staged in h->d_img / h->d_mask: full pyramid, FAST + Harris per level, the two retainBest steps on the
+// host (std::nth_element / std::partition), descriptors.  kps == nullptr: only the intermediates (ps_cvorb_debug_read).
+int single_host_selected(ps_cvorb* h, int w, bool has_mask, ps_keypoint* kps, uint8_t* desc, int cap, int* n) {
   hipStream_t st = h->stream;
-  PS_HIP(hipMemcpy2DAsync(h->d_img, w, img, stride, w, hgt, hipMemcpyHostToDevice, st));
-  if (mask) PS_HIP(hipMemcpy2DAsync(h->d_mask, w, mask, mask_stride, w, hgt, hipMemcpyHostToDevice, st));
   CvPlanDev P = h->plan;
-  if (!mask) for (int l = 0; l < P.nlevels; l++) P.lv[l].mask = nullptr;
-  h->last_had_mask = mask != nullptr;
+  if (!has_mask) for (int l = 0; l < P.nlevels; l++) P.lv[l].mask = nullptr;
   // pyramid, detection
-  psk_cv_level0(&P.lv[0], h->d_img, w, mask ? h->d_mask : nullptr, w, st);
+  psk_cv_level0(&P.lv[0], h->d_img, w, has_mask ? h->d_mask : nullptr, w, st);
   for (int l = 1; l < P.nlevels; l++) psk_cv_resize(&P.lv[l], &P.lv[l - 1], h->d_xtab[l], h->d_ytab[l], st);
   for (int l = 0; l < P.nlevels; l++) psk_cv_detect(&P.lv[l], h->fast_th, h->edge, h->cap[l], h->d_total + l, st);
   for (int l = 0; l < P.nlevels; l++) psk_cv_blur(&P.lv[l], h->kq, st);   // (independent of the selection: queued before the host waits)
@@ -229,6 +234,8 @@ int ps_cvorb_detect_and_compute(ps_cvorb* h, const uint8_t* img, const uint8_t* 
     retain_best(kp, h->quota[l]);                           // cull to the quota by the Harris score
     for (CvSel& k : kp) { k.level = l; selected.push_back(k); }
   }
+  h->last_fast = false;
+  if (!kps && !desc && !n) return PS_OK;
   const int nsel = (int)selected.size();
   if (nsel > h->sel_cap) return ps_set_error(PS_ERR_CAPACITY, "%d keypoints selected, internal capacity %d", nsel, h->sel_cap);
   *n = nsel;
@@ -244,11 +251,95 @@ int ps_cvorb_detect_and_compute(ps_cvorb* h, const uint8_t* img, const uint8_t* 
   return PS_OK;
 }
 
+// The batched form on the same staged inputs as a batch of one.  *served = false: the image does not fit that form (its plan's limits, or
+// more FAST keypoints under the mask than its per-level / per-image stores hold) - the caller runs the per-level form instead.
+int single_batched(ps_cvorb* h, int w, int hgt, ps_keypoint* kps, uint8_t* desc, int cap, int* n, bool* served) {
+  *served = false;
+  hipStream_t st = h->stream;
+  if (psi_cvorb_batch_begin(h, 1, w, hgt, st, nullptr, nullptr, nullptr) != PS_OK) return PS_OK;
+  int rc = psi_cvorb_batch_run(h, h->d_img, h->d_mask, 1, w, (size_t)w * hgt, w, (size_t)w * hgt, 0, st);
+  if (rc != PS_OK) return rc;
+  const size_t ocap = (size_t)h->bplan.ocap, need = 64 + ocap * (sizeof(ps_keypoint) + 32);
+  if (need > h->h_out_bytes) {
+    if (h->h_out) hipHostFree(h->h_out);
+    h->h_out = nullptr; h->h_out_bytes = 0;
+    PS_HIP(hipHostMalloc(&h->h_out, need, hipHostMallocDefault));
+    h->h_out_bytes = need;
+  }
+  int32_t* hc = (int32_t*)h->h_out;
+  uint8_t* hk = h->h_out + 64;
+  uint8_t* hd = hk + ocap * sizeof(ps_keypoint);
+  PS_HIP(hipMemcpyAsync(hc, h->bplan.count, 4, hipMemcpyDeviceToHost, st));
+  PS_HIP(hipMemcpyAsync(hc + 1, h->bplan.overflow, 4, hipMemcpyDeviceToHost, st));
+  PS_HIP(hipMemcpyAsync(hk, h->bplan.kps, ocap * sizeof(ps_keypoint), hipMemcpyDeviceToHost, st));
+  PS_HIP(hipMemcpyAsync(hd, h->bplan.desc, ocap * 32, hipMemcpyDeviceToHost, st));
+  PS_HIP(hipStreamSynchronize(st));
+  if (hc[1]) return PS_OK;                                  // a store overflowed: not served
+  *served = true;
+  h->last_fast = true;
+  const int cnt = hc[0];
+  *n = cnt;
+  if (cnt == 0) return PS_OK;
+  if (cnt > cap) return ps_set_error(PS_ERR_CAPACITY, "%d keypoints, caller capacity %d", cnt, cap);
+  if (!kps || !desc) return ps_set_error(PS_ERR_INVALID, "null output buffer");
+  memcpy(kps, hk, (size_t)cnt * sizeof(ps_keypoint));
+  memcpy(desc, hd, (size_t)cnt * 32);
+  return PS_OK;
+}
+}  // namespace
+
+extern "C" {
+int ps_cvorb_detect_and_compute(ps_cvorb* h, const uint8_t* img, const uint8_t* mask, int w, int hgt, int stride, int mask_stride, ps_keypoint* kps,
+                                uint8_t* desc, int cap, int* n) {
+  if (!h || !n) return ps_set_error(PS_ERR_INVALID, "ps_cvorb_detect_and_compute: null argument");
+  *n = 0;
+  if (!img || w <= 0 || hgt <= 0) return PS_OK;
+  if (stride < w || (mask && mask_stride < w)) return ps_set_error(PS_ERR_INVALID, "stride < width");
+  PS_HIP(hipSetDevice(h->device));
+  if (!h->planned || h->w != w || h->h != hgt) {
+    int rc = build_plan(h, w, hgt);
+    if (rc != PS_OK) return rc;
+  }
+  hipStream_t st = h->stream;
+  {
+    // image and mask, rows packed, through page-locked staging: two host memcpys and two DMA transfers
+    const size_t px = (size_t)w * hgt, need = 2 * px;
+    if (need > h->h_in_bytes) {
+      if (h->h_in) hipHostFree(h->h_in);
+      h->h_in = nullptr; h->h_in_bytes = 0;
+      PS_HIP(hipHostMalloc(&h->h_in, need, hipHostMallocDefault));
+      h->h_in_bytes = need;
+    }
+    auto pack = [&](uint8_t* dst, const uint8_t* src, int sstride) {
+      if (sstride == w) memcpy(dst, src, px);
+      else for (int y = 0; y < hgt; y++) memcpy(dst + (size_t)y * w, src + (size_t)y * sstride, w);
+    };
+    pack(h->h_in, img, stride);
+    PS_HIP(hipMemcpyAsync(h->d_img, h->h_in, px, hipMemcpyHostToDevice, st));
+    if (mask) {
+      pack(h->h_in + px, mask, mask_stride);
+      PS_HIP(hipMemcpyAsync(h->d_mask, h->h_in + px, px, hipMemcpyHostToDevice, st));
+    }
+  }
+  h->last_had_mask = mask != nullptr;
+  if (mask && h->fast) {
+    bool served = false;
+    const int rc = single_batched(h, w, hgt, kps, desc, cap, n, &served);
+    if (rc != PS_OK || served) return rc;
+    *n = 0;
+  }
+  return single_host_selected(h, w, mask != nullptr, kps, desc, cap, n);
+}
+
 // Test access to intermediates of the last call.  what: 0 level image (tight w x h), 1 blurred level, 2 level mask,
 // 3 the FAST keypoints after the mask / border filters as float rows (x, y, score, Harris), count in *n; 4: level size as int32[2]
 int ps_cvorb_debug_read(ps_cvorb* h, int level, int what, void* out, size_t out_bytes, int* n) {
   if (!h || !h->planned || level < 0 || level >= h->nlevels || !out) return ps_set_error(PS_ERR_INVALID, "ps_cvorb_debug_read: bad argument");
   PS_HIP(hipSetDevice(h->device));
+  if (h->last_fast) {   // the last call was served by the batched form: the per-level intermediates are made now, from the inputs still staged
+    const int rc = single_host_selected(h, h->w, h->last_had_mask, nullptr, nullptr, 0, nullptr);
+    if (rc != PS_OK) return rc;
+  }
   PS_HIP(hipDeviceSynchronize());
   const CvLevelDev& L = h->plan.lv[level];
   if (what == 4) { if (out_bytes < 8) return ps_set_error(PS_ERR_CAPACITY, "buffer too small"); ((int32_t*)out)[0] = L.w; ((int32_t*)out)[1] = L.h; return PS_OK; }

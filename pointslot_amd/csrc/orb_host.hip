@@ -67,6 +67,9 @@ struct ps_orb {
   uint8_t* d_mask_buf = nullptr; size_t d_mask_bytes = 0;
   uint8_t* h_frames = nullptr;    // pinned staging of ps_orb_stereo_fetch_frames
   size_t h_frames_bytes = 0;
+  uint8_t* h_in = nullptr; size_t h_in_bytes = 0;   // pinned staging of ps_orb_extract's image when the caller's buffer is pageable
+  uint8_t* h_one = nullptr;       // pinned staging of the single-image calls (ps_orb_extract, ps_orb_stereo_match_pair): count + the whole
+  size_t h_one_bytes = 0;         // output capacity come back in one transfer group and one wait, not one blocking copy per array
   hipStream_t stream = nullptr;
   // host-image batches: the upload of a batch runs on its own stream, behind the level-0 kernel of the batch before it (the only
   // reader of the staging buffer) and ahead of its own kernels - it overlaps the rest of the previous batch's work
@@ -177,7 +180,10 @@ int free_device(ps_orb* h) {
   if (h->d_objkeys) hipFree(h->d_objkeys);
   if (h->h_objkeys) hipHostFree(h->h_objkeys);
   if (h->h_frames) hipHostFree(h->h_frames);
-  h->d_objkeys = nullptr; h->h_objkeys = nullptr; h->h_frames = nullptr; h->h_frames_bytes = 0;
+  if (h->h_one) hipHostFree(h->h_one);
+  if (h->h_in) hipHostFree(h->h_in);
+  h->h_in = nullptr; h->h_in_bytes = 0;
+  h->d_objkeys = nullptr; h->h_objkeys = nullptr; h->h_frames = nullptr; h->h_frames_bytes = 0; h->h_one = nullptr; h->h_one_bytes = 0;
   h->d_uright = nullptr; h->d_depth = nullptr; h->d_sad = nullptr; h->d_kept = nullptr; h->d_pairs = nullptr;
   h->d_arena = nullptr; h->d_tabs = nullptr; h->d_kps = nullptr; h->d_desc = nullptr; h->d_counts = nullptr;
   return 0;
@@ -515,11 +521,52 @@ int ps_orb_extract(ps_orb* h, const uint8_t* img, int w, int hgt, int stride, ps
     PS_HIP(hipMalloc(&h->d_img, bytes));
     h->d_img_bytes = bytes;
   }
-  PS_HIP(hipMemcpyAsync(h->d_img, img, bytes, hipMemcpyHostToDevice, h->stream));
+  {
+    // a copy from pageable memory is staged by the runtime in pieces with a wait each; from page-locked memory it is one DMA transfer
+    hipPointerAttribute_t at;
+    const bool pinned = hipPointerGetAttributes(&at, img) == hipSuccess && at.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    const uint8_t* src = img;
+    if (!pinned) {
+      if (bytes > h->h_in_bytes) {
+        if (h->h_in) hipHostFree(h->h_in);
+        h->h_in = nullptr; h->h_in_bytes = 0;
+        PS_HIP(hipHostMalloc(&h->h_in, bytes, hipHostMallocDefault));
+        h->h_in_bytes = bytes;
+      }
+      memcpy(h->h_in, img, bytes);
+      src = h->h_in;
+    }
+    PS_HIP(hipMemcpyAsync(h->d_img, src, bytes, hipMemcpyHostToDevice, h->stream));
+  }
   int rc = ps_orb_extract_batch_device(h, h->d_img, 1, w, hgt, stride, bytes, nullptr);
   if (rc != PS_OK) return rc;
-  rc = ps_orb_batch_fetch(h, 0, kps, desc, cap, n);
-  if (rc != PS_OK) return rc;
+  {
+    // count, keypoints and descriptors of the one image: three copies into page-locked memory behind the kernels, ONE wait on this handle's
+    // stream (ps_orb_batch_fetch waits for the whole device - the other extractor's thread included - and blocks once per array)
+    const size_t kc = (size_t)h->plan.kp_cap, need = 64 + kc * (sizeof(ps_keypoint) + 32);
+    if (need > h->h_one_bytes) {
+      if (h->h_one) hipHostFree(h->h_one);
+      h->h_one = nullptr; h->h_one_bytes = 0;
+      PS_HIP(hipHostMalloc(&h->h_one, need, hipHostMallocDefault));
+      h->h_one_bytes = need;
+    }
+    hipStream_t st = h->last_stream ? h->last_stream : h->stream;
+    uint8_t* hk = h->h_one + 64;
+    uint8_t* hd = hk + kc * sizeof(ps_keypoint);
+    PS_HIP(hipMemcpyAsync(h->h_one, h->d_counts, 4, hipMemcpyDeviceToHost, st));
+    PS_HIP(hipMemcpyAsync(hk, h->d_kps, kc * sizeof(ps_keypoint), hipMemcpyDeviceToHost, st));
+    PS_HIP(hipMemcpyAsync(hd, h->d_desc, kc * 32, hipMemcpyDeviceToHost, st));
+    PS_HIP(hipStreamSynchronize(st));
+    const int cnt = *(const int32_t*)h->h_one;
+    *n = cnt;
+    if (cnt > cap) return ps_set_error(PS_ERR_CAPACITY, "%d keypoints, caller capacity %d", cnt, cap);
+    if (cnt > 0) {
+      if (!kps || !desc) return ps_set_error(PS_ERR_INVALID, "null output buffer");
+      memcpy(kps, hk, (size_t)cnt * sizeof(ps_keypoint));
+      memcpy(desc, hd, (size_t)cnt * 32);
+    }
+  }
   if (pyramid_out) {
     for (int l = 0; l < h->plan.nlevels; l++) {
       const OrbLevel& L = h->plan.lv[l];
@@ -793,7 +840,9 @@ int ps_orb_stereo_match_pair(ps_orb* left, ps_orb* right, float mb, float mbf, f
     return ps_set_error(PS_ERR_INVALID, "left and right extractor differ in device, image size or level count");
   if (left->plan.kp_cap > 4096) return ps_set_error(PS_ERR_CAPACITY, "stereo matcher supports at most 4096 keypoints per image");
   PS_HIP(hipSetDevice(left->cfg.device));
-  PS_HIP(hipDeviceSynchronize());
+  // both extractions must be complete (ps_orb_extract returns with its stream idle; a batch queued with ps_orb_extract_batch_device may not be)
+  PS_HIP(hipStreamSynchronize(left->last_stream ? left->last_stream : left->stream));
+  PS_HIP(hipStreamSynchronize(right->last_stream ? right->last_stream : right->stream));
   std::vector<StPair> pairs(1);
   StPair& s = pairs[0];
   s.arena_l = left->d_arena; s.arena_r = right->d_arena;
@@ -804,7 +853,32 @@ int ps_orb_stereo_match_pair(ps_orb* left, ps_orb* right, float mb, float mbf, f
   int rc = stereo_run(left, pairs, mb, mbf);
   if (rc != PS_OK) return rc;
   left->last_nimg = 1;
-  return ps_orb_stereo_fetch(left, 0, u_right, depth, cap, n_left, nullptr);
+  {
+    // counts and the two result arrays in one transfer group and one wait (see ps_orb_extract)
+    ps_orb* h = left;
+    const size_t kc = (size_t)h->plan.kp_cap, need = 64 + kc * (sizeof(ps_keypoint) + 32);   // (the size ps_orb_extract keeps: one block serves both)
+    if (need > h->h_one_bytes) {
+      if (h->h_one) hipHostFree(h->h_one);
+      h->h_one = nullptr; h->h_one_bytes = 0;
+      PS_HIP(hipHostMalloc(&h->h_one, need, hipHostMallocDefault));
+      h->h_one_bytes = need;
+    }
+    float* hu = (float*)(h->h_one + 64);
+    float* hd = hu + kc;
+    PS_HIP(hipMemcpyAsync(h->h_one, h->d_counts, 4, hipMemcpyDeviceToHost, h->stream));
+    PS_HIP(hipMemcpyAsync(hu, h->d_uright, kc * 4, hipMemcpyDeviceToHost, h->stream));
+    PS_HIP(hipMemcpyAsync(hd, h->d_depth, kc * 4, hipMemcpyDeviceToHost, h->stream));
+    PS_HIP(hipStreamSynchronize(h->stream));
+    const int nl = *(const int32_t*)h->h_one;
+    *n_left = nl;
+    if (nl > cap) return ps_set_error(PS_ERR_CAPACITY, "%d keypoints, caller capacity %d", nl, cap);
+    if (nl > 0) {
+      if (!u_right || !depth) return ps_set_error(PS_ERR_INVALID, "null output buffer");
+      memcpy(u_right, hu, (size_t)nl * 4);
+      memcpy(depth, hd, (size_t)nl * 4);
+    }
+  }
+  return PS_OK;
 }
 
 

@@ -77,12 +77,14 @@ struct ps_tracker {
   BfBlock* d_bf_blocks = nullptr; int32_t* d_bf_count = nullptr; int bf_blocks_per_prob = 0;
   PjArrays pj_obj;
   double* ob_chi2 = nullptr; uint8_t* ob_state = nullptr; float* ob_cedge = nullptr;
-  // ExtractObjORB does not depend on the camera chain of its frame: with PS_TRK_OVERLAP=1 it runs on a second (low-priority) stream
-  // beside the stereo matching, the searches and PoseOptimization and joins before ComputeObjStereoMatches.  Measured (r03, 512
-  // sequences): 16.16 against 16.34 ms per step - the kernels of both streams slow each other down by what the overlap saves - so
-  // the default is one stream, where the stage times add up to the step.
+  // ExtractObjORB does not depend on the camera chain of its frame: with the overlap on, the head of the object chain - masks, cv::ORB,
+  // ComputeObjStereoMatches (behind the extractor's pyramids), ob_begin - runs on a second (low-priority) stream beside the camera chain
+  // and joins before TrackMapObject.  Measured with 512 sequences (r03): 16.16 against 16.34 ms per step - the kernels of both streams
+  // slow each other down by what the overlap saves - so a throughput-sized handle keeps one stream, where the stage times add up to the
+  // step.  A handle of a few sequences (r06: BASELINE configs[4] is ONE sequence per GPU) leaves the GPU almost empty, every kernel runs
+  // at its own latency, and the overlap takes the head's ~0.3 ms off the frame: default on up to 32 sequences (PS_TRK_OVERLAP=0 / 1 decides).
   hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_orb = nullptr;
   hipEvent_t ev_obj[64][2] = {};     // timing of the object features on stream2 (ring as below)
   bool overlap = false;
   // stage timing
@@ -234,6 +236,41 @@ size_t carve_obj(ps_tracker* t, uint8_t* base) {
   return c.off;
 }
 
+// ExtractObjORB (Frame.cc:711, 2623-2665) with its masks (Frame.cc:2318-2503) on stream `so`
+int queue_object_features(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_pitch, const uint8_t* d_masks, int mask_stride, size_t mask_pitch,
+                          const ps_detection* d_dets, hipStream_t so) {
+  ObArrays* O = &t->OA;
+  const int S = t->A.S;
+  O->idmask = d_masks; O->mask_stride = mask_stride; O->mask_pitch = mask_pitch; O->dets_in = (const ObDet*)d_dets;
+  const int W = t->cfg.width, H = t->cfg.height;
+  uint8_t* occ = nullptr; int ocw = 0, och = 0;
+  int r = psi_cvorb_batch_begin(t->cvorb, 2 * S, W, H, so, &occ, &ocw, &och);
+  if (r != PS_OK) return r;
+  const int ostride = (W + 15) & ~15;                          // rows of the object masks start on 16-byte boundaries
+  psk_ob_masks(O, t->d_objmask, W, H, ostride, occ, ocw, och, so);   // ... and fills the detector's cell occupancy on the way
+  return psi_cvorb_batch_run(t->cvorb, d_imgs, t->d_objmask, 2 * S, stride, image_pitch, ostride, (size_t)ostride * H, 1, so);
+}
+
+// The head of the object chain on the second stream, in two parts around the extraction the caller queues on the main stream: the object
+// features start with the frame (they read the images and the masks only); ComputeObjStereoMatches reads the extractor's pyramids and
+// waits for them; ob_begin follows.  The main stream joins in front of TrackMapObject (queue_chain).
+int overlap_head_before_orb(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_pitch, const uint8_t* d_masks, int mask_stride, size_t mask_pitch,
+                            const ps_detection* d_dets) {
+  PS_HIP(hipEventRecord(t->ev_fork, t->stream));                // behind the previous frame's chain, which still reads this stream's arrays
+  PS_HIP(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+  if (t->timing) hipEventRecord(t->ev_obj[t->timed % ps_tracker::RING][0], t->stream2);
+  return queue_object_features(t, d_imgs, stride, image_pitch, d_masks, mask_stride, mask_pitch, d_dets, t->stream2);
+}
+int overlap_head_after_orb(ps_tracker* t) {
+  PS_HIP(hipEventRecord(t->ev_orb, t->stream));
+  PS_HIP(hipStreamWaitEvent(t->stream2, t->ev_orb, 0));
+  psk_stereo_launch(psi_orb_plan(t->orb), t->d_obj_pairs, t->A.S, t->OA.OC, t->mb, t->mbf, t->stream2);
+  psk_ob_begin(&t->OA, t->step, t->stream2);
+  if (t->timing) hipEventRecord(t->ev_obj[t->timed % ps_tracker::RING][1], t->stream2);
+  PS_HIP(hipEventRecord(t->ev_join, t->stream2));
+  return PS_OK;
+}
+
 int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_pitch, const uint8_t* d_masks, int mask_stride, size_t mask_pitch,
                 const ps_detection* d_dets) {
   TrkArrays* A = &t->A;
@@ -253,27 +290,7 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
   mark(TS_ORB);
   int rc = PS_OK;
   const bool objects = d_masks && t->cvorb;
-  // ExtractObjORB (Frame.cc:711, 2623-2665) with its masks (Frame.cc:2318-2503): on the second stream from here, or in line below
-  auto object_features = [&](hipStream_t so) -> int {
-    ObArrays* O = &t->OA;
-    O->idmask = d_masks; O->mask_stride = mask_stride; O->mask_pitch = mask_pitch; O->dets_in = (const ObDet*)d_dets;
-    const int W = t->cfg.width, H = t->cfg.height;
-    uint8_t* occ = nullptr; int ocw = 0, och = 0;
-    int r = psi_cvorb_batch_begin(t->cvorb, 2 * S, W, H, so, &occ, &ocw, &och);
-    if (r != PS_OK) return r;
-    const int ostride = (W + 15) & ~15;                          // rows of the object masks start on 16-byte boundaries
-    psk_ob_masks(O, t->d_objmask, W, H, ostride, occ, ocw, och, so);   // ... and fills the detector's cell occupancy on the way
-    return psi_cvorb_batch_run(t->cvorb, d_imgs, t->d_objmask, 2 * S, stride, image_pitch, ostride, (size_t)ostride * H, 1, so);
-  };
-  if (objects && t->overlap) {
-    PS_HIP(hipEventRecord(t->ev_fork, st));
-    PS_HIP(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
-    if (tm) hipEventRecord(t->ev_obj[t->timed % ps_tracker::RING][0], t->stream2);
-    rc = object_features(t->stream2);
-    if (rc != PS_OK) return rc;
-    if (tm) hipEventRecord(t->ev_obj[t->timed % ps_tracker::RING][1], t->stream2);
-    PS_HIP(hipEventRecord(t->ev_join, t->stream2));
-  }
+  auto object_features = [&](hipStream_t so) -> int { return queue_object_features(t, d_imgs, stride, image_pitch, d_masks, mask_stride, mask_pitch, d_dets, so); };
   rc = ps_orb_stereo_match_batch(t->orb, S, t->mb, t->mbf);
   if (rc != PS_OK) return rc;
   mark(TS_STEREO);
@@ -297,14 +314,14 @@ int queue_chain(ps_tracker* t, const uint8_t* d_imgs, int stride, size_t image_p
     // ---- the object half of Tracking::Track, behind the camera chain of the same frame ----
     ObArrays* O = &t->OA;
     const int K = O->K;
-    if (t->overlap) { PS_HIP(hipStreamWaitEvent(st, t->ev_join, 0)); mark(TS_OBJ_WAIT); }
+    if (t->overlap) { PS_HIP(hipStreamWaitEvent(st, t->ev_join, 0)); mark(TS_OBJ_WAIT); }   // the head ran on the second stream (overlap_head_*)
     else {
       rc = object_features(st);
       if (rc != PS_OK) return rc;
       mark(TS_OBJ_FEATURES);
+      psk_stereo_launch(psi_orb_plan(t->orb), t->d_obj_pairs, S, O->OC, t->mb, t->mbf, st); mark(TS_OBJ_STEREO);
+      psk_ob_begin(O, t->step, st);
     }
-    psk_stereo_launch(psi_orb_plan(t->orb), t->d_obj_pairs, S, O->OC, t->mb, t->mbf, st); mark(TS_OBJ_STEREO);
-    psk_ob_begin(O, t->step, st);
     psk_ob_track(O, t->step, st);
     psk_ob_bf_blocks(O->bf_prob, t->d_bf_blocks, t->d_bf_count, S * K, t->bf_blocks_per_prob, st); mark(TS_OBJ_GLUE);
     psk_bf_launch_dev(t->d_bf_blocks, t->d_bf_count, 1024, O->bf_prob, S * K, O->last.desc, O->last.angle, O->bf_qvalid, O->cur.desc, O->cur.angle,
@@ -422,12 +439,13 @@ int ps_tracker_create(const ps_tracker_config* cfg, ps_tracker** out) {
     for (ObMapObject& m : mo) m.id = -1;
     hipMemcpy(O.mobj, mo.data(), mo.size() * sizeof(ObMapObject), hipMemcpyHostToDevice);
     O.cam_traj = A.traj; O.cam_stats = (const int32_t*)A.stats; O.cam_stat_words = (int32_t)(sizeof(TrkStat) / 4);
-    t->overlap = getenv("PS_TRK_OVERLAP") != nullptr;
+    const char* ov = getenv("PS_TRK_OVERLAP");
+    t->overlap = ov ? atoi(ov) != 0 : A.S <= 32;
     if (t->overlap) {
       int least = 0, greatest = 0;
       hipDeviceGetStreamPriorityRange(&least, &greatest);          // the camera chain is the critical path: the object features fill in behind it
       if (hipStreamCreateWithPriority(&t->stream2, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) != hipSuccess) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_HIP, "ps_tracker_create: second stream"); }
+          hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t->ev_orb, hipEventDisableTiming) != hipSuccess) { ps_tracker_destroy(t); return ps_set_error(PS_ERR_HIP, "ps_tracker_create: second stream"); }
       for (int r = 0; r < ps_tracker::RING; r++) { hipEventCreate(&t->ev_obj[r][0]); hipEventCreate(&t->ev_obj[r][1]); }
     }
   }
@@ -445,6 +463,7 @@ void ps_tracker_destroy(ps_tracker* t) {
   if (t->stream2) { hipStreamSynchronize(t->stream2); hipStreamDestroy(t->stream2); }
   if (t->ev_fork) hipEventDestroy(t->ev_fork);
   if (t->ev_join) hipEventDestroy(t->ev_join);
+  if (t->ev_orb) hipEventDestroy(t->ev_orb);
   for (int r = 0; r < ps_tracker::RING; r++) for (int i = 0; i < 2; i++) if (t->ev_obj[r][i]) hipEventDestroy(t->ev_obj[r][i]);
   if (t->d_buf) hipFree(t->d_buf);
   if (t->d_obj) hipFree(t->d_obj);
@@ -477,8 +496,11 @@ int ps_tracker_step_slot_device(ps_tracker* t, const uint8_t* d_imgs, int stride
   if (t->step >= t->A.max_steps) return ps_set_error(PS_ERR_CAPACITY, "the tracker was created for %d steps", t->A.max_steps);
   PS_HIP(hipSetDevice(t->cfg.device));
   if (t->timing) PS_HIP(hipEventRecord(t->ev[t->timed % ps_tracker::RING][0], t->stream));
-  int rc = ps_orb_extract_batch_device(t->orb, d_imgs, 2 * t->A.S, t->cfg.width, t->cfg.height, stride, image_pitch, nullptr);
+  int rc = PS_OK;
+  if (t->overlap && (rc = overlap_head_before_orb(t, d_imgs, stride, image_pitch, d_masks, mask_stride, mask_pitch, d_dets)) != PS_OK) return rc;
+  rc = ps_orb_extract_batch_device(t->orb, d_imgs, 2 * t->A.S, t->cfg.width, t->cfg.height, stride, image_pitch, nullptr);
   if (rc != PS_OK) return rc;
+  if (t->overlap && (rc = overlap_head_after_orb(t)) != PS_OK) return rc;
   return queue_chain(t, d_imgs, stride, image_pitch, d_masks, mask_stride, mask_pitch, d_dets);
 }
 

@@ -76,6 +76,7 @@ class ORBmatcher {
     for (int i = 0; i < n; i++) total += p[i].nmatches;
     return total;
   }
+  ps_matcher* handle() { return h_; }   // (kernel time of the last call: ps_matcher_last_kernel_ms)
   static float RadiusByViewingCos(const float& viewCos) { return viewCos > 0.998 ? 2.5f : 4.0f; }   // ORBmatcher.cc:252-258
 
   // ------------------------------------------------------------------------------------------------------------------

@@ -388,8 +388,22 @@ class StereoOdometry {
     left.mbDownloadPyramid = false; right.mbDownloadPyramid = false;
   }
 
+  // Where a frame's wall time goes ("marshaling to SoA every call must be measured and reported separately from kernel
+  // time"), accumulated over Track calls: wall seconds inside the C-ABI calls by kind, the kernels' own time inside the matcher / optimiser
+  // calls (HIP events around the launches, read back through ps_*_last_kernel_ms), and everything else = the host side of Tracking::Track
+  // (marshalling into the problem structs, match application, grids).
+  struct Split {
+    double extract = 0, stereo = 0, search = 0, pose = 0, host = 0;     // wall seconds
+    double searchKernelMs = 0, poseKernelMs = 0;
+    long searchCalls = 0, poseCalls = 0, frames = 0;
+    void clear() { *this = Split(); }
+  } split;
+
   // Tracking::Track for one stereo frame; returns true when the frame has a pose
   bool Track(const pscv::Mat& imLeft, const pscv::Mat& imRight) {
+    typedef std::chrono::steady_clock clk;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t0 = clk::now();
     std::unique_ptr<OdoFrame> F(new OdoFrame);
     std::vector<pscv::KeyPoint> keysR;
     pscv::Mat descR;
@@ -399,19 +413,39 @@ class StereoOdometry {
     std::thread threadRight([&]() { right(imRight, pscv::Mat(), keysR, descR); });
     threadLeft.join();
     threadRight.join();
+    const auto t1 = clk::now();
     const int N = (int)F->mvKeys.size();
     F->mvuRight.assign(N, -1.f); F->mvDepth.assign(N, -1.f);
     int n = 0;
     if (N > 0 && ps_orb_stereo_match_pair(left.handle(), right.handle(), cam.mb, cam.mbf, F->mvuRight.data(), F->mvDepth.data(), N, &n) != PS_OK)
       throw std::runtime_error(ps_last_error());                                         // Frame::ComputeStereoMatches
+    const auto t2 = clk::now();
+    split.extract += secs(t0, t1); split.stereo += secs(t1, t2);
+    double inCalls = 0;
     OdoSequence::Request rq = seq.begin(std::move(F));
     while (rq != OdoSequence::NONE) {
-      if (rq == OdoSequence::SEARCH) matcher.SearchByProjectionBatch(&seq.proj, 1);
-      else Optimizer::PoseOptimization(&seq.posep);
+      const auto a = clk::now();
+      float kms = 0;
+      if (rq == OdoSequence::SEARCH) {
+        matcher.SearchByProjectionBatch(&seq.proj, 1);
+        const double d = secs(a, clk::now());
+        ps_matcher_last_kernel_ms(matcher.handle(), &kms);
+        split.search += d; split.searchKernelMs += kms; split.searchCalls++; inCalls += d;
+      } else {
+        Optimizer::PoseOptimization(&seq.posep);
+        const double d = secs(a, clk::now());
+        ps_optimizer_last_kernel_ms(Optimizer::handle(), &kms);
+        split.pose += d; split.poseKernelMs += kms; split.poseCalls++; inCalls += d;
+      }
       rq = seq.advance();
     }
+    split.host += secs(t2, clk::now()) - inCalls;
+    split.frames++;
     return seq.lastFrameTracked;
   }
+
+  ORBextractor& leftExtractor() { return left; }
+  ORBextractor& rightExtractor() { return right; }
 
  private:
   ORBextractor left, right;
@@ -599,7 +633,7 @@ class StereoOdometryBatch {
 // the library between the hot-path kernels, nothing is packed or copied per call, and results are read when asked for.
 class StereoOdometryDevice {
  public:
-  // maxObjects > 0 (at most 8): the handle also carries the object half of Tracking::Track in SLOT.MODE 4 (TrackAllSlotDevice)
+  // maxObjects > 0 (at most 16 detections per frame; maxMapObjects 0 = 8 MapObjects per sequence, at most 16): the handle also carries the object half of Tracking::Track in SLOT.MODE 4 (TrackAllSlotDevice)
   StereoOdometryDevice(int nSequences, float fx, float fy, float cx, float cy, float bf, int width, int height, int maxFrames, float thDepth = 35.f,
                        int nFeatures = 2000, float scale = 1.2f, int nLevels = 8, int iniTh = 20, int minTh = 5, int device = 0, int maxObjects = 0, int maxMapObjects = 0)
       : nseq(nSequences), nobj(maxObjects) {
