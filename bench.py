@@ -39,7 +39,13 @@ ALGO_BYTES_PER_FRAME_POSE_ITER = 2000 * 29 + 224      # pose-opt, 
 ALGO_FLOP_PER_OBJECT_BA_ITER = 103e6                  # object BA, per LM iteration per object (P=50, L=300, E=15000)
 RED_DEV = "cuda"              # device of the tensors used for cross-rank reductions
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r05"   # the committed counter tables the line reads its traffic figures from (tools/reproduce_profiles.sh)
+# FP64 on the VECTOR ALUs (the pose-only optimisers: dependent scalar FP64 chains per edge, no matrix shape): measured issue rate of v_fma_f64
+# with 8 waves per SIMD on every CU, 4.82 cycles per wave-instruction and SIMD (profiles/r05_valu_rate.txt, tools/ubench/valu_rate.hip) =
+# 64 lanes x 2 flop / 4.82 cycles x 1024 SIMDs x 2.3 GHz (the clock that run assumed)
+FP64_VALU_PEAK_TFLOPS = 64 * 2 / 4.82 * 1024 * 2.3e9 / 1e12
+POSE_FLOP_PER_EDGE_ITER = 240.0    # errors + linearisation + errors of one LM iteration
+POSE_FLOP_PER_EDGE_TRIAL = 45.0    # one more error pass (map, project, chi2, Huber) for every damping trial beyond an iteration's first
+PROFILE_ROUND = "r06"   # the committed counter tables the line reads its traffic figures from (tools/reproduce_profiles.sh)
 
 
 def _profile_json(name):
@@ -89,6 +95,32 @@ def pmc_traffic(kernel, nimg):
         if found:
             return tot, "profiles/" + name
     return None, None
+
+
+def unit_busy(kernels):
+    """The roofline of a stage that SURVEY 8d does not price in bytes (latency / issue bound kernels): how busy the busiest execution unit of
+    its kernels was - vector ALUs, the CU's scalar unit, LDS - as a fraction of the kernels' own cycles, weighted by those cycles, from the
+    committed counter passes of tools/valu_busy.sh (profiles/<round>_unit_busy.json: one lockstep group of 512 sequences, kernels one after
+    the other).  1.0 would be a unit issuing every cycle on every CU.  Counters need rocprofv3 around the process, so the figure is read from
+    profiles/, not measured in this run.  -> dict or None."""
+    for rnd in (PROFILE_ROUND, "r05"):
+        t = _profile_json(rnd + "_unit_busy.json")
+        if t:
+            break
+    else:
+        return None
+    cyc, acc = 0.0, {"valu": 0.0, "salu": 0.0, "lds": 0.0}
+    for k, v in t.get("kernels", {}).items():
+        if any(k == n or k.startswith(n) for n in kernels):
+            c = float(v.get("cycles", 0.0))
+            cyc += c
+            for u in acc:
+                acc[u] += c * float(v.get(u, 0.0))
+    if cyc <= 0:
+        return None
+    busy = {u: acc[u] / cyc for u in acc}
+    top = max(busy, key=busy.get)
+    return {"busy": {u: round(x, 4) for u, x in busy.items()}, "unit": top, "frac": busy[top], "source": "profiles/%s_unit_busy.json" % rnd}
 
 
 def pmc_valu_issue(kernel, nimg, ms_per_step=None):
@@ -651,6 +683,17 @@ def optimizer_legs(rank, world, local_rank, guard, with_cpu, fp64_peak):
                                              "traffic": legs_pmc("pose", ("pose_lm",))[0], "traffic_source": legs_pmc("pose", ("pose_lm",))[2],
                                              "algorithmic_bytes_per_launch": algo, "avg_launch_ms": kern_ms,
                                              "note": "edge passes x 58 KB (SURVEY 8d streaming model); the persistent kernel keeps its edges in L2 and is latency-bound"}}
+    # ... and against what actually bounds it: FP64 on the vector ALUs.  flops of the passes the kernel ran (its own per-iteration log: SURVEY's
+    # 240 flop per edge and LM iteration, 45 for every further damping trial's error pass; 2000 edges minus the ones sitting a round out are
+    # not discounted: an upper bound of the work, hence of the fraction)
+    flop = 2000.0 * (POSE_FLOP_PER_EDGE_ITER * iters + POSE_FLOP_PER_EDGE_TRIAL * max(trials - iters, 0))
+    ach = flop / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
+    ub = unit_busy(("pose_lm",))
+    out["pose_optimization"]["roofline_fp64"] = {"bound": "fp64-valu", "kernel": "pose_lm", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                 "frac": ach / FP64_VALU_PEAK_TFLOPS if ach else None, "flop_per_launch": flop,
+                                                 "vector_alu_busy_in_the_tracker_step": ub["busy"]["valu"] if ub else None, "unit_busy_source": ub["source"] if ub else None,
+                                                 "note": "64 workgroups of 256 threads on 256 CUs: a quarter of the chip holds one wave per SIMD; the fraction is of the WHOLE chip's "
+                                                         "vector FP64 issue rate (measured v_fma_f64 rate, profiles/r05_valu_rate.txt)"}
     mine = list(parallel.shard_units(8, world, rank))
     graphs = [synth.object_ba_problem(0x51070004 + j) for j in mine]
     if graphs:
@@ -1139,7 +1182,7 @@ def _pick(d, keys):
     return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
 
 
-_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "images_per_launch")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_ms", "images_per_launch")
 
 
 def compact_line(full):
@@ -1412,27 +1455,40 @@ def main():
             rl.append({"stage": name, "bound": "hbm", "ms_per_step": round(ms, 5), "algorithmic_bytes_per_step": algo, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": a / HBM_PEAK_GBS if a else None, "traffic": traffic, "traffic_source": src, "note": note})
 
-        def other(name, ms, bound, note):
-            rl.append({"stage": name, "bound": bound, "ms_per_step": round(ms, 5), "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "note": note})
+        def other(name, ms, bound, note, kernels=()):
+            # no byte figure in SURVEY 8d for these: the roofline is the busiest execution unit of the stage's kernels (unit_busy)
+            ub = unit_busy(kernels) if kernels else None
+            rl.append({"stage": name, "bound": ("unit-busy:" + ub["unit"]) if ub else bound, "ms_per_step": round(ms, 5), "achieved": ub["frac"] if ub else None,
+                       "peak": 1.0 if ub else None, "unit": "busy fraction of the busiest unit (vector ALU / scalar unit / LDS)" if ub else None, "frac": ub["frac"] if ub else None,
+                       "traffic": None, "unit_busy": ub["busy"] if ub else None, "unit_busy_source": ub["source"] if ub else None, "character": bound, "note": note})
         for k in ("orb_level_fused", "orb_fast_cells", "orb_describe"):
             if "orb/" + k in stage:
                 hbm("orb/" + k, stage["orb/" + k], ALGO_BYTES_PER_IMAGE[k] * nimg, "SURVEY 8d bytes per image x %d images; bound by instruction issue (profiles/)" % nimg)
+                ub = unit_busy((k,))
+                if ub:
+                    rl[-1]["unit_busy"] = ub["busy"]; rl[-1]["unit_busy_source"] = ub["source"]
         if "orb/orb_quadtree" in stage:
-            other("orb/orb_quadtree", stage["orb/orb_quadtree"], "latency", "serial list semantics of DistributeOctTree; candidate lists only, no pixel bytes")
-        other("stereo_match", stage.get("stereo_match", 0.0), "latency", "8f-1 ComputeStereoMatches: row-bucket scan + 11 x 11 SAD slide per left keypoint")
-        other("search_by_projection", stage.get("search_by_projection", 0.0), "latency", "a11 + a12: three windowed searches per frame (th 7, its 2 th retry, the local map)")
-        other("pose_optimization", stage.get("pose_optimization", 0.0), "latency", "a14: two PoseOptimization calls per frame, one persistent workgroup per frame; streaming-model roofline in secondary_metrics.pose_optimization")
-        other("track_glue", stage.get("track_glue", 0.0), "latency", "the host side of Tracking::Track between the kernels, on the device")
+            other("orb/orb_quadtree", stage["orb/orb_quadtree"], "latency", "serial list semantics of DistributeOctTree; candidate lists only, no pixel bytes", ("orb_quadtree",))
+        other("stereo_match", stage.get("stereo_match", 0.0), "latency", "8f-1 ComputeStereoMatches: row-bucket scan + 11 x 11 SAD slide per left keypoint", ("st_bucket", "st_match", "st_median"))
+        other("search_by_projection", stage.get("search_by_projection", 0.0), "latency", "a11 + a12: three windowed searches per frame (th 7, its 2 th retry, the local map)",
+              ("pj_project", "pj_gather", "pj_resolve"))
+        other("pose_optimization", stage.get("pose_optimization", 0.0), "fp64-valu latency",
+              "a14: two PoseOptimization calls per frame, one persistent workgroup per frame (dependent FP64 chains at 1 - 2 waves per SIMD); flop-based figure in secondary_metrics.pose_optimization", ("pose_lm",))
+        other("track_glue", stage.get("track_glue", 0.0), "latency", "the host side of Tracking::Track between the kernels, on the device", ("trk_",))
         if objects:
             hbm("object_features", stage.get("object_features", 0.0), 2 * 465750 * nimg + 465750 * S,
                 "8f-2 + masks: image + object mask of %d images and %d id masks read once; the work is the part of the pyramid a masked keypoint can reach (tile kernels, latency-bound)" % (nimg, S),
                 kernels=("ob_masks", "cvb_plan", "cvb_level0", "cvb_resize", "cvb_detect", "cvb_blur", "cvb_select", "cvb_describe"))
-            other("object_stereo_match", stage.get("object_stereo_match", 0.0), "latency", "8f-1 ComputeObjStereoMatches on the object keys")
+            ub = unit_busy(("ob_masks", "cvb_"))
+            if ub:
+                rl[-1]["unit_busy"] = ub["busy"]; rl[-1]["unit_busy_source"] = ub["source"]
+            other("object_stereo_match", stage.get("object_stereo_match", 0.0), "latency", "8f-1 ComputeObjStereoMatches on the object keys", ("st_bucket", "st_match", "st_median"))
             ob = head["objects"] or {}
-            other("object_bruteforce", stage.get("object_bruteforce", 0.0), "int-alu", "a10: one problem per tracked detection (last-frame x current features of the object); pairs / s in secondary_metrics.object_kernels")
-            other("object_cfse3", stage.get("object_cfse3", 0.0), "latency", "a15: two CFSE3ObjStateOptimization calls per frame (after the brute-force matches, after the local-map search)")
-            other("object_search_by_projection", stage.get("object_search_by_projection", 0.0), "latency", "a13: SearchByProjection(F, nOrder, MOPs) per tracked detection")
-            other("object_glue", stage.get("object_glue", 0.0), "latency", "AssignFeatures, TrackMapObject (RANSAC centroid, box fine tuning, MapObjectInit / ReInit), bookkeeping: %s" % json.dumps(ob))
+            other("object_bruteforce", stage.get("object_bruteforce", 0.0), "int-alu", "a10: one problem per tracked detection (last-frame x current features of the object); pairs / s in secondary_metrics.object_kernels",
+                  ("bf_topk", "bf_resolve"))
+            other("object_cfse3", stage.get("object_cfse3", 0.0), "fp64-valu latency", "a15: two CFSE3ObjStateOptimization calls per frame (after the brute-force matches, after the local-map search)", ("pose_lm",))
+            other("object_search_by_projection", stage.get("object_search_by_projection", 0.0), "latency", "a13: SearchByProjection(F, nOrder, MOPs) per tracked detection", ("pj_gather", "pj_resolve"))
+            other("object_glue", stage.get("object_glue", 0.0), "latency", "AssignFeatures, TrackMapObject (RANSAC centroid, box fine tuning, MapObjectInit / ReInit), bookkeeping: %s" % json.dumps(ob), ("ob_begin", "ob_track", "ob_after", "ob_finish", "ob_bf_blocks"))
         # the headline roofline is a single KERNEL's (the stages that are several kernels stay in `rooflines`)
         # (by the kernels' OWN times - the single-group pass the roofline is measured in - where that pass ran: in the timed region the
         # event-to-event time of a stage includes the other groups' kernels, and `orb_level_fused` (8 launches) and `orb_fast_cells`
@@ -1521,7 +1577,16 @@ def main():
                              "achieved": ALGO_BYTES_PER_IMAGE[k] * alone["images_per_launch"] / (alone["stage_ms"]["orb/" + k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ALGO_BYTES_PER_IMAGE[k] * alone["images_per_launch"] / (alone["stage_ms"]["orb/" + k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "traffic": pmc_traffic(k, alone["images_per_launch"])[0], "traffic_source": pmc_traffic(k, alone["images_per_launch"])[1]}
-                            for k in ("orb_level_fused", "orb_fast_cells", "orb_describe") if "orb/" + k in alone["stage_ms"]]},
+                            for k in ("orb_level_fused", "orb_fast_cells", "orb_describe") if "orb/" + k in alone["stage_ms"]] +
+                           # the kernels SURVEY 8d does not price in bytes: the busiest unit's busy fraction (committed counter pass), the stage's own time in this pass
+                           [dict(kernel=kn, bound="unit-busy:" + ub["unit"], avg_ms_per_step=alone["stage_ms"].get(stg), achieved=ub["frac"], peak=1.0, unit="busy fraction",
+                                 frac=ub["frac"], unit_busy=ub["busy"], source=ub["source"])
+                            for kn, stg, ub in ((kn, stg, unit_busy((kn,))) for kn, stg in (("pose_lm", "pose_optimization"), ("orb_quadtree", "orb/orb_quadtree"), ("st_match", "stereo_match"),
+                                                                                             ("pj_gather", "search_by_projection"), ("pj_resolve", "search_by_projection"),
+                                                                                             ("cvb_plan", "object_features"), ("cvb_resize", "object_features"), ("cvb_detect", "object_features"),
+                                                                                             ("cvb_blur", "object_features"), ("cvb_select", "object_features"), ("cvb_describe", "object_features"),
+                                                                                             ("ob_masks", "object_features"), ("bf_topk", "object_bruteforce"), ("bf_resolve", "object_bruteforce"),
+                                                                                             ("trk_begin", "track_glue"), ("ob_track", "object_glue"))) if ub]},
             "stage_ms": {k: round(v, 5) for k, v in stage.items()},
             "stage_ms_note": "HIP events on group 0's stream over the timed steps; with %d groups the stages of different groups overlap in time" % args.groups,
         }
