@@ -246,8 +246,9 @@ def cfse3_optimize(objs, K):
     off = np.zeros(k + 1, np.int32)
     for i, o in enumerate(objs):
         off[i + 1] = off[i] + len(o["xo"])
-    cat = lambda key, dt: np.ascontiguousarray(np.concatenate([np.asarray(o[key], dt).reshape(len(o["xo"]), -1) for o in objs]), dt) if k else np.zeros((0, 1), dt)
-    xo, obs, is2, valid = cat("xo", np.float32), cat("obs", np.float32), cat("inv_sigma2", np.float32), cat("valid", np.uint8)
+    # (explicit widths: an object that has just left the image has no features, and a 0-row array has no -1 to infer)
+    cat = lambda key, dt, wd: np.ascontiguousarray(np.concatenate([np.asarray(o[key], dt).reshape(len(o["xo"]), wd) for o in objs]), dt) if k else np.zeros((0, wd), dt)
+    xo, obs, is2, valid = cat("xo", np.float32, 3), cat("obs", np.float32, 3), cat("inv_sigma2", np.float32, 1), cat("valid", np.uint8, 1)
     poses = np.ascontiguousarray(np.stack([o["pose7"] for o in objs]), np.float64).copy() if k else np.zeros((0, 7))
     outlier = np.zeros(max(int(off[-1]), 1), np.uint8)
     r = lib().orc_cfse3_optimize(k, off.ctypes.data, xo.ctypes.data, obs.ctypes.data, is2.ctypes.data, valid.ctypes.data,

@@ -192,3 +192,80 @@ def test_full_size_frames_of_the_headline_chain_against_the_cpu_restatement():
     assert worst < 1e-4, worst
     assert records >= S * (n - 1) and int(st["tracked"].sum()) == S * n
     assert dsd > 0, "DynamicStaticDiscrimination's reprojection test never ran in 112 frames"
+
+
+@pytest.mark.gpu
+def test_config5_length_full_size_slot_chain_against_the_cpu_restatement():
+    """BASELINE configs[4] / SURVEY 8d config 5 as written: the 154-frame generated SLOT.MODE-4 sequence at 1242 x 375
+    (seed 0, the bench's config-5 leg) through the device-resident camera + object chain with one sequence per handle (the small-handle
+    path: object head on the second stream) and through the CPU restatement of the same loop, frame by frame: tracked flags, the camera
+    chain's match counts, every object record, |dTcw|.  What is asserted is what holds for two correct runs of a chained estimator (see
+    test_154_frames_against_the_cpu_restatement): identical results for the first frames, single borderline matches afterwards, poses
+    that stay far closer to each other than to the truth.  The per-frame record - first divergent frame included - goes to
+    gpurun_out/config5_chain_parity.json; DESIGN section 2 quotes it."""
+    import json
+    import os
+    import sys
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle_backend import OracleBackend
+    from pointslot_amd.tracker_device import LockstepTracker, pack_detections
+    n = 154
+    q = bench._config5_sequence(0, n)
+    h, w = q["left"][0].shape
+    assert (w, h) == (1242, 375)
+    imgs = torch.from_numpy(np.stack([q["left"], q["right"]], 1)).cuda()
+    masks = torch.from_numpy(q["masks"]).cuda()
+    dets = torch.from_numpy(np.stack([pack_detections([q["dets"][i]], bench.MAX_OBJECTS) for i in range(n)]).view(np.uint8)).cuda()
+    trk = LockstepTracker(1, q["K"], q["bf"], w, h, max_steps=n, max_objects=bench.MAX_OBJECTS)
+    for i in range(n):
+        trk.step_slot_device(imgs[i].data_ptr(), masks[i].data_ptr(), dets[i].data_ptr())
+        trk.sync()
+    tcw, st = trk.fetch()
+    obj = trk.fetch_objects()
+    trk.close()
+    vo, _ = bench._cpu_chain(q, n, OracleBackend(), True)
+    worst, first_cam, first_obj, cam_differ, obj_differ, records = 0.0, None, None, 0, 0, 0
+    per = []
+    for i in range(n):
+        a = vo.trajectory[i]
+        assert (a is not None) == bool(st["tracked"][i, 0]), i
+        d = float(np.abs(a - tcw[i, 0]).max()) if a is not None else 0.0
+        worst = max(worst, d)
+        cd = 0
+        if i > 0 and "matches" in vo.stats[i]:
+            cd = abs(vo.stats[i]["matches"] - int(st["matches"][i, 0])) + abs(vo.stats[i]["map_matches"] - int(st["map_matches"][i, 0]))
+            assert cd <= 3, (i, vo.stats[i], st[i, 0])
+            if cd:
+                cam_differ += 1
+                first_cam = i if first_cam is None else first_cam
+        od = 0
+        for j, o in enumerate(vo.objects.stats[i]["objects"]):
+            g = obj[i, 0, j]
+            got = (int(g["id"]), int(g["n"]), int(g["stereo"]), int(g["tracked"]), int(g["track_ok"]), int(g["bf_matches"]), int(g["lm_matches"]), int(g["inliers"]))
+            want = (o["id"], o["n"], o["stereo"], int(o["tracked"]), int(o["track_ok"]), o["bf_matches"], o["lm_matches"], o["inliers"])
+            records += 1
+            # the detections, their features and their MapObjects are the same in both runs as long as the object is tracked in both
+            assert got[:4] == want[:4], (i, j, got, want)
+            if got != want:
+                od += 1
+        if od:
+            obj_differ += od
+            first_obj = i if first_obj is None else first_obj
+        per.append({"frame": i, "max_abs_dTcw": d, "camera_match_count_differs": bool(cd), "object_records_differing": od})
+    twc = -(tcw[-1, 0, :3, :3].T @ tcw[-1, 0, :3, 3])
+    drift = float(np.abs(twc - q["twc"][-1][:, 3]).max())
+    summary = {"frames": n, "tracked": int(st["tracked"].sum()), "max_abs_dTcw": worst, "first_frame_with_a_differing_camera_match_count": first_cam,
+               "frames_with_a_differing_camera_match_count": cam_differ, "object_records": records, "object_records_differing": obj_differ,
+               "first_frame_with_a_differing_object_record": first_obj, "final_position_error_m": drift}
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_chain_parity.json"), "w") as f:
+            json.dump({"summary": summary, "per_frame": per}, f, indent=1)
+    print("config 5, full size, camera + object chain: %s" % json.dumps(summary))
+    assert int(st["tracked"].sum()) >= n - 2
+    assert worst < 5e-3 and worst < 0.1 * max(drift, 0.02), (worst, drift)
+    assert (first_cam is None or first_cam >= 20) and (first_obj is None or first_obj >= 10), (first_cam, first_obj)
+    assert obj_differ <= 0.2 * records, (obj_differ, records)
