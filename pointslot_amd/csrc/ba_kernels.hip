@@ -712,9 +712,11 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     const long long dg0b = wall_clock64();
 #endif
     double a[NB];
-#pragma unroll
     // (every lane loads - from a clamped position where it has no entry - and a select zeroes what does not exist: 24 loads under 24
     // different lane masks were 250 instructions of mask bookkeeping; the same in the two substitutions below)
+    // (r06, measured and not kept: the next diagonal block handed over in LDS by the tiles of (3a) instead of re-read from L2 - 6.25
+    // against 6.24 ms for the 8-object BA: the round trip sits under the other waves' trailing tiles)
+#pragma unroll
     for (int c = 0; c < NB; c++) a[c] = Sm[(size_t)(J + min(lane, jb - 1)) * lda + min(J + c, n - 1)];      // all loads first, then the selects
 #pragma unroll
     for (int c = 0; c < NB; c++) a[c] = (lane < jb && c <= lane) ? a[c] : 0.0;
@@ -841,11 +843,13 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     if (fail) break;
     // ---- (2) panel rows below the block: coalesced load into LDS, thread-per-row solve in LDS, coalesced store ----
     const int m0 = J + jb, m = n - m0;
-    for (int q = tid; q < m * jb; q += SOL_T) {
-      const int i = q / jb, c = q - i * jb;
-      panel[(size_t)i * PST + c] = Sm[(size_t)(m0 + i) * lda + J + c];
+    if (NB % 4 != 0) {
+      for (int q = tid; q < m * NB; q += SOL_T) {      // (rows below exist under full blocks only: jb == NB, a constant divisor)
+        const int i = q / NB, c = q - i * NB;
+        panel[(size_t)i * PST + c] = Sm[(size_t)(m0 + i) * lda + J + c];
+      }
+      sol_lds_barrier();
     }
-    sol_lds_barrier();
     SOLP_MARK(5);
     if (NB % 4 == 0) {
       // x L_JJ^T D = row of S: column q of the row is final once columns < q have been eliminated from it.  Right-looking order: as
@@ -854,12 +858,30 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
       // the quad owns the columns 4 u + g: a step is the pivot column's value out of its owner's register (quad_perm broadcast) and
       // at most NB / 4 FMAs per lane, where a thread per row did up to NB - 1 - with 270 rows on 1024 threads three quarters of the
       // workgroup had no row at all, and the 24-step chain of each row was 2.7 of a block step's 16 us.  Only full blocks have rows below.
+      // (r06) The rows come from global memory straight into the registers the solve works on - a quad's lanes take the row's doubles
+      // 4 u + g, 32 contiguous bytes per u - and the solved row goes to the LDS panel AND back to global memory from those registers: the
+      // staging pass (global -> LDS, barrier, LDS -> registers) and the store pass (LDS -> global, with a division per element to find its
+      // row) are gone, one workgroup barrier and two LDS round trips per block step with them.  Same operations on the same values.
       const int g = lane & 3;
-      for (int i = tid >> 2; i < m; i += SOL_T / 4) {
+      constexpr int RP = (6 * PS_BA_MAX_POSES + SOL_T / 4 - 1) / (SOL_T / 4);       // rows a quad can own
+      // (two rows of a quad requested together: 300 rows - BASELINE config 4 - are two per quad; a third set of registers spills)
+      for (int r0 = 0; r0 < RP && (tid >> 2) + r0 * (SOL_T / 4) < m; r0 += 2) {
+      double vin[2][NB / 4];
+#pragma unroll
+      for (int rp = 0; rp < 2; rp++) {
+        const int i = (tid >> 2) + (r0 + rp) * (SOL_T / 4);
+        const double* grow = Sm + (size_t)(m0 + min(i, m - 1)) * lda + J;
+#pragma unroll
+        for (int u = 0; u < NB / 4; u++) vin[rp][u] = grow[4 * u + g];
+      }
+#pragma unroll
+      for (int rp = 0; rp < 2; rp++) {
+        const int i = (tid >> 2) + (r0 + rp) * (SOL_T / 4);
+        if (i >= m) break;
         double* prow = panel + (size_t)i * PST;
         double v[NB / 4];
 #pragma unroll
-        for (int u = 0; u < NB / 4; u++) v[u] = prow[4 * u + g];
+        for (int u = 0; u < NB / 4; u++) v[u] = vin[rp][u];
 #pragma unroll
         for (int uq = 0; uq < NB / 4; uq++) {
           // the multipliers of the group's four steps first (LDS), then the four dependent steps on registers
@@ -881,11 +903,15 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
           }
         }
         // a lane's registers now hold the final un-divided values of its columns
+        double* grow = Sm + (size_t)(m0 + i) * lda + J;
 #pragma unroll
         for (int u = 0; u < NB / 4; u++) {
-          prow[4 * u + g] = v[u] * rdj[4 * u + g];
+          const double lv = v[u] * rdj[4 * u + g];
+          prow[4 * u + g] = lv;
+          grow[4 * u + g] = lv;
           if (PB) panelB[(size_t)i * PST + 4 * u + g] = -v[u];
         }
+      }
       }
     } else
     for (int i = tid; i < m; i += SOL_T) {
@@ -915,19 +941,22 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
     }
     sol_lds_barrier();
     SOLP_MARK(6);
-    for (int q = tid; q < m * jb; q += SOL_T) {
-      const int i = q / jb, c = q - i * jb;
-      Sm[(size_t)(m0 + i) * lda + J + c] = panel[(size_t)i * PST + c];
-    }
+    if (NB % 4 != 0)
+      for (int q = tid; q < m * NB; q += SOL_T) {
+        const int i = q / NB, c = q - i * NB;
+        Sm[(size_t)(m0 + i) * lda + J + c] = panel[(size_t)i * PST + c];
+      }
     // ... and the diagonal block's multipliers (wave 0 left them in LDS: 24 store instructions of 23 scattered rows each were 2 us of
     // its serial path per block)
-    for (int q = SOL_T - 1 - tid; q < jb * jb; q += SOL_T) {
-      const int r = q / jb, c = q - r * jb;
-      if (c < r) Sm[(size_t)(J + r) * lda + J + c] = Ljj[r * (NB + 1) + c];
+    for (int q = SOL_T - 1 - tid; q < NB * NB; q += SOL_T) {      // (a constant divisor; the rows / columns a partial last block lacks are skipped)
+      const int r = q / NB, c = q - r * NB;
+      if (c < r && r < jb) Sm[(size_t)(J + r) * lda + J + c] = Ljj[r * (NB + 1) + c];
     }
-    // forward substitution of this block column while its panel is still in LDS: y_J = L_JJ^-1 b_J (wave 0, after
-    // which the rows below subtract L_panel y_J) — no extra pass over L in global memory
-    if (tid < 64) {
+    // forward substitution of this block column while its panel is still in LDS: y_J = L_JJ^-1 b_J, after which the rows below subtract
+    // L_panel y_J - no extra pass over L in global memory.  r06: ONE wave does both, in phase (3b) below, beside the diagonal block of the
+    // next step and the trailing tiles (nothing in the factorisation reads the right-hand side): the two were 1.4 us of every block step's
+    // serial path - wave 0's 24-step chain, a workgroup barrier, the rows' update.  Same operations in the same order.
+    auto fwd_rhs = [&]() {
       double y = lane < jb ? rhs[J + lane] : 0.0;
       double lrow[NB];   // the lane's row of the block factor, fetched before the chain of broadcasts starts
 #pragma unroll
@@ -942,19 +971,23 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
         }
       }
       if (lane < jb) rhs[J + lane] = y;
-    }
-    sol_lds_barrier();   // (the panel's global stores above are read by the backward substitution only)
+      if (m > 0) {                                 // (only full blocks have rows below them: lane c < NB holds y_c)
+        double yj[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) yj[c] = shfl_d(y, c);
+        for (int i = lane; i < m; i += 64) {
+          double v = rhs[m0 + i];
+          const double* prow = panel + (size_t)i * PST;
+          double pr[NB];
+#pragma unroll
+          for (int c = 0; c < NB; c++) pr[c] = prow[c];
+#pragma unroll
+          for (int c = 0; c < NB; c++) v -= pr[c] * yj[c];
+          rhs[m0 + i] = v;
+        }
+      }
+    };
     SOLP_MARK(7);
-    for (int i = tid; i < m; i += SOL_T) {
-      double v = rhs[m0 + i];
-      const double* prow = panel + (size_t)i * PST;
-      double pr[NB], yj[NB];   // all operands first (only full blocks have rows below them), then the chain
-#pragma unroll
-      for (int c = 0; c < NB; c++) { pr[c] = prow[c]; yj[c] = rhs[J + c]; }
-#pragma unroll
-      for (int c = 0; c < NB; c++) v -= pr[c] * yj[c];
-      rhs[m0 + i] = v;
-    }
     SOLP_MARK(1);
     // ---- (3) trailing update S_22 -= L_21 D L_21^T on the FP64 matrix cores: 16 x 16 tiles of the lower triangle, one tile per wave
     // at a time, K = NB in steps of 4 (v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
@@ -1045,6 +1078,7 @@ __global__ __launch_bounds__(SOL_T) void ba_solve(BaArrays A) {
         tph[8] += wall_clock64() - dg0;
 #endif
       } else {
+        if (wave == nwave - 1) fwd_rhs();
         run_tiles(wave - 1, nB, nwave - 1, [&](int t, int& ti, int& tj) {
           int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
           while (i * (i + 1) / 2 > t) i--;
