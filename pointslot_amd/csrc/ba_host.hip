@@ -65,7 +65,6 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   static const bool twins_on = !(getenv("PS_BA_TWINS") && getenv("PS_BA_TWINS")[0] == '0');
   // (a batch of more than 24 problems fills the chip's CUs with solver workgroups by itself: measured 16 / 32 / 64 objects 0.63 / 0.81 / 1.18 ms per
   // iteration without twins, 0.55 / 0.86 / 1.32 with)
-  const int twins = (twins_on && nprob <= 24) ? 1 : 0;
   const int user_nprob = nprob;
   for (int p = 0; p < user_nprob; p++) {
     const ps_ba_problem& P = probs[p];
@@ -84,6 +83,10 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
     NW += (size_t)P.np * P.nl * 18;
     NS += (size_t)36 * P.np * P.np;
   }
+  // ... and a twin doubles every arena (W: 144 bytes per pose x point, S: 288 per pose x pose) and every grid: only while the doubled W + S
+  // stay under a cap (PS_BA_TWINS_MAX_MB, default 1024: BASELINE config 4's 8 objects take 38 MB) - one huge local-BA problem runs single
+  static const size_t twins_cap = (size_t)(getenv("PS_BA_TWINS_MAX_MB") ? atoi(getenv("PS_BA_TWINS_MAX_MB")) : 1024) << 20;
+  const int twins = (twins_on && nprob <= 24 && 2 * (NW + NS) * sizeof(double) <= twins_cap) ? 1 : 0;
   if (twins) { NP *= 2; NL *= 2; NE *= 2; NW *= 2; NS *= 2; nprob *= 2; }
   auto user = [&](int p) -> ps_ba_problem& { return probs[twins ? p / 2 : p]; };
   const int nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;

@@ -378,14 +378,16 @@ int ps_orb_create(const ps_orb_config* cfg, ps_orb** out) {
   h->cfg = *cfg;
   build_tables(h);
   hipError_t e;
+#ifdef PS_DEV_CU_PARTITION
+  // developer experiment, compiled in with -DPS_DEV_CU_PARTITION only (profiles/r05_cu_partition.txt: rejected): the k-th
+  // extractor handle of the process gets its own share of the compute units: PS_CU_PARTITION=N cuts the CU mask bits into N ranges (the driver
+  // deals consecutive bits round-robin over the 8 XCDs, so a range is a slice of every XCD), PS_CU_SHARE=k gives a handle k consecutive ranges.
+  // The masked stream is a BLOCKING stream (it synchronises with the null stream), and the handle counter is process-wide and not thread-safe.
   if (const char* part = getenv("PS_CU_PARTITION")) {
-    // experiment: the k-th extractor handle of the process - the k-th lockstep group of a tracker bench - gets its own
-    // share of the compute units instead of competing for all of them: PS_CU_PARTITION=N cuts the CU mask bits into N ranges (the driver
-    // deals consecutive bits round-robin over the 8 XCDs, so a range is a slice of every XCD), PS_CU_SHARE=k gives a handle k consecutive ranges
     static int created = 0;
     const int N = atoi(part) > 0 ? atoi(part) : 1, K = getenv("PS_CU_SHARE") ? atoi(getenv("PS_CU_SHARE")) : 1;
     hipDeviceProp_t prop;
-    PS_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { delete h; return ps_set_error(PS_ERR_HIP, "hipGetDeviceProperties failed"); }
     const int ncu = prop.multiProcessorCount;
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
     for (int kk = 0; kk < K; kk++) {
@@ -394,9 +396,9 @@ int ps_orb_create(const ps_orb_config* cfg, ps_orb** out) {
     }
     created++;
     e = hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)mask.size(), mask.data());
-  } else {
-    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-  }
+  } else
+#endif
+  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return ps_set_error(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
   for (int r = 0; r < ps_orb::RING; r++)
     for (int c = 0; c < ps_orb::MAXCHUNK; c++)

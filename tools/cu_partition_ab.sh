@@ -1,5 +1,6 @@
 #!/bin/bash
 # experiment: lockstep groups on CU partitions instead of all groups on all CUs; the headline loop alone per setting
+# (r06: the knob is compiled in only with -DPS_DEV_CU_PARTITION: tools/build_all_variant.sh cupart -DPS_DEV_CU_PARTITION, then PS_LIB_PATH=build_exp/libps_cupart.so)
 run() {  # label, env...
   label=$1; shift
   for rep in 1 2; do
