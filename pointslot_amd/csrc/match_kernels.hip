@@ -569,8 +569,11 @@ __global__ __launch_bounds__(256) void pj_gather(PjArrays A, int nprob) {
 #ifndef PJ_TBL
 #define PJ_TBL 4096   // (8192: 3 % fewer lanes lose the parallel path to a hash collision, but 16 KB more LDS per problem - measured slower)
 #endif
+// (r06) Launched with 64 threads per problem in a throughput-sized batch, with 256 when the call holds a few problems (one sequence per
+// handle: BASELINE configs[4]): the order-dependent loop is wave 0's either way, the set-up (occupancy bitmap, claim table, match array,
+// octave copy) and the rotation-histogram tail are spread over all the threads there are - a third of the kernel's 115 us at one problem.
 template <int IDXB>
-__global__ __launch_bounds__(64) void pj_resolve(PjArrays A, int nprob_total) {
+__global__ __launch_bounds__(256) void pj_resolve(PjArrays A, int nprob_total) {
   constexpr int CAP = 1 << (23 - IDXB);
   constexpr uint32_t IDXM = (1u << IDXB) - 1u;
   __shared__ uint32_t blocked[1024];   // up to 32768 train features
@@ -579,12 +582,15 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A, int nprob_total) {
   extern __shared__ uint8_t loct[];    // train octaves (ratio test), staged once: no global load inside the serial loop; sized by the launch
                                        // for the call's largest train set (with room for all 32768 the workgroup took 72 KB: two per CU)
   __shared__ uint32_t first_lane[PJ_TBL];   // hashed train -> earliest lane of the current block that lists it among its four keys
+  __shared__ int s_removed, s_nm;
+  const int nth = (int)blockDim.x;
   const int pbi = ((int)blockIdx.x & ~7) | (((int)blockIdx.x + ((int)blockIdx.x >> 3)) & 7);      // (rotated inside every group of eight: see bf_resolve)
   if (pbi >= nprob_total) return;
   const PjProb P = A.prob[pbi];
   const int lane = threadIdx.x;
   int32_t* match = A.match + P.t_off;
-  for (int w = lane; w < (P.nt + 31) / 32; w += 64) {
+  if (lane == 0) { s_removed = 0; s_nm = 0; }
+  for (int w = lane; w < (P.nt + 31) / 32; w += nth) {
     uint32_t bits = 0;
     for (int b = 0; b < 32; b++) {
       const int j = w * 32 + b;
@@ -594,10 +600,10 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A, int nprob_total) {
     newly[w] = 0;
   }
   if (lane < 32) hist[lane] = 0;
-  for (int w = lane; w < PJ_TBL; w += 64) first_lane[w] = 0xFFFFFFFFu;
-  for (int j = lane; j < P.nt; j += 64) match[j] = -1;
+  for (int w = lane; w < PJ_TBL; w += nth) first_lane[w] = 0xFFFFFFFFu;
+  for (int j = lane; j < P.nt; j += nth) match[j] = -1;
   if (P.ratio_test)
-    for (int j = lane; j < P.nt; j += 64) loct[j] = (uint8_t)A.toct[P.t_off + j];
+    for (int j = lane; j < P.nt; j += nth) loct[j] = (uint8_t)A.toct[P.t_off + j];
   __syncthreads();
   const float factor = 30 / 360.0f;
   int nm = 0;
@@ -606,6 +612,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A, int nprob_total) {
   long long pj_t1 = 0;
   int pj_clean = 0, pj_dirty = 0, pj_serial_blocks = 0;
 #endif
+  if (lane < 64) {       // ---- the order-dependent part: wave 0 ----
   // Queries are taken in order (the assignment is order dependent), 64 at a time: the lane-resident candidate counts give
   // the non-empty queries of the block as a bit mask, and the first 64 candidate keys of the NEXT non-empty query are
   // requested before the current one is reduced, so the global-memory latency is paid once per block, not once per query.
@@ -773,13 +780,16 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A, int nprob_total) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  if (lane == 0) s_nm = nm;
+  }                      // ---- wave 0 ----
   __syncthreads();
+  nm = s_nm;
 #ifdef PS_PJ_PROFILE
   pj_t1 = wall_clock64();
 #endif
   if (P.check_ori) {
     // rotHist[bin].push_back(...) of every assignment (ORBmatcher.cc:1716-1726); order inside a bin is irrelevant
-    for (int qi = lane; qi < P.nq; qi += 64) {
+    for (int qi = lane; qi < P.nq; qi += nth) {
       const int q = P.q_off + qi;
       const int bi = A.qbest[q];
       if (bi >= 0) {
@@ -802,7 +812,7 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A, int nprob_total) {
     if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
     else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
     int removed = 0;
-    for (int qi = lane; qi < P.nq; qi += 64) {
+    for (int qi = lane; qi < P.nq; qi += nth) {
       const int q = P.q_off + qi;
       const int bi = A.qbest[q];
       if (bi >= 0) {
@@ -812,7 +822,9 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A, int nprob_total) {
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d);
-    nm -= removed;
+    if ((lane & 63) == 0 && removed) atomicAdd(&s_removed, removed);
+    __syncthreads();
+    nm -= s_removed;
   }
   if (lane == 0) A.nmatch[pbi] = nm;
 #ifdef PS_PJ_PROFILE
@@ -826,13 +838,14 @@ __global__ __launch_bounds__(64) void pj_resolve(PjArrays A, int nprob_total) {
 extern "C" void psk_pj_launch(const PjArrays* arrays, int nprob, int max_nq, int max_nt, int any_frame_mode, int wide, hipStream_t st) {
   const PjArrays A = *arrays;
   const size_t lds = (size_t)((max_nt < 1 ? 1 : max_nt > 32768 ? 32768 : max_nt) + 15) & ~(size_t)15;
+  const int rt = nprob <= 64 ? 256 : 64;       // pj_resolve's threads per problem: see the kernel
   if (any_frame_mode) hipLaunchKernelGGL(pj_project, dim3((max_nq + 255) / 256, nprob), dim3(256), 0, st, A);
   if (wide) {
     hipLaunchKernelGGL(pj_gather<13>, dim3(8 * ((max_nq + 15) / 16), (nprob + 7) / 8), dim3(256), 0, st, A, nprob);
-    hipLaunchKernelGGL(pj_resolve<13>, dim3((nprob + 7) & ~7), dim3(64), lds, st, A, nprob);
+    hipLaunchKernelGGL(pj_resolve<13>, dim3((nprob + 7) & ~7), dim3(rt), lds, st, A, nprob);
   } else {
     hipLaunchKernelGGL(pj_gather<15>, dim3(8 * ((max_nq + 15) / 16), (nprob + 7) / 8), dim3(256), 0, st, A, nprob);
-    hipLaunchKernelGGL(pj_resolve<15>, dim3((nprob + 7) & ~7), dim3(64), lds, st, A, nprob);
+    hipLaunchKernelGGL(pj_resolve<15>, dim3((nprob + 7) & ~7), dim3(rt), lds, st, A, nprob);
   }
 }
 
