@@ -633,7 +633,7 @@ class StereoOdometryBatch {
 // the library between the hot-path kernels, nothing is packed or copied per call, and results are read when asked for.
 class StereoOdometryDevice {
  public:
-  // maxObjects > 0 (at most 16 detections per frame; maxMapObjects 0 = 8 MapObjects per sequence, at most 16): the handle also carries the object half of Tracking::Track in SLOT.MODE 4 (TrackAllSlotDevice)
+  // maxObjects > 0 (at most 16 detections per frame; maxMapObjects 0 = 8 MapObjects per sequence, at most 64): the handle also carries the object half of Tracking::Track in SLOT.MODE 4 (TrackAllSlotDevice)
   StereoOdometryDevice(int nSequences, float fx, float fy, float cx, float cy, float bf, int width, int height, int maxFrames, float thDepth = 35.f,
                        int nFeatures = 2000, float scale = 1.2f, int nLevels = 8, int iniTh = 20, int minTh = 5, int device = 0, int maxObjects = 0, int maxMapObjects = 0)
       : nseq(nSequences), nobj(maxObjects) {

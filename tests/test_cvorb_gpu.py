@@ -130,3 +130,33 @@ def test_randomised_batched_detector_sweep():
     r = subprocess.run([sys.executable, tool, "7", "10"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "identical to the CPU restatement" in r.stdout
+
+
+def test_single_image_call_batched_form_equals_per_level_form(monkeypatch):
+    """r06: ps_cvorb_detect_and_compute with a mask is served by the batched device form on a batch of one (PS_CVORB_FAST, default on) and by
+    the per-level host-selected form otherwise - also when the batched form's per-level store overflows.  Same keypoints in the same order,
+    same descriptors, both ways; the intermediates ps_cvorb_debug_read hands out come from the per-level form in either case."""
+    import os
+    from PIL import Image
+    from pointslot_amd.object_orb import ORB
+    seq = sequence.generate(n_frames=1, seed=9)
+    img = seq["left"][0]
+    small = np.where(seq["seg"][0] != 0, 255, 0).astype(np.uint8)                    # two boxes: served by the batched form
+    kitti = np.ascontiguousarray(np.asarray(Image.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_000212_gray.png"))))
+    big = np.zeros_like(kitti); big[40:360, 100:1200] = 255                          # most of a textured frame: more FAST keypoints than its stores hold
+    for im, mask in ((img, small), (kitti, big)):
+        monkeypatch.setenv("PS_CVORB_FAST", "1")
+        a = ORB()
+        monkeypatch.setenv("PS_CVORB_FAST", "0")
+        b = ORB()
+        ka, da = a.detectAndCompute(im, mask)
+        kb, db = b.detectAndCompute(im, mask)
+        assert len(ka) == len(kb) > 30
+        assert np.array_equal(ka.view(np.uint8), kb.view(np.uint8)) and np.array_equal(da, db)
+        for l in (0, 3, 7):
+            assert np.array_equal(a.debug_plane(l, 1), b.debug_plane(l, 1))
+            assert np.array_equal(a.debug_fast(l).view(np.uint32), b.debug_fast(l).view(np.uint32))
+        # a second call on the same handle (plans and staging buffers are reused)
+        k2, d2 = a.detectAndCompute(im, mask)
+        assert np.array_equal(k2.view(np.uint8), ka.view(np.uint8)) and np.array_equal(d2, da)
+        a.close(); b.close()

@@ -295,3 +295,18 @@ def test_object_features_on_a_second_stream_give_the_same_results():
         outs.append(pickle.loads(r.stdout))
     assert outs[0] == outs[1]
     assert len(outs[0][2]) > 0
+
+
+def test_object_head_on_the_second_stream_changes_nothing(monkeypatch):
+    """r06: a tracker of a few sequences runs masks / cv::ORB / ComputeObjStereoMatches / AssignFeatures on a second stream beside the camera
+    chain (PS_TRK_OVERLAP, default on up to 32 sequences).  With it forced off and on: every pose, every camera statistic and every object
+    record bit for bit the same."""
+    n = 6
+    seqs = [sequence.generate_drive(n_frames=n, seed=40 + 7 * i, texture=sequence.kitti_texture()) for i in range(2)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PS_TRK_OVERLAP", mode)
+        res[mode] = _run_device(seqs, n)
+    for a, b in zip(res["0"], res["1"]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert int((res["1"][2]["track_ok"] != 0).sum()) > n
