@@ -62,7 +62,9 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   int max_np = 0, max_nl = 0, max_ne = 0, max_free = 0;
   // Speculative twins (ba_kernels.hip, ba_decide): every problem is in the batch twice - the twin runs the damping trial g2o would run
   // next if the current one is rejected, so that "first trial rejected, second accepted" costs one round of kernels.  PS_BA_TWINS=0: off.
-  static const bool twins_on = !(getenv("PS_BA_TWINS") && getenv("PS_BA_TWINS")[0] == '0');
+  // r06: up to four members per problem (member s runs the s-th trial ahead).  PS_BA_TWINS=N (2 .. 4) caps the group size.
+  static const int twins_max = getenv("PS_BA_TWINS") ? atoi(getenv("PS_BA_TWINS")) : 4;
+  static const bool twins_on = twins_max >= 2;
   // (a batch of more than 24 problems fills the chip's CUs with solver workgroups by itself: measured 16 / 32 / 64 objects 0.63 / 0.81 / 1.18 ms per
   // iteration without twins, 0.55 / 0.86 / 1.32 with)
   const int user_nprob = nprob;
@@ -86,9 +88,19 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   // ... and a twin doubles every arena (W: 144 bytes per pose x point, S: 288 per pose x pose) and every grid: only while the doubled W + S
   // stay under a cap (PS_BA_TWINS_MAX_MB, default 1024: BASELINE config 4's 8 objects take 38 MB) - one huge local-BA problem runs single
   static const size_t twins_cap = (size_t)(getenv("PS_BA_TWINS_MAX_MB") ? atoi(getenv("PS_BA_TWINS_MAX_MB")) : 1024) << 20;
-  const int twins = (twins_on && nprob <= 24 && 2 * (NW + NS) * sizeof(double) <= twins_cap) ? 1 : 0;
-  if (twins) { NP *= 2; NL *= 2; NE *= 2; NW *= 2; NS *= 2; nprob *= 2; }
-  auto user = [&](int p) -> ps_ba_problem& { return probs[twins ? p / 2 : p]; };
+  // members per problem: as many as keep the batch at <= PS_BA_GROUP_INSTANCES solver workgroups and the arenas under the cap - but never fewer than
+  // the twin for batches <= 24.  Measured: four members pay up to 4 problems in every scene (- 12 % on SURVEY's config 4, where a quarter
+  // of the iterations needs three or four trials; + 0 .. 1 % where nearly all need two); at 8 problems they are - 10 % on the first and + 6 % on the
+  // second scene (every member adds its Schur complement to a launch that already fills the chip): the default stops at 16 instances.
+  static const int inst_cap = getenv("PS_BA_GROUP_INSTANCES") ? atoi(getenv("PS_BA_GROUP_INSTANCES")) : 16;
+  int G = 1;
+  if (twins_on) {
+    for (int g = std::min(twins_max, 4); g >= 2; g--)
+      if (nprob * g <= std::max(inst_cap, 2 * std::min(nprob, 24)) && (nprob <= 24) && (size_t)g * (NW + NS) * sizeof(double) <= twins_cap) { G = g; break; }
+  }
+  const int twins = G > 1 ? 1 : 0;
+  if (twins) { NP *= G; NL *= G; NE *= G; NW *= G; NS *= G; nprob *= G; }
+  auto user = [&](int p) -> ps_ba_problem& { return probs[p / G]; };
   const int nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
   const int part_cap = max_np + (max_nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB + nbp + nbe + 8;
   NPART = (size_t)part_cap * nprob;
@@ -129,7 +141,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
     d.csr_pose_edges_base = (int32_t)ceb; d.csr_point_edges_base = (int32_t)(ceb + P.ne);
     d.W_base = (int64_t)wb; d.S_base = (int64_t)sb;
     d.part_base = p * part_cap; d.part_cap = part_cap;
-    if (twins && (p & 1)) { const BaProb& q = hp[p - 1]; d.lin_pose_base = q.pose_base; d.lin_point_base = q.point_base; d.lin_part_base = q.part_base; d.lin_W_base = q.W_base; }
+    if (twins && (p % G)) { const BaProb& q = hp[p - p % G]; d.lin_pose_base = q.pose_base; d.lin_point_base = q.point_base; d.lin_part_base = q.part_base; d.lin_W_base = q.W_base; }
     else { d.lin_pose_base = d.pose_base; d.lin_point_base = d.point_base; d.lin_part_base = d.part_base; d.lin_W_base = d.W_base; }
     d.fx = P.fx; d.fy = P.fy; d.cx = P.cx; d.cy = P.cy; d.bf = P.bf;
     memcpy(H + L.poses + pb * 56, P.poses7, (size_t)P.np * 56);
@@ -154,7 +166,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
       csr_edges[ceb + cur_p[P.e_pose[e]]++] = e;
       csr_edges[ceb + P.ne + cur_l[P.e_point[e]]++] = e;
     }
-    hs[p].stage = 0; hs[p].phase = BA_PH_BEGIN; hs[p].spec = twins ? (p & 1) : 0;
+    hs[p].stage = 0; hs[p].phase = BA_PH_BEGIN; hs[p].spec = p % G; hs[p].depth = G - 1;
     pb += P.np; lb += P.nl; eb += P.ne; cb += P.np + P.nl + 2; ceb += 2 * (size_t)P.ne;
     wb += (size_t)P.np * P.nl * 18; sb += (size_t)36 * P.np * P.np;
   }
@@ -195,7 +207,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   // stream drain + PCIe round trip.
   const int steps_per_sync = 3;
   for (;;) {
-    for (int k = 0; k < steps_per_sync; k++) psk_ba_global_step(&A, nprob, max_np, max_nl, max_ne, max_tilepairs, max_free, steps + k == 0, twins, st);
+    for (int k = 0; k < steps_per_sync; k++) psk_ba_global_step(&A, nprob, max_np, max_nl, max_ne, max_tilepairs, max_free, steps + k == 0, G, st);
     PS_HIP(hipGetLastError());
     PS_HIP(hipMemcpyAsync(h_done, A.ndone, 4, hipMemcpyDeviceToHost, st));
     PS_HIP(hipStreamSynchronize(st));
@@ -212,7 +224,7 @@ extern "C" int ps_object_ba_batch(ps_optimizer* m, ps_ba_problem* probs, int npr
   pb = lb = eb = 0;
   for (int p = 0; p < nprob; p++) {
     ps_ba_problem& P = user(p);
-    if (twins && (p & 1)) { pb += P.np; lb += P.nl; eb += P.ne; continue; }   // the results are the primaries'
+    if (p % G) { pb += P.np; lb += P.nl; eb += P.ne; continue; }   // the results are the primaries'
     memcpy(P.poses7, H + L.poses + pb * 56, (size_t)P.np * 56);
     if (P.nl) memcpy(P.points, H + L.points + lb * 24, (size_t)P.nl * 24);
     int ner = 0;

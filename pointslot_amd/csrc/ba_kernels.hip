@@ -454,7 +454,11 @@ __device__ __forceinline__ double ba_post_lin(const BaArrays& A, const BaProb& P
 
 // The damping a problem's trial runs with.  A speculative twin (BaState::spec, see ba_decide) runs the trial its primary would run NEXT if the
 // current one is rejected: g2o's retry is lambda *= ni (levenberg.cpp:139-141) on the same linearisation - this very product.
-__device__ __forceinline__ double ba_trial_lambda(const BaState& S, double lambda, double ni) { return S.spec ? lambda * ni : lambda; }
+// (r06: spec = s > 1 - the s-th trial ahead: every rejection multiplies lambda by ni and doubles ni)
+__device__ __forceinline__ double ba_trial_lambda(const BaState& S, double lambda, double ni) {
+  for (int s = 0; s < S.spec; s++) { lambda *= ni; ni *= 2; }
+  return lambda;
+}
 
 // D^-1 per point; b_s per active pose (block_solver.hpp:367-439)
 __global__ __launch_bounds__(256) void ba_prep(BaArrays A) {
@@ -1260,32 +1264,36 @@ __global__ __launch_bounds__(256) void ba_error_k(BaArrays A, int err_part_off) 
 // estimate the sequence ends with, the increments and - when a stage ends here - the cached chi2 of the LAST trial g2o ran.
 // A twin whose factorisation failed is ignored (its "whatever x holds" update would need the primary's x of this same round): the
 // primary runs that lambda itself in the next round.
-__global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off, int twins) {
-  const int pa = twins ? 2 * blockIdx.x : blockIdx.x, pb = pa + 1;
+// r06: `grp` members per problem instead of a pair (2, 3 or 4: member s runs the s-th trial ahead) - BASELINE config 4 has 1 / 2 / 3 / 4 trials in
+// 29 / 62 / 22 / 7 of its 120 iterations; with three members the 22 three-trial iterations take one round of kernels as well.
+__global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off, int grp) {
+  const int pa = grp * blockIdx.x;
+  const bool twins = grp > 1;
   const BaProb P = A.prob[pa];
   BaState& S = A.state[pa];
   if (S.phase != BA_PH_TRIAL && S.phase != BA_PH_LINEARIZE) return;
   __shared__ int s_acc, s_last;
-  __shared__ double s_part[2][1024];
+  __shared__ double s_part[4][1024];
   const int tid = threadIdx.x;
   // the partial sums of the trial (scale: one per block of ba_update, chi2: one per block of ba_error_k) come in with one round trip for
   // all of them; thread 0 then adds them in the order it always did (it used to fetch them one dependent load after the other: 15 us)
   const int nbl = (P.nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB, nbp = (P.np + 255) / 256, nbe = (P.ne + 255) / 256;
   const int ns = nbl + nbp, staged = ns + nbe <= 1024;
-  const int part_b = twins ? A.prob[pb].part_base : 0;
   if (staged)
-    for (int b = tid; b < ns + nbe; b += 256) {
-      s_part[0][b] = b < ns ? A.part[P.part_base + P.np + b] : A.part[P.part_base + err_part_off + (b - ns)];
-      if (twins) s_part[1][b] = b < ns ? A.part[part_b + P.np + b] : A.part[part_b + err_part_off + (b - ns)];
-    }
+    for (int b = tid; b < ns + nbe; b += 256)
+      for (int w = 0; w < grp; w++) {
+        const int pbw = A.prob[pa + w].part_base;
+        s_part[w][b] = b < ns ? A.part[pbw + P.np + b] : A.part[pbw + err_part_off + (b - ns)];
+      }
   __syncthreads();
   if (tid == 0) {
     int accepted = -1, last = 0;
     double rho = 0;
-    for (int w = 0; w < (twins ? 2 : 1); w++) {
+    const int act = min(grp, S.depth + 1);               // members that ran a trial this round
+    for (int w = 0; w < act; w++) {
       const BaState& T = A.state[pa + w];
-      if (w == 1 && !T.ok2) break;                       // the twin's trial is void: the primary repeats it
-      const int pbase = w ? part_b : P.part_base;
+      if (w >= 1 && !T.ok2) break;                       // a speculative member's trial is void: the primary repeats it
+      const int pbase = A.prob[pa + w].part_base;
       double scale = 0, temp = 0;
       if (staged) {
         for (int b = 0; b < ns; b++) scale += s_part[w][b];
@@ -1330,6 +1338,10 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off, i
       if (terminate || S.iter >= S.max_iter) { S.stage++; S.phase = BA_PH_BEGIN; }
       else S.phase = BA_PH_LINEARIZE;
     } else S.phase = BA_PH_TRIAL;   // another damping trial on the same linearisation
+    // (r06, measured and not kept: an ADAPTIVE number of members per round - as many as the last iteration needed trials, all of them after a
+    // round of rejections, the rest parked in BA_PH_IDLE.  SURVEY's config 4 at 8 objects: 18 rounds where the fixed twin takes 20 and four
+    // fixed members 15, at nearly the four members' cost per round: 6.35 against 5.66 / 5.10 ms.  Trial counts do not come in runs.)
+    S.depth = grp - 1;
   }
   __syncthreads();
   const int acc = s_acc, last = s_last;
@@ -1339,49 +1351,66 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off, i
       for (int q = tid; q < P.nl * 3; q += 256) A.points[(size_t)P.point_base * 3 + q] = A.points_bak[(size_t)P.point_base * 3 + q];
     }
   } else {
-    const BaProb Q = A.prob[pb];
-    // the estimate the sequence ends with: the accepted trial's, or the one before the trials (pop) - into both twins
-    const double* ps = acc == 0 ? A.poses + (size_t)P.pose_base * 7 : (acc == 1 ? A.poses + (size_t)Q.pose_base * 7 : A.poses_bak + (size_t)P.pose_base * 7);
-    const double* xs = acc == 0 ? A.points + (size_t)P.point_base * 3 : (acc == 1 ? A.points + (size_t)Q.point_base * 3 : A.points_bak + (size_t)P.point_base * 3);
-    for (int q = tid; q < P.np * 7; q += 256) { const double v = ps[q]; A.poses[(size_t)P.pose_base * 7 + q] = v; A.poses[(size_t)Q.pose_base * 7 + q] = v; }
-    for (int q = tid; q < P.nl * 3; q += 256) { const double v = xs[q]; A.points[(size_t)P.point_base * 3 + q] = v; A.points[(size_t)Q.point_base * 3 + q] = v; }
-    // g2o's increment vectors persist between trials (a failed factorisation updates with what they hold): those of the last trial that ran
-    const BaProb& F = last ? Q : P;
-    const BaProb& G = last ? P : Q;
-    for (int q = tid; q < P.np * 6; q += 256) A.xp[(size_t)G.pose_base * 6 + q] = A.xp[(size_t)F.pose_base * 6 + q];
-    for (int q = tid; q < P.nl * 3; q += 256) A.xl[(size_t)G.point_base * 3 + q] = A.xl[(size_t)F.point_base * 3 + q];
-    // the edge errors g2o has cached are those of the last trial it ran; they are read when a stage ends (classification / erase list) -
+    // the estimate the sequence ends with: the accepted trial's, or the one before the trials (pop) - into every member
+    const double* ps = acc >= 0 ? A.poses + (size_t)A.prob[pa + acc].pose_base * 7 : A.poses_bak + (size_t)P.pose_base * 7;
+    const double* xs = acc >= 0 ? A.points + (size_t)A.prob[pa + acc].point_base * 3 : A.points_bak + (size_t)P.point_base * 3;
+    // g2o's increment vectors persist between trials (a failed factorisation updates with what they hold): those of the last trial that ran;
+    // the edge errors g2o has cached are those of the last trial it ran too: they are read when a stage ends (classification / erase list) -
     // the next linearisation overwrites them otherwise
-    if (S.phase == BA_PH_BEGIN)
-      for (int e = tid; e < P.ne; e += 256) A.chi2c[G.edge_base + e] = A.chi2c[F.edge_base + e];
-    __syncthreads();
-    if (tid == 0) {   // the twin continues from the primary's state
-      BaState& T = A.state[pb];
-      const int ok2 = T.ok2;
-      T = S;
-      T.spec = 1; T.ok2 = ok2;
+    const BaProb F = A.prob[pa + last];
+    for (int q = tid; q < P.np * 7; q += 256) {
+      const double v = ps[q];
+      for (int w = 0; w < grp; w++) if (w != acc) A.poses[(size_t)A.prob[pa + w].pose_base * 7 + q] = v;
     }
+    for (int q = tid; q < P.nl * 3; q += 256) {
+      const double v = xs[q];
+      for (int w = 0; w < grp; w++) if (w != acc) A.points[(size_t)A.prob[pa + w].point_base * 3 + q] = v;
+    }
+    for (int q = tid; q < P.np * 6; q += 256) {
+      const double v = A.xp[(size_t)F.pose_base * 6 + q];
+      for (int w = 0; w < grp; w++) if (w != last) A.xp[(size_t)A.prob[pa + w].pose_base * 6 + q] = v;
+    }
+    for (int q = tid; q < P.nl * 3; q += 256) {
+      const double v = A.xl[(size_t)F.point_base * 3 + q];
+      for (int w = 0; w < grp; w++) if (w != last) A.xl[(size_t)A.prob[pa + w].point_base * 3 + q] = v;
+    }
+    if (S.phase == BA_PH_BEGIN)
+      for (int e = tid; e < P.ne; e += 256) {
+        const double v = A.chi2c[F.edge_base + e];
+        for (int w = 0; w < grp; w++) if (w != last) A.chi2c[A.prob[pa + w].edge_base + e] = v;
+      }
+    __syncthreads();
+    if (tid == 0)    // the speculative members continue from the primary's state; those beyond the round's depth sit it out
+      for (int w = 1; w < grp; w++) {
+        BaState& T = A.state[pa + w];
+        const int ok2 = T.ok2;
+        T = S;
+        T.spec = w; T.ok2 = ok2;
+      }
   }
   // a stage ended: its successor's entry (classification, active sets) right here instead of in a launch of its own per global step
   __syncthreads();
   if (S.phase == BA_PH_BEGIN) {
     ba_stage_entry(A, pa);
     if (twins) {
-      // the twin starts the stage from the same estimate and the same cached errors: it takes over what the entry decided (edge levels / erase
-      // list, active sets, cleared increments) instead of working it out again (50 us of classification and compaction)
+      // the other members start the stage from the same estimate and the same cached errors: they take over what the entry decided (edge
+      // levels / erase list, active sets, cleared increments) instead of working it out again (50 us of classification and compaction)
       __syncthreads();
-      const BaProb Q = A.prob[pb];
-      for (int e = tid; e < P.ne; e += 256) { A.e_state[Q.edge_base + e] = A.e_state[P.edge_base + e]; A.erase[Q.edge_base + e] = A.erase[P.edge_base + e]; }
-      for (int i = tid; i < P.np; i += 256) { A.pidx[Q.pose_base + i] = A.pidx[P.pose_base + i]; A.pact[Q.pose_base + i] = A.pact[P.pose_base + i]; }
-      for (int l = tid; l < P.nl; l += 256) A.lact[Q.point_base + l] = A.lact[P.point_base + l];
-      for (int q = tid; q < P.np * 6; q += 256) A.xp[(size_t)Q.pose_base * 6 + q] = A.xp[(size_t)P.pose_base * 6 + q];
-      for (int q = tid; q < P.nl * 3; q += 256) A.xl[(size_t)Q.point_base * 3 + q] = A.xl[(size_t)P.point_base * 3 + q];
-      if (tid == 0) {
-        BaState& T = A.state[pb];
-        T = S;
-        T.spec = 1;
-        if (S.phase == BA_PH_DONE) atomicAdd(A.ndone, 1);
+      for (int w = 1; w < grp; w++) {
+        const BaProb Q = A.prob[pa + w];
+        for (int e = tid; e < P.ne; e += 256) { A.e_state[Q.edge_base + e] = A.e_state[P.edge_base + e]; A.erase[Q.edge_base + e] = A.erase[P.edge_base + e]; }
+        for (int i = tid; i < P.np; i += 256) { A.pidx[Q.pose_base + i] = A.pidx[P.pose_base + i]; A.pact[Q.pose_base + i] = A.pact[P.pose_base + i]; }
+        for (int l = tid; l < P.nl; l += 256) A.lact[Q.point_base + l] = A.lact[P.point_base + l];
+        for (int q = tid; q < P.np * 6; q += 256) A.xp[(size_t)Q.pose_base * 6 + q] = A.xp[(size_t)P.pose_base * 6 + q];
+        for (int q = tid; q < P.nl * 3; q += 256) A.xl[(size_t)Q.point_base * 3 + q] = A.xl[(size_t)P.point_base * 3 + q];
       }
+      if (tid == 0)
+        for (int w = 1; w < grp; w++) {
+          BaState& T = A.state[pa + w];
+          T = S;
+          T.spec = w;
+          if (S.phase == BA_PH_DONE) atomicAdd(A.ndone, 1);
+        }
     }
   }
 }
@@ -1391,7 +1420,7 @@ __global__ __launch_bounds__(256) void ba_decide(BaArrays A, int err_part_off, i
 // one "global step": every unfinished problem advances by one LM trial (plus linearisation / stage entry
 // when it is due).  max_* are maxima over the batch.
 extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int max_nl, int max_ne, int max_tilepairs,
-                                   int max_free, int first, int twins, hipStream_t st) {
+                                   int max_free, int first, int grp, hipStream_t st) {
   const int nbl = (max_nl + 255) / 256, nbp = (max_np + 255) / 256, nbe = (max_ne + 255) / 256;
   const int nblu = (max_nl + PS_BA_UPD_PPB - 1) / PS_BA_UPD_PPB;   // ba_update's point blocks
   const int err_off = max_np + nblu + nbp;   // layout of `part`: [np chi partials][update partials][error partials]
@@ -1425,7 +1454,7 @@ extern "C" void psk_ba_global_step(const BaArrays* A, int nprob, int max_np, int
   }
   hipLaunchKernelGGL(ba_update, dim3(nblu + nbp, nprob), dim3(256), 0, st, *A);
   hipLaunchKernelGGL(ba_error_k, dim3(nbe, nprob), dim3(256), 0, st, *A, err_off);
-  hipLaunchKernelGGL(ba_decide, dim3(twins ? nprob / 2 : nprob), dim3(256), 0, st, *A, err_off, twins);
+  hipLaunchKernelGGL(ba_decide, dim3(nprob / grp), dim3(256), 0, st, *A, err_off, grp);
 }
 // the stage-2 pass of ba_begin (erase list) needs one more launch once every problem left its last trial
 extern "C" void psk_ba_finalize(const BaArrays* A, int nprob, hipStream_t st) {

@@ -8,7 +8,8 @@
 #define PS_BA_TRACE 40        // LM iterations recorded per problem
 #define PS_BA_MAX_POSES 128   // FREE poses per problem (the LDL^T panel of the reduced system lives in LDS)
 
-enum { BA_PH_BEGIN = 0, BA_PH_LINEARIZE = 1, BA_PH_TRIAL = 2, BA_PH_DONE = 3 };
+enum { BA_PH_BEGIN = 0, BA_PH_LINEARIZE = 1, BA_PH_TRIAL = 2, BA_PH_DONE = 3,
+       BA_PH_IDLE = 4 };   // (unused since the adaptive-depth experiment of r06 was dropped: a member parked for a round; every kernel passes it by)
 
 struct BaProb {
   int32_t np, nl, ne;               // poses (free + fixed), points, edges
@@ -37,8 +38,9 @@ struct BaState {
   int32_t ntrace;
   int32_t iters_done;   // LM iterations executed over both stages (for ms/iter reporting)
   int32_t trials_done;
-  int32_t spec;         // 1: the speculative twin of the problem in front of it (ba_decide): its damping trial runs with lambda * ni, the value
-                        // the primary's next trial would use if this one is rejected
+  int32_t spec;         // s >= 1: the s-th speculative member of the problem in front of it (ba_decide): its damping trial runs with the lambda the
+                        // primary's s-th next trial would use if the ones before are rejected
+  int32_t depth;        // (primary) speculative members that run beside it in the current round: 1 .. group size - 1
   double lambda, ni, current_chi, ini_chi, rho;
 };
 

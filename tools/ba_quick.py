@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointslot_amd import synth
 from pointslot_amd.optimizer import Optimizer
 nobj = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-graphs = [synth.object_ba_problem(0x51070004 + j, perturb=(0.05, 1.0, 0.02), perturb_axis="z") for j in range(nobj)]
+survey = len(sys.argv) > 2 and sys.argv[2] == "survey"      # SURVEY 8d's own perturbation (the bench's metric_ba) instead of the small z-axis one
+graphs = [synth.object_ba_problem(0x51070004 + j) if survey else synth.object_ba_problem(0x51070004 + j, perturb=(0.05, 1.0, 0.02), perturb_axis="z") for j in range(nobj)]
 opt = Optimizer()
 opt.ObjectLocalBundleAdjustment(graphs[:1])
 for _ in range(2):
