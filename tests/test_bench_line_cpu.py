@@ -92,3 +92,27 @@ def test_rendered_sequences_are_cached_and_read_back(tmp_path, monkeypatch):
     b = bench._load_cached(job)
     assert b is not None and np.array_equal(a["left"], b["left"]) and np.array_equal(a["masks"], b["masks"])
     assert bench._seq_cache_path(("lateral", 2, 42, 0, "synthetic", 2)) != bench._seq_cache_path(job)
+
+
+def test_r06_line_carries_the_boundary_numbers_and_a_fraction_for_every_stage():
+    """VERDICT r05 items 1 and 4, on the committed full result of the round (profiles/r06_bench_full.json): the compact line holds the one-sequence-
+    per-GPU number of BASELINE configs[4] and the drop-in boundary's per-frame time with its split, `traffic` says where it comes from, and no stage
+    that is 1 % of the step or more is left without a roofline fraction."""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_full.json")))
+    text = bench.compact_line(full)
+    assert len(text.encode()) < 8192, len(text)
+    line = _strict(text)
+    c5 = line["config5_one_sequence_per_gpu"]
+    assert 0.3 < c5["ms_per_frame"] < 5 and c5["camera_chain_only_ms_per_frame"] < c5["ms_per_frame"] and c5["tracked"] == 154
+    di = line["drop_in_api"]
+    sp = di["cpp_shim_camera_chain"]["split_ms"]
+    parts = sp["extract_call_ms"] + sp["stereo_call_ms"] + sp["search_call_ms"] + sp["pose_call_ms"] + sp["host_marshalling_ms"]
+    assert abs(parts - sp["wall_ms"]) < 0.02 * sp["wall_ms"]                       # the split adds up to the frame
+    assert sp["extract_kernels_ms"] < sp["extract_call_ms"] and sp["pose_kernels_ms"] < sp["pose_call_ms"]
+    assert di["cpp_shim_camera_chain"]["frames_with_pose"] == 154 and di["per_call_slot_chain"]["c_abi_calls_per_frame"] >= 10
+    assert line["roofline"]["traffic_source"].startswith("profiles/")
+    step = sum(r[2] for r in line["rooflines"])
+    for stage, bound, ms, frac, _ in line["rooflines"]:
+        if ms >= 0.01 * step:
+            assert frac is not None and 0 < frac <= 1.0, (stage, bound, ms, frac)
+    assert all(v is not None for v in line["kernels_alone"]["frac"].values())
