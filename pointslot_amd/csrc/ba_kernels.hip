@@ -567,6 +567,9 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A, int nprob) {
   // 48 x 48 tile = 3 x 3 tiles of the FP64 matrix cores (v_mfma_f64_16x16x4_f64); wave w (< 3) owns tile row w.  The vector
   // form of this contraction (3 x 3 register blocks, six LDS reads per nine FMAs) was bound by LDS instruction issue.
   const int wv = tid >> 6, ln = tid & 63, li = ln & 15, lk = ln >> 4;
+  // 16-row blocks of the two tile rows that hold rows of the matrix (n = 6 npa rows in all)
+  const int na = min(3, (6 * npa - ta * 48 + 15) >> 4), nc = min(3, (6 * npa - tb * 48 + 15) >> 4);
+  const bool full_tile = na == 3 && nc == 3;
   sch_d4 acc[3][3];
 #pragma unroll
   for (int a = 0; a < 3; a++)
@@ -604,6 +607,7 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A, int nprob) {
       constexpr int KL = SCH_LC * 3 / 4, KW = KL / 4;
       static_assert(4 * 2304 * 8 <= SCH_LDS_BYTES && KW % 2 == 0, "ba_schur: two K-steps per 128-bit read");
       const int k0 = KL * lk + KW * wv;
+      if (full_tile) {
 #pragma unroll
       for (int i = 0; i < KW; i += 2) {
         sch_d2 a2[3], b2[3];
@@ -616,6 +620,25 @@ __global__ __launch_bounds__(256) void ba_schur(BaArrays A, int nprob) {
             acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[a].x, b2[c].x, acc[a][c], 0, 0, 0);
             acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[a].y, b2[c].y, acc[a][c], 0, 0, 0);
           }
+      }
+      } else {
+        // (r06) a tile row at the end of the matrix that holds fewer than 33 rows: only its first (two) 16-row blocks exist - with 49 free
+        // poses (BASELINE config 4) the seventh tile row is 6 rows, and 7 of a problem's 28 workgroups ran 9 matrix tiles for one
+#pragma unroll
+      for (int i = 0; i < KW; i += 2) {
+        sch_d2 a2[3], b2[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) { a2[a] = *reinterpret_cast<const sch_d2*>(&As[a * 16 + li][k0 + i]); b2[a] = *reinterpret_cast<const sch_d2*>(&Bs[a * 16 + li][k0 + i]); }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            if (a < na && c < nc) {      // wave-uniform
+              acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[a].x, b2[c].x, acc[a][c], 0, 0, 0);
+              acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[a].y, b2[c].y, acc[a][c], 0, 0, 0);
+            }
+          }
+      }
       }
     }
   }
