@@ -105,3 +105,49 @@ def test_se3_conversions_agree_with_the_restatement():
         assert np.array_equal(T, oracle_lib.se3_to_mat4f(p7))
         back = so.se3_from_mat4f(T)
         assert np.abs(np.concatenate([back[1], so.normalize_rotation(back[0])]) - oracle_lib.se3_from_mat4f(T)).max() < 1e-12
+
+
+# ---- ObjectLocalBundleAdjustment (a16 / a17 / a19): tests/ba_second_opinion.py, dense solves of the full normal equations -------------------
+def _compare_ba(p, name):
+    import ba_second_opinion as bso
+    n, poses, pts, erase, tr = bso.object_local_bundle_adjustment(p)
+    no, poseso, ptso, eraseo, tro = oracle_lib.object_ba(p)
+    assert len(tr) == len(tro), (name, len(tr), len(tro))
+    for k, ((c, lam, q), (co, lo, qo)) in enumerate(zip(tr, tro)):
+        assert abs(c - co) <= 1e-8 * max(1.0, abs(co)), (name, k, c, co)
+        d = abs(co - tro[k - 1][0]) / max(1.0, abs(co)) if k > 0 else 1.0
+        if d > 1e-9:      # (see _compare_pose: lambda and the trial count of an iteration that still moves chi2)
+            assert q == int(qo) and abs(lam - lo) <= max(1e-6, 1e-10 / d) * abs(lo), (name, k, q, qo, lam, lo, d)
+    assert n == no and np.array_equal(erase, eraseo), (name, n, no, int((erase != eraseo).sum()))
+    # poses as (t, q): q and -q are the same rotation, both sides keep w >= 0
+    assert np.abs(poses - poseso).max() <= 1e-6, (name, np.abs(poses - poseso).max())
+    assert np.abs(pts - ptso).max() <= 1e-6 * max(1.0, np.abs(ptso).max()), name
+    return n, tr
+
+
+def test_object_ba_schedule_equals_the_restatement_on_the_golden_graphs():
+    """Schur LM of the restatement against a dense LM on the full normal equations with its own edges: 5 robust iterations, the chi2 / depth pass,
+    10 plain iterations, erase list - every iteration's chi2 to 1e-8, lambda, trial counts, erase lists identical, poses and points to 1e-6"""
+    from golden_cases import ba_cases
+    for name, p in ba_cases():
+        n, tr = _compare_ba(p, name)
+        assert len(tr) >= 6 and n > 0
+
+
+def test_object_ba_with_monocular_edges_fixed_extra_cameras_and_full_se3_poses():
+    p = synth.object_ba_problem(0x51070044, n_kf=5, n_pts=14, p_vis=0.8, outlier_frac=0.1, mono_frac=0.3, perturb=(0.1, 2.0, 0.05), perturb_axis="z", n_fixed_extra=1)
+    _compare_ba(p, "mono + fixed extra")
+    # LocalBundleAdjustment's vertices (SURVEY 8f-3): plain VertexSE3Expmap poses - the roll / pitch lock off
+    q = synth.object_ba_problem(0x51070045, n_kf=6, n_pts=30, p_vis=0.7, perturb=(0.05, 1.0, 0.02), perturb_axis="z")
+    q["pose_flags"] = (np.asarray(q["pose_flags"]) & 1).astype(np.uint8)
+    _compare_ba(q, "full SE3")
+
+
+def test_norollpitch_update_against_the_restatement():
+    import ba_second_opinion as bso
+    rng = np.random.default_rng(11)
+    for _ in range(20):
+        u = rng.normal(size=6) * np.array([0.0, 0.0, 0.4, 1, 1, 1])
+        q, t = bso.exptwist_norollpitch(u)
+        p7 = oracle_lib.se3_exp(u, True)
+        assert np.abs(np.concatenate([t, so.normalize_rotation(q)]) - p7).max() < 1e-12
