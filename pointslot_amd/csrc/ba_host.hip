@@ -34,7 +34,10 @@ int ensure(BaCtx* c, size_t dbytes, size_t hbytes) {
     if (c->d_buf) hipFree(c->d_buf);
     c->d_buf = nullptr;
     PS_HIP(hipMalloc(&c->d_buf, dbytes));
-    if (const char* fill = getenv("PS_DEBUG_FILL")) PS_HIP(hipMemset(c->d_buf, atoi(fill), dbytes));   // diagnostic: poison fresh device memory
+    if (const char* fill = getenv("PS_DEBUG_FILL")) {   // diagnostic: poison fresh device memory.  hipMemset on device memory returns before the fill has run, and it runs
+      PS_HIP(hipMemset(c->d_buf, atoi(fill), dbytes));                 // on the null stream, which the handle's non-blocking stream does not wait for: without the wait the fill
+      PS_HIP(hipDeviceSynchronize());        // landed on top of the call's uploads now and then (r06: 2 of 50 runs of the poisoned test slice died of it)
+    }
     c->d_bytes = dbytes;
   }
   if (hbytes > c->h_bytes) {

@@ -41,7 +41,10 @@ int ensure(ps_optimizer* m, size_t need) {
     if (m->d_buf) hipFree(m->d_buf);
     m->d_buf = nullptr;
     PS_HIP(hipMalloc(&m->d_buf, bytes));
-    if (const char* fill = getenv("PS_DEBUG_FILL")) PS_HIP(hipMemset(m->d_buf, atoi(fill), bytes));   // diagnostic: poison fresh device memory
+    if (const char* fill = getenv("PS_DEBUG_FILL")) {   // diagnostic: poison fresh device memory.  hipMemset on device memory returns before the fill has run, and it runs
+      PS_HIP(hipMemset(m->d_buf, atoi(fill), bytes));                 // on the null stream, which the handle's non-blocking stream does not wait for: without the wait the fill
+      PS_HIP(hipDeviceSynchronize());        // landed on top of the call's uploads now and then (r06: 2 of 50 runs of the poisoned test slice died of it)
+    }
     m->d_bytes = bytes;
   }
   if (bytes > m->h_bytes) {
