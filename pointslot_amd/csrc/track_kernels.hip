@@ -21,6 +21,12 @@ namespace {
                         // 0.23 ms per step with 1024), but a 1024-thread workgroup needs sixteen free wave slots on ONE CU at the same moment: beside
                         // the other lockstep groups' kernels trk_finish waited 500 us for its turn (89 us alone).  r04: 256 -> +1.3 % frames/s
 #endif
+#ifndef TRK_T_SMALL
+#define TRK_T_SMALL 1024   // ... and a handle of a few sequences (one per GPU: BASELINE configs[4]) has the chip to itself: every kernel is instantiated for
+#endif                     // both widths and the launchers below pick by the handle's size.  Results do not depend on the width (integer sums, ordered scans, minima)
+#ifndef TRK_SMALL_S
+#define TRK_SMALL_S 32
+#endif
 
 __device__ __forceinline__ void mul4(const float* a, const float* b, float* o) {   // OdoSequence::mul4
   float t[16];
@@ -41,7 +47,8 @@ __device__ __forceinline__ void unproject(const TrkCam& C, const float* T, float
   for (int r = 0; r < 3; r++) X[r] = (T[r] * xc + T[4 + r] * yc + T[8 + r] * z) + Ow[r];
 }
 
-// sum of v over the workgroup (every thread gets it); red: TRK_T / 64 ints of LDS
+// sum of v over the workgroup (every thread gets it); red: NTH / 64 ints of LDS
+template <int NTH>
 __device__ __forceinline__ int block_sum_i(int v, int* red) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
@@ -50,11 +57,12 @@ __device__ __forceinline__ int block_sum_i(int v, int* red) {
   __syncthreads();
   int t = 0;
 #pragma unroll
-  for (int w = 0; w < TRK_T / 64; w++) t += red[w];
+  for (int w = 0; w < NTH / 64; w++) t += red[w];
   return t;
 }
 
 // exclusive prefix of v over the workgroup in thread order; *total = the sum
+template <int NTH>
 __device__ __forceinline__ int block_scan_excl(int v, int* red, int* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int incl = v;
@@ -67,7 +75,7 @@ __device__ __forceinline__ int block_scan_excl(int v, int* red, int* total) {
   for (int w = 0; w < wave; w++) base += red[w];
   int t = 0;
 #pragma unroll
-  for (int w = 0; w < TRK_T / 64; w++) t += red[w];
+  for (int w = 0; w < NTH / 64; w++) t += red[w];
   *total = t;
   return base + incl - v;
 }
@@ -105,10 +113,11 @@ __device__ void seq_fail(const TrkArrays& A, int s, int step, TrkStat& st) {
 }
 
 // copies sequence s of frame `src` over frame `dst` (last = F)
+template <int NTH>
 __device__ void copy_frame(const TrkArrays& A, const TrkFrame& dst, const TrkFrame& src, int s) {
   const int tid = threadIdx.x, n = src.n[s];
   const size_t b = (size_t)s * A.cap;
-  for (int i = tid; i < n; i += TRK_T) {
+  for (int i = tid; i < n; i += NTH) {
     dst.x[b + i] = src.x[b + i]; dst.y[b + i] = src.y[b + i]; dst.angle[b + i] = src.angle[b + i];
     dst.uright[b + i] = src.uright[b + i]; dst.depth[b + i] = src.depth[b + i]; dst.octave[b + i] = src.octave[b + i];
     dst.mp_id[b + i] = src.mp_id[b + i]; dst.mp_valid[b + i] = src.mp_valid[b + i]; dst.mp_observed[b + i] = src.mp_observed[b + i];
@@ -117,7 +126,7 @@ __device__ void copy_frame(const TrkArrays& A, const TrkFrame& dst, const TrkFra
   }
   const uint4* sd = reinterpret_cast<const uint4*>(src.desc + b * 32);
   uint4* dd = reinterpret_cast<uint4*>(dst.desc + b * 32);
-  for (int i = tid; i < 2 * n; i += TRK_T) dd[i] = sd[i];
+  for (int i = tid; i < 2 * n; i += NTH) dd[i] = sd[i];
   // (the grid of the last frame is never read: SearchByProjection walks the CURRENT frame's grid)
   if (tid < 16) dst.tcw[s * 16 + tid] = src.tcw[s * 16 + tid];
   if (tid == 0) dst.n[s] = n;
@@ -128,12 +137,13 @@ __device__ void copy_frame(const TrkArrays& A, const TrkFrame& dst, const TrkFra
 // StereoInitialization (Tracking.cc:2840-2910) or UpdateLastFrame + the motion-model prediction + the first
 // SearchByProjection(cur, last, th = 7) problem (Tracking.cc:2971-3048).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
+template <int NTH>
+__global__ __launch_bounds__(NTH) void trk_begin(TrkArrays A, int step) {
   __shared__ int cnt[PS_TRK_NCELL + 1];
   __shared__ int cursor[PS_TRK_NCELL];
   __shared__ float sdepth[4352];
-  __shared__ int red[TRK_T / 64];
-  __shared__ unsigned long long far_red[TRK_T / 64];
+  __shared__ int red[NTH / 64];
+  __shared__ unsigned long long far_red[NTH / 64];
   __shared__ float pose_pred[16];
   const int s = blockIdx.x, tid = threadIdx.x;
   const TrkCam& C = A.cam;
@@ -148,13 +158,13 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
   st.n = N;
 
   // ---- per-keypoint arrays ----
-  for (int i = tid; i <= PS_TRK_NCELL; i += TRK_T) cnt[i] = 0;
+  for (int i = tid; i <= PS_TRK_NCELL; i += NTH) cnt[i] = 0;
   __syncthreads();
   {
     // with an instance mask (SLOT.MODE 4) Frame::AssignFeatures keeps the keypoints on background pixels, in order (Frame.cc:811-822)
     const uint8_t* M = A.idmask ? A.idmask + (size_t)s * A.mask_pitch : nullptr;
     int kept = 0;
-    for (int i0 = 0; i0 < N; i0 += TRK_T) {
+    for (int i0 = 0; i0 < N; i0 += NTH) {
       const int i = i0 + tid;
       ps_keypoint k;
       bool keep = i < N;
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
       int pos = i;
       if (M) {
         int total;
-        pos = kept + block_scan_excl(keep ? 1 : 0, red, &total);
+        pos = kept + block_scan_excl<NTH>(keep ? 1 : 0, red, &total);
         kept += total;
       }
       if (keep) {
@@ -188,26 +198,27 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
   __syncthreads();
   // ---- mGrid as CSR: exclusive scan of the cell counts (12 cells per thread), fill, then every cell's list in keypoint order ----
   {
-    const int per = PS_TRK_NCELL / TRK_T;   // 3072 / 256
+    static_assert(PS_TRK_NCELL % NTH == 0, "the cell scan takes PS_TRK_NCELL / NTH cells per thread");
+    const int per = PS_TRK_NCELL / NTH;   // 12 or 3
     int local[per];
     int sum = 0;
     for (int k = 0; k < per; k++) { local[k] = cnt[tid * per + k]; sum += local[k]; }
     int total;
-    int base = block_scan_excl(sum, red, &total);
+    int base = block_scan_excl<NTH>(sum, red, &total);
     for (int k = 0; k < per; k++) { cnt[tid * per + k] = base; cursor[tid * per + k] = base; base += local[k]; }
     if (tid == 0) cnt[PS_TRK_NCELL] = total;
   }
   __syncthreads();
   int32_t* coff = A.cur.cell_off + (size_t)s * (PS_TRK_NCELL + 1);
   int32_t* cidx = A.cur.cell_idx + b;
-  for (int i = tid; i <= PS_TRK_NCELL; i += TRK_T) coff[i] = cnt[i];
-  for (int i = tid; i < N; i += TRK_T) {
+  for (int i = tid; i <= PS_TRK_NCELL; i += NTH) coff[i] = cnt[i];
+  for (int i = tid; i < N; i += NTH) {
     const float x = A.cur.x[b + i], y = A.cur.y[b + i];
     const int px = (int)roundf((x - 0.f) * C.gw_inv), py = (int)roundf((y - 0.f) * C.gh_inv);
     if (px >= 0 && px < PS_GRID_COLS && py >= 0 && py < PS_GRID_ROWS) cidx[atomicAdd(&cursor[px * PS_GRID_ROWS + py], 1)] = i;
   }
   __syncthreads();
-  for (int c = tid; c < PS_TRK_NCELL; c += TRK_T) {   // mGrid[x][y].push_back(i) in keypoint order: insertion sort of a short list
+  for (int c = tid; c < PS_TRK_NCELL; c += NTH) {   // mGrid[x][y].push_back(i) in keypoint order: insertion sort of a short list
     const int b0 = cnt[c], e0 = cnt[c + 1];
     for (int i = b0 + 1; i < e0; i++) {
       const int v = cidx[i];
@@ -231,11 +242,11 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
     float I[16];
     set_identity(I);
     int lm_base = 0;
-    for (int i0 = 0; i0 < N; i0 += TRK_T) {
+    for (int i0 = 0; i0 < N; i0 += NTH) {
       const int i = i0 + tid;
       const bool has = i < N && A.cur.depth[b + i] > 0;
       int total;
-      const int id = lm_base + block_scan_excl(has ? 1 : 0, red, &total);
+      const int id = lm_base + block_scan_excl<NTH>(has ? 1 : 0, red, &total);
       if (has) {
         float P[3];
         unproject(C, I, A.cur.x[b + i], A.cur.y[b + i], A.cur.depth[b + i], P);
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
     }
     if (tid < 16) { A.cur.tcw[s * 16 + tid] = I[tid]; tr[tid] = I[tid]; }
     __syncthreads();
-    copy_frame(A, A.last, A.cur, s);   // last = F
+    copy_frame<NTH>(A, A.last, A.cur, s);   // last = F
     if (tid == 0) {
       q.state = TRK_OK; q.have_velocity = 0; q.lm_n = lm_base; q.phase = TRK_PH_IDLE;
       st.state = TRK_OK; st.tracked = 1;
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
   // ---- Tracking::UpdateLastFrame (localisation mode): the closest keypoints with depth get temporal map points ----
   const int NL = A.last.n[s];
   const float* Tl = A.last.tcw + s * 16;
-  for (int i = tid; i < NL; i += TRK_T) sdepth[i] = A.last.depth[b + i];
+  for (int i = tid; i < NL; i += NTH) sdepth[i] = A.last.depth[b + i];
   __syncthreads();
   {
     // The reference sorts (depth, index) and walks the list until it has passed 100 points AND the first one beyond
@@ -276,13 +287,13 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
     const float thr = 2 * C.th_depth;
     int near = 0;
     unsigned long long far_min = ~0ull;   // (depth bits, index) of the nearest far point: positive floats order like their bit patterns
-    for (int i = tid; i < NL; i += TRK_T) {
+    for (int i = tid; i < NL; i += NTH) {
       const float d = sdepth[i];
       if (!(d > 0)) continue;
       if (!(d > thr)) near++;
       else { const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i; far_min = k < far_min ? k : far_min; }
     }
-    const int c = block_sum_i(near, red);
+    const int c = block_sum_i<NTH>(near, red);
     const int J = c > 100 ? c : 100;
     if (c >= 100) {
 #pragma unroll
@@ -294,10 +305,10 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
       if ((tid & 63) == 0) far_red[tid >> 6] = far_min;
       __syncthreads();
       far_min = far_red[0];
-      for (int w = 1; w < TRK_T / 64; w++) far_min = far_red[w] < far_min ? far_red[w] : far_min;
+      for (int w = 1; w < NTH / 64; w++) far_min = far_red[w] < far_min ? far_red[w] : far_min;
     }
     const int far_first = (c >= 100 && far_min != ~0ull) ? (int)(unsigned)far_min : -1;
-    for (int i0 = 0; i0 < NL; i0 += TRK_T) {
+    for (int i0 = 0; i0 < NL; i0 += NTH) {
       const int i = i0 + tid;
       const float d = i < NL ? sdepth[i] : -1.f;
       if (!(d > 0)) continue;
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
     mul4(q.velocity, Tl, P);
     for (int i = 0; i < 16; i++) { pose_pred[i] = P[i]; A.cur.tcw[s * 16 + i] = P[i]; }
   }
-  for (int i = tid; i < NL; i += TRK_T) A.qvalid[b + i] = (A.last.mp_valid[b + i] && !A.last.outlier[b + i]) ? 1 : 0;
+  for (int i = tid; i < NL; i += NTH) A.qvalid[b + i] = (A.last.mp_valid[b + i] && !A.last.outlier[b + i]) ? 1 : 0;
   __syncthreads();
   if (tid == 0) {
     // matcher(0.9, true).SearchByProjection(mCurrentFrame, mLastFrame, th, false) (Tracking.cc:3030-3048), th = 7 then 14
@@ -350,14 +361,15 @@ __global__ __launch_bounds__(TRK_T) void trk_begin(TrkArrays A, int step) {
 }
 
 // Step 2: `if (nmatches < 20) retry with 2 * th` (Tracking.cc:3042-3048)
-__global__ __launch_bounds__(TRK_T) void trk_after_mm1(TrkArrays A) {
+template <int NTH>
+__global__ __launch_bounds__(NTH) void trk_after_mm1(TrkArrays A) {
   const int s = blockIdx.x, tid = threadIdx.x;
   TrkSeq& q = A.seq[s];
   if (q.phase != TRK_PH_MM) return;
   const size_t b = (size_t)s * A.cap;
   if (A.nmatch_mm1[s] < 20) {
     const int NL = A.last.n[s];
-    for (int i = tid; i < NL; i += TRK_T) A.qvalid[b + i] = (A.last.mp_valid[b + i] && !A.last.outlier[b + i]) ? 1 : 0;   // pj_project cleared the misses
+    for (int i = tid; i < NL; i += NTH) A.qvalid[b + i] = (A.last.mp_valid[b + i] && !A.last.outlier[b + i]) ? 1 : 0;   // pj_project cleared the misses
     if (tid == 0) q.retried = 1;
   } else if (tid == 0) {
     A.prob_mm2[s].nq = 0; A.prob_mm2[s].nt = 0;
@@ -365,16 +377,17 @@ __global__ __launch_bounds__(TRK_T) void trk_after_mm1(TrkArrays A) {
 }
 
 // Optimizer::PoseOptimization(&mCurrentFrame) problem of sequence s (OdoSequence::fillPose)
+template <int NTH>
 __device__ void fill_pose(const TrkArrays& A, int s, int N, int* red) {
   const int tid = threadIdx.x;
   const size_t b = (size_t)s * A.cap;
   int nv = 0;
-  for (int i = tid; i < N; i += TRK_T) {
+  for (int i = tid; i < N; i += NTH) {
     A.po_obs[3 * (b + i)] = A.cur.x[b + i]; A.po_obs[3 * (b + i) + 1] = A.cur.y[b + i]; A.po_obs[3 * (b + i) + 2] = A.cur.uright[b + i];
     A.po_is2[b + i] = A.cam.inv_sigma2[A.cur.octave[b + i]];
     nv += A.cur.mp_valid[b + i] ? 1 : 0;
   }
-  nv = block_sum_i(nv, red);
+  nv = block_sum_i<NTH>(nv, red);
   if (tid == 0) {
     A.seq[s].nvalid_pose = nv;
     const Se3 T = se3_from_mat4f(A.cur.tcw + s * 16);   // Converter::toSE3Quat(pFrame->mTcw)
@@ -396,8 +409,9 @@ __device__ void take_pose(const TrkArrays& A, int s) {
 }
 
 // Step 3: the matches of the motion-model search become the frame's map points (Tracking.cc:3050-3056), then the pose problem
-__global__ __launch_bounds__(TRK_T) void trk_after_mm(TrkArrays A, int step) {
-  __shared__ int red[TRK_T / 64];
+template <int NTH>
+__global__ __launch_bounds__(NTH) void trk_after_mm(TrkArrays A, int step) {
+  __shared__ int red[NTH / 64];
   const int s = blockIdx.x, tid = threadIdx.x;
   TrkSeq& q = A.seq[s];
   if (q.phase != TRK_PH_MM) return;
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(TRK_T) void trk_after_mm(TrkArrays A, int step) {
   __syncthreads();
   if (nm < 20) { if (tid == 0) seq_fail(A, s, step, st); return; }
   const int N = A.cur.n[s];
-  for (int j = tid; j < N; j += TRK_T) {
+  for (int j = tid; j < N; j += NTH) {
     const int i = A.match[b + j];
     A.cur.mp_valid[b + j] = i >= 0;
     if (i >= 0) {
@@ -417,14 +431,15 @@ __global__ __launch_bounds__(TRK_T) void trk_after_mm(TrkArrays A, int step) {
     }
   }
   __syncthreads();
-  fill_pose(A, s, N, red);
+  fill_pose<NTH>(A, s, N, red);
   if (tid == 0) { q.phase = TRK_PH_POSE1; A.stats[(size_t)step * A.S + s] = st; }
 }
 
 // Step 4: discard outliers (Tracking.cc:3062-3082), then SearchLocalPoints: Frame::isInFrustum (Frame.cc:1686-1743) +
 // the SearchByProjection(mCurrentFrame, points, th = 1) problem with matcher(0.8) (Tracking.cc:3097-3160)
-__global__ __launch_bounds__(TRK_T) void trk_after_pose1(TrkArrays A, int step) {
-  __shared__ int red[TRK_T / 64];
+template <int NTH>
+__global__ __launch_bounds__(NTH) void trk_after_pose1(TrkArrays A, int step) {
+  __shared__ int red[NTH / 64];
   __shared__ uint8_t already[4352];
   const int s = blockIdx.x, tid = threadIdx.x;
   TrkSeq& q = A.seq[s];
@@ -434,17 +449,17 @@ __global__ __launch_bounds__(TRK_T) void trk_after_pose1(TrkArrays A, int step) 
   TrkStat st = A.stats[(size_t)step * A.S + s];
   take_pose(A, s);
   const int N = A.cur.n[s], n = q.lm_n;
-  for (int i = tid; i < n; i += TRK_T) already[i] = 0;
+  for (int i = tid; i < n; i += NTH) already[i] = 0;
   __syncthreads();
   int nmatches = 0, nmap = 0;
-  for (int i = tid; i < N; i += TRK_T) {
+  for (int i = tid; i < N; i += NTH) {
     if (!A.cur.mp_valid[b + i]) continue;
     if (A.cur.outlier[b + i]) { A.cur.mp_valid[b + i] = 0; A.cur.outlier[b + i] = 0; continue; }
     nmatches++;
     if (A.cur.mp_observed[b + i]) nmap++;
   }
-  nmatches = block_sum_i(nmatches, red);
-  nmap = block_sum_i(nmap, red);
+  nmatches = block_sum_i<NTH>(nmatches, red);
+  nmap = block_sum_i<NTH>(nmap, red);
   st.matches = nmatches; st.map_matches = nmap;
   if (!(nmatches > 20)) { if (tid == 0) seq_fail(A, s, step, st); return; }
   if (nmap < 10) {   // mbVO: the frame is kept without TrackLocalMap
@@ -453,7 +468,7 @@ __global__ __launch_bounds__(TRK_T) void trk_after_pose1(TrkArrays A, int step) 
     if (tid == 0) { q.phase = TRK_PH_FINISH; A.po_vert[s] = PoVertex{(int32_t)b, (int32_t)b}; A.stats[(size_t)step * A.S + s] = st; }
     return;
   }
-  for (int i = tid; i < N; i += TRK_T) {
+  for (int i = tid; i < N; i += NTH) {
     const bool v = A.cur.mp_valid[b + i];
     if (A.cur.mp_id[b + i] >= 0) already[A.cur.mp_id[b + i]] = 1;   // mnLastFrameSeen: matched points and the outliers just discarded (Tracking.cc:3071-3075)
     A.occupied[b + i] = (v && A.cur.mp_observed[b + i]) ? 1 : 0;
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(TRK_T) void trk_after_pose1(TrkArrays A, int step) 
   float Ow[3];
   for (int r = 0; r < 3; r++) Ow[r] = -(T[r] * T[3] + T[4 + r] * T[7] + T[8 + r] * T[11]);
   int nto = 0;
-  for (int i = tid; i < n; i += TRK_T) {
+  for (int i = tid; i < n; i += NTH) {
     A.qvalid[b + i] = 0; A.qu[b + i] = 0.f; A.qv[b + i] = 0.f; A.qur[b + i] = 0.f; A.qrad[b + i] = 0.f; A.qminl[b + i] = 0; A.qmaxl[b + i] = 0;
     if (already[i]) continue;
     const float* P = A.lm_xw + 3 * (b + i);
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(TRK_T) void trk_after_pose1(TrkArrays A, int step) 
     A.qminl[b + i] = level - 1; A.qmaxl[b + i] = level;
     nto++;
   }
-  nto = block_sum_i(nto, red);
+  nto = block_sum_i<NTH>(nto, red);
   st.lm_candidates = nto;
   if (nto > 0) {
     if (tid == 0) {
@@ -502,32 +517,34 @@ __global__ __launch_bounds__(TRK_T) void trk_after_pose1(TrkArrays A, int step) 
     }
     return;
   }
-  fill_pose(A, s, N, red);
+  fill_pose<NTH>(A, s, N, red);
   if (tid == 0) { q.lm_searched = 0; q.phase = TRK_PH_POSE2; A.stats[(size_t)step * A.S + s] = st; }
 }
 
 // Step 5: the local-map matches join the frame's map points, then the second pose problem
-__global__ __launch_bounds__(TRK_T) void trk_after_lm(TrkArrays A) {
-  __shared__ int red[TRK_T / 64];
+template <int NTH>
+__global__ __launch_bounds__(NTH) void trk_after_lm(TrkArrays A) {
+  __shared__ int red[NTH / 64];
   const int s = blockIdx.x, tid = threadIdx.x;
   TrkSeq& q = A.seq[s];
   if (q.phase != TRK_PH_LM) return;
   const size_t b = (size_t)s * A.cap;
   const int N = A.cur.n[s];
-  for (int j = tid; j < N; j += TRK_T) {
+  for (int j = tid; j < N; j += NTH) {
     const int i = A.match[b + j];
     if (i < 0) continue;
     A.cur.mp_valid[b + j] = 1; A.cur.mp_observed[b + j] = 1; A.cur.mp_id[b + j] = i;
     for (int c = 0; c < 3; c++) A.cur.xw[3 * (b + j) + c] = A.lm_xw[3 * (b + i) + c];
   }
   __syncthreads();
-  fill_pose(A, s, N, red);
+  fill_pose<NTH>(A, s, N, red);
   if (tid == 0) q.phase = TRK_PH_POSE2;
 }
 
 // Step 6: TrackLocalMap's inlier count (Tracking.cc:3128-3158), the motion model (Tracking.cc:1260-1286), last = current
-__global__ __launch_bounds__(TRK_T) void trk_finish(TrkArrays A, int step) {
-  __shared__ int red[TRK_T / 64];
+template <int NTH>
+__global__ __launch_bounds__(NTH) void trk_finish(TrkArrays A, int step) {
+  __shared__ int red[NTH / 64];
   const int s = blockIdx.x, tid = threadIdx.x;
   TrkSeq& q = A.seq[s];
   const int ph = q.phase;
@@ -539,17 +556,17 @@ __global__ __launch_bounds__(TRK_T) void trk_finish(TrkArrays A, int step) {
   if (ph == TRK_PH_POSE2) {
     take_pose(A, s);
     int inl = 0;
-    for (int i = tid; i < N; i += TRK_T) {
+    for (int i = tid; i < N; i += NTH) {
       if (!A.cur.mp_valid[b + i]) continue;
       if (A.cur.outlier[b + i]) A.cur.mp_valid[b + i] = 0;   // stereo: outliers lose their map point (Tracking.cc:3141-3142)
       else inl++;
     }
-    inl = block_sum_i(inl, red);
+    inl = block_sum_i<NTH>(inl, red);
     st.lm_inliers = inl;
     if (inl < 30) { if (tid == 0) seq_fail(A, s, step, st); return; }
   }
   // clean VO matches (Tracking.cc:1274-1286)
-  for (int i = tid; i < N; i += TRK_T)
+  for (int i = tid; i < N; i += NTH)
     if (A.cur.mp_valid[b + i] && !A.cur.mp_observed[b + i]) { A.cur.mp_valid[b + i] = 0; A.cur.outlier[b + i] = 0; }
   if (tid == 0) {
     // mVelocity = mCurrentFrame.mTcw * LastTwc (Tracking.cc:1260-1270)
@@ -571,7 +588,7 @@ __global__ __launch_bounds__(TRK_T) void trk_finish(TrkArrays A, int step) {
     for (int i = 0; i < 16; i++) tr[i] = F[i];
   }
   __syncthreads();
-  copy_frame(A, A.last, A.cur, s);
+  copy_frame<NTH>(A, A.last, A.cur, s);
   if (tid == 0) {
     q.phase = TRK_PH_IDLE; q.state = TRK_OK;   // `if (bOK) mState = OK;` - also after a frame that was lost
     st.state = TRK_OK; st.tracked = 1;
@@ -594,10 +611,29 @@ extern "C" {
 void psk_trk_stamp_overflow(const TrkArrays* A, int32_t* overflow, int step, hipStream_t st) {
   hipLaunchKernelGGL(trk_stamp_overflow, dim3((A->S + 255) / 256), dim3(256), 0, st, *A, overflow, step);
 }
-void psk_trk_begin(const TrkArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(trk_begin, dim3(A->S), dim3(TRK_T), 0, st, *A, step); }
-void psk_trk_after_mm1(const TrkArrays* A, hipStream_t st) { hipLaunchKernelGGL(trk_after_mm1, dim3(A->S), dim3(TRK_T), 0, st, *A); }
-void psk_trk_after_mm(const TrkArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(trk_after_mm, dim3(A->S), dim3(TRK_T), 0, st, *A, step); }
-void psk_trk_after_pose1(const TrkArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(trk_after_pose1, dim3(A->S), dim3(TRK_T), 0, st, *A, step); }
-void psk_trk_after_lm(const TrkArrays* A, hipStream_t st) { hipLaunchKernelGGL(trk_after_lm, dim3(A->S), dim3(TRK_T), 0, st, *A); }
-void psk_trk_finish(const TrkArrays* A, int step, hipStream_t st) { hipLaunchKernelGGL(trk_finish, dim3(A->S), dim3(TRK_T), 0, st, *A, step); }
+static inline bool trk_small(const TrkArrays* A) { return A->S <= TRK_SMALL_S; }
+void psk_trk_begin(const TrkArrays* A, int step, hipStream_t st) {
+  if (trk_small(A)) hipLaunchKernelGGL(trk_begin<TRK_T_SMALL>, dim3(A->S), dim3(TRK_T_SMALL), 0, st, *A, step);
+  else hipLaunchKernelGGL(trk_begin<TRK_T>, dim3(A->S), dim3(TRK_T), 0, st, *A, step);
+}
+void psk_trk_after_mm1(const TrkArrays* A, hipStream_t st) {
+  if (trk_small(A)) hipLaunchKernelGGL(trk_after_mm1<TRK_T_SMALL>, dim3(A->S), dim3(TRK_T_SMALL), 0, st, *A);
+  else hipLaunchKernelGGL(trk_after_mm1<TRK_T>, dim3(A->S), dim3(TRK_T), 0, st, *A);
+}
+void psk_trk_after_mm(const TrkArrays* A, int step, hipStream_t st) {
+  if (trk_small(A)) hipLaunchKernelGGL(trk_after_mm<TRK_T_SMALL>, dim3(A->S), dim3(TRK_T_SMALL), 0, st, *A, step);
+  else hipLaunchKernelGGL(trk_after_mm<TRK_T>, dim3(A->S), dim3(TRK_T), 0, st, *A, step);
+}
+void psk_trk_after_pose1(const TrkArrays* A, int step, hipStream_t st) {
+  if (trk_small(A)) hipLaunchKernelGGL(trk_after_pose1<TRK_T_SMALL>, dim3(A->S), dim3(TRK_T_SMALL), 0, st, *A, step);
+  else hipLaunchKernelGGL(trk_after_pose1<TRK_T>, dim3(A->S), dim3(TRK_T), 0, st, *A, step);
+}
+void psk_trk_after_lm(const TrkArrays* A, hipStream_t st) {
+  if (trk_small(A)) hipLaunchKernelGGL(trk_after_lm<TRK_T_SMALL>, dim3(A->S), dim3(TRK_T_SMALL), 0, st, *A);
+  else hipLaunchKernelGGL(trk_after_lm<TRK_T>, dim3(A->S), dim3(TRK_T), 0, st, *A);
+}
+void psk_trk_finish(const TrkArrays* A, int step, hipStream_t st) {
+  if (trk_small(A)) hipLaunchKernelGGL(trk_finish<TRK_T_SMALL>, dim3(A->S), dim3(TRK_T_SMALL), 0, st, *A, step);
+  else hipLaunchKernelGGL(trk_finish<TRK_T>, dim3(A->S), dim3(TRK_T), 0, st, *A, step);
+}
 }
